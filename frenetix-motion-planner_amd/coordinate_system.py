@@ -1,0 +1,169 @@
+"""Host-side reference-path preparation.
+
+`CoordinateSystem` mirrors cr_scenario_handler/utils/utils_coordinate_system.py:187-274 of the
+reference: it owns the reference polyline and the per-knot arrays ref_pos / ref_theta / ref_curv /
+ref_curv_d that the hot path interpolates, and converts between curvilinear (s, d) and Cartesian
+(x, y).  In the reference these come from commonroad-drivability-checker (C++ CCosy and
+commonroad_dc.geometry.util), which is not in the reference tree; they are restated here
+(parity unpinned, DESIGN.md "Third-party arithmetic"):
+
+  pathlength  : cumulative Euclidean segment length
+  orientation : atan2 of the forward segment, last value repeated
+  curvature   : (x'y'' - x''y') / (x'^2 + y'^2)^(3/2) with np.gradient
+  projection  : foot point on the segment containing s, offset d along the normalised linear
+                interpolation of the vertex normals (vertex normal = left normal of P[i+1]-P[i-1])
+
+All of this runs once per reference-path change on the host; the arrays are kernel inputs.
+"""
+import math
+
+import numpy as np
+
+
+def compute_pathlength_from_polyline(polyline: np.ndarray) -> np.ndarray:
+    seg = np.diff(np.asarray(polyline, dtype=np.float64), axis=0)
+    out = np.zeros(len(polyline))
+    acc = 0.0
+    for i in range(len(seg)):
+        acc = acc + math.sqrt(seg[i, 0] * seg[i, 0] + seg[i, 1] * seg[i, 1])
+        out[i + 1] = acc
+    return out
+
+
+def compute_orientation_from_polyline(polyline: np.ndarray) -> np.ndarray:
+    p = np.asarray(polyline, dtype=np.float64)
+    seg = p[1:] - p[:-1]
+    th = np.arctan2(seg[:, 1], seg[:, 0])
+    return np.append(th, th[-1])
+
+
+def compute_curvature_from_polyline(polyline: np.ndarray) -> np.ndarray:
+    p = np.asarray(polyline, dtype=np.float64)
+    x_d = np.gradient(p[:, 0])
+    x_dd = np.gradient(x_d)
+    y_d = np.gradient(p[:, 1])
+    y_dd = np.gradient(y_d)
+    return (x_d * y_dd - x_dd * y_d) / ((x_d ** 2 + y_d ** 2) ** (3. / 2.))
+
+
+def vertex_normals(polyline: np.ndarray) -> np.ndarray:
+    p = np.asarray(polyline, dtype=np.float64)
+    t = np.empty_like(p)
+    t[1:-1] = p[2:] - p[:-2]
+    t[0] = p[1] - p[0]
+    t[-1] = p[-1] - p[-2]
+    nrm = np.sqrt(t[:, 0] * t[:, 0] + t[:, 1] * t[:, 1])
+    t = t / nrm[:, None]
+    return np.stack([-t[:, 1], t[:, 0]], axis=1)
+
+
+def time_power_table(dt: float, n_samples: int) -> np.ndarray:
+    """tpow[k, i] = round(t_i**(k+1), 10) with t_i = round(i*dt, 5): the reference's time grid
+    (reactive_planner.py:296-300; np.arange(0, T+dt, dt)[i] == i*dt for every T)."""
+    t = np.round(np.arange(n_samples) * dt, 5)
+    return np.stack([t] + [np.round(np.power(t, k), 10) for k in (2, 3, 4, 5)]).astype(np.float64)
+
+
+def simpson_even_correction(dt: float):
+    """alpha, beta, eta of scipy.integrate.simpson's correction for an even number of samples with
+    h = [dt, dt] (scipy/integrate/_quadrature.py, 'simpson' rule; used by the zero-weight-by-default
+    jerk / orientation_offset costs, partial_cost_functions.py:41-46,146-151)."""
+    h = np.asarray([dt, dt], dtype=np.float64)
+    alpha = (2 * h[1] ** 2 + 3 * h[0] * h[1]) / (6 * (h[1] + h[0]))
+    beta = (h[1] ** 2 + 3.0 * h[0] * h[1]) / (6 * h[0])
+    eta = (1 * h[1] ** 3) / (6 * h[0] * (h[0] + h[1]))
+    return float(alpha), float(beta), float(eta)
+
+
+def make_valid_orientation(angle: float) -> float:
+    """commonroad.common.util.make_valid_orientation (restated): into [-2pi, 2pi]."""
+    two_pi = 2.0 * np.pi
+    while angle > two_pi:
+        angle = angle - two_pi
+    while angle < -two_pi:
+        angle = angle + two_pi
+    return angle
+
+
+def interpolate_angle(x: float, x1: float, x2: float, y1: float, y2: float) -> float:
+    """utils_coordinate_system.py:137-155."""
+    delta = y2 - y1
+    return make_valid_orientation(delta * (x - x1) / (x2 - x1) + y1)
+
+
+class CoordinateSystem:
+    """Reference path + curvilinear frame (utils_coordinate_system.py:187-274)."""
+
+    def __init__(self, reference: np.ndarray):
+        ref = np.ascontiguousarray(np.asarray(reference, dtype=np.float64))
+        if ref.ndim != 2 or ref.shape[1] != 2 or ref.shape[0] < 3:
+            raise ValueError("<CoordinateSystem>: reference must be an (M>=3, 2) polyline")
+        self._reference = ref
+        self._ref_pos = compute_pathlength_from_polyline(ref)
+        if np.any(np.diff(self._ref_pos) <= 0):
+            raise ValueError("<CoordinateSystem>: reference has repeated vertices")
+        self._ref_curv = compute_curvature_from_polyline(ref)
+        self._ref_theta = np.unwrap(compute_orientation_from_polyline(ref))
+        self._ref_curv_d = np.gradient(self._ref_curv, self._ref_pos)
+        self._ref_curv_dd = np.gradient(self._ref_curv_d, self._ref_pos)
+        self._normals = vertex_normals(ref)
+
+    reference = property(lambda self: self._reference)
+    ref_pos = property(lambda self: self._ref_pos)
+    ref_curv = property(lambda self: self._ref_curv)
+    ref_curv_d = property(lambda self: self._ref_curv_d)
+    ref_cruv_dd = property(lambda self: self._ref_curv_dd)  # (sic) reference spelling, :215
+    ref_theta = property(lambda self: self._ref_theta)
+    normals = property(lambda self: self._normals)
+
+    def segment_of(self, s: float) -> int:
+        k = int(np.searchsorted(self._ref_pos, s, side="right")) - 1
+        return min(max(k, 0), len(self._ref_pos) - 2)
+
+    def convert_to_cartesian_coords(self, s: float, d: float):
+        rp = self._ref_pos
+        if not (rp[0] <= s <= rp[-1]):
+            return None
+        k = self.segment_of(s)
+        lam = (s - rp[k]) / (rp[k + 1] - rp[k])
+        p = self._reference[k] + lam * (self._reference[k + 1] - self._reference[k])
+        n = self._normals[k] + lam * (self._normals[k + 1] - self._normals[k])
+        nn = math.sqrt(n[0] * n[0] + n[1] * n[1])
+        return np.array([p[0] + d * (n[0] / nn), p[1] + d * (n[1] / nn)])
+
+    def convert_to_curvilinear_coords(self, x: float, y: float) -> np.ndarray:
+        """Inverse of convert_to_cartesian_coords: the (s, d) with smallest |d| whose foot point and
+        interpolated normal pass through (x, y).  Raises ValueError outside the projection domain
+        (planner.py:574-578 expects that)."""
+        P, Nrm, rp = self._reference, self._normals, self._ref_pos
+        q = np.array([x, y], dtype=np.float64)
+        best = None
+        for k in range(len(P) - 1):
+            a = P[k] - q
+            b = P[k + 1] - P[k]
+            n0 = Nrm[k]
+            dn = Nrm[k + 1] - Nrm[k]
+            # cross(a + lam b, n0 + lam dn) = 0
+            c2 = b[0] * dn[1] - b[1] * dn[0]
+            c1 = a[0] * dn[1] - a[1] * dn[0] + b[0] * n0[1] - b[1] * n0[0]
+            c0 = a[0] * n0[1] - a[1] * n0[0]
+            if abs(c2) < 1e-14:
+                roots = [] if abs(c1) < 1e-300 else [-c0 / c1]
+            else:
+                disc = c1 * c1 - 4 * c2 * c0
+                if disc < 0:
+                    continue
+                sq = math.sqrt(disc)
+                roots = [(-c1 + sq) / (2 * c2), (-c1 - sq) / (2 * c2)]
+            for lam in roots:
+                if -1e-12 <= lam <= 1 + 1e-12:
+                    lam = min(max(lam, 0.0), 1.0)
+                    foot = P[k] + lam * b
+                    n = n0 + lam * dn
+                    n = n / math.sqrt(n[0] * n[0] + n[1] * n[1])
+                    d = float((q - foot) @ n)
+                    if best is None or abs(d) < abs(best[1]):
+                        best = (float(rp[k] + lam * (rp[k + 1] - rp[k])), d)
+        if best is None:
+            raise ValueError("<CoordinateSystem>: point outside projection domain")
+        return np.array(best)

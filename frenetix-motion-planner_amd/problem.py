@@ -1,0 +1,211 @@
+"""PlanInputs: the shared, candidate-independent inputs of one plan step, packed for the C-ABI.
+
+Everything `ReactivePlannerPython.plan()` reads from `self` (reactive_planner.py:67-130,
+planner.py:172-217) ends up here as plain numbers and C-contiguous f64 arrays; `as_struct()` yields the
+`FxProblem` of include/fxplan.h with pointers into arrays this object keeps alive.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _abi
+from .coordinate_system import CoordinateSystem, simpson_even_correction, time_power_table
+
+
+@dataclass
+class VehicleParams:
+    """The fields of config_sim.vehicle the hot path reads (configuration.py:58-83).  Defaults are the
+    commonroad-vehicle-models id 2 (BMW 320i) table quoted in SURVEY.md 8c -- plain inputs, override
+    them exactly like configurations/simulation/vehicle.yaml does."""
+    length: float = 4.508
+    width: float = 1.610
+    wheelbase: float = 2.5789
+    wb_rear_axle: float = 1.4227
+    a_max: float = 11.5
+    v_max: float = 50.8
+    v_switch: float = 7.319
+    delta_max: float = 1.066
+    v_delta_max: float = 0.4
+
+    @property
+    def kappa_max(self) -> float:
+        return float(np.tan(self.delta_max) / self.wheelbase)  # reactive_planner.py:492
+
+    def as_struct(self) -> _abi.FxVehicle:
+        return _abi.FxVehicle(self.a_max, self.v_switch, self.delta_max, self.wheelbase, self.length, self.width,
+                              self.wb_rear_axle, self.kappa_max)
+
+
+DEFAULT_COST_WEIGHTS = {  # configurations/frenetix_motion_planner/cost.yaml:3-17 (non-zero entries)
+    "lateral_jerk": 0.2, "longitudinal_jerk": 0.2, "velocity_offset": 1.0,
+    "distance_to_reference_path": 5.0, "prediction": 0.2,
+}
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _ptr(a, typ=C.c_double):
+    return a.ctypes.data_as(C.POINTER(typ)) if a is not None and a.size else C.POINTER(typ)()
+
+
+def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
+    """predictions dict {id: {'pos_list' [P,2], 'cov_list' [P,2,2], 'orientation_list' [P],
+    'shape': {'length','width'}}} (prediction_helpers.py:209-261) -> packed arrays.
+
+    Iteration order = dict order, as in get_inv_mahalanobis_dist (collision_probability.py:276-279).
+    cov is inverted with np.linalg.inv exactly like :281.  build_hulls(n, pos, yaw, L, W) returns the
+    OBB-sum hulls [n-1, 6] (fx_build_obstacle_hulls).  Collision uses the first min(S, P_k)
+    predictions (collision_check.py:150)."""
+    if not predictions:
+        z = np.zeros(0)
+        return dict(K=0, P=0, pos=z, cov_inv=z, npred=np.zeros(0, np.int32), hull=z, nhull=np.zeros(0, np.int32))
+    keys = list(predictions.keys())
+    K = len(keys)
+    P = max(2, max(len(predictions[k]["pos_list"]) for k in keys))
+    pos = np.zeros((K, P, 2))
+    cov_inv = np.zeros((K, P, 4))
+    npred = np.zeros(K, np.int32)
+    hull = np.zeros((K, P - 1, 6))
+    nhull = np.zeros(K, np.int32)
+    for i, k in enumerate(keys):
+        pr = predictions[k]
+        pl = np.asarray(pr["pos_list"], dtype=np.float64).reshape(-1, 2)
+        n = len(pl)
+        npred[i] = n
+        if n == 0:
+            continue
+        pos[i, :n] = pl
+        cov_inv[i, :n] = np.linalg.inv(np.asarray(pr["cov_list"], dtype=np.float64)).reshape(n, 4)
+        n_use = min(n_samples, n)
+        if build_hulls is not None and "orientation_list" in pr and "shape" in pr:
+            yaw = _f64(pr["orientation_list"])[:n_use]
+            h = build_hulls(n_use, _f64(pl[:n_use]), yaw, float(pr["shape"]["length"]), float(pr["shape"]["width"]))
+            nhull[i] = len(h)
+            hull[i, :len(h)] = h
+    return dict(K=K, P=P, pos=_f64(pos), cov_inv=_f64(cov_inv), npred=npred, hull=_f64(hull), nhull=nhull)
+
+
+@dataclass
+class PlanInputs:
+    # horizon / mode
+    N: int
+    dt: float
+    low_vel_mode: bool
+    x0_lon: np.ndarray
+    x0_lat: np.ndarray
+    x0_orientation: float
+    v_des: float
+    vehicle: VehicleParams
+    coordinate_system: CoordinateSystem
+    # sampling: ordered ranges or an explicit C x 13 matrix
+    t_samp: Optional[np.ndarray] = None
+    v_samp: Optional[np.ndarray] = None
+    d_samp: Optional[np.ndarray] = None
+    sampling_matrix: Optional[np.ndarray] = None
+    cost_weights: Dict[str, float] = field(default_factory=lambda: dict(DEFAULT_COST_WEIGHTS))
+    draw_traj_set: bool = False
+    kinematic_debug: bool = False
+    write_bundle: bool = True
+    write_costmap: bool = True
+    collision: bool = True
+    # packed predictions (pack_predictions) and distance_to_obstacles positions
+    obstacles: Optional[dict] = None
+    dto_pos: Optional[np.ndarray] = None
+
+    def __post_init__(self):
+        self.x0_lon = _f64(self.x0_lon)
+        self.x0_lat = _f64(self.x0_lat)
+        S = self.N + 1
+        self._tpow = _f64(time_power_table(self.dt, S))
+        cs = self.coordinate_system
+        self._ref = {k: _f64(v) for k, v in dict(
+            x=cs.reference[:, 0], y=cs.reference[:, 1], nx=cs.normals[:, 0], ny=cs.normals[:, 1], pos=cs.ref_pos,
+            theta=cs.ref_theta, curv=cs.ref_curv, curv_d=cs.ref_curv_d).items()}
+        if self.sampling_matrix is not None:
+            self.sampling_matrix = _f64(self.sampling_matrix)
+            if self.sampling_matrix.ndim != 2 or self.sampling_matrix.shape[1] != 13:
+                raise ValueError("sampling_matrix must be C x 13")
+        else:
+            if self.t_samp is None or self.v_samp is None or self.d_samp is None:
+                raise ValueError("either sampling_matrix or t_samp/v_samp/d_samp are required")
+            self.t_samp, self.v_samp, self.d_samp = _f64(self.t_samp), _f64(self.v_samp), _f64(self.d_samp)
+        bad = [n for n, w in self.cost_weights.items() if w != 0 and n not in _abi.COST_ID]
+        if bad:
+            raise NotImplementedError(f"cost terms outside the hot-path scope: {bad}")
+        names = sorted(n for n, w in self.cost_weights.items() if w != 0)  # cost_function.py:52-60
+        self.cost_names = names
+        self._cost_id = np.array([_abi.COST_ID[n] for n in names], dtype=np.int32)
+        self._cost_w = _f64([self.cost_weights[n] for n in names])
+        if self.obstacles is None:
+            self.obstacles = pack_predictions(None, S, None)
+        self._dto = _f64(self.dto_pos).reshape(-1, 2) if self.dto_pos is not None else np.zeros((0, 2))
+
+    @property
+    def n_samples(self) -> int:
+        return self.N + 1
+
+    @property
+    def n_candidates(self) -> int:
+        if self.sampling_matrix is not None:
+            return int(self.sampling_matrix.shape[0])
+        return int(len(self.t_samp) * len(self.v_samp) * len(self.d_samp))
+
+    @property
+    def mode(self) -> int:
+        m = 0
+        if self.draw_traj_set:
+            m |= _abi.FX_MODE_DRAW_TRAJ_SET
+        if self.kinematic_debug:
+            m |= _abi.FX_MODE_KINEMATIC_DEBUG
+        if self.write_bundle:
+            m |= _abi.FX_MODE_WRITE_BUNDLE
+        if self.write_costmap:
+            m |= _abi.FX_MODE_WRITE_COSTMAP
+        if self.collision and self.obstacles["K"] > 0:
+            m |= _abi.FX_MODE_COLLISION
+        return m
+
+    def candidate_params(self, g: int):
+        """(t0, t1, s0, ss0, sss0, ss1, sss1, d0, dd0, ddd0, d1, dd1, ddd1) of candidate g -- the
+        `sampling_parameters` attribute of frenetix.TrajectorySample (reactive_planner_cpp.py:456)."""
+        if self.sampling_matrix is not None:
+            return self.sampling_matrix[g].copy()
+        nD, nV = len(self.d_samp), len(self.v_samp)
+        i_d, i_v, i_t = g % nD, (g // nD) % nV, g // (nD * nV)
+        return np.array([0.0, self.t_samp[i_t], *self.x0_lon, self.v_samp[i_v], 0.0, *self.x0_lat,
+                         self.d_samp[i_d], 0.0, 0.0])
+
+    def as_struct(self) -> _abi.FxProblem:
+        p = _abi.FxProblem()
+        p.N, p.dt, p.mode, p.low_vel_mode = self.N, self.dt, self.mode, int(bool(self.low_vel_mode))
+        p.x0_lon = (C.c_double * 3)(*self.x0_lon)
+        p.x0_lat = (C.c_double * 3)(*self.x0_lat)
+        p.x0_orientation, p.v_des = float(self.x0_orientation), float(self.v_des)
+        p.veh = self.vehicle.as_struct()
+        p.tpow = _ptr(self._tpow)
+        if self.sampling_matrix is not None:
+            p.sampling_matrix, p.n_rows = _ptr(self.sampling_matrix), self.sampling_matrix.shape[0]
+            p.nT = p.nV = p.nD = 0
+        else:
+            p.nT, p.nV, p.nD = len(self.t_samp), len(self.v_samp), len(self.d_samp)
+            p.t_samp, p.v_samp, p.d_samp = _ptr(self.t_samp), _ptr(self.v_samp), _ptr(self.d_samp)
+            p.n_rows = 0
+        r = self._ref
+        p.M = len(r["pos"])
+        p.ref_x, p.ref_y, p.ref_nx, p.ref_ny = _ptr(r["x"]), _ptr(r["y"]), _ptr(r["nx"]), _ptr(r["ny"])
+        p.ref_pos, p.ref_theta, p.ref_curv, p.ref_curv_d = (_ptr(r["pos"]), _ptr(r["theta"]), _ptr(r["curv"]),
+                                                             _ptr(r["curv_d"]))
+        p.n_cost = len(self._cost_id)
+        p.cost_id, p.cost_w = _ptr(self._cost_id, C.c_int32), _ptr(self._cost_w)
+        p.simpson_corr = (C.c_double * 3)(*simpson_even_correction(self.dt))
+        o = self.obstacles
+        p.K, p.P = int(o["K"]), int(o["P"])
+        p.obs_pos, p.obs_cov_inv, p.obs_npred = _ptr(o["pos"]), _ptr(o["cov_inv"]), _ptr(o["npred"], C.c_int32)
+        p.obs_hull, p.obs_nhull = _ptr(o["hull"]), _ptr(o["nhull"], C.c_int32)
+        p.n_dto, p.dto_pos = len(self._dto), _ptr(self._dto)
+        return p

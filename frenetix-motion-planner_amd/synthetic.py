@@ -1,0 +1,118 @@
+"""Seeded synthetic inputs of the hot path (SURVEY.md 8d "Common synthetic inputs").
+
+Used by the parity tests, the golden-vector generator, __graft_entry__.smoke() and bench.py.
+There is no network and no CommonRoad stack on the GPU box, so reference paths, ego states and
+obstacle predictions are generated here; shapes and magnitudes follow the reference's defaults
+(configurations/frenetix_motion_planner/planning.yaml, cost.yaml; 5.0 x 2.0 m cars, cov 0.1*I as in
+prediction_helpers.py:245).
+"""
+import numpy as np
+
+from .coordinate_system import CoordinateSystem
+from .problem import DEFAULT_COST_WEIGHTS, PlanInputs, VehicleParams, pack_predictions
+from .sampling import SamplingHandler, v_sampling_bounds
+
+SEED = 20241008
+
+
+def reference_polyline(kind: str = "arc", n_knots: int = 400, spacing: float = 0.5, kappa: float = 0.01):
+    """straight | arc (constant curvature) | scurve (curvature sign change) polyline."""
+    s = np.arange(n_knots) * spacing
+    if kind == "straight":
+        return np.stack([s, np.zeros_like(s)], axis=1)
+    if kind == "arc":
+        r = 1.0 / kappa
+        return np.stack([r * np.sin(s * kappa), r * (1 - np.cos(s * kappa))], axis=1)
+    if kind == "scurve":
+        L = s[-1]
+        k = kappa * 2.0 * np.cos(2 * np.pi * s / L)  # curvature changes sign twice
+        th = np.concatenate([[0.0], np.cumsum(0.5 * (k[1:] + k[:-1]) * spacing)])
+        x = np.concatenate([[0.0], np.cumsum(np.cos(0.5 * (th[1:] + th[:-1])) * spacing)])
+        y = np.concatenate([[0.0], np.cumsum(np.sin(0.5 * (th[1:] + th[:-1])) * spacing)])
+        return np.stack([x, y], axis=1)
+    raise ValueError(kind)
+
+
+def dense_ranges(n_t: int, n_v: int, n_d: int, v0: float, veh: VehicleParams, horizon: float, dt: float, d0: float,
+                 t_min: float = 1.1, d_min: float = -3.0, d_max: float = 3.0):
+    """Dense grid in natural (ascending) order: T = t_min .. horizon-dt step dt (first n_t),
+    V = linspace(v-range, n_v), D = linspace(d_min, d_max, n_d) plus d0 appended if absent.
+    BASELINE config 2: n_t=19, n_v=51, n_d=51 -> 19 x 51 x 52 = 50 388 candidates."""
+    t = np.round(t_min + dt * np.arange(n_t), 2)
+    t = t[t <= horizon + 1e-9]
+    v_lo, v_hi = v_sampling_bounds(v0, veh.a_max, horizon, veh.v_max)
+    v = np.linspace(v_lo, v_hi, n_v)
+    d = np.linspace(d_min, d_max, n_d)
+    if d0 not in d:
+        d = np.append(d, d0)
+    return t, v, d
+
+
+def synthetic_predictions(cs: CoordinateSystem, n_obstacles: int, n_pred: int, dt: float, s_center: float,
+                          rng: np.random.Generator, corridor=(120.0, 12.0)):
+    """K obstacles, constant velocity along/against the reference tangent."""
+    preds = {}
+    for k in range(n_obstacles):
+        s0 = s_center + rng.uniform(-0.15, 0.85) * corridor[0]
+        d0 = rng.uniform(-0.5, 0.5) * corridor[1]
+        s0 = float(np.clip(s0, cs.ref_pos[2], cs.ref_pos[-3]))
+        seg = cs.segment_of(s0)
+        yaw_ref = float(cs.ref_theta[seg])
+        direction = 1.0 if rng.uniform() < 0.7 else -1.0
+        speed = rng.uniform(3.0, 12.0)
+        yaw = yaw_ref if direction > 0 else yaw_ref + np.pi
+        p0 = cs.convert_to_cartesian_coords(s0, d0)
+        steps = np.arange(1, n_pred + 1) * dt
+        pos = p0[None, :] + steps[:, None] * speed * np.array([np.cos(yaw), np.sin(yaw)])[None, :]
+        grow = (1.02 ** np.arange(n_pred))[:, None, None]
+        cov = np.tile(np.diag([0.1, 0.1])[None], (n_pred, 1, 1)) * grow
+        preds[100 + k] = dict(pos_list=pos, cov_list=cov, orientation_list=np.full(n_pred, yaw),
+                              v_list=np.full(n_pred, speed),
+                              shape=dict(length=float(rng.uniform(4.5, 5.5)), width=float(rng.uniform(1.8, 2.2))))
+    return preds
+
+
+def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0, a0=0.0, d0=0.2, dd0=0.0, ddd0=0.0,
+                s_knot=40, s_off=0.1, horizon=3.0, dt=0.1, level=None, grid=None, cpp_style=False, v_des=12.0,
+                n_obstacles=0, n_pred=30, cost_weights=None, draw_traj_set=False, kinematic_debug=False,
+                write_bundle=True, write_costmap=True, collision=True, low_vel_threshold=2.0, hull_builder=None,
+                seed=SEED, vehicle=None, x0_orientation=None, as_matrix=False):
+    """One agent's PlanInputs on a synthetic reference.
+
+    level: reference sampling level (set-ordered ranges, SamplingHandler) -- or
+    grid=(n_t, n_v, n_d): dense grid (BASELINE configs 2/3/5)."""
+    veh = vehicle or VehicleParams()
+    cs = CoordinateSystem(reference_polyline(ref_kind, n_knots, spacing, kappa))
+    N = int(horizon / dt)
+    s0 = float(cs.ref_pos[s_knot] + s_off)
+    low_vel = v0 < low_vel_threshold
+    if grid is not None:
+        t, v, d = dense_ranges(grid[0], grid[1], grid[2], v0, veh, horizon, dt, d0)
+    else:
+        sh = SamplingHandler(dt=dt, max_sampling_number=max((level or 2) + 1, 3), t_min=1.1, horizon=horizon,
+                             delta_d_min=-3.0, delta_d_max=3.0, d_ego_pos=False)
+        sh.set_v_sampling(*v_sampling_bounds(v0, veh.a_max, horizon, veh.v_max))
+        t, v, d = sh.ordered_ranges(level if level is not None else 2, d0, cpp_style=cpp_style, ss0=v0, t_full=N * dt)
+    seg = cs.segment_of(s0)
+    if x0_orientation is None:
+        x0_orientation = float(cs.ref_theta[seg])
+    rng = np.random.default_rng(seed)
+    preds = synthetic_predictions(cs, n_obstacles, n_pred, dt, s0, rng) if n_obstacles else None
+    weights = dict(cost_weights if cost_weights is not None else DEFAULT_COST_WEIGHTS)
+    if not preds:
+        weights.pop("prediction", None) if cost_weights is None else None
+    obstacles = pack_predictions(preds, N + 1, hull_builder)
+    kw = dict(N=N, dt=dt, low_vel_mode=low_vel, x0_lon=[s0, v0, a0], x0_lat=[d0, dd0, ddd0],
+              x0_orientation=x0_orientation, v_des=v_des, vehicle=veh, coordinate_system=cs, cost_weights=weights,
+              draw_traj_set=draw_traj_set, kinematic_debug=kinematic_debug, write_bundle=write_bundle,
+              write_costmap=write_costmap, collision=collision, obstacles=obstacles)
+    if as_matrix:
+        from .sampling import generate_sampling_matrix
+        m = generate_sampling_matrix(t0_range=0.0, t1_range=t, s0_range=s0, ss0_range=v0, sss0_range=a0, ss1_range=v,
+                                     sss1_range=0.0, d0_range=d0, dd0_range=dd0, ddd0_range=ddd0, d1_range=d,
+                                     dd1_range=0.0, ddd1_range=0.0)
+        inp = PlanInputs(sampling_matrix=m, **kw)
+    else:
+        inp = PlanInputs(t_samp=t, v_samp=v, d_samp=d, **kw)
+    inp.predictions = preds
+    return inp

@@ -1,0 +1,217 @@
+/*
+ * fxplan.h -- C-ABI of libfxplan.so, the MI355X (gfx950) Frenet sampling-and-evaluation engine.
+ *
+ * The reference (TUM-AVS/Frenetix-Motion-Planner @ 2024_10_08) has no C-ABI: its hot path is
+ * reached through the pybind11 module `frenetix` (C++ wheel, not in tree) that
+ * frenetix_motion_planner/reactive_planner_cpp.py drives, or through the pure-Python
+ * frenetix_motion_planner/reactive_planner.py.  This header is the boundary a maintainer binds
+ * instead (ctypes stub: INTEGRATION.md).  Every entry point cites the reference interface it
+ * replaces.  Plain pointers and sizes only; all floating point is IEEE binary64.
+ *
+ * Semantics follow the reference *Python* path (reactive_planner.py:132-577,
+ * trajectories.py:524-561, cost_function.py:78-91, planner.py:329-392); the `frenetix` handler is
+ * only the calling convention.  See DESIGN.md for the normative definitions of the two pieces
+ * of third-party arithmetic that are not in the reference tree (curvilinear->Cartesian projection
+ * and the OBB-sum collision test).
+ */
+#ifndef FXPLAN_H
+#define FXPLAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FX_ABI_VERSION 1
+
+/* ---- status codes (planner.py / reactive_planner_cpp.py raise Python exceptions; the shim maps
+ *      <0 -> ValueError, >0 -> RuntimeError, see SURVEY 8b "Error conventions") ---- */
+#define FX_OK 0
+#define FX_ERR_INVALID_ARGUMENT (-1)
+#define FX_ERR_NOT_READY (-2)     /* reference / vehicle / sampling not set before a plan step */
+#define FX_ERR_CAPACITY (-3)      /* problem larger than the context was created for */
+#define FX_ERR_HIP 1              /* a HIP runtime call failed; text in fx_last_error() */
+#define FX_ERR_NO_DEVICE 2
+
+/* ---- trajectory planes of the structure-of-arrays TrajectoryBundle.
+ *      trajectories.py:56-197 (CartesianSample) and :200-334 (CurviLinearSample).
+ *      Device layout: plane[p][step][ld] (ld = candidate count rounded up to 64), f64. ---- */
+enum {
+    FX_PL_X = 0, FX_PL_Y, FX_PL_THETA, FX_PL_V, FX_PL_A, FX_PL_KAPPA, FX_PL_KAPPA_DOT,
+    FX_PL_S, FX_PL_D, FX_PL_THETA_CL, FX_PL_S_DOT, FX_PL_S_DDOT, FX_PL_D_DOT, FX_PL_D_DDOT,
+    FX_NUM_PLANES
+};
+
+/* ---- partial cost functions (partial_cost_functions.py).  Ids are in alphabetical order of the
+ *      reference names because cost_function.py:55-60 sorts the active names; callers list the
+ *      active ids ascending. ---- */
+enum {
+    FX_COST_ACCELERATION = 0,            /* :24-33  */
+    FX_COST_DISTANCE_TO_OBSTACLES,       /* :172-186 */
+    FX_COST_DISTANCE_TO_REFERENCE_PATH,  /* :154-169 */
+    FX_COST_JERK,                        /* :36-46  */
+    FX_COST_LATERAL_JERK,                /* :49-55  */
+    FX_COST_LONGITUDINAL_JERK,           /* :58-64  */
+    FX_COST_ORIENTATION_OFFSET,          /* :141-151 */
+    FX_COST_PATH_LENGTH,                 /* :189-196 */
+    FX_COST_PREDICTION,                  /* :341-356 + collision_probability.py:264-299 */
+    FX_COST_VELOCITY_OFFSET,             /* :120-130 */
+    FX_NUM_COSTS
+};
+
+/* ---- per-candidate flag word ---- */
+#define FX_FLAG_VALID      (1u << 0)  /* reactive_planner.py:293,350-351,544 */
+#define FX_FLAG_FEASIBLE   (1u << 1)  /* :292 and the five constraints :480-533 */
+#define FX_FLAG_COLLISION  (1u << 2)  /* planner.py:348-357 (dynamic-obstacle prediction check) */
+#define FX_FLAG_RETURNED   (1u << 3)  /* member of check_feasibility's return list (:353,379,385,567) */
+#define FX_FLAG_COSTED     (1u << 4)  /* cost evaluated (:244-253: all returned in debug, feasible otherwise) */
+#define FX_FLAG_SELECTABLE (1u << 5)  /* walked by trajectory_collision_check (:248,251,258) */
+#define FX_REASON_SHIFT 8             /* bits 8..18: reasons 0..10 flagged as in :352,378,384,418,485-531,545 */
+#define FX_REASON_MASK  (0x7FFu << FX_REASON_SHIFT)
+#define FX_NUM_REASONS 11
+
+/* evaluation mode bits (configurations/frenetix_motion_planner/debug.yaml) */
+#define FX_MODE_DRAW_TRAJ_SET   (1u << 0)  /* debug.draw_traj_set : evaluate everything, no pre-filter */
+#define FX_MODE_KINEMATIC_DEBUG (1u << 1)  /* debug.kinematic_debug: keep checking after first violation */
+#define FX_MODE_WRITE_BUNDLE    (1u << 2)  /* materialise the 14-plane SoA TrajectoryBundle in HBM */
+#define FX_MODE_WRITE_COSTMAP   (1u << 3)  /* keep the per-name raw costs (TrajectorySample.costMap) */
+#define FX_MODE_COLLISION       (1u << 4)  /* run the OBB collision stage (planner.use_prediction) */
+
+/* vehicle parameters: configuration.py:58-83 (VehicleConfiguration); kappa_max is
+ * tan(delta_max)/wheelbase as computed at reactive_planner.py:492 (host computes it once). */
+typedef struct FxVehicle {
+    double a_max, v_switch, delta_max, wheelbase, length, width, wb_rear_axle, kappa_max;
+} FxVehicle;
+
+/* Everything a plan step needs that is shared by all candidates of one agent.
+ * reactive_planner.py:67-130 (plan), planner.py:172-217 (update_externals). */
+typedef struct FxProblem {
+    /* horizon: planner.py:63-65 */
+    int32_t N;              /* steps; every trajectory has S = N+1 samples */
+    double dt;
+    uint32_t mode;          /* FX_MODE_* */
+    int32_t low_vel_mode;   /* planner.py:222-230 */
+    double x0_lon[3];       /* x_cl[0] = [s, s_dot, s_ddot]   planner.py:567-635 */
+    double x0_lat[3];       /* x_cl[1] = [d, d_dot, d_ddot] */
+    double x0_orientation;  /* x_0.orientation, used at reactive_planner.py:447 */
+    double v_des;           /* desired_velocity (cost_function.py:70) */
+    FxVehicle veh;
+
+    /* time grid: t[i]=round(arange(0,..,dt),5) and its powers rounded to 10 dp
+     * (reactive_planner.py:296-300).  tpow[k*S + i] = t_i^(k+1), k = 0..4, i = 0..S-1.
+     * Host-computed with the reference's own expressions so the device never calls pow(). */
+    const double *tpow;
+
+    /* sampling: ordered ranges in *iteration order* (sampling_matrix.py:141-195; CPython set
+     * order, reactive_planner.py:149-158).  Candidate g = (it*nV + iv)*nD + id. */
+    int32_t nT, nV, nD;
+    const double *t_samp, *v_samp, *d_samp;
+    /* ...or an explicit C x 13 matrix (sampling_matrix.py:85-121, reactive_planner_cpp.py:228-253)
+     * when sampling_matrix != NULL; then nT/nV/nD are ignored and C = n_rows. */
+    const double *sampling_matrix;
+    int64_t n_rows;
+
+    /* reference path: utils_coordinate_system.py:189-207 (ref_pos/ref_theta/ref_curv/ref_curv_d),
+     * plus vertices and vertex normals for the projection (DESIGN.md "projection"). */
+    int32_t M;
+    const double *ref_x, *ref_y, *ref_nx, *ref_ny, *ref_pos, *ref_theta, *ref_curv, *ref_curv_d;
+
+    /* cost function: cost_function.py:40-64.  ids ascending (== name-sorted). */
+    int32_t n_cost;
+    const int32_t *cost_id;
+    const double *cost_w;
+    double simpson_corr[3]; /* alpha, beta, eta of scipy.integrate.simpson's even-N correction for h=[dt,dt] */
+
+    /* predictions (prediction_helpers.py:209-261 dict -> packed): K obstacles, P steps each.
+     * obs_pos[K][P][2], obs_cov_inv[K][P][4] (np.linalg.inv(cov_list), row-major 2x2),
+     * obs_npred[K] = len(pos_list) (<= P).  collision_probability.py:264-299. */
+    int32_t K, P;
+    const double *obs_pos, *obs_cov_inv;
+    const int32_t *obs_npred;
+    /* collision stage: OBB hulls of consecutive predicted boxes, obs_hull[K][P-1][6] =
+     * (cx, cy, ex, ey, h1, h2) with unit axis e and half extents h; obs_nhull[K] = number of hulls
+     * (0 when the obstacle is skipped, collision_check.py:165-168).  Built by fx_build_obstacle_hulls. */
+    const double *obs_hull;
+    const int32_t *obs_nhull;
+    /* distance_to_obstacles cost: obstacle positions at the current step, dto_pos[n_dto][2]
+     * (partial_cost_functions.py:179-184). */
+    int32_t n_dto;
+    const double *dto_pos;
+} FxProblem;
+
+/* Result of one plan step (what _get_optimal_trajectory returns plus the counters it sets,
+ * reactive_planner.py:184-272; planner.py:329-392). */
+typedef struct FxResult {
+    int64_t n_candidates;
+    int64_t best_index;        /* uniqueId of the selected trajectory, -1 if none */
+    double best_cost;
+    int64_t n_returned;        /* len(trajectories_all) */
+    int64_t n_feasible;        /* len(feasible_trajectories) (valid and feasible) */
+    int64_t n_infeasible;      /* _infeasible_count_kinematics[0] */
+    int64_t n_collisions;      /* _collision_counter: colliding candidates walked before the winner */
+    int64_t reason_hist[FX_NUM_REASONS]; /* infeasible_invalid_count_kinematics (queue_2 payload) */
+    double feasible_percentage;/* infeasible_kinematics_percentage (is the feasible %, :235) */
+    double kernel_ms;          /* HIP-event time of the device work of this step */
+} FxResult;
+
+typedef struct FxContext FxContext;
+
+/* ---- library ---- */
+int32_t fx_abi_version(void);
+const char *fx_last_error(void);          /* thread-local text of the last failure */
+int32_t fx_device_count(int32_t *count);  /* no context needed */
+
+/* ---- context: owns device buffers sized for up to max_candidates x (max_steps+1); one per
+ *      planner instance (frenetix.TrajectoryHandler(dt=) at reactive_planner_cpp.py:49).
+ *      stream: a hipStream_t as void* (0 -> the context creates its own). ---- */
+int32_t fx_create(FxContext **out, int32_t device, int64_t max_candidates, int32_t max_steps,
+                  int32_t max_ref_knots, int32_t max_obstacles, int32_t max_pred_steps);
+int32_t fx_destroy(FxContext *ctx);
+int32_t fx_set_stream(FxContext *ctx, void *hip_stream);
+
+/* ---- staging: copy the shared inputs of a plan step to the device (borrowed for the call).
+ *      Replaces handler.generate_trajectories(matrix, low_vel_mode) + the functor registration
+ *      at reactive_planner_cpp.py:96-178,256. ---- */
+int32_t fx_upload(FxContext *ctx, const FxProblem *prob);
+
+/* ---- evaluation: fused sample -> solve -> evaluate -> Frenet->Cartesian -> feasibility -> cost
+ *      -> collision launch plus the (cost, index) selection.  Replaces
+ *      handler.evaluate_all_current_functions(True) (:347-349) and, in the Python path,
+ *      check_feasibility + TrajectoryBundle.sort + trajectory_collision_check.
+ *      fx_evaluate only enqueues on the context stream; fx_finish synchronises and fills *res. ---- */
+int32_t fx_evaluate(FxContext *ctx);
+int32_t fx_finish(FxContext *ctx, FxResult *res);
+/* convenience: upload + evaluate + finish */
+int32_t fx_plan_step(FxContext *ctx, const FxProblem *prob, FxResult *res);
+
+/* ---- read-back (TrajectorySample views are materialised lazily from the SoA bundle;
+ *      reactive_planner_cpp.py:353 get_sorted_trajectories, trajectories.py:337-477) ---- */
+int32_t fx_read_costs(FxContext *ctx, double *cost /*[C]*/, uint32_t *flags /*[C]*/);
+int32_t fx_read_costmap(FxContext *ctx, double *raw /*[n_cost][C]*/);
+int32_t fx_read_coeffs(FxContext *ctx, int64_t index, double *lon6, double *lat6, int32_t *traj_len);
+int32_t fx_read_sample(FxContext *ctx, int64_t index, double *planes /*[FX_NUM_PLANES][S]*/);
+int32_t fx_read_plane(FxContext *ctx, int32_t plane, double *out /*[S][C]*/);
+/* k best selectable, collision-free candidates in (cost, index) order; returns count in *n_out.
+ * Used for the host-side road-boundary walk (planner.py:362-390) and the multi-GPU exchange. */
+int32_t fx_read_topk(FxContext *ctx, int32_t k, double *cost, int64_t *index, int32_t *n_out);
+/* same, but left in device memory (caller-provided device pointers, e.g. torch tensors) so the
+ * survivors can go straight into an RCCL all-gather; enqueued on the context stream. */
+int32_t fx_topk_to_device(FxContext *ctx, int32_t k, void *d_cost /*f64[k]*/, void *d_index /*i64[k]*/);
+
+/* ---- host-side helpers (pure CPU, no context) ---- */
+/* OBB hulls of consecutive predicted boxes (collision_check.py:170-186 create_tvobstacle +
+ * trajectory_preprocess_obb_sum; normative definition in DESIGN.md). pos[P][2], yaw[P]. */
+int32_t fx_build_obstacle_hulls(int32_t n_pred, const double *pos, const double *yaw,
+                                double length, double width, double *hull /*[n_pred-1][6]*/,
+                                int32_t *n_hull);
+
+/* ---- measurement hooks (bench.py): device bytes owned, last kernel time ---- */
+int64_t fx_device_bytes(const FxContext *ctx);
+double fx_last_kernel_ms(const FxContext *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FXPLAN_H */

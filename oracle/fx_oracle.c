@@ -1,0 +1,673 @@
+/*
+ * fx_oracle.c -- CPU restatement of the reference's Frenet sampling-and-evaluation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (frenetix-motion-planner_amd/, libfxplan.so)
+ * may import, link or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, as the checker / reported baseline.
+ *
+ * What it restates (TUM-AVS/Frenetix-Motion-Planner @ 2024_10_08, Python back-end, multiproc=False):
+ *   frenetix_motion_planner/reactive_planner.py:132-182   _create_trajectory_bundle
+ *   frenetix_motion_planner/reactive_planner.py:274-577   check_feasibility
+ *   frenetix_motion_planner/reactive_planner.py:184-272   _get_optimal_trajectory (counters, pool)
+ *   frenetix_motion_planner/polynomial_trajectory.py:172-272,293-343,452-488
+ *   frenetix_motion_planner/cost_functions/cost_function.py:78-91
+ *   frenetix_motion_planner/cost_functions/partial_cost_functions.py:24-64,120-196,341-356
+ *   risk_assessment/collision_probability.py:264-299      get_inv_mahalanobis_dist
+ *   frenetix_motion_planner/trajectories.py:524-561       stable sort by cost
+ *   frenetix_motion_planner/planner.py:329-392            trajectory_collision_check (walk order)
+ *   cr_scenario_handler/utils/utils_coordinate_system.py:137-155 interpolate_angle
+ *
+ * Parity pin: tests/test_oracle_golden.py checks this file against tests/golden/ (.npz vectors
+ * produced by importing the reference's own Python modules (tests/golden/gen_golden.py).
+ * Two pieces are NOT in the reference tree (commonroad-drivability-checker 2024.1, C++):
+ * (s,d)->(x,y) projection and the OBB-sum collision test.  For those "parity unpinned": this file
+ * is the normative definition, the golden (x,y) come from an independent numpy
+ * restatement of the same definition inside gen_golden.py.
+ *
+ * Arithmetic order mirrors the NumPy expressions term by term (compile with -ffp-contract=off);
+ * np.sum is reproduced as NumPy's 8-accumulator pairwise summation.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/fxplan.h"
+
+#define EPS 1e-5 /* reactive_planner.py:26 */
+#define TWO_PI 6.283185307179586
+
+/* ---------------------------------------------------------------- numpy helpers */
+
+/* numpy/core/src/umath/loops_utils.h.src DOUBLE_pairwise_sum; np.sum(a) == 0.0 + this */
+static double np_pairwise(const double *a, int n) {
+    if (n < 8) {
+        double res = -0.0;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        int i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+    }
+}
+static double np_sum(const double *a, int n) { return 0.0 + np_pairwise(a, n); }
+
+/* np.round(x, 5) == rint(x*1e5)/1e5 */
+static double np_round5(double x) { return rint(x * 1e5) / 1e5; }
+
+/* commonroad.common.util.make_valid_orientation (commonroad-io 2024.2, not in tree; restated:
+ * brings an angle into [-2pi, 2pi] by +-2pi steps) -- used by interpolate_angle */
+static double make_valid_orientation(double a) {
+    while (a > TWO_PI) a -= TWO_PI;
+    while (a < -TWO_PI) a += TWO_PI;
+    return a;
+}
+
+/* utils_coordinate_system.py:137-155 */
+static double interpolate_angle(double x, double x1, double x2, double y1, double y2) {
+    double delta = y2 - y1;
+    return make_valid_orientation(delta * (x - x1) / (x2 - x1) + y1);
+}
+
+/* scipy.integrate.simpson(y, dx=dx) (scipy 1.13.1 'simpson' rule == 1.15 default) */
+static double simpson(const double *y, int n, double dx, const double corr[3]) {
+    double tmp[256];
+    if (n % 2 == 1) { /* _basic_simpson(y, 0, n-2) */
+        int m = 0;
+        for (int j = 0; j < n - 2; j += 2) tmp[m++] = (y[j] + 4.0 * y[j + 1]) + y[j + 2];
+        double r = np_sum(tmp, m);
+        r *= dx / 3.0;
+        return r;
+    }
+    if (n == 2) return 0.0 + 0.5 * dx * (y[1] + y[0]);
+    int m = 0;
+    for (int j = 0; j < n - 3; j += 2) tmp[m++] = (y[j] + 4.0 * y[j + 1]) + y[j + 2];
+    double r = np_sum(tmp, m);
+    r *= dx / 3.0;
+    r += (corr[0] * y[n - 1] + corr[1] * y[n - 2]) - corr[2] * y[n - 3];
+    r += 0.0;
+    return r;
+}
+
+/* ---------------------------------------------------------------- polynomials */
+
+/* polynomial_trajectory.py:452-488: [[3T^2,4T^3],[6T,12T^2]] [a3,a4] = [v1-v0-a0 T, a1-a0];
+ * the reference calls LAPACK gesv, this is the closed form of the same 2x2 system
+ * (agreement with np.linalg.solve is pinned by golden G2 at 1e-10 relative). */
+static void quartic_coeffs(double xs, double vxs, double axs, double T, double vxe, double axe, double *c) {
+    double b1 = vxe - vxs - axs * T;
+    double b2 = axe - axs;
+    double T2 = T * T;
+    c[0] = xs;
+    c[1] = vxs;
+    c[2] = .5 * axs;
+    c[3] = (3.0 * b1 - T * b2) / (3.0 * T2);
+    c[4] = (T * b2 - 2.0 * b1) / (4.0 * T2 * T);
+    c[5] = 0.0;
+}
+
+/* polynomial_trajectory.py:293-343 closed form of the 3x3 system */
+static void quintic_coeffs(double xs, double vxs, double axs, double xe, double vxe, double axe, double T, double *c) {
+    double T2 = T * T, T3 = T2 * T, T4 = T3 * T, T5 = T4 * T;
+    double b0 = xe - xs - vxs * T - .5 * axs * T2;
+    double b1 = vxe - vxs - axs * T;
+    double b2 = axe - axs;
+    c[0] = xs;
+    c[1] = vxs;
+    c[2] = .5 * axs;
+    c[3] = (10.0 * b0 - 4.0 * b1 * T + .5 * b2 * T2) / T3;
+    c[4] = (-15.0 * b0 + 7.0 * b1 * T - b2 * T2) / T4;
+    c[5] = (6.0 * b0 - 3.0 * b1 * T + .5 * b2 * T2) / T5;
+}
+
+/* polynomial_trajectory.py:259-272, :253-257, :241-251 -- monomial basis, left to right */
+static double poly_pos(const double *c, double t, double t2, double t3, double t4, double t5) {
+    return c[0] + c[1] * t + c[2] * t2 + c[3] * t3 + c[4] * t4 + c[5] * t5;
+}
+static double poly_vel(const double *c, double t, double t2, double t3, double t4) {
+    return c[1] + 2. * c[2] * t + 3. * c[3] * t2 + 4. * c[4] * t3 + 5. * c[5] * t4;
+}
+static double poly_acc(const double *c, double t, double t2, double t3) {
+    return 2 * c[2] + 6 * c[3] * t + 12 * c[4] * t2 + 20 * c[5] * t3;
+}
+/* polynomial_trajectory.py:172-191 */
+static double sq_jerk_integral(const double *c, double t) {
+    double t2 = t * t, t3 = t2 * t, t4 = t3 * t, t5 = t4 * t;
+    return (36 * c[3] * c[3] * t + 144 * c[3] * c[4] * t2 + 240 * c[3] * c[5] * t3 + 192 * c[4] * c[4] * t3 +
+            720 * c[4] * c[5] * t4 + 720 * c[5] * c[5] * t5);
+}
+
+/* ---------------------------------------------------------------- projection (normative) */
+
+/* first index with ref_pos > s, 0 if none: np.argmax(ref_pos > s)  (reactive_planner.py:415) */
+static int argmax_gt(const double *ref_pos, int M, double s) {
+    int lo = 0, hi = M; /* upper_bound */
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (ref_pos[mid] > s) hi = mid; else lo = mid + 1;
+    }
+    return lo == M ? 0 : lo;
+}
+
+/* (s,d) -> (x,y): foot point on segment k at s, offset d along the normalised interpolated vertex
+ * normal.  Returns 0 outside the projection domain [ref_pos[0], ref_pos[M-1]]. */
+static int project(const FxProblem *p, double s, double d, double *x, double *y) {
+    int M = p->M;
+    if (!(s >= p->ref_pos[0] && s <= p->ref_pos[M - 1])) return 0;
+    int lo = 0, hi = M;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (p->ref_pos[mid] > s) hi = mid; else lo = mid + 1;
+    }
+    int k = lo - 1;
+    if (k < 0) k = 0;
+    if (k > M - 2) k = M - 2;
+    double lam = (s - p->ref_pos[k]) / (p->ref_pos[k + 1] - p->ref_pos[k]);
+    double px = p->ref_x[k] + lam * (p->ref_x[k + 1] - p->ref_x[k]);
+    double py = p->ref_y[k] + lam * (p->ref_y[k + 1] - p->ref_y[k]);
+    double nx = p->ref_nx[k] + lam * (p->ref_nx[k + 1] - p->ref_nx[k]);
+    double ny = p->ref_ny[k] + lam * (p->ref_ny[k + 1] - p->ref_ny[k]);
+    double nn = sqrt(nx * nx + ny * ny);
+    *x = px + d * (nx / nn);
+    *y = py + d * (ny / nn);
+    return 1;
+}
+
+/* ---------------------------------------------------------------- OBB hull + SAT (normative) */
+
+/* hull of two boxes (centre c, unit heading u, half extents hl, hw): heading = normalised sum of
+ * the headings, extents = tight range of both boxes on the hull axes.  out = cx,cy,ex,ey,h1,h2 */
+static void obb_hull(double c0x, double c0y, double u0x, double u0y, double c1x, double c1y, double u1x, double u1y,
+                     double hl, double hw, double *out) {
+    double mx = u0x + u1x, my = u0y + u1y;
+    double mn = sqrt(mx * mx + my * my);
+    double ex, ey;
+    if (mn < 1e-12) { ex = u0x; ey = u0y; } else { ex = mx / mn; ey = my / mn; }
+    double fx = -ey, fy = ex;
+    double lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;
+    for (int b = 0; b < 2; b++) {
+        double cx = b ? c1x : c0x, cy = b ? c1y : c0y, ux = b ? u1x : u0x, uy = b ? u1y : u0y;
+        double vx = -uy, vy = ux;
+        double p1 = cx * ex + cy * ey, p2 = cx * fx + cy * fy;
+        double r1 = hl * fabs(ux * ex + uy * ey) + hw * fabs(vx * ex + vy * ey);
+        double r2 = hl * fabs(ux * fx + uy * fy) + hw * fabs(vx * fx + vy * fy);
+        if (b == 0) { lo1 = p1 - r1; hi1 = p1 + r1; lo2 = p2 - r2; hi2 = p2 + r2; }
+        else {
+            lo1 = fmin(lo1, p1 - r1); hi1 = fmax(hi1, p1 + r1);
+            lo2 = fmin(lo2, p2 - r2); hi2 = fmax(hi2, p2 + r2);
+        }
+    }
+    double m1 = 0.5 * (lo1 + hi1), m2 = 0.5 * (lo2 + hi2);
+    out[0] = m1 * ex + m2 * fx;
+    out[1] = m1 * ey + m2 * fy;
+    out[2] = ex;
+    out[3] = ey;
+    out[4] = 0.5 * (hi1 - lo1);
+    out[5] = 0.5 * (hi2 - lo2);
+}
+
+/* separating-axis test of two OBBs a,b = (cx,cy,ex,ey,h1,h2); touching counts as collision */
+static int obb_overlap_m(const double *a, const double *b, double *margin) {
+    double tx = b[0] - a[0], ty = b[1] - a[1];
+    double c = a[2] * b[2] + a[3] * b[3];  /* e_a . e_b */
+    double s = a[2] * b[3] - a[3] * b[2];  /* e_a x e_b */
+    double ac = fabs(c), as = fabs(s);
+    double g0 = fabs(tx * a[2] + ty * a[3]) - (a[4] + (b[4] * ac + b[5] * as));
+    double g1 = fabs(-tx * a[3] + ty * a[2]) - (a[5] + (b[4] * as + b[5] * ac));
+    double g2 = fabs(tx * b[2] + ty * b[3]) - (b[4] + (a[4] * ac + a[5] * as));
+    double g3 = fabs(-tx * b[3] + ty * b[2]) - (b[5] + (a[4] * as + a[5] * ac));
+    if (margin) {
+        /* the decision is max(g) > 0 <=> separated; it is fragile when that maximum is near zero */
+        double gm = fmax(fmax(g0, g1), fmax(g2, g3));
+        if (fabs(gm) < *margin) *margin = fabs(gm);
+    }
+    return !(g0 > 0 || g1 > 0 || g2 > 0 || g3 > 0);
+}
+static int obb_overlap(const double *a, const double *b) { return obb_overlap_m(a, b, NULL); }
+
+int32_t fxo_build_obstacle_hulls(int32_t n_pred, const double *pos, const double *yaw, double length, double width,
+                                 double *hull, int32_t *n_hull) {
+    /* collision_check.py:165-168: obstacles with <= 2 predicted steps are skipped */
+    if (n_pred <= 2) { *n_hull = 0; return 0; }
+    for (int j = 0; j + 1 < n_pred; j++)
+        obb_hull(pos[2 * j], pos[2 * j + 1], cos(yaw[j]), sin(yaw[j]), pos[2 * j + 2], pos[2 * j + 3], cos(yaw[j + 1]),
+                 sin(yaw[j + 1]), length / 2, width / 2, hull + 6 * j);
+    *n_hull = n_pred - 1;
+    return 0;
+}
+
+/* planner.py:342-357 + collision_check.py:110-200: ego boxes (centre = rear axle + wb_rear_axle along
+ * heading, half extents length/2 x width/2) at time t0+i, OBB-sum hull of steps (i,i+1) at time t0+i;
+ * obstacle hull j covers predictions (j,j+1) at time t0+1+j.  Equal time index <=> j = i-1. */
+static int ego_collides(const FxProblem *p, const double *x, const double *y, const double *th, double *margin) {
+    int S = p->N + 1;
+    double hull[6];
+    for (int i = 1; i + 1 < S; i++) {
+        int any = 0;
+        for (int k = 0; k < p->K; k++) if (i - 1 < p->obs_nhull[k]) { any = 1; break; }
+        if (!any) continue;
+        double c0 = cos(th[i]), s0 = sin(th[i]), c1 = cos(th[i + 1]), s1 = sin(th[i + 1]);
+        double wb = p->veh.wb_rear_axle;
+        obb_hull(x[i] + wb * c0, y[i] + wb * s0, c0, s0, x[i + 1] + wb * c1, y[i + 1] + wb * s1, c1, s1,
+                 p->veh.length / 2, p->veh.width / 2, hull);
+        for (int k = 0; k < p->K; k++) {
+            if (i - 1 >= p->obs_nhull[k]) continue;
+            const double *oh = p->obs_hull + ((size_t)k * (p->P - 1) + (i - 1)) * 6;
+            if (obb_overlap_m(hull, oh, margin)) return 1;
+        }
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- one candidate */
+
+typedef struct {
+    double T, tau_lat;
+    double cl[6], ct[6]; /* longitudinal / lateral coefficients */
+    int traj_len;
+} Cand;
+
+static void candidate_params(const FxProblem *p, int64_t g, double *T, double *lon0, double *v1, double *a1,
+                             double *lat0, double *lat1) {
+    if (p->sampling_matrix) {
+        const double *r = p->sampling_matrix + 13 * g; /* sampling_matrix.py:91-104 column order */
+        *T = r[1] - r[0];
+        lon0[0] = r[2]; lon0[1] = r[3]; lon0[2] = r[4];
+        *v1 = r[5]; *a1 = r[6];
+        lat0[0] = r[7]; lat0[1] = r[8]; lat0[2] = r[9];
+        lat1[0] = r[10]; lat1[1] = r[11]; lat1[2] = r[12];
+    } else {
+        int64_t id = g % p->nD, iv = (g / p->nD) % p->nV, it = g / ((int64_t)p->nD * p->nV);
+        *T = p->t_samp[it];
+        memcpy(lon0, p->x0_lon, 3 * sizeof(double));
+        *v1 = p->v_samp[iv]; *a1 = 0.0;
+        memcpy(lat0, p->x0_lat, 3 * sizeof(double));
+        lat1[0] = p->d_samp[id]; lat1[1] = 0.0; lat1[2] = 0.0;
+    }
+}
+
+/* evaluates candidate g; pl = 14 x S planes (zero-initialised by the caller) */
+#define MARGIN(expr) do { double m_ = fabs(expr); if (m_ < mg) mg = m_; } while (0)
+static uint32_t eval_candidate(const FxProblem *p, int64_t g, Cand *cd, double *pl, double *cost_raw, double *cost_total,
+                               double *margin_out) {
+    double mg = 1e300; /* smallest distance of any discrete decision from its threshold (test bookkeeping) */
+    const int S = p->N + 1;
+    const int D = (p->mode & FX_MODE_DRAW_TRAJ_SET) != 0, KD = (p->mode & FX_MODE_KINEMATIC_DEBUG) != 0;
+    double *x = pl + FX_PL_X * S, *y = pl + FX_PL_Y * S, *theta_gl = pl + FX_PL_THETA * S, *v = pl + FX_PL_V * S;
+    double *a = pl + FX_PL_A * S, *kappa_gl = pl + FX_PL_KAPPA * S, *kappa_dot = pl + FX_PL_KAPPA_DOT * S;
+    double *s = pl + FX_PL_S * S, *d = pl + FX_PL_D * S, *theta_cl = pl + FX_PL_THETA_CL * S;
+    double *sv = pl + FX_PL_S_DOT * S, *sa = pl + FX_PL_S_DDOT * S, *dv = pl + FX_PL_D_DOT * S, *da = pl + FX_PL_D_DDOT * S;
+    const double *tp = p->tpow;
+    const double dt = p->dt;
+
+    double T, lon0[3], v1, a1, lat0[3], lat1[3];
+    candidate_params(p, g, &T, lon0, &v1, &a1, lat0, lat1);
+
+    /* reactive_planner.py:154 */
+    quartic_coeffs(lon0[0], lon0[1], lon0[2], T, v1, a1, cd->cl);
+    /* :161-171 */
+    double tau = T;
+    if (p->low_vel_mode) {
+        double t2 = T * T, t3 = t2 * T, t4 = t2 * t2, t5 = t3 * t2; /* evaluate_state_at_tau :213-216 */
+        double s_lon_goal = poly_pos(cd->cl, T, t2, t3, t4, t5) - lon0[0];
+        MARGIN(s_lon_goal);
+        if (s_lon_goal <= 0) s_lon_goal = T;
+        tau = s_lon_goal;
+    }
+    quintic_coeffs(lat0[0], lat0[1], lat0[2], lat1[0], lat1[1], lat1[2], tau, cd->ct);
+    cd->T = T;
+    cd->tau_lat = tau;
+
+    /* :296-303 len(np.arange(0, T+dt, dt)) = ceil((T+dt)/dt); clamped to the horizon */
+    int traj_len = (int)ceil((T + dt) / dt);
+    if (traj_len > S) traj_len = S;
+    if (traj_len < 1) traj_len = 1;
+    cd->traj_len = traj_len;
+
+    /* :313-346 */
+    for (int i = 0; i < traj_len; i++) {
+        double t1 = tp[i], t2 = tp[S + i], t3 = tp[2 * S + i], t4 = tp[3 * S + i], t5 = tp[4 * S + i];
+        s[i] = poly_pos(cd->cl, t1, t2, t3, t4, t5);
+        sv[i] = poly_vel(cd->cl, t1, t2, t3, t4);
+        sa[i] = poly_acc(cd->cl, t1, t2, t3);
+    }
+    for (int i = traj_len; i < S; i++) {
+        s[i] = s[i - 1] + dt * sv[traj_len - 1];
+        sv[i] = sv[traj_len - 1];
+        sa[i] = 0.0;
+    }
+    for (int i = 0; i < traj_len; i++) {
+        double t1, t2, t3, t4, t5;
+        if (!p->low_vel_mode) {
+            t1 = tp[i]; t2 = tp[S + i]; t3 = tp[2 * S + i]; t4 = tp[3 * S + i]; t5 = tp[4 * S + i];
+        } else {
+            t1 = s[i] - s[0]; t2 = t1 * t1; t3 = t2 * t1; t4 = t2 * t2; t5 = t4 * t1; /* :331-335 */
+        }
+        d[i] = poly_pos(cd->ct, t1, t2, t3, t4, t5);
+        dv[i] = poly_vel(cd->ct, t1, t2, t3, t4);
+        da[i] = poly_acc(cd->ct, t1, t2, t3);
+    }
+    for (int i = traj_len; i < S; i++) { d[i] = d[traj_len - 1]; dv[i] = 0.0; da[i] = 0.0; }
+
+    uint32_t flags = FX_FLAG_VALID | FX_FLAG_FEASIBLE;
+    uint32_t reasons = 0;
+
+    /* :350-355 */
+    int neg = 0;
+    for (int i = 0; i < S; i++) { MARGIN(sv[i] + EPS); MARGIN(fabs(sv[i]) - EPS); if (sv[i] < -EPS) neg = 1; }
+    if (neg) {
+        flags &= ~FX_FLAG_VALID;
+        reasons |= 1u << 10;
+        if (!D && !KD) { if (margin_out) *margin_out = mg; return flags | (reasons << FX_REASON_SHIFT); }
+    }
+    for (int i = 0; i < S; i++) if (fabs(sv[i]) < EPS) sv[i] = 0.0;
+
+    /* :373-386 */
+    if (!D) {
+        int acc = 0;
+        for (int i = 0; i < S; i++) { MARGIN(fabs(sa[i]) - p->veh.a_max); if (fabs(sa[i]) > p->veh.a_max) acc = 1; }
+        if (acc) {
+            flags &= ~FX_FLAG_FEASIBLE;
+            reasons |= 1u << 1;
+            if (margin_out) *margin_out = mg;
+            return flags | FX_FLAG_RETURNED | (reasons << FX_REASON_SHIFT);
+        }
+        if (neg) {
+            flags &= ~FX_FLAG_FEASIBLE;
+            reasons |= 1u << 2;
+            if (margin_out) *margin_out = mg;
+            return flags | FX_FLAG_RETURNED | (reasons << FX_REASON_SHIFT);
+        }
+    }
+
+    /* :389-533 */
+    const double *rp = p->ref_pos, *rth = p->ref_theta, *rc = p->ref_curv, *rcd = p->ref_curv_d;
+    const int M = p->M;
+    const double kappa_max = p->veh.kappa_max;
+    for (int i = 0; i < S; i++) {
+        double dp, dpp;
+        if (!p->low_vel_mode) MARGIN(sv[i] - 0.001);
+        if (!p->low_vel_mode) {
+            dp = sv[i] > 0.001 ? dv[i] / sv[i] : 0.;
+            double ddot = da[i] - dp * sa[i];
+            dpp = sv[i] > 0.001 ? ddot / (sv[i] * sv[i]) : 0.;
+        } else {
+            dp = dv[i];
+            dpp = da[i];
+        }
+        int i1 = argmax_gt(rp, M, s[i]); /* s_idx + 1 */
+        int i0 = i1 - 1;                 /* s_idx, -1 wraps to the last knot like a Python index */
+        if (i0 < 0) i0 = M - 1;
+        double s_lambda = (s[i] - rp[i0]) / (rp[i1] - rp[i0]);
+
+        if (sv[i] > 0.001 || p->low_vel_mode) {
+            theta_cl[i] = atan2(dp, 1.0);
+            theta_gl[i] = theta_cl[i] + interpolate_angle(s[i], rp[i0], rp[i1], rth[i0], rth[i1]);
+        } else {
+            theta_gl[i] = i == 0 ? p->x0_orientation : theta_gl[i - 1];
+            theta_cl[i] = theta_gl[i] - interpolate_angle(s[i], rp[i0], rp[i1], rth[i0], rth[i1]);
+        }
+        double k_r = (rc[i1] - rc[i0]) * s_lambda + rc[i0];
+        double k_r_d = (rcd[i1] - rcd[i0]) * s_lambda + rcd[i0];
+
+        double oneKrD = (1 - k_r * d[i]);
+        double cosTheta = cos(theta_cl[i]);
+        double tanTheta = tan(theta_cl[i]);
+        double cok = cosTheta / oneKrD;
+        kappa_gl[i] = (dpp + (k_r * dp + k_r_d * d[i]) * tanTheta) * cosTheta * (cok * cok) + cok * k_r;
+        /* kappa_cl = kappa_gl - k_r is computed but never stored (:470) */
+        v[i] = sv[i] * (oneKrD / cosTheta);
+        a[i] = sa[i] * (oneKrD / cosTheta) +
+               ((sv[i] * sv[i]) / cosTheta) *
+                   (oneKrD * tanTheta * (kappa_gl[i] * (oneKrD / cosTheta) - k_r) - (k_r_d * d[i] + k_r * dp));
+
+        MARGIN(v[i] + EPS);
+        if (v[i] < -EPS) { reasons |= 1u << 4; if (!D && !KD) break; }
+        MARGIN(fabs(kappa_gl[i]) - kappa_max);
+        if (fabs(kappa_gl[i]) > kappa_max) { reasons |= 1u << 5; if (!D && !KD) break; }
+        double yaw_rate = i > 0 ? (theta_gl[i] - theta_gl[i - 1]) / dt : 0.;
+        double theta_dot_max = kappa_max * v[i];
+        double yr5 = fabs(np_round5(yaw_rate));
+        /* the 5-decimal rounding moves the value by up to 5e-6: near the limit the rint tie matters too */
+        if (fabs(yr5 - theta_dot_max) < 2e-5) MARGIN((fabs(fabs(yaw_rate * 1e5) - floor(fabs(yaw_rate * 1e5)) - 0.5)) * 1e-5);
+        if (!(i == 0 && theta_dot_max == 0.0)) MARGIN(yr5 - theta_dot_max); /* 0 > 0 at standstill is exact, not noise */
+        if (yr5 > theta_dot_max) { reasons |= 1u << 6; if (!D && !KD) break; }
+        double kd = i > 0 ? (kappa_gl[i] - kappa_gl[i - 1]) / dt : 0.;
+        MARGIN(fabs(kd) - 0.4);
+        if (fabs(kd) > 0.4) { reasons |= 1u << 7; if (!D && !KD) break; }
+        double a_hi = v[i] > p->veh.v_switch ? p->veh.a_max * p->veh.v_switch / v[i] : p->veh.a_max;
+        double a_lo = -p->veh.a_max;
+        MARGIN(a[i] - a_lo);
+        MARGIN(a[i] - a_hi);
+        if (!(a_lo <= a[i] && a[i] <= a_hi)) { reasons |= 1u << 8; if (!D && !KD) break; }
+    }
+    if (reasons & 0x1F8u) flags &= ~FX_FLAG_FEASIBLE; /* reasons 3..8 */
+
+    /* :536-567 */
+    if ((flags & FX_FLAG_FEASIBLE) || D) {
+        for (int i = 0; i < S; i++) {
+            MARGIN(s[i] - p->ref_pos[0]);
+            MARGIN(s[i] - p->ref_pos[M - 1]);
+            if (!project(p, s[i], d[i], &x[i], &y[i])) {
+                flags &= ~FX_FLAG_VALID;
+                reasons |= 1u << 9;
+                break;
+            }
+        }
+        kappa_dot[0] = 0.0; /* np.append([0], np.diff(kappa_gl)) -- not divided by dt (:552) */
+        for (int i = 1; i < S; i++) kappa_dot[i] = kappa_gl[i] - kappa_gl[i - 1];
+        flags |= FX_FLAG_RETURNED;
+    }
+    flags |= reasons << FX_REASON_SHIFT;
+
+    /* pool that gets costs (:244-253) and that the collision walk sees (:248,251) */
+    int costed, selectable;
+    if (D) {
+        costed = (flags & FX_FLAG_RETURNED) != 0;
+        selectable = costed && (flags & FX_FLAG_FEASIBLE);
+    } else {
+        costed = (flags & FX_FLAG_RETURNED) && (flags & FX_FLAG_VALID) && (flags & FX_FLAG_FEASIBLE);
+        selectable = costed;
+    }
+    if (margin_out) *margin_out = mg;
+    if (!costed) return flags;
+    flags |= FX_FLAG_COSTED;
+    if (selectable) flags |= FX_FLAG_SELECTABLE;
+
+    /* cost_function.py:78-91 */
+    double weighted[FX_NUM_COSTS], tmp[256];
+    for (int n = 0; n < p->n_cost; n++) {
+        double c = 0.0;
+        switch (p->cost_id[n]) {
+        case FX_COST_ACCELERATION: /* :29-31 */
+            for (int i = 0; i < S; i++) tmp[i] = a[i] * a[i];
+            c = simpson(tmp, S, dt, p->simpson_corr);
+            break;
+        case FX_COST_JERK: /* :41-44 */
+            for (int i = 0; i + 1 < S; i++) { double j = (a[i + 1] - a[i]) / dt; tmp[i] = j * j; }
+            c = simpson(tmp, S - 1, dt, p->simpson_corr);
+            break;
+        case FX_COST_LATERAL_JERK: c = sq_jerk_integral(cd->ct, dt); break;      /* :54 */
+        case FX_COST_LONGITUDINAL_JERK: c = sq_jerk_integral(cd->cl, dt); break; /* :63 */
+        case FX_COST_ORIENTATION_OFFSET: /* :146-149 */
+            for (int i = 0; i + 1 < S; i++) { double w = (theta_cl[i + 1] - theta_cl[i]) / dt; tmp[i] = w * w; }
+            c = simpson(tmp, S - 1, dt, p->simpson_corr);
+            break;
+        case FX_COST_PATH_LENGTH: c = simpson(v, S, dt, p->simpson_corr); break; /* :194-195 */
+        case FX_COST_VELOCITY_OFFSET: { /* :125-128 */
+            int half = S / 2, m = 0;
+            for (int i = half; i < S - 1; i++) tmp[m++] = fabs(v[i] - p->v_des);
+            c = np_sum(tmp, m);
+            double e = v[S - 1] - p->v_des;
+            c += fabs(e * e);
+            break;
+        }
+        case FX_COST_DISTANCE_TO_REFERENCE_PATH: /* :166-167 */
+            for (int i = 0; i < S; i++) tmp[i] = fabs(d[i]);
+            c = (np_sum(tmp, S) + fabs(d[S - 1]) * 5) / S;
+            break;
+        case FX_COST_DISTANCE_TO_OBSTACLES: /* :177-184 */
+            for (int o = 0; o < p->n_dto; o++) {
+                for (int i = 0; i < S; i++) {
+                    double ex = x[i] - p->dto_pos[2 * o], ey = y[i] - p->dto_pos[2 * o + 1];
+                    double dist = sqrt(ex * ex + ey * ey);
+                    tmp[i] = 1.0 / (dist * dist);
+                }
+                c += np_sum(tmp, S);
+            }
+            break;
+        case FX_COST_PREDICTION: { /* collision_probability.py:279-297, partial_cost_functions.py:352-354 */
+            double pc = 0;
+            for (int k = 0; k < p->K; k++) {
+                int np_ = p->obs_npred[k];
+                for (int i = 1; i < S; i++) {
+                    if (i < np_) {
+                        const double *mu = p->obs_pos + ((size_t)k * p->P + (i - 1)) * 2;
+                        const double *iv = p->obs_cov_inv + ((size_t)k * p->P + (i - 1)) * 4;
+                        double d0 = x[i] - mu[0], d1 = y[i] - mu[1];
+                        double r0 = d0 * iv[0] + d1 * iv[2], r1 = d0 * iv[1] + d1 * iv[3];
+                        double m = r0 * d0 + r1 * d1;
+                        tmp[i - 1] = 1.0 / (m * m);
+                    } else tmp[i - 1] = 0.0;
+                }
+                pc += np_sum(tmp, S - 1);
+            }
+            c = pc;
+            break;
+        }
+        default: c = 0.0;
+        }
+        if (cost_raw) cost_raw[n] = c;
+        weighted[n] = p->cost_w[n] * c;
+    }
+    *cost_total = np_sum(weighted, p->n_cost);
+    return flags;
+}
+
+/* ---------------------------------------------------------------- whole plan step */
+
+typedef struct { double c; int64_t i; } CostIdx;
+static int cmp_costidx(const void *a, const void *b) {
+    const CostIdx *x = a, *y = b;
+    if (x->c < y->c) return -1;
+    if (x->c > y->c) return 1;
+    return (x->i > y->i) - (x->i < y->i); /* stable: creation order breaks ties (trajectories.py:560) */
+}
+
+int64_t fxo_num_candidates(const FxProblem *p) {
+    return p->sampling_matrix ? p->n_rows : (int64_t)p->nT * p->nV * p->nD;
+}
+
+/*
+ * Evaluate every candidate.  All output arrays are candidate-major and optional (NULL) except
+ * flags and cost:  coeff_lon/lat [C][6], traj_len [C], planes [C][14][S], costmap [C][n_cost],
+ * order [C] (ids of COSTED candidates sorted by (cost,id); rest filled with -1), margin [C] (smallest
+ * distance of any of the candidate's discrete decisions from its threshold: lets the parity tests tell
+ * a real mismatch from a coin-flip on a comparison that is decided by the last ulp).
+ * first_only != 0 skips the plane/collision work that the winner search does not need -- unused
+ * here, the oracle always does everything.
+ */
+int32_t fxo_plan_step(const FxProblem *p, double *coeff_lon, double *coeff_lat, int32_t *traj_len, double *planes,
+                      uint32_t *flags, double *cost, double *costmap, int64_t *order, double *margin, FxResult *res) {
+    const int S = p->N + 1;
+    if (S > 255 || p->n_cost > FX_NUM_COSTS) return FX_ERR_INVALID_ARGUMENT;
+    const int64_t C = fxo_num_candidates(p);
+    double *pl_local = planes ? NULL : malloc(sizeof(double) * FX_NUM_PLANES * S);
+    CostIdx *ci = malloc(sizeof(CostIdx) * (size_t)(C > 0 ? C : 1));
+    int64_t n_ci = 0;
+    memset(res, 0, sizeof(*res));
+    res->n_candidates = C;
+    res->best_index = -1;
+    res->best_cost = 0.0;
+
+    for (int64_t g = 0; g < C; g++) {
+        double *pl = planes ? planes + (size_t)g * FX_NUM_PLANES * S : pl_local;
+        memset(pl, 0, sizeof(double) * FX_NUM_PLANES * S);
+        Cand cd;
+        double raw[FX_NUM_COSTS], total = 0.0;
+        double mg = 1e300;
+        uint32_t f = eval_candidate(p, g, &cd, pl, raw, &total, &mg);
+        if ((f & FX_FLAG_SELECTABLE) && (p->mode & FX_MODE_COLLISION) && p->K > 0) {
+            if (ego_collides(p, pl + FX_PL_X * S, pl + FX_PL_Y * S, pl + FX_PL_THETA * S, &mg)) f |= FX_FLAG_COLLISION;
+        }
+        if (margin) margin[g] = mg;
+        flags[g] = f;
+        cost[g] = (f & FX_FLAG_COSTED) ? total : 0.0;
+        if (coeff_lon) memcpy(coeff_lon + 6 * g, cd.cl, sizeof(cd.cl));
+        if (coeff_lat) memcpy(coeff_lat + 6 * g, cd.ct, sizeof(cd.ct));
+        if (traj_len) traj_len[g] = cd.traj_len;
+        if (costmap) for (int n = 0; n < p->n_cost; n++) costmap[g * p->n_cost + n] = (f & FX_FLAG_COSTED) ? raw[n] : 0.0;
+        if (f & FX_FLAG_COSTED) { ci[n_ci].c = total; ci[n_ci].i = g; n_ci++; }
+        if (f & FX_FLAG_RETURNED) {
+            res->n_returned++;
+            if ((f & FX_FLAG_VALID) && (f & FX_FLAG_FEASIBLE)) res->n_feasible++;
+        }
+        for (int r = 0; r < FX_NUM_REASONS; r++) if (f & (1u << (FX_REASON_SHIFT + r))) res->reason_hist[r]++;
+    }
+    res->n_infeasible = res->n_returned - res->n_feasible;
+    res->feasible_percentage = res->n_returned ? 100.0 * ((double)res->n_feasible / (double)res->n_returned) : 0.0;
+
+    qsort(ci, (size_t)n_ci, sizeof(CostIdx), cmp_costidx);
+    if (order) {
+        for (int64_t j = 0; j < C; j++) order[j] = j < n_ci ? ci[j].i : -1;
+    }
+    /* planner.py:336-390: first selectable, collision-free trajectory in cost order */
+    for (int64_t j = 0; j < n_ci; j++) {
+        uint32_t f = flags[ci[j].i];
+        if (!(f & FX_FLAG_SELECTABLE)) continue;
+        if (f & FX_FLAG_COLLISION) { res->n_collisions++; continue; }
+        res->best_index = ci[j].i;
+        res->best_cost = ci[j].c;
+        break;
+    }
+    free(ci);
+    free(pl_local);
+    return FX_OK;
+}
+
+/* bench.py cpu_baseline leg: same work as fxo_plan_step without keeping the planes (the planes of
+ * one candidate live in a stack buffer), optionally over [g0,g1) so a bounded sample can be timed. */
+int32_t fxo_plan_range(const FxProblem *p, int64_t g0, int64_t g1, uint32_t *flags, double *cost, int64_t *best,
+                       double *best_cost) {
+    const int S = p->N + 1;
+    if (S > 255) return FX_ERR_INVALID_ARGUMENT;
+    double pl[FX_NUM_PLANES * 256];
+    *best = -1;
+    *best_cost = 0.0;
+    for (int64_t g = g0; g < g1; g++) {
+        memset(pl, 0, sizeof(double) * FX_NUM_PLANES * S);
+        Cand cd;
+        double raw[FX_NUM_COSTS], total = 0.0;
+        uint32_t f = eval_candidate(p, g, &cd, pl, raw, &total, NULL);
+        if ((f & FX_FLAG_SELECTABLE) && (p->mode & FX_MODE_COLLISION) && p->K > 0)
+            if (ego_collides(p, pl + FX_PL_X * S, pl + FX_PL_Y * S, pl + FX_PL_THETA * S, NULL)) f |= FX_FLAG_COLLISION;
+        flags[g - g0] = f;
+        cost[g - g0] = (f & FX_FLAG_COSTED) ? total : 0.0;
+        if ((f & FX_FLAG_SELECTABLE) && !(f & FX_FLAG_COLLISION) && (*best < 0 || total < *best_cost)) {
+            *best = g;
+            *best_cost = total;
+        }
+    }
+    return FX_OK;
+}
+
+/* exported for tests of the normative pieces */
+int32_t fxo_project(const FxProblem *p, double s, double d, double *xy) { return project(p, s, d, &xy[0], &xy[1]); }
+int32_t fxo_obb_overlap(const double *a, const double *b) { return obb_overlap(a, b); }
+void fxo_obb_hull(const double *c0, const double *u0, const double *c1, const double *u1, double hl, double hw, double *out) {
+    obb_hull(c0[0], c0[1], u0[0], u0[1], c1[0], c1[1], u1[0], u1[1], hl, hw, out);
+}
+double fxo_np_sum(const double *a, int32_t n) { return np_sum(a, n); }
+double fxo_simpson(const double *y, int32_t n, double dx, const double *corr) { return simpson(y, n, dx, corr); }
+void fxo_quartic(double xs, double vxs, double axs, double T, double vxe, double axe, double *c) { quartic_coeffs(xs, vxs, axs, T, vxe, axe, c); }
+void fxo_quintic(double xs, double vxs, double axs, double xe, double vxe, double axe, double T, double *c) { quintic_coeffs(xs, vxs, axs, xe, vxe, axe, T, c); }

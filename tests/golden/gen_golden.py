@@ -1,0 +1,141 @@
+"""Generate the golden vectors under tests/golden/*.npz by running the REFERENCE's own Python hot path
+(/root/reference, imported through ref_harness.py).  Run in the build container only:
+
+    python tests/golden/gen_golden.py
+
+Each fixture holds the inputs needed to rebuild the plan step (reference polyline, x_cl, ordered
+sampling ranges as the reference's SamplingHandler iterates them, vehicle, weights, predictions, mode
+flags) and the reference's outputs (coefficients, traj_len, validity/feasibility, histogram, the 14
+trajectory planes, per-name costs, total cost, stable-sorted ids, walk order).  Fixtures are data only.
+
+x/y planes and everything derived from them (prediction / distance_to_obstacles costs) depend on the
+(s,d)->(x,y) projection, which the reference delegates to commonroad-drivability-checker (not in
+tree); the harness substitutes an independent numpy restatement of the build's normative definition,
+so those columns are "self-consistency", everything else is reference parity.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_harness  # noqa: E402
+from frenetix_motion_planner_amd import synthetic  # noqa: E402
+from frenetix_motion_planner_amd.problem import DEFAULT_COST_WEIGHTS  # noqa: E402
+
+ALL_TRAJ_COSTS = dict(DEFAULT_COST_WEIGHTS, acceleration=0.3, jerk=0.15, orientation_offset=0.4, path_length=0.05,
+                      distance_to_obstacles=0.7)
+
+# name -> (make_inputs kwargs, plane_stride)
+SCENARIOS = {
+    "arc_hv_l1_debug": (dict(ref_kind="arc", v0=10.0, level=1, draw_traj_set=True, kinematic_debug=True), 1),
+    "arc_hv_l1_prod": (dict(ref_kind="arc", v0=10.0, level=1), 1),
+    "arc_hv_l2_debug_obs5": (dict(ref_kind="arc", v0=10.0, level=2, n_obstacles=5, draw_traj_set=True,
+                                  kinematic_debug=True), 7),
+    "arc_hv_l2_prod_obs1": (dict(ref_kind="arc", v0=10.0, level=2, n_obstacles=1), 7),
+    "straight_hv_l1_debug": (dict(ref_kind="straight", v0=10.0, d0=0.0, level=1, draw_traj_set=True,
+                                  kinematic_debug=True), 1),
+    "scurve_hv_l1_debug": (dict(ref_kind="scurve", kappa=0.02, v0=8.0, level=1, draw_traj_set=True,
+                                kinematic_debug=True), 1),
+    "scurve_hv_l2_kd": (dict(ref_kind="scurve", kappa=0.03, v0=14.0, level=2, kinematic_debug=True), 7),
+    "arc_lv_l1_debug": (dict(ref_kind="arc", v0=1.5, level=1, draw_traj_set=True, kinematic_debug=True, v_des=3.0), 1),
+    "arc_lv_l1_prod": (dict(ref_kind="arc", v0=1.5, level=1, v_des=3.0), 1),
+    "arc_standstill_l1_debug": (dict(ref_kind="arc", v0=0.0, level=1, draw_traj_set=True, kinematic_debug=True,
+                                     v_des=2.0), 1),
+    "short_ref_hv_l1_debug": (dict(ref_kind="arc", n_knots=120, s_knot=40, v0=12.0, level=1, draw_traj_set=True,
+                                   kinematic_debug=True), 1),
+    "short_ref_hv_l1_prod": (dict(ref_kind="arc", n_knots=120, s_knot=40, v0=12.0, level=1), 1),
+    "arc_hv_l1_allcosts_obs3": (dict(ref_kind="arc", v0=10.0, level=1, n_obstacles=3, draw_traj_set=True,
+                                     kinematic_debug=True, cost_weights=ALL_TRAJ_COSTS), 1),
+    "arc_hv_l0_horizon5": (dict(ref_kind="arc", n_knots=600, v0=10.0, level=0, horizon=5.0, n_pred=50, n_obstacles=2,
+                                draw_traj_set=True, kinematic_debug=True), 1),
+    "arc_hv_decel_l1_prod": (dict(ref_kind="arc", v0=10.0, a0=-3.0, d0=-0.6, dd0=0.4, ddd0=0.1, level=1), 1),
+    "arc_slow_brake_l1_debug": (dict(ref_kind="arc", v0=3.0, a0=-6.0, level=1, draw_traj_set=True, kinematic_debug=True,
+                                     v_des=5.0), 1),
+    "arc_slow_brake_l1_prod": (dict(ref_kind="arc", v0=3.0, a0=-6.0, level=1, v_des=5.0), 1),
+    "arc_slow_brake_l1_kd": (dict(ref_kind="arc", v0=3.0, a0=-6.0, level=1, kinematic_debug=True, v_des=5.0), 1),
+}
+
+
+class _ObsState:
+    def __init__(self, pos):
+        self.position = np.asarray(pos)
+
+
+class _Obstacle:
+    def __init__(self, pos):
+        self._s = _ObsState(pos)
+
+    def state_at_time(self, t):
+        return self._s
+
+
+def to_reference_problem(inp, kw):
+    veh = inp.vehicle
+    cs = inp.coordinate_system
+    prob = dict(
+        horizon=inp.N * inp.dt if abs(inp.N * inp.dt - round(inp.N * inp.dt, 6)) > 1e-12 else round(inp.N * inp.dt, 6),
+        dt=inp.dt, low_vel_mode=inp.low_vel_mode, draw_traj_set=inp.draw_traj_set, kinematic_debug=inp.kinematic_debug,
+        vehicle=dict(a_max=veh.a_max, v_switch=veh.v_switch, delta_max=veh.delta_max, wheelbase=veh.wheelbase,
+                     length=veh.length, width=veh.width, wb_rear_axle=veh.wb_rear_axle, v_max=veh.v_max),
+        ref_xy=cs.reference, ref_pos=cs.ref_pos, ref_theta=cs.ref_theta, ref_curv=cs.ref_curv, ref_curv_d=cs.ref_curv_d,
+        x0_orientation=inp.x0_orientation, x0_lon=[float(v) for v in inp.x0_lon], x0_lat=[float(v) for v in inp.x0_lat],
+        v_des=inp.v_des, predictions=inp.predictions, sampling_level=kw["level"], t_min=1.1, d_min=-3.0, d_max=3.0,
+        cost_weights=inp.cost_weights)
+    from frenetix_motion_planner_amd.sampling import v_sampling_bounds
+    prob["v_min"], prob["v_max"] = v_sampling_bounds(float(inp.x0_lon[1]), veh.a_max, kw.get("horizon", 3.0), veh.v_max)
+    prob["horizon"] = kw.get("horizon", 3.0)
+    if inp.predictions and "distance_to_obstacles" in inp.cost_weights:
+        prob["scenario_obstacles"] = [_Obstacle(p["pos_list"][0]) for p in inp.predictions.values()]
+    return prob
+
+
+def main():
+    ref_harness.install()
+    index = {}
+    for name, (kw, stride) in SCENARIOS.items():
+        inp = synthetic.make_inputs(**kw)
+        prob = to_reference_problem(inp, kw)
+        out = ref_harness.run_reference(prob)
+        # G1: the build's own SamplingHandler must iterate in the same order as the reference's
+        assert np.array_equal(out["t_order"], inp.t_samp), (name, out["t_order"], inp.t_samp)
+        assert np.array_equal(out["v_order"], inp.v_samp), name
+        assert np.array_equal(out["d_order"], inp.d_samp), name
+        Cn = len(out["valid"])
+        sel = np.arange(0, Cn, stride)
+        fx = dict(
+            kw=json.dumps(kw, sort_keys=True), plane_ids=sel, planes=out["planes"][sel],
+            ref_xy=inp.coordinate_system.reference, x0_lon=inp.x0_lon, x0_lat=inp.x0_lat,
+            x0_orientation=inp.x0_orientation, low_vel_mode=inp.low_vel_mode, N=inp.N, dt=inp.dt, v_des=inp.v_des,
+            dto_pos=(np.array([p["pos_list"][0] for p in inp.predictions.values()])
+                     if "scenario_obstacles" in prob else np.zeros((0, 2))),
+        )
+        for k in ("t_order", "v_order", "d_order", "coeff_lon", "coeff_lat", "tau_lat", "valid", "feasible", "returned",
+                  "has_cart", "traj_len", "hist", "reasons", "cost", "costmap", "costed", "sorted_ids", "walk_ids", "cost_names"):
+            fx[k] = out[k]
+        fx["cost_weight_values"] = np.array([inp.cost_weights[n] for n in out["cost_names"]])
+        if inp.predictions:
+            keys = list(inp.predictions.keys())
+            fx["pred_keys"] = np.array(keys)
+            fx["pred_pos"] = np.stack([inp.predictions[k]["pos_list"] for k in keys])
+            fx["pred_cov"] = np.stack([inp.predictions[k]["cov_list"] for k in keys])
+            fx["pred_yaw"] = np.stack([inp.predictions[k]["orientation_list"] for k in keys])
+            fx["pred_shape"] = np.array([[inp.predictions[k]["shape"]["length"], inp.predictions[k]["shape"]["width"]]
+                                         for k in keys])
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **fx)
+        index[name] = dict(candidates=int(Cn), returned=int(out["n_returned"]), feasible=int(out["n_feasible"]),
+                           bytes=os.path.getsize(path))
+        print(f"{name:28s} C={Cn:4d} returned={out['n_returned']:4d} feasible={out['n_feasible']:4d} "
+              f"hist={out['hist'].tolist()} best={out['walk_ids'][:1].tolist()} {os.path.getsize(path)/1024:.0f} KiB")
+    with open(os.path.join(HERE, "INDEX.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
