@@ -1,0 +1,108 @@
+"""Loader of csrc/libfxplan.so (the HIP engine) and its ctypes prototypes (include/fxplan.h).
+
+The product path has NO CPU fallback: if the shared library is missing or cannot be loaded, or no GPU is
+visible when an engine is created, this raises -- it never routes to the oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libfxplan.so")
+_LIB = None
+
+
+class FxError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("fx_kernels.hip", "fx_api.hip", "fx_device.h")]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "fxplan.h"))
+    stale = not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", CSRC, "-s"] + (["-B"] if force else []), check=True)
+    return SO_PATH
+
+
+def exported_symbols():
+    """Entry points include/fxplan.h declares (checked against the .so by the CPU test-suite)."""
+    return [
+        "fx_abi_version", "fx_last_error", "fx_device_count", "fx_create", "fx_create_batch", "fx_destroy",
+        "fx_set_stream", "fx_upload", "fx_upload_batch", "fx_evaluate", "fx_finish", "fx_finish_batch", "fx_plan_step",
+        "fx_read_costs", "fx_read_costs_agent", "fx_read_costmap", "fx_read_costmap_agent", "fx_read_coeffs",
+        "fx_read_coeffs_agent", "fx_read_sample", "fx_read_sample_agent", "fx_read_plane", "fx_read_plane_agent",
+        "fx_read_topk", "fx_read_topk_batch", "fx_topk_to_device", "fx_build_obstacle_hulls", "fx_device_bytes",
+        "fx_last_kernel_ms", "fx_last_eval_kernel_ms", "fx_device_views",
+    ]
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(SO_PATH):
+        raise FxError(f"{SO_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()); "
+                      "the engine has no CPU fallback")
+    try:
+        L = C.CDLL(SO_PATH)
+    except OSError as e:
+        raise FxError(f"cannot load {SO_PATH}: {e}") from e
+    pd, pi32, pi64, pu32 = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint32)
+    vp = C.c_void_p
+    PP, PR = C.POINTER(_abi.FxProblem), C.POINTER(_abi.FxResult)
+    sig = {
+        "fx_abi_version": ([], C.c_int32),
+        "fx_last_error": ([], C.c_char_p),
+        "fx_device_count": ([pi32], C.c_int32),
+        "fx_create": ([C.POINTER(vp), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32], C.c_int32),
+        "fx_create_batch": ([C.POINTER(vp), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32],
+                            C.c_int32),
+        "fx_destroy": ([vp], C.c_int32),
+        "fx_set_stream": ([vp, vp], C.c_int32),
+        "fx_upload": ([vp, PP], C.c_int32),
+        "fx_upload_batch": ([vp, C.c_int32, PP], C.c_int32),
+        "fx_evaluate": ([vp], C.c_int32),
+        "fx_finish": ([vp, PR], C.c_int32),
+        "fx_finish_batch": ([vp, PR], C.c_int32),
+        "fx_plan_step": ([vp, PP, PR], C.c_int32),
+        "fx_read_costs": ([vp, pd, pu32], C.c_int32),
+        "fx_read_costs_agent": ([vp, C.c_int32, pd, pu32], C.c_int32),
+        "fx_read_costmap": ([vp, pd], C.c_int32),
+        "fx_read_costmap_agent": ([vp, C.c_int32, pd], C.c_int32),
+        "fx_read_coeffs": ([vp, C.c_int64, pd, pd, pi32], C.c_int32),
+        "fx_read_coeffs_agent": ([vp, C.c_int32, C.c_int64, pd, pd, pi32], C.c_int32),
+        "fx_read_sample": ([vp, C.c_int64, pd], C.c_int32),
+        "fx_read_sample_agent": ([vp, C.c_int32, C.c_int64, pd], C.c_int32),
+        "fx_read_plane": ([vp, C.c_int32, pd], C.c_int32),
+        "fx_read_plane_agent": ([vp, C.c_int32, C.c_int32, pd], C.c_int32),
+        "fx_read_topk": ([vp, C.c_int32, pd, pi64, pi32], C.c_int32),
+        "fx_read_topk_batch": ([vp, C.c_int32, pd, pi64], C.c_int32),
+        "fx_topk_to_device": ([vp, C.c_int32, vp, vp], C.c_int32),
+        "fx_build_obstacle_hulls": ([C.c_int32, pd, pd, C.c_double, C.c_double, pd, pi32], C.c_int32),
+        "fx_device_bytes": ([vp], C.c_int64),
+        "fx_last_kernel_ms": ([vp], C.c_double),
+        "fx_last_eval_kernel_ms": ([vp], C.c_double),
+        "fx_device_views": ([vp, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), pi64], C.c_int32),
+    }
+    for name, (args, ret) in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes, fn.restype = args, ret
+    if L.fx_abi_version() != _abi.FX_ABI_VERSION:
+        raise FxError(f"ABI mismatch: library {L.fx_abi_version()} vs python {_abi.FX_ABI_VERSION}")
+    _LIB = L
+    return L
+
+
+def check(rc: int):
+    """Map a status code to the reference's exception convention: <0 ValueError, >0 RuntimeError."""
+    if rc == 0:
+        return
+    msg = lib().fx_last_error().decode(errors="replace")
+    if rc < 0:
+        raise ValueError(f"fxplan: {msg} (status {rc})")
+    raise FxError(f"fxplan: {msg} (status {rc})")

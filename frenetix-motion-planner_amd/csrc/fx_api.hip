@@ -1,0 +1,625 @@
+// fx_api.hip -- host side of libfxplan.so: the C-ABI declared in include/fxplan.h.
+//
+// A context owns (a) one pinned host staging buffer + one device arena for all per-step inputs, so a plan
+// step is ONE H2D copy, (b) the per-candidate outputs (cost, flags, cost map, SoA bundle), (c) a pinned
+// read-back block for the counters/winner, so a plan step is ONE small D2H copy.  All work is enqueued on the
+// context's HIP stream; nothing synchronises until fx_finish().
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "fx_device.h"
+
+extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, int max_blocks, int M_max, bool bundle,
+                                     bool obst, bool extra, hipStream_t stream);
+extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, hipStream_t stream);
+extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int k, double *out_cost, long long *out_idx,
+                                     hipStream_t stream);
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int set_err(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return set_err(FX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                             __FILE__, __LINE__);                                           \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+struct FxAgentSlot {
+    int64_t C = 0, ld = 0, cand_off = 0;  // cand_off: offset of this agent in the per-candidate arrays
+    int32_t S = 0, n_cost = 0, n_blocks = 0;
+    uint32_t mode = 0;
+};
+
+struct FxContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;
+    // capacities
+    int64_t max_cand = 0;
+    int32_t max_steps = 0, max_knots = 0, max_obs = 0, max_pred = 0, max_agents = 1;
+    // input arena
+    size_t in_bytes = 0;
+    char *h_in = nullptr;   // pinned
+    char *d_in = nullptr;
+    // problems
+    DevProblem *h_probs = nullptr;  // pinned [max_agents]
+    DevProblem *d_probs = nullptr;
+    // outputs
+    double *d_cost = nullptr;
+    uint32_t *d_flags = nullptr;
+    double *d_costmap = nullptr;
+    double *d_coeffs = nullptr;
+    int32_t *d_trajlen = nullptr;
+    double *d_planes = nullptr;
+    size_t planes_bytes = 0;
+    double *d_part_cost = nullptr;
+    int64_t *d_part_idx = nullptr;
+    unsigned long long *d_counters = nullptr;  // [max_agents][FX_CNT_COUNT]
+    unsigned long long *h_counters = nullptr;  // pinned
+    double *d_topk_cost = nullptr;
+    long long *d_topk_idx = nullptr;
+    double *h_topk_cost = nullptr;
+    long long *h_topk_idx = nullptr;
+    int64_t total_ld = 0;  // capacity of per-candidate arrays (elements)
+    int64_t max_blocks_total = 0;
+    // current step
+    int n_agents = 0;
+    std::vector<FxAgentSlot> slots;
+    bool uploaded = false, evaluated = false;
+    int max_blocks_step = 0, M_max_step = 0;
+    bool any_bundle = false, any_obst = false, any_extra = false;
+    float last_ms = 0.f, last_eval_ms = 0.f;
+    int64_t dev_bytes = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(FxContext *c, T **p, size_t n) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(n, 1) * sizeof(T)));
+    c->dev_bytes += (int64_t)(std::max<size_t>(n, 1) * sizeof(T));
+    return FX_OK;
+}
+
+size_t input_bytes_for(int64_t cand, int S, int M, int K, int Pn, bool matrix) {
+    size_t b = 0;
+    b += align_up(sizeof(double) * 5 * S, 256);
+    b += align_up(sizeof(double) * 3 * 4096, 256);              // t/v/d ranges
+    if (matrix) b += align_up(sizeof(double) * 13 * (size_t)cand, 256);
+    b += align_up(sizeof(double) * FX_REF_FIELDS * (size_t)M, 256);
+    b += align_up(sizeof(double) * 2 * (size_t)K * Pn, 256);
+    b += align_up(sizeof(double) * 4 * (size_t)K * Pn, 256);
+    b += align_up(sizeof(double) * 6 * (size_t)K * (Pn > 0 ? Pn : 1), 256);
+    b += 2 * align_up(sizeof(int32_t) * (size_t)K, 256);
+    b += align_up(sizeof(double) * 2 * (size_t)K, 256);           // dto positions (<= K)
+    return b + 4096;
+}
+
+struct Arena {
+    char *h, *d;
+    size_t off, cap;
+    template <typename T>
+    const T *put(const T *src, size_t n, bool *ok) {
+        size_t bytes = align_up(n * sizeof(T), 256);
+        if (off + bytes > cap) { *ok = false; return nullptr; }
+        if (n && src) memcpy(h + off, src, n * sizeof(T));
+        const T *dp = reinterpret_cast<const T *>(d + off);
+        off += bytes;
+        return dp;
+    }
+    template <typename T>
+    T *host_slot(size_t n, const T **dev, bool *ok) {
+        size_t bytes = align_up(n * sizeof(T), 256);
+        if (off + bytes > cap) { *ok = false; return nullptr; }
+        T *hp = reinterpret_cast<T *>(h + off);
+        *dev = reinterpret_cast<const T *>(d + off);
+        off += bytes;
+        return hp;
+    }
+};
+
+int ensure_planes(FxContext *c, size_t bytes) {
+    if (bytes <= c->planes_bytes) return FX_OK;
+    if (c->d_planes) {
+        HIP_TRY(hipFree(c->d_planes));
+        c->dev_bytes -= (int64_t)c->planes_bytes;
+        c->d_planes = nullptr;
+        c->planes_bytes = 0;
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_planes), bytes));
+    c->planes_bytes = bytes;
+    c->dev_bytes += (int64_t)bytes;
+    return FX_OK;
+}
+
+int validate(const FxProblem *p) {
+    if (!p) return set_err(FX_ERR_INVALID_ARGUMENT, "problem is NULL");
+    if (p->N < 1 || p->N + 1 > FX_MAX_SAMPLES) return set_err(FX_ERR_INVALID_ARGUMENT, "N=%d outside [1,%d]", p->N, FX_MAX_SAMPLES - 1);
+    if (!(p->dt > 0)) return set_err(FX_ERR_INVALID_ARGUMENT, "dt must be > 0");
+    if (p->M < 2 || !p->ref_pos || !p->ref_x || !p->ref_y || !p->ref_nx || !p->ref_ny || !p->ref_theta || !p->ref_curv ||
+        !p->ref_curv_d)
+        return set_err(FX_ERR_NOT_READY, "reference path not set (M=%d)", p->M);
+    if (!p->tpow) return set_err(FX_ERR_INVALID_ARGUMENT, "tpow table missing");
+    if (p->sampling_matrix) {
+        if (p->n_rows < 0) return set_err(FX_ERR_INVALID_ARGUMENT, "n_rows < 0");
+    } else {
+        if (p->nT < 0 || p->nV < 0 || p->nD < 0 || (p->nT && !p->t_samp) || (p->nV && !p->v_samp) || (p->nD && !p->d_samp))
+            return set_err(FX_ERR_INVALID_ARGUMENT, "sampling ranges missing");
+        if (p->nT > 4096 || p->nV > 4096 || p->nD > 4096) return set_err(FX_ERR_CAPACITY, "sampling range longer than 4096");
+    }
+    if (p->n_cost < 0 || p->n_cost > FX_NUM_COSTS) return set_err(FX_ERR_INVALID_ARGUMENT, "n_cost=%d", p->n_cost);
+    for (int n = 0; n < p->n_cost; n++) {
+        if (p->cost_id[n] < 0 || p->cost_id[n] >= FX_NUM_COSTS) return set_err(FX_ERR_INVALID_ARGUMENT, "unknown cost id %d", p->cost_id[n]);
+        if (n && p->cost_id[n] <= p->cost_id[n - 1]) return set_err(FX_ERR_INVALID_ARGUMENT, "cost ids must be strictly ascending");
+    }
+    if (p->K < 0 || p->P < 0 || (p->K > 0 && (p->P < 2 || !p->obs_pos || !p->obs_cov_inv || !p->obs_npred)))
+        return set_err(FX_ERR_INVALID_ARGUMENT, "obstacle arrays inconsistent (K=%d, P=%d)", p->K, p->P);
+    if ((p->mode & FX_MODE_COLLISION) && p->K > 0 && (!p->obs_hull || !p->obs_nhull))
+        return set_err(FX_ERR_INVALID_ARGUMENT, "collision stage requested without obstacle hulls");
+    if (p->n_dto < 0 || (p->n_dto > 0 && !p->dto_pos)) return set_err(FX_ERR_INVALID_ARGUMENT, "dto_pos missing");
+    return FX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t fx_abi_version(void) { return FX_ABI_VERSION; }
+const char *fx_last_error(void) { return g_err; }
+
+int32_t fx_device_count(int32_t *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); return set_err(FX_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return FX_OK;
+}
+
+int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int64_t max_candidates_total,
+                        int32_t max_steps, int32_t max_ref_knots, int32_t max_obstacles, int32_t max_pred_steps) {
+    if (!out || max_candidates_total < 1 || max_steps < 1 || max_steps + 1 > FX_MAX_SAMPLES || max_ref_knots < 2 ||
+        max_agents < 1 || max_obstacles < 0 || max_pred_steps < 0)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "fx_create: bad capacity arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return set_err(FX_ERR_NO_DEVICE, "no HIP device visible");
+    }
+    if (device < 0 || device >= ndev) return set_err(FX_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    FxContext *c = new (std::nothrow) FxContext();
+    if (!c) return set_err(FX_ERR_HIP, "out of host memory");
+    c->device = device;
+    c->max_cand = max_candidates_total;
+    c->max_steps = max_steps;
+    c->max_knots = max_ref_knots;
+    c->max_obs = max_obstacles;
+    c->max_pred = std::max(max_pred_steps, 2);
+    c->max_agents = max_agents;
+    *out = c;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipEventCreate(&c->ev_mid));
+    const int S = max_steps + 1;
+    // every agent's leading dimension is rounded up to 64 candidates
+    c->total_ld = (int64_t)align_up((size_t)max_candidates_total, 64) + 64 * (int64_t)max_agents;
+    c->max_blocks_total = c->total_ld / FX_BLOCK + max_agents + 1;
+    c->in_bytes = (size_t)max_agents * input_bytes_for(0, S, max_ref_knots, max_obstacles, c->max_pred, false) +
+                  align_up(sizeof(double) * 13 * (size_t)max_candidates_total, 256) + 4096;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_in), c->in_bytes, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_in), c->in_bytes));
+    c->dev_bytes += (int64_t)c->in_bytes;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_probs), sizeof(DevProblem) * max_agents, hipHostMallocDefault));
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_probs, max_agents))) return rc;
+    if ((rc = dev_alloc(c, &c->d_cost, c->total_ld))) return rc;
+    if ((rc = dev_alloc(c, &c->d_flags, c->total_ld))) return rc;
+    if ((rc = dev_alloc(c, &c->d_costmap, (size_t)FX_NUM_COSTS * c->total_ld))) return rc;
+    if ((rc = dev_alloc(c, &c->d_coeffs, (size_t)12 * c->total_ld))) return rc;
+    if ((rc = dev_alloc(c, &c->d_trajlen, c->total_ld))) return rc;
+    if ((rc = dev_alloc(c, &c->d_part_cost, c->max_blocks_total))) return rc;
+    if ((rc = dev_alloc(c, &c->d_part_idx, c->max_blocks_total))) return rc;
+    if ((rc = dev_alloc(c, &c->d_counters, (size_t)max_agents * FX_CNT_COUNT))) return rc;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), sizeof(unsigned long long) * max_agents * FX_CNT_COUNT,
+                          hipHostMallocDefault));
+    if ((rc = dev_alloc(c, &c->d_topk_cost, (size_t)max_agents * 64))) return rc;
+    if ((rc = dev_alloc(c, &c->d_topk_idx, (size_t)max_agents * 64))) return rc;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_topk_cost), sizeof(double) * max_agents * 64, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_topk_idx), sizeof(long long) * max_agents * 64, hipHostMallocDefault));
+    c->slots.resize(max_agents);
+    return FX_OK;
+}
+
+int32_t fx_create(FxContext **out, int32_t device, int64_t max_candidates, int32_t max_steps, int32_t max_ref_knots,
+                  int32_t max_obstacles, int32_t max_pred_steps) {
+    return fx_create_batch(out, device, 1, max_candidates, max_steps, max_ref_knots, max_obstacles, max_pred_steps);
+}
+
+int32_t fx_destroy(FxContext *c) {
+    if (!c) return FX_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *dev[] = {c->d_in, c->d_probs, c->d_cost, c->d_flags, c->d_costmap, c->d_coeffs, c->d_trajlen, c->d_planes,
+                   c->d_part_cost, c->d_part_idx, c->d_counters, c->d_topk_cost, c->d_topk_idx};
+    for (void *p : dev) if (p) (void)hipFree(p);
+    void *host[] = {c->h_in, c->h_probs, c->h_counters, c->h_topk_cost, c->h_topk_idx};
+    for (void *p : host) if (p) (void)hipHostFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return FX_OK;
+}
+
+int32_t fx_set_stream(FxContext *c, void *hip_stream) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    c->own_stream = false;
+    return FX_OK;
+}
+
+// Stage n_agents problems.  Agent a's candidates occupy [cand_off, cand_off + ld) of every per-candidate array.
+int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) {
+    if (!c || !probs) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_upload: NULL argument");
+    if (n_agents < 1 || n_agents > c->max_agents) return set_err(FX_ERR_CAPACITY, "n_agents=%d exceeds capacity %d", n_agents, c->max_agents);
+    HIP_TRY(hipSetDevice(c->device));
+    c->uploaded = c->evaluated = false;
+    Arena ar{c->h_in, c->d_in, 0, c->in_bytes};
+    int64_t cand_off = 0, block_off = 0;
+    size_t planes_need = 0;
+    c->any_bundle = c->any_obst = c->any_extra = false;
+    c->max_blocks_step = 0;
+    c->M_max_step = 0;
+    for (int a = 0; a < n_agents; a++) {
+        const FxProblem *p = &probs[a];
+        int rc = validate(p);
+        if (rc) return rc;
+        const int S = p->N + 1;
+        const int64_t C = p->sampling_matrix ? p->n_rows : (int64_t)p->nT * p->nV * p->nD;
+        if (p->N > c->max_steps) return set_err(FX_ERR_CAPACITY, "N=%d exceeds context capacity %d", p->N, c->max_steps);
+        if (p->M > c->max_knots) return set_err(FX_ERR_CAPACITY, "M=%d reference knots exceed capacity %d", p->M, c->max_knots);
+        if (p->K > c->max_obs || (p->K > 0 && p->P > c->max_pred))
+            return set_err(FX_ERR_CAPACITY, "obstacles K=%d P=%d exceed capacity %d x %d", p->K, p->P, c->max_obs, c->max_pred);
+        if ((size_t)p->M * FX_REF_FIELDS * sizeof(double) > 160 * 1024 - 1024)
+            return set_err(FX_ERR_CAPACITY, "reference with %d knots does not fit the 160 KiB LDS", p->M);
+        const int64_t ld = (int64_t)align_up((size_t)std::max<int64_t>(C, 1), 64);
+        if (cand_off + ld > c->total_ld) return set_err(FX_ERR_CAPACITY, "candidates exceed context capacity %lld", (long long)c->max_cand);
+        DevProblem &d = c->h_probs[a];
+        memset(&d, 0, sizeof(d));
+        d.N = p->N; d.S = S; d.mode = p->mode; d.low_vel_mode = p->low_vel_mode; d.dt = p->dt;
+        memcpy(d.x0_lon, p->x0_lon, sizeof(d.x0_lon));
+        memcpy(d.x0_lat, p->x0_lat, sizeof(d.x0_lat));
+        d.x0_orientation = p->x0_orientation; d.v_des = p->v_des; d.veh = p->veh;
+        d.nT = p->nT; d.nV = p->nV; d.nD = p->nD; d.has_matrix = p->sampling_matrix != nullptr;
+        d.C = C; d.ld = ld; d.M = p->M; d.K = p->K; d.P = p->P; d.n_cost = p->n_cost; d.n_dto = p->n_dto;
+        bool extra = false;
+        for (int n = 0; n < p->n_cost; n++) {
+            d.cost_id[n] = p->cost_id[n];
+            d.cost_w[n] = p->cost_w[n];
+            const int id = p->cost_id[n];
+            extra |= id == FX_COST_ACCELERATION || id == FX_COST_JERK || id == FX_COST_ORIENTATION_OFFSET ||
+                     id == FX_COST_PATH_LENGTH || id == FX_COST_DISTANCE_TO_OBSTACLES;
+        }
+        memcpy(d.simpson_corr, p->simpson_corr, sizeof(d.simpson_corr));
+        bool ok = true;
+        d.tpow = ar.put(p->tpow, (size_t)5 * S, &ok);
+        if (d.has_matrix) {
+            d.matrix = ar.put(p->sampling_matrix, (size_t)13 * C, &ok);
+        } else {
+            d.t_samp = ar.put(p->t_samp, p->nT, &ok);
+            d.v_samp = ar.put(p->v_samp, p->nV, &ok);
+            d.d_samp = ar.put(p->d_samp, p->nD, &ok);
+        }
+        {   // reference knots, AoS: pos, theta, curv, curv_d, x, y, nx, ny
+            const double *dev = nullptr;
+            double *h = ar.host_slot<double>((size_t)p->M * FX_REF_FIELDS, &dev, &ok);
+            if (h) {
+                for (int k = 0; k < p->M; k++) {
+                    double *q = h + (size_t)k * FX_REF_FIELDS;
+                    q[0] = p->ref_pos[k]; q[1] = p->ref_theta[k]; q[2] = p->ref_curv[k]; q[3] = p->ref_curv_d[k];
+                    q[4] = p->ref_x[k]; q[5] = p->ref_y[k]; q[6] = p->ref_nx[k]; q[7] = p->ref_ny[k];
+                }
+            }
+            d.ref = dev;
+        }
+        if (p->K > 0) {
+            d.obs_pos = ar.put(p->obs_pos, (size_t)2 * p->K * p->P, &ok);
+            d.obs_cov_inv = ar.put(p->obs_cov_inv, (size_t)4 * p->K * p->P, &ok);
+            d.obs_npred = ar.put(p->obs_npred, p->K, &ok);
+            if (p->obs_hull && p->obs_nhull) {
+                d.obs_hull = ar.put(p->obs_hull, (size_t)6 * p->K * (p->P - 1), &ok);
+                d.obs_nhull = ar.put(p->obs_nhull, p->K, &ok);
+            } else {
+                d.mode &= ~FX_MODE_COLLISION;
+            }
+        } else {
+            d.mode &= ~FX_MODE_COLLISION;
+        }
+        if (p->n_dto > 0) d.dto_pos = ar.put(p->dto_pos, (size_t)2 * p->n_dto, &ok);
+        if (!ok) return set_err(FX_ERR_CAPACITY, "input arena too small (%zu bytes)", c->in_bytes);
+        d.cost = c->d_cost + cand_off;
+        d.flags = c->d_flags + cand_off;
+        d.costmap = c->d_costmap + (size_t)FX_NUM_COSTS * cand_off;  // [n_cost][ld] inside this agent's slab
+        d.coeffs = c->d_coeffs + (size_t)12 * cand_off;
+        d.traj_len = c->d_trajlen + cand_off;
+        d.n_blocks = (int)((C + FX_BLOCK - 1) / FX_BLOCK);
+        d.part_cost = c->d_part_cost + block_off;
+        d.part_idx = c->d_part_idx + block_off;
+        d.counters = c->d_counters + (size_t)a * FX_CNT_COUNT;
+        if (d.mode & FX_MODE_WRITE_BUNDLE) {
+            d.planes = reinterpret_cast<double *>(planes_need);  // offset for now, patched below
+            planes_need += sizeof(double) * FX_NUM_PLANES * (size_t)S * (size_t)ld;
+            c->any_bundle = true;
+        }
+        c->any_obst |= p->K > 0;
+        c->any_extra |= extra;
+        c->max_blocks_step = std::max(c->max_blocks_step, d.n_blocks);
+        c->M_max_step = std::max(c->M_max_step, p->M);
+        FxAgentSlot &sl = c->slots[a];
+        sl.C = C; sl.ld = ld; sl.cand_off = cand_off; sl.S = S; sl.n_cost = p->n_cost; sl.n_blocks = d.n_blocks; sl.mode = d.mode;
+        cand_off += ld;
+        block_off += d.n_blocks;
+    }
+    if (planes_need) {
+        int rc = ensure_planes(c, planes_need);
+        if (rc) return rc;
+        for (int a = 0; a < n_agents; a++)
+            if (c->h_probs[a].mode & FX_MODE_WRITE_BUNDLE)
+                c->h_probs[a].planes = reinterpret_cast<double *>(reinterpret_cast<char *>(c->d_planes) +
+                                                                  reinterpret_cast<size_t>(c->h_probs[a].planes));
+    }
+    c->n_agents = n_agents;
+    HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, ar.off, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_probs, c->h_probs, sizeof(DevProblem) * n_agents, hipMemcpyHostToDevice, c->stream));
+    c->uploaded = true;
+    return FX_OK;
+}
+
+int32_t fx_upload(FxContext *c, const FxProblem *prob) { return fx_upload_batch(c, 1, prob); }
+
+int32_t fx_evaluate(FxContext *c) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (!c->uploaded) return set_err(FX_ERR_NOT_READY, "fx_evaluate before fx_upload");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * FX_CNT_COUNT * c->n_agents, c->stream));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (c->max_blocks_step > 0)
+        HIP_TRY(fx_launch_eval(c->d_probs, c->n_agents, c->max_blocks_step, c->M_max_step, c->any_bundle, c->any_obst,
+                               c->any_extra, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
+    HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(unsigned long long) * FX_CNT_COUNT * c->n_agents,
+                           hipMemcpyDeviceToHost, c->stream));
+    c->evaluated = true;
+    return FX_OK;
+}
+
+int32_t fx_finish_batch(FxContext *c, FxResult *res) {
+    if (!c || !res) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_finish: NULL argument");
+    if (!c->evaluated) return set_err(FX_ERR_NOT_READY, "fx_finish before fx_evaluate");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    HIP_TRY(hipEventElapsedTime(&c->last_eval_ms, c->ev0, c->ev_mid));
+    for (int a = 0; a < c->n_agents; a++) {
+        const unsigned long long *cn = c->h_counters + (size_t)a * FX_CNT_COUNT;
+        FxResult &r = res[a];
+        memset(&r, 0, sizeof(r));
+        r.n_candidates = c->slots[a].C;
+        r.n_returned = (int64_t)cn[FX_CNT_RETURNED];
+        r.n_feasible = (int64_t)cn[FX_CNT_FEASIBLE];
+        r.n_infeasible = r.n_returned - r.n_feasible;
+        for (int k = 0; k < FX_NUM_REASONS; k++) r.reason_hist[k] = (int64_t)cn[FX_CNT_HIST0 + k];
+        r.best_index = cn[FX_CNT_BEST_IDX] == ~0ULL ? -1 : (int64_t)cn[FX_CNT_BEST_IDX];
+        double bc;
+        memcpy(&bc, &cn[FX_CNT_BEST_COST], sizeof(bc));
+        r.best_cost = r.best_index < 0 ? 0.0 : bc;
+        r.n_collisions = (int64_t)cn[FX_CNT_COLLISIONS];
+        r.feasible_percentage = r.n_returned ? 100.0 * ((double)r.n_feasible / (double)r.n_returned) : 0.0;
+        r.kernel_ms = c->last_ms;
+    }
+    return FX_OK;
+}
+
+int32_t fx_finish(FxContext *c, FxResult *res) { return fx_finish_batch(c, res); }
+
+int32_t fx_plan_step(FxContext *c, const FxProblem *prob, FxResult *res) {
+    int rc = fx_upload(c, prob);
+    if (rc) return rc;
+    if ((rc = fx_evaluate(c))) return rc;
+    return fx_finish(c, res);
+}
+
+// ---- read-back ----
+static int check_agent(FxContext *c, int a) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (!c->evaluated) return set_err(FX_ERR_NOT_READY, "no evaluated plan step");
+    if (a < 0 || a >= c->n_agents) return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d out of range", a);
+    return FX_OK;
+}
+
+int32_t fx_read_costs_agent(FxContext *c, int32_t agent, double *cost, uint32_t *flags) {
+    int rc = check_agent(c, agent);
+    if (rc) return rc;
+    const FxAgentSlot &s = c->slots[agent];
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (cost) HIP_TRY(hipMemcpy(cost, c->d_cost + s.cand_off, sizeof(double) * s.C, hipMemcpyDeviceToHost));
+    if (flags) HIP_TRY(hipMemcpy(flags, c->d_flags + s.cand_off, sizeof(uint32_t) * s.C, hipMemcpyDeviceToHost));
+    return FX_OK;
+}
+int32_t fx_read_costs(FxContext *c, double *cost, uint32_t *flags) { return fx_read_costs_agent(c, 0, cost, flags); }
+
+int32_t fx_read_costmap_agent(FxContext *c, int32_t agent, double *raw) {
+    int rc = check_agent(c, agent);
+    if (rc) return rc;
+    const FxAgentSlot &s = c->slots[agent];
+    if (!(s.mode & FX_MODE_WRITE_COSTMAP)) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_COSTMAP");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy2D(raw, sizeof(double) * s.C, c->d_costmap + (size_t)FX_NUM_COSTS * s.cand_off, sizeof(double) * s.ld,
+                        sizeof(double) * s.C, s.n_cost, hipMemcpyDeviceToHost));
+    return FX_OK;
+}
+int32_t fx_read_costmap(FxContext *c, double *raw) { return fx_read_costmap_agent(c, 0, raw); }
+
+int32_t fx_read_coeffs_agent(FxContext *c, int32_t agent, int64_t index, double *lon6, double *lat6, int32_t *traj_len) {
+    int rc = check_agent(c, agent);
+    if (rc) return rc;
+    const FxAgentSlot &s = c->slots[agent];
+    if (!(s.mode & FX_MODE_WRITE_BUNDLE)) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_BUNDLE");
+    if (index < 0 || index >= s.C) return set_err(FX_ERR_INVALID_ARGUMENT, "candidate %lld out of range", (long long)index);
+    double tmp[12];
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy2D(tmp, sizeof(double), c->d_coeffs + (size_t)12 * s.cand_off + index, sizeof(double) * s.ld,
+                        sizeof(double), 12, hipMemcpyDeviceToHost));
+    if (lon6) memcpy(lon6, tmp, 6 * sizeof(double));
+    if (lat6) memcpy(lat6, tmp + 6, 6 * sizeof(double));
+    if (traj_len) HIP_TRY(hipMemcpy(traj_len, c->d_trajlen + s.cand_off + index, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return FX_OK;
+}
+int32_t fx_read_coeffs(FxContext *c, int64_t index, double *lon6, double *lat6, int32_t *traj_len) {
+    return fx_read_coeffs_agent(c, 0, index, lon6, lat6, traj_len);
+}
+
+int32_t fx_read_sample_agent(FxContext *c, int32_t agent, int64_t index, double *planes) {
+    int rc = check_agent(c, agent);
+    if (rc) return rc;
+    const FxAgentSlot &s = c->slots[agent];
+    if (!(s.mode & FX_MODE_WRITE_BUNDLE)) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_BUNDLE");
+    if (index < 0 || index >= s.C) return set_err(FX_ERR_INVALID_ARGUMENT, "candidate %lld out of range", (long long)index);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // one strided gather: 14*S elements, pitch = ld doubles
+    HIP_TRY(hipMemcpy2D(planes, sizeof(double), c->h_probs[agent].planes + index, sizeof(double) * s.ld, sizeof(double),
+                        (size_t)FX_NUM_PLANES * s.S, hipMemcpyDeviceToHost));
+    return FX_OK;
+}
+int32_t fx_read_sample(FxContext *c, int64_t index, double *planes) { return fx_read_sample_agent(c, 0, index, planes); }
+
+int32_t fx_read_plane_agent(FxContext *c, int32_t agent, int32_t plane, double *out) {
+    int rc = check_agent(c, agent);
+    if (rc) return rc;
+    const FxAgentSlot &s = c->slots[agent];
+    if (!(s.mode & FX_MODE_WRITE_BUNDLE)) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_BUNDLE");
+    if (plane < 0 || plane >= FX_NUM_PLANES) return set_err(FX_ERR_INVALID_ARGUMENT, "plane %d out of range", plane);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy2D(out, sizeof(double) * s.C, c->h_probs[agent].planes + (size_t)plane * s.S * s.ld, sizeof(double) * s.ld,
+                        sizeof(double) * s.C, s.S, hipMemcpyDeviceToHost));
+    return FX_OK;
+}
+int32_t fx_read_plane(FxContext *c, int32_t plane, double *out) { return fx_read_plane_agent(c, 0, plane, out); }
+
+int32_t fx_topk_to_device(FxContext *c, int32_t k, void *d_cost, void *d_index) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (!c->evaluated) return set_err(FX_ERR_NOT_READY, "no evaluated plan step");
+    if (k < 1 || k > 64) return set_err(FX_ERR_INVALID_ARGUMENT, "k=%d outside [1,64]", k);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(fx_launch_topk(c->d_probs, c->n_agents, k, reinterpret_cast<double *>(d_cost), reinterpret_cast<long long *>(d_index),
+                           c->stream));
+    return FX_OK;
+}
+
+int32_t fx_read_topk_batch(FxContext *c, int32_t k, double *cost, int64_t *index) {
+    int rc = fx_topk_to_device(c, k, c->d_topk_cost, c->d_topk_idx);
+    if (rc) return rc;
+    const size_t n = (size_t)k * c->n_agents;
+    HIP_TRY(hipMemcpyAsync(c->h_topk_cost, c->d_topk_cost, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_topk_idx, c->d_topk_idx, sizeof(long long) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(cost, c->h_topk_cost, sizeof(double) * n);
+    for (size_t i = 0; i < n; i++) index[i] = (int64_t)c->h_topk_idx[i];
+    return FX_OK;
+}
+
+int32_t fx_read_topk(FxContext *c, int32_t k, double *cost, int64_t *index, int32_t *n_out) {
+    if (c && c->n_agents != 1) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_read_topk is single-agent; use fx_read_topk_batch");
+    int rc = fx_read_topk_batch(c, k, cost, index);
+    if (rc) return rc;
+    int n = 0;
+    while (n < k && index[n] >= 0) n++;
+    if (n_out) *n_out = n;
+    return FX_OK;
+}
+
+int32_t fx_build_obstacle_hulls(int32_t n_pred, const double *pos, const double *yaw, double length, double width,
+                                double *hull, int32_t *n_hull) {
+    if (!n_hull || (n_pred > 0 && (!pos || !yaw))) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_build_obstacle_hulls: NULL argument");
+    // collision_check.py:165-168: an obstacle with <= 2 predicted steps is skipped
+    if (n_pred <= 2) { *n_hull = 0; return FX_OK; }
+    if (!hull) return set_err(FX_ERR_INVALID_ARGUMENT, "hull output is NULL");
+    const double hl = length / 2, hw = width / 2;
+    for (int j = 0; j + 1 < n_pred; j++) {
+        const double c0x = pos[2 * j], c0y = pos[2 * j + 1], c1x = pos[2 * j + 2], c1y = pos[2 * j + 3];
+        const double u0x = std::cos(yaw[j]), u0y = std::sin(yaw[j]), u1x = std::cos(yaw[j + 1]), u1y = std::sin(yaw[j + 1]);
+        double mx = u0x + u1x, my = u0y + u1y;
+        double mn = std::sqrt(mx * mx + my * my);
+        double ex, ey;
+        if (mn < 1e-12) { ex = u0x; ey = u0y; } else { ex = mx / mn; ey = my / mn; }
+        const double fx = -ey, fy = ex;
+        double lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;
+        for (int b = 0; b < 2; b++) {
+            const double cx = b ? c1x : c0x, cy = b ? c1y : c0y, ux = b ? u1x : u0x, uy = b ? u1y : u0y;
+            const double p1 = cx * ex + cy * ey, p2 = cx * fx + cy * fy;
+            const double r1 = hl * std::fabs(ux * ex + uy * ey) + hw * std::fabs(-uy * ex + ux * ey);
+            const double r2 = hl * std::fabs(ux * fx + uy * fy) + hw * std::fabs(-uy * fx + ux * fy);
+            if (b == 0) { lo1 = p1 - r1; hi1 = p1 + r1; lo2 = p2 - r2; hi2 = p2 + r2; }
+            else {
+                lo1 = std::fmin(lo1, p1 - r1); hi1 = std::fmax(hi1, p1 + r1);
+                lo2 = std::fmin(lo2, p2 - r2); hi2 = std::fmax(hi2, p2 + r2);
+            }
+        }
+        const double m1 = 0.5 * (lo1 + hi1), m2 = 0.5 * (lo2 + hi2);
+        double *o = hull + 6 * j;
+        o[0] = m1 * ex + m2 * fx;
+        o[1] = m1 * ey + m2 * fy;
+        o[2] = ex;
+        o[3] = ey;
+        o[4] = 0.5 * (hi1 - lo1);
+        o[5] = 0.5 * (hi2 - lo2);
+    }
+    *n_hull = n_pred - 1;
+    return FX_OK;
+}
+
+int64_t fx_device_bytes(const FxContext *c) { return c ? c->dev_bytes : 0; }
+double fx_last_kernel_ms(const FxContext *c) { return c ? (double)c->last_ms : 0.0; }
+double fx_last_eval_kernel_ms(const FxContext *c) { return c ? (double)c->last_eval_ms : 0.0; }
+
+// device pointers of agent 0's outputs, for callers that keep working on the GPU (torch tensors via
+// from_blob-style wrapping or RCCL sends): cost f64[ld], flags u32[ld], planes f64[14][S][ld]
+int32_t fx_device_views(FxContext *c, int32_t agent, void **cost, void **flags, void **planes, int64_t *ld) {
+    int rc = check_agent(c, agent);
+    if (rc) return rc;
+    if (cost) *cost = c->h_probs[agent].cost;
+    if (flags) *flags = c->h_probs[agent].flags;
+    if (planes) *planes = (c->slots[agent].mode & FX_MODE_WRITE_BUNDLE) ? c->h_probs[agent].planes : nullptr;
+    if (ld) *ld = c->slots[agent].ld;
+    return FX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// fx_device.h -- device-side problem description shared by the kernels and the host API.
+//
+// One DevProblem per agent lives in device memory; every field is wave-uniform, so the kernels read it
+// with scalar loads.  Pointers are device pointers into the context's arenas.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fxplan.h"
+
+#define FX_BLOCK 256            // candidates per workgroup (4 wave64)
+#define FX_REF_FIELDS 8         // per knot: pos, theta, curv, curv_d, x, y, nx, ny  (64 B, AoS in LDS)
+#define FX_MAX_SAMPLES 128      // N+1 <= 128
+
+struct DevProblem {
+    // ---- scalars (FxProblem) ----
+    int32_t N, S;
+    uint32_t mode;
+    int32_t low_vel_mode;
+    double dt;
+    double x0_lon[3], x0_lat[3];
+    double x0_orientation, v_des;
+    FxVehicle veh;
+    int32_t nT, nV, nD;
+    int32_t has_matrix;
+    int64_t C;       // candidates of this agent
+    int64_t ld;      // leading dimension of every per-candidate output (C rounded up to 64)
+    int32_t M, K, P;
+    int32_t n_cost, n_dto;
+    int32_t cost_id[FX_NUM_COSTS];
+    double cost_w[FX_NUM_COSTS];
+    double simpson_corr[3];
+    // ---- inputs (device) ----
+    const double *tpow;        // [5][S]
+    const double *t_samp, *v_samp, *d_samp;
+    const double *matrix;      // [C][13] or null
+    const double *ref;         // [M][FX_REF_FIELDS]
+    const double *obs_pos;     // [K][P][2]
+    const double *obs_cov_inv; // [K][P][4]
+    const int32_t *obs_npred;  // [K]
+    const double *obs_hull;    // [K][P-1][6]
+    const int32_t *obs_nhull;  // [K]
+    const double *dto_pos;     // [n_dto][2]
+    // ---- outputs (device) ----
+    double *cost;              // [ld]
+    uint32_t *flags;           // [ld]
+    double *costmap;           // [n_cost][ld]      (FX_MODE_WRITE_COSTMAP)
+    double *planes;            // [14][S][ld]       (FX_MODE_WRITE_BUNDLE)
+    double *coeffs;            // [12][ld]          (FX_MODE_WRITE_BUNDLE)
+    int32_t *traj_len;         // [ld]              (FX_MODE_WRITE_BUNDLE)
+    // ---- selection scratch ----
+    double *part_cost;         // [n_blocks]
+    int64_t *part_idx;         // [n_blocks]
+    unsigned long long *counters; // [FX_CNT_COUNT]
+    int32_t n_blocks;
+};
+
+// counters[] layout
+enum {
+    FX_CNT_RETURNED = 0, FX_CNT_FEASIBLE, FX_CNT_HIST0, /* 11 entries */
+    FX_CNT_BEST_IDX = FX_CNT_HIST0 + FX_NUM_REASONS, FX_CNT_BEST_COST, FX_CNT_COLLISIONS, FX_CNT_COUNT
+};

@@ -1,0 +1,159 @@
+"""FrenetEngine: thin object wrapper over the C-ABI (one context = one planner's device state).
+
+Plays the role of `frenetix.TrajectoryHandler` behind reactive_planner_cpp.py:49,255-256,345-353: it takes
+the shared inputs of a plan step, runs the fused HIP pipeline and hands back the winner, counters and
+lazily-materialised per-candidate data.  Batched form (`plan_batch`) evaluates several agents in one launch
+(the GPU analogue of AgentBatch._step_agents, agent_batch.py:186-189).
+"""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from ._lib import check, lib
+from .problem import PlanInputs
+
+
+def build_obstacle_hulls(n_pred, pos, yaw, length, width) -> np.ndarray:
+    """OBB-sum hulls of consecutive predicted boxes (host helper of the library)."""
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    yaw = np.ascontiguousarray(yaw, dtype=np.float64)
+    out = np.zeros((max(int(n_pred) - 1, 1), 6))
+    n = C.c_int32(0)
+    check(lib().fx_build_obstacle_hulls(int(n_pred), pos.ctypes.data_as(C.POINTER(C.c_double)),
+                                        yaw.ctypes.data_as(C.POINTER(C.c_double)), float(length), float(width),
+                                        out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n)))
+    return out[:n.value]
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    lib().fx_device_count(C.byref(n))
+    return n.value
+
+
+class FrenetEngine:
+    def __init__(self, max_candidates: int, max_steps: int = 30, max_ref_knots: int = 1024, max_obstacles: int = 32,
+                 max_pred_steps: int = 64, device: int = 0, max_agents: int = 1):
+        self._ctx = C.c_void_p()
+        self._inputs: List[PlanInputs] = []
+        check(lib().fx_create_batch(C.byref(self._ctx), device, max_agents, int(max_candidates), int(max_steps),
+                                    int(max_ref_knots), int(max_obstacles), int(max_pred_steps)))
+        self.device = device
+        self.max_agents = max_agents
+
+    # -- lifetime --
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            lib().fx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream_ptr: int):
+        """Run on an external HIP stream (e.g. torch.cuda.current_stream().cuda_stream)."""
+        check(lib().fx_set_stream(self._ctx, C.c_void_p(hip_stream_ptr)))
+
+    # -- plan step, split so callers can overlap host work (upload/evaluate enqueue only) --
+    def upload(self, inputs):
+        batch = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
+        self._inputs = batch
+        arr = (_abi.FxProblem * len(batch))(*[b.as_struct() for b in batch])
+        self._structs = arr  # keep pointers alive until the copy has been enqueued (h2d staging is synchronous memcpy)
+        check(lib().fx_upload_batch(self._ctx, len(batch), arr))
+
+    def evaluate(self):
+        check(lib().fx_evaluate(self._ctx))
+
+    def finish(self):
+        n = len(self._inputs)
+        res = (_abi.FxResult * n)()
+        check(lib().fx_finish_batch(self._ctx, res))
+        out = [r.as_dict() for r in res]
+        return out
+
+    def plan_step(self, inputs: PlanInputs) -> dict:
+        self.upload(inputs)
+        self.evaluate()
+        return self.finish()[0]
+
+    def plan_batch(self, inputs: Sequence[PlanInputs]) -> List[dict]:
+        self.upload(list(inputs))
+        self.evaluate()
+        return self.finish()
+
+    # -- read-back --
+    def costs(self, agent: int = 0):
+        n = self._inputs[agent].n_candidates
+        cost = np.zeros(n)
+        flags = np.zeros(n, np.uint32)
+        check(lib().fx_read_costs_agent(self._ctx, agent, cost.ctypes.data_as(C.POINTER(C.c_double)),
+                                        flags.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return cost, flags
+
+    def costmap(self, agent: int = 0) -> np.ndarray:
+        """[C, n_cost] raw (unweighted) partial costs, columns in inputs.cost_names order."""
+        inp = self._inputs[agent]
+        raw = np.zeros((max(len(inp.cost_names), 1), inp.n_candidates))
+        check(lib().fx_read_costmap_agent(self._ctx, agent, raw.ctypes.data_as(C.POINTER(C.c_double))))
+        return np.ascontiguousarray(raw[:len(inp.cost_names)].T)
+
+    def coeffs(self, index: int, agent: int = 0):
+        lon, lat = np.zeros(6), np.zeros(6)
+        tl = C.c_int32(0)
+        check(lib().fx_read_coeffs_agent(self._ctx, agent, int(index), lon.ctypes.data_as(C.POINTER(C.c_double)),
+                                         lat.ctypes.data_as(C.POINTER(C.c_double)), C.byref(tl)))
+        return lon, lat, tl.value
+
+    def sample(self, index: int, agent: int = 0) -> np.ndarray:
+        """[14, S] planes of one candidate (gathered from the SoA bundle)."""
+        inp = self._inputs[agent]
+        out = np.zeros((_abi.FX_NUM_PLANES, inp.n_samples))
+        check(lib().fx_read_sample_agent(self._ctx, agent, int(index), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def plane(self, name_or_index, agent: int = 0) -> np.ndarray:
+        """[S, C] one plane of every candidate."""
+        inp = self._inputs[agent]
+        p = _abi.PLANE_INDEX[name_or_index] if isinstance(name_or_index, str) else int(name_or_index)
+        out = np.zeros((inp.n_samples, inp.n_candidates))
+        check(lib().fx_read_plane_agent(self._ctx, agent, p, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def bundle(self, agent: int = 0) -> np.ndarray:
+        """[C, 14, S] whole bundle (D2H of every plane; debugging / logging only)."""
+        return np.ascontiguousarray(np.stack([self.plane(p, agent) for p in range(_abi.FX_NUM_PLANES)]).transpose(2, 0, 1))
+
+    def topk(self, k: int):
+        n = len(self._inputs)
+        cost = np.zeros((n, k))
+        idx = np.zeros((n, k), np.int64)
+        check(lib().fx_read_topk_batch(self._ctx, int(k), cost.ctypes.data_as(C.POINTER(C.c_double)),
+                                       idx.ctypes.data_as(C.POINTER(C.c_int64))))
+        return cost, idx
+
+    def topk_to_device(self, k: int, d_cost_ptr: int, d_index_ptr: int):
+        check(lib().fx_topk_to_device(self._ctx, int(k), C.c_void_p(d_cost_ptr), C.c_void_p(d_index_ptr)))
+
+    @property
+    def device_bytes(self) -> int:
+        return int(lib().fx_device_bytes(self._ctx))
+
+    @property
+    def last_kernel_ms(self) -> float:
+        return float(lib().fx_last_kernel_ms(self._ctx))
+
+    @property
+    def last_eval_kernel_ms(self) -> float:
+        return float(lib().fx_last_eval_kernel_ms(self._ctx))

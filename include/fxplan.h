@@ -207,9 +207,30 @@ int32_t fx_build_obstacle_hulls(int32_t n_pred, const double *pos, const double 
                                 double length, double width, double *hull /*[n_pred-1][6]*/,
                                 int32_t *n_hull);
 
-/* ---- measurement hooks (bench.py): device bytes owned, last kernel time ---- */
+/* ---- multi-agent batching: several agents evaluated by ONE launch (grid.y = agent).  The reference steps
+ *      agents sequentially inside AgentBatch processes (cr_scenario_handler/simulation/agent_batch.py:186-189,
+ *      simulation.py:449-470); agents are independent given the frozen predictions, so the batch is a pure
+ *      concatenation.  max_candidates_total bounds the sum over agents.  res[n_agents]. ---- */
+int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int64_t max_candidates_total,
+                        int32_t max_steps, int32_t max_ref_knots, int32_t max_obstacles, int32_t max_pred_steps);
+int32_t fx_upload_batch(FxContext *ctx, int32_t n_agents, const FxProblem *probs);
+int32_t fx_finish_batch(FxContext *ctx, FxResult *res);
+int32_t fx_read_costs_agent(FxContext *ctx, int32_t agent, double *cost, uint32_t *flags);
+int32_t fx_read_costmap_agent(FxContext *ctx, int32_t agent, double *raw);
+int32_t fx_read_coeffs_agent(FxContext *ctx, int32_t agent, int64_t index, double *lon6, double *lat6, int32_t *traj_len);
+int32_t fx_read_sample_agent(FxContext *ctx, int32_t agent, int64_t index, double *planes);
+int32_t fx_read_plane_agent(FxContext *ctx, int32_t agent, int32_t plane, double *out);
+int32_t fx_read_topk_batch(FxContext *ctx, int32_t k, double *cost /*[n_agents][k]*/, int64_t *index /*[n_agents][k]*/);
+
+/* device pointers of one agent's outputs for callers that keep working on the GPU:
+ * cost f64[ld], flags u32[ld], planes f64[14][S][ld] (NULL without FX_MODE_WRITE_BUNDLE) */
+int32_t fx_device_views(FxContext *ctx, int32_t agent, void **cost, void **flags, void **planes, int64_t *ld);
+
+/* ---- measurement hooks (bench.py): device bytes owned; HIP-event time of the last step's device work
+ *      (evaluation + selection kernels) and of the evaluation kernel alone ---- */
 int64_t fx_device_bytes(const FxContext *ctx);
 double fx_last_kernel_ms(const FxContext *ctx);
+double fx_last_eval_kernel_ms(const FxContext *ctx);
 
 #ifdef __cplusplus
 }

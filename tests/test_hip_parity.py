@@ -1,0 +1,271 @@
+"""Parity of the HIP engine (through the C-ABI, libfxplan.so) against the CPU oracle on a real MI355X.
+
+Bit-exact on every index / mask / counter for candidates whose decisions are not taken by the last ulp
+(oracle margin >= FRAGILE, see tests/test_oracle_golden.py); floating-point planes within 1e-9 (the
+north-star bound on Cartesian states is 1e-6), costs within 1e-9 relative.
+"""
+import numpy as np
+import pytest
+
+from frenetix_motion_planner_amd import _abi, synthetic
+from tests.fixtures import golden_names, inputs_from_fixture, load_golden
+
+pytestmark = pytest.mark.gpu
+
+STATE_TOL = 1e-9
+COST_RTOL = 1e-9
+FRAGILE = 1e-9
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    e = FrenetEngine(max_candidates=120_000, max_steps=60, max_ref_knots=1024, max_obstacles=32, max_pred_steps=64,
+                     max_agents=8)
+    yield e
+    e.close()
+
+
+def hip_hulls():
+    from frenetix_motion_planner_amd.engine import build_obstacle_hulls
+    return build_obstacle_hulls
+
+
+def compare(eng, inp, out, res, *, check_planes=True, agent=0):
+    """out = oracle.plan_step(inp) ; res = engine result of the same inputs."""
+    robust = out["margin"] >= FRAGILE
+    n_frag = int((~robust).sum())
+    cost, flags = eng.costs(agent)
+    # masks / reasons, exact
+    for name, bit in (("valid", _abi.FX_FLAG_VALID), ("feasible", _abi.FX_FLAG_FEASIBLE),
+                      ("returned", _abi.FX_FLAG_RETURNED), ("costed", _abi.FX_FLAG_COSTED),
+                      ("selectable", _abi.FX_FLAG_SELECTABLE), ("collision", _abi.FX_FLAG_COLLISION)):
+        got = (flags & bit) != 0
+        assert np.array_equal(got[robust], out[name][robust]), name
+    got_reasons = (flags >> _abi.FX_REASON_SHIFT) & 0x7FF
+    assert np.array_equal(got_reasons[robust], out["reasons"][robust])
+    if n_frag == 0:
+        assert np.array_equal(flags, out["flags"])
+    # counters
+    ref = out["result"]
+    assert abs(res["n_returned"] - ref["n_returned"]) <= n_frag
+    assert abs(res["n_feasible"] - ref["n_feasible"]) <= n_frag
+    assert np.abs(np.array(res["reason_hist"]) - np.array(ref["reason_hist"])).max() <= n_frag
+    assert res["n_candidates"] == ref["n_candidates"]
+    # costs
+    c = out["costed"] & robust & ((flags & _abi.FX_FLAG_COSTED) != 0)
+    if c.any():
+        rel = np.abs(cost[c] - out["cost"][c]) / np.maximum(np.abs(out["cost"][c]), 1e-12)
+        assert rel.max() < COST_RTOL, f"cost rel err {rel.max()}"
+        if inp.write_costmap and len(inp.cost_names):
+            cm = eng.costmap(agent)
+            relm = np.abs(cm[c] - out["costmap"][c]) / np.maximum(np.abs(out["costmap"][c]), 1e-9)
+            assert relm.max() < 1e-8, f"costmap rel err {relm.max()}"
+    # winner: identical unless a fragile candidate or a sub-tolerance cost gap is involved
+    if res["best_index"] != ref["best_index"]:
+        a, b = res["best_index"], ref["best_index"]
+        involved = [g for g in (a, b) if g >= 0]
+        gap = abs(out["cost"][a] - out["cost"][b]) if a >= 0 and b >= 0 else np.inf
+        assert (not all(robust[g] for g in involved)) or gap < 1e-9 * max(1.0, abs(out["cost"][b])), (a, b, gap)
+    else:
+        if ref["best_index"] >= 0:
+            assert abs(res["best_cost"] - ref["best_cost"]) <= COST_RTOL * max(1.0, abs(ref["best_cost"]))
+        assert res["n_collisions"] == ref["n_collisions"] or n_frag > 0
+    # planes
+    if check_planes and inp.write_bundle:
+        stored = out["returned"] & robust & (out["costed"] | (inp.draw_traj_set))
+        got = eng.bundle(agent)
+        refp = out["planes"]
+        err = np.abs(got - refp) / (1.0 + np.abs(refp).max(axis=2, keepdims=True))
+        err[~stored] = 0
+        assert err.max() < STATE_TOL, f"plane err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+        # coefficients / traj_len of a few candidates
+        for g in np.linspace(0, inp.n_candidates - 1, 5).astype(int):
+            lon, lat, tl = eng.coeffs(int(g), agent)
+            assert np.allclose(lon, out["coeff_lon"][g], rtol=1e-13, atol=0)
+            assert np.allclose(lat, out["coeff_lat"][g], rtol=1e-13, atol=0)
+            assert tl == out["traj_len"][g]
+            assert np.array_equal(eng.sample(int(g), agent), got[g])
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_cases_vs_oracle(eng, name):
+    from oracle import oracle
+    fx = load_golden(name)
+    inp = inputs_from_fixture(fx, hip_hulls())
+    ref_inp = inputs_from_fixture(fx, oracle.build_obstacle_hulls)
+    if inp.obstacles["K"]:
+        assert np.allclose(inp.obstacles["hull"], ref_inp.obstacles["hull"], rtol=0, atol=1e-12)
+    out = oracle.plan_step(ref_inp)
+    res = eng.plan_step(inp)
+    compare(eng, inp, out, res)
+
+
+@pytest.mark.parametrize("name", ["arc_hv_l2_debug_obs5", "arc_lv_l1_debug", "short_ref_hv_l1_prod"])
+def test_golden_cases_vs_reference_vectors(eng, name):
+    """HIP output against the reference's own vectors directly (not via the oracle)."""
+    fx = load_golden(name)
+    inp = inputs_from_fixture(fx, hip_hulls(), collision=False)
+    res = eng.plan_step(inp)
+    cost, flags = eng.costs()
+    ids = fx["plane_ids"]
+    got = eng.bundle()[ids]
+    stored = fx["has_cart"][ids]
+    err = np.abs(got - fx["planes"]) / (1.0 + np.abs(fx["planes"]).max(axis=2, keepdims=True))
+    err[~stored] = 0
+    # a fragile candidate shows up as an O(1e-4) heading difference; everything else must be < 1e-6 (north star)
+    bad = (err.max(axis=(1, 2)) > 1e-6)
+    assert bad.mean() <= 1.0 / len(fx["v_order"]) + 0.05
+    assert err[~bad].max() < 1e-9
+    agree = ((flags & _abi.FX_FLAG_FEASIBLE) != 0)[fx["returned"]] == fx["feasible"][fx["returned"]]
+    assert agree.mean() >= 1 - (1.0 / len(fx["v_order"]) + 0.05)
+    if len(fx["walk_ids"]):
+        assert res["best_index"] == int(fx["walk_ids"][0])
+
+
+CASES = {
+    "dense_debug_obs": dict(ref_kind="arc", v0=10.0, grid=(9, 21, 21), n_obstacles=8, draw_traj_set=True, kinematic_debug=True),
+    "dense_prod_obs": dict(ref_kind="arc", v0=10.0, grid=(9, 21, 21), n_obstacles=20),
+    "dense_prod_scurve": dict(ref_kind="scurve", kappa=0.03, v0=13.0, grid=(7, 15, 17), n_obstacles=6, seed=7),
+    "dense_lowvel": dict(ref_kind="arc", v0=1.2, v_des=3.0, grid=(6, 11, 13), n_obstacles=3, seed=3),
+    "dense_horizon5": dict(ref_kind="arc", n_knots=700, v0=11.0, grid=(12, 9, 11), horizon=5.0, n_pred=50, n_obstacles=5,
+                           draw_traj_set=True, kinematic_debug=True),
+    "allcosts": dict(ref_kind="scurve", v0=9.0, grid=(5, 9, 9), n_obstacles=4, draw_traj_set=True, kinematic_debug=True,
+                     cost_weights=dict(acceleration=0.3, jerk=0.15, orientation_offset=0.4, path_length=0.05,
+                                       lateral_jerk=0.2, longitudinal_jerk=0.2, velocity_offset=1.0,
+                                       distance_to_reference_path=5.0, prediction=0.2)),
+    "ragged_tail": dict(ref_kind="arc", v0=10.0, grid=(3, 7, 13), n_obstacles=2),  # C not a multiple of 64
+    "single_candidate": dict(ref_kind="arc", v0=10.0, grid=(1, 1, 1), d0=0.0),
+    "no_costs": dict(ref_kind="arc", v0=10.0, grid=(3, 5, 5), cost_weights={}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_synthetic_cases_vs_oracle(eng, name):
+    from oracle import oracle
+    kw = CASES[name]
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    ref_inp = synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw)
+    out = oracle.plan_step(ref_inp)
+    res = eng.plan_step(inp)
+    compare(eng, inp, out, res)
+    if name == "dense_prod_obs":
+        # a meaningful share of otherwise-best candidates must collide
+        assert out["collision"].sum() > 0
+
+
+def test_sampling_matrix_mode_matches_ranges(eng):
+    kw = dict(ref_kind="arc", v0=10.0, grid=(5, 9, 11), n_obstacles=4)
+    a = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    b = synthetic.make_inputs(hull_builder=hip_hulls(), as_matrix=True, **kw)
+    ra = eng.plan_step(a)
+    ca, fa = eng.costs()
+    pa = eng.bundle()
+    rb = eng.plan_step(b)
+    cb, fb = eng.costs()
+    pb = eng.bundle()
+    assert np.array_equal(fa, fb) and np.array_equal(ca, cb) and np.array_equal(pa, pb)
+    for k in ("best_index", "best_cost", "n_returned", "n_feasible", "n_collisions", "reason_hist"):
+        assert ra[k] == rb[k]
+
+
+def test_select_only_mode_equals_bundle_mode(eng):
+    kw = dict(ref_kind="arc", v0=10.0, grid=(5, 9, 11), n_obstacles=4)
+    a = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    b = synthetic.make_inputs(hull_builder=hip_hulls(), write_bundle=False, write_costmap=False, **kw)
+    ra = eng.plan_step(a)
+    ca, fa = eng.costs()
+    rb = eng.plan_step(b)
+    cb, fb = eng.costs()
+    assert np.array_equal(fa, fb) and np.array_equal(ca, cb)
+    assert ra["best_index"] == rb["best_index"] and ra["best_cost"] == rb["best_cost"]
+    with pytest.raises(Exception):
+        eng.sample(0)
+
+
+def test_topk_is_sorted_prefix(eng):
+    from oracle import oracle
+    kw = dict(ref_kind="arc", v0=10.0, grid=(7, 13, 13), n_obstacles=10)
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    res = eng.plan_step(inp)
+    cost, flags = eng.costs()
+    k = 32
+    tc, ti = eng.topk(k)
+    ok = ((flags & _abi.FX_FLAG_SELECTABLE) != 0) & ((flags & _abi.FX_FLAG_COLLISION) == 0)
+    ids = np.nonzero(ok)[0]
+    order = ids[np.lexsort((ids, cost[ids]))][:k]
+    assert np.array_equal(ti[0][:len(order)], order)
+    assert np.array_equal(tc[0][:len(order)], cost[order])
+    assert ti[0][0] == res["best_index"]
+    assert np.all(ti[0][len(order):] == -1)
+
+
+def test_batch_of_agents_equals_individual_steps(eng):
+    kws = [dict(ref_kind="arc", v0=10.0, grid=(5, 9, 11), n_obstacles=4, seed=1),
+           dict(ref_kind="scurve", kappa=0.02, v0=6.0, grid=(4, 7, 9), n_obstacles=2, seed=2, draw_traj_set=True,
+                kinematic_debug=True),
+           dict(ref_kind="straight", v0=1.0, v_des=2.0, d0=0.0, grid=(3, 5, 5), seed=3),
+           dict(ref_kind="arc", n_knots=300, v0=15.0, grid=(6, 11, 9), n_obstacles=7, seed=4, write_bundle=False)]
+    inps = [synthetic.make_inputs(hull_builder=hip_hulls(), **kw) for kw in kws]
+    singles = []
+    for inp in inps:
+        r = eng.plan_step(inp)
+        singles.append((r, *eng.costs()))
+    batch = eng.plan_batch(inps)
+    for a, (r, c, f) in enumerate(singles):
+        cb, fb = eng.costs(a)
+        assert np.array_equal(c, cb) and np.array_equal(f, fb)
+        for k in ("best_index", "best_cost", "n_returned", "n_feasible", "n_collisions", "reason_hist", "n_candidates"):
+            assert batch[a][k] == r[k], (a, k)
+    assert np.array_equal(eng.sample(3, 1).shape, (14, 31))
+
+
+def test_error_conventions(eng):
+    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(2, 3, 3))
+    st = inp.as_struct()
+    st.N = 0
+    from frenetix_motion_planner_amd._lib import lib, check
+    import ctypes as C
+    res = _abi.FxResult()
+    with pytest.raises(ValueError):
+        check(lib().fx_plan_step(eng._ctx, C.byref(st), C.byref(res)))
+    big = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(19, 120, 120))
+    with pytest.raises(ValueError):  # capacity exceeded -> negative status -> ValueError
+        eng.plan_step(big)
+    # the context stays usable
+    assert eng.plan_step(inp)["n_candidates"] == inp.n_candidates
+
+
+def test_config2_full_size_properties():
+    """BASELINE config 2 at full size (50 388 x 31, no obstacles): size-independent properties."""
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    from oracle import oracle
+    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(19, 51, 51), hull_builder=hip_hulls())
+    assert inp.n_candidates == 50388
+    with FrenetEngine(max_candidates=inp.n_candidates) as e:
+        res = e.plan_step(inp)
+        cost, flags = e.costs()
+        sel = ((flags & _abi.FX_FLAG_SELECTABLE) != 0)
+        # winner is the lexicographic (cost, index) minimum of the selectable set
+        ids = np.nonzero(sel)[0]
+        best = ids[np.lexsort((ids, cost[ids]))][0]
+        assert res["best_index"] == best and res["best_cost"] == cost[best]
+        # counters are consistent with the flag words
+        assert res["n_returned"] == int(((flags & _abi.FX_FLAG_RETURNED) != 0).sum())
+        assert res["n_feasible"] == int((((flags & 3) == 3) & ((flags & _abi.FX_FLAG_RETURNED) != 0)).sum())
+        # idempotence
+        res2 = e.plan_step(inp)
+        c2, f2 = e.costs()
+        assert np.array_equal(c2, cost) and np.array_equal(f2, flags) and res2["best_index"] == res["best_index"]
+        # s is non-decreasing for valid candidates; kappa_dot is the first difference of kappa
+        s_pl, k_pl, kd_pl = e.plane("s"), e.plane("kappa"), e.plane("kappa_dot")
+        valid = (flags & _abi.FX_FLAG_VALID) != 0
+        assert np.all(np.diff(s_pl[:, valid], axis=0) >= -1e-4)
+        assert np.array_equal(kd_pl[1:], k_pl[1:] - k_pl[:-1])
+        # spot-check 600 candidates against the oracle
+        out = oracle.plan_step(synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(19, 51, 51)), want_planes=False)
+        robust = out["margin"] >= FRAGILE
+        assert np.array_equal(flags[robust], out["flags"][robust])
+        c = out["costed"] & robust
+        assert (np.abs(cost[c] - out["cost"][c]) / np.maximum(np.abs(out["cost"][c]), 1e-12)).max() < COST_RTOL
+        assert res["best_index"] == out["result"]["best_index"]
