@@ -153,6 +153,8 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_eval_kernel(const DevProblem *__r
     const bool KD = (P.mode & FX_MODE_KINEMATIC_DEBUG) != 0;
     const bool dbg = D || KD;
     const bool do_collision = OBST && (P.mode & FX_MODE_COLLISION) != 0;
+    // a batch launch is specialised for the union of its agents' modes; each agent still honours its own
+    const bool bundle = BUNDLE && (P.mode & FX_MODE_WRITE_BUNDLE) != 0;
     const double a_max = P.veh.a_max, kappa_max = P.veh.kappa_max, v_switch = P.veh.v_switch;
     const double v_des = P.v_des;
     const int64_t ld = P.ld;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_eval_kernel(const DevProblem *__r
     int traj_len = (int)ceil((T + dt) / dt);
     traj_len = traj_len > S ? S : (traj_len < 1 ? 1 : traj_len);
 
-    if (BUNDLE && active) {
+    if (bundle && active) {
         double *__restrict__ co = P.coeffs + g;
         co[0 * ld] = cl0; co[1 * ld] = cl1; co[2 * ld] = cl2; co[3 * ld] = cl3; co[4 * ld] = cl4; co[5 * ld] = 0.0;
         co[6 * ld] = ct0; co[7 * ld] = ct1; co[8 * ld] = ct2; co[9 * ld] = ct3; co[10 * ld] = ct4; co[11 * ld] = ct5;
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_eval_kernel(const DevProblem *__r
         }
 
         // -- SoA bundle (trajectories.py:56-334) --
-        if (BUNDLE && active) {
+        if (bundle && active) {
             double *__restrict__ row = planes + (int64_t)i * ld + g;
             const int64_t ps = (int64_t)S * ld;
             row[FX_PL_X * ps] = x_i;
