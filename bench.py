@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Frenet sampling-and-evaluation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): single agent, dense grid 19 x 51 x 52 = 50 388 candidates x 31 samples
+(30-step horizon), no obstacles, constant-curvature reference with 400 knots, default cost weights,
+materialised SoA TrajectoryBundle ("Mode B": every candidate's 14 planes written to HBM, as the reference's
+default `draw_traj_set` configuration keeps them).  `--workload config3` adds 20 predicted obstacles
+(prediction cost + OBB collision stage); `--select-only` drops the bundle ("Mode A").
+
+A step = one plan step of the hot path with the inputs already resident in HBM: evaluation kernel + selection
+kernel + (N > 1) top-k kernel and ONE RCCL all-gather of the per-GPU survivors, finished on the host (the
+winner is in host memory when the step ends).  For N > 1 the global grid is N x 50 388 candidates (the
+velocity range is sampled N times denser) and each rank evaluates a contiguous shard: weak scaling.
+
+Prints ONE JSON line (rank 0).  `value` = candidates evaluated by all ranks / wall time of the K timed steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+BYTES_PER_CAND_MODE_A = 40     # 3 x 8 B read + 8 B cost + 4 B flags + 4 B index
+GRID = (19, 51, 51)            # n_t, n_v, n_d (+ d0) -> 50 388
+
+
+def bundle_bytes_per_candidate(n_samples):
+    return 14 * n_samples * 8  # 3 472 B at 31 samples
+
+
+def make_workload(args, world):
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.engine import build_obstacle_hulls
+    n_obst = 20 if args.workload == "config3" else 0
+    grid = (GRID[0], GRID[1] * world, GRID[2])
+    return synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=grid, n_obstacles=n_obst, n_pred=30,
+                                 write_bundle=not args.select_only, write_costmap=not args.select_only,
+                                 draw_traj_set=False, kinematic_debug=False,
+                                 hull_builder=build_obstacle_hulls if n_obst else None)
+
+
+def cpu_baseline(args, seconds=12.0):
+    """The CPU oracle (scalar C port of the reference's algorithm, 1 thread) on the same workload, on this
+    box's host cores.  Reported, not optimised; a bounded sample of whole plan steps."""
+    from frenetix_motion_planner_amd import synthetic
+    from oracle import oracle
+    n_obst = 20 if args.workload == "config3" else 0
+    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=GRID, n_obstacles=n_obst, n_pred=30,
+                                hull_builder=oracle.build_obstacle_hulls if n_obst else None)
+    C = inp.n_candidates
+    oracle.plan_range(inp, 0, min(C, 2000))  # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    reps = 0
+    while time.perf_counter() - t0 < seconds:
+        oracle.plan_range(inp, 0, C)
+        done += C
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} whole plan steps of the same workload ({C} candidates x {inp.n_samples} samples) in {dt:.1f} s, "
+                      "oracle/fx_oracle.c single thread",
+            "cpu": _cpu_model(), "host_cores": os.cpu_count()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=["config2", "config3"], default="config2")
+    ap.add_argument("--select-only", action="store_true", help="Mode A: no SoA bundle write")
+    ap.add_argument("--topk", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} ...`",
+              file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible -- the engine has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+
+    inp = make_workload(args, world)
+    C_global = inp.n_candidates_global
+    eng = FrenetEngine(max_candidates=C_global // world + 64, max_steps=inp.N, max_ref_knots=1024, max_obstacles=32,
+                       max_pred_steps=64, device=local_rank)
+    ev = ShardedEvaluator(eng, k=args.topk)
+    ev.shard(inp)
+    C_local = inp.n_candidates
+    S = inp.n_samples
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        # inputs are resident: upload happened once; a step re-runs evaluation + selection (+ exchange)
+        if world == 1:
+            eng.evaluate()
+            return eng.finish()[0]
+        eng.evaluate()
+        eng.topk_to_device(ev.k, ev._cost.data_ptr(), ev._idx.data_ptr())
+        dist.all_gather_into_tensor(ev._gcost, ev._cost)
+        dist.all_gather_into_tensor(ev._gidx, ev._idx)
+        res = eng.finish()[0]
+        from frenetix_motion_planner_amd.distributed import merge_survivors
+        bc, bi, _ = merge_survivors(ev._gcost.cpu().numpy(), ev._gidx.cpu().numpy())
+        res["global_best_cost"], res["global_best_index"] = bc, bi
+        return res
+
+    eng.upload(inp)
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    lat, kern, evalk = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        res = step()
+        lat.append(time.perf_counter() - ts)
+        kern.append(eng.last_kernel_ms)
+        evalk.append(eng.last_eval_kernel_ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # device-throughput figure: K evaluations enqueued back to back, one sync (informational)
+    barrier()
+    tq = time.perf_counter()
+    for _ in range(args.steps):
+        eng.evaluate()
+    eng.finish()
+    torch.cuda.synchronize()
+    pipelined = time.perf_counter() - tq
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = C_global * args.steps / elapsed
+        eval_ms = float(np.mean(evalk))
+        per_cand = BYTES_PER_CAND_MODE_A + (0 if args.select_only else bundle_bytes_per_candidate(S))
+        if not args.select_only:
+            per_cand = bundle_bytes_per_candidate(S)  # SURVEY 8(d) Mode-B figure: 3 472 B / candidate at 31 samples
+        alg_bytes = per_cand * C_local
+        achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
+        out = {
+            "metric": "candidate trajectories/sec (30-step horizon)",
+            "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE {args.workload}: single agent, {C_local} candidates/GPU x {S} samples "
+                                   f"({GRID[0]}x{GRID[1]}x{GRID[2] + 1} grid per GPU), "
+                                   f"{'20 predicted obstacles (prediction cost + OBB collision)' if args.workload == 'config3' else 'no obstacles'}, "
+                                   f"{'select-only (Mode A)' if args.select_only else 'SoA TrajectoryBundle materialised (Mode B)'}",
+                       "candidates_global": C_global, "candidates_per_gpu": C_local, "samples": S,
+                       "reference_knots": int(inp.coordinate_system.ref_pos.shape[0]), "obstacles": int(inp.obstacles["K"]),
+                       "parallelism": f"candidate-shard x{world}, all-gather top-{args.topk}" if world > 1 else "single GPU"},
+            "plan_step_p50_ms": float(np.percentile(lat, 50) * 1e3), "plan_step_p95_ms": float(np.percentile(lat, 95) * 1e3),
+            "device_ms_per_step": float(np.mean(kern)), "eval_kernel_ms": eval_ms,
+            "pipelined_value": C_global * args.steps / pipelined,
+            "winner": {"index": int(res.get("global_best_index", res["best_index"])),
+                       "cost": float(res.get("global_best_cost", res["best_cost"])), "n_feasible_local": int(res["n_feasible"])},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fx_eval_kernel", "algorithmic_bytes_per_launch": alg_bytes,
+                         "bytes_per_candidate": per_cand, "avg_launch_ms": eval_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,6 +61,7 @@ class FxProblem(C.Structure):
         ("nT", C.c_int32), ("nV", C.c_int32), ("nD", C.c_int32),
         ("t_samp", _pd), ("v_samp", _pd), ("d_samp", _pd),
         ("sampling_matrix", _pd), ("n_rows", C.c_int64),
+        ("shard_begin", C.c_int64), ("shard_count", C.c_int64),
         ("M", C.c_int32),
         ("ref_x", _pd), ("ref_y", _pd), ("ref_nx", _pd), ("ref_ny", _pd),
         ("ref_pos", _pd), ("ref_theta", _pd), ("ref_curv", _pd), ("ref_curv_d", _pd),

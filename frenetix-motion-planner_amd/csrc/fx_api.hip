@@ -302,7 +302,12 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         int rc = validate(p);
         if (rc) return rc;
         const int S = p->N + 1;
-        const int64_t C = p->sampling_matrix ? p->n_rows : (int64_t)p->nT * p->nV * p->nD;
+        const int64_t C_global = p->sampling_matrix ? p->n_rows : (int64_t)p->nT * p->nV * p->nD;
+        if (p->shard_count < 0 || p->shard_begin < 0 || (p->shard_count > 0 && p->shard_begin + p->shard_count > C_global))
+            return set_err(FX_ERR_INVALID_ARGUMENT, "shard [%lld, +%lld) outside the grid of %lld candidates",
+                           (long long)p->shard_begin, (long long)p->shard_count, (long long)C_global);
+        const int64_t C = p->shard_count > 0 ? p->shard_count : C_global;
+        const int64_t g_base = p->shard_count > 0 ? p->shard_begin : 0;
         if (p->N > c->max_steps) return set_err(FX_ERR_CAPACITY, "N=%d exceeds context capacity %d", p->N, c->max_steps);
         if (p->M > c->max_knots) return set_err(FX_ERR_CAPACITY, "M=%d reference knots exceed capacity %d", p->M, c->max_knots);
         if (p->K > c->max_obs || (p->K > 0 && p->P > c->max_pred))
@@ -318,7 +323,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         memcpy(d.x0_lat, p->x0_lat, sizeof(d.x0_lat));
         d.x0_orientation = p->x0_orientation; d.v_des = p->v_des; d.veh = p->veh;
         d.nT = p->nT; d.nV = p->nV; d.nD = p->nD; d.has_matrix = p->sampling_matrix != nullptr;
-        d.C = C; d.ld = ld; d.M = p->M; d.K = p->K; d.P = p->P; d.n_cost = p->n_cost; d.n_dto = p->n_dto;
+        d.C = C; d.g_base = g_base; d.ld = ld; d.M = p->M; d.K = p->K; d.P = p->P; d.n_cost = p->n_cost; d.n_dto = p->n_dto;
         bool extra = false;
         for (int n = 0; n < p->n_cost; n++) {
             d.cost_id[n] = p->cost_id[n];
@@ -331,7 +336,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         bool ok = true;
         d.tpow = ar.put(p->tpow, (size_t)5 * S, &ok);
         if (d.has_matrix) {
-            d.matrix = ar.put(p->sampling_matrix, (size_t)13 * C, &ok);
+            d.matrix = ar.put(p->sampling_matrix, (size_t)13 * C_global, &ok);
         } else {
             d.t_samp = ar.put(p->t_samp, p->nT, &ok);
             d.v_samp = ar.put(p->v_samp, p->nV, &ok);

@@ -23,7 +23,8 @@ struct DevProblem {
     FxVehicle veh;
     int32_t nT, nV, nD;
     int32_t has_matrix;
-    int64_t C;       // candidates of this agent
+    int64_t C;       // candidates of this agent evaluated here (the shard)
+    int64_t g_base;  // global index of local candidate 0 (multi-GPU candidate sharding)
     int64_t ld;      // leading dimension of every per-candidate output (C rounded up to 64)
     int32_t M, K, P;
     int32_t n_cost, n_dto;

@@ -162,14 +162,15 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_eval_kernel(const DevProblem *__r
     // ---- candidate parameters (reactive_planner.py:149-171 / sampling matrix row) ----
     double T, s0, ss0, sss0, v1, a1, d0, dd0, ddd0, d1, dd1, ddd1;
     if (P.has_matrix) {
-        const double *__restrict__ r = P.matrix + 13 * g;
+        const double *__restrict__ r = P.matrix + 13 * (g + P.g_base);
         T = r[1] - r[0];
         s0 = r[2]; ss0 = r[3]; sss0 = r[4]; v1 = r[5]; a1 = r[6];
         d0 = r[7]; dd0 = r[8]; ddd0 = r[9]; d1 = r[10]; dd1 = r[11]; ddd1 = r[12];
     } else {
         const int nD = P.nD, nV = P.nV;
-        const int64_t q = g / nD;
-        const int id = (int)(g - q * nD);
+        const int64_t gg = g + P.g_base;
+        const int64_t q = gg / nD;
+        const int id = (int)(gg - q * nD);
         const int it = (int)(q / nV);
         const int iv = (int)(q - (int64_t)it * nV);
         T = P.t_samp[it];
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(FX_BLOCK) void fx_eval_kernel(const DevProblem *__r
     }
     const bool eligible = active && selectable && !(flags & FX_FLAG_COLLISION) && total == total;
     double bc = eligible ? total : INFINITY;
-    long long bi = eligible ? (long long)g : 0x7fffffffffffffffLL;
+    long long bi = eligible ? (long long)(g + P.g_base) : 0x7fffffffffffffffLL;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const double oc = __shfl_xor(bc, off);
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(1024) void fx_select_kernel(const DevProblem *__res
             const uint32_t f = P.flags[g];
             if ((f & FX_FLAG_SELECTABLE) && (f & FX_FLAG_COLLISION)) {
                 const double c = P.cost[g];
-                if (none || c < bc || (c == bc && g < bi)) cnt++;
+                if (none || c < bc || (c == bc && g + P.g_base < bi)) cnt++;
             }
         }
         for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
@@ -629,8 +630,9 @@ __global__ __launch_bounds__(1024) void fx_topk_kernel(const DevProblem *__restr
             const uint32_t f = P.flags[g];
             if ((f & FX_FLAG_SELECTABLE) && !(f & FX_FLAG_COLLISION)) {
                 const double c = P.cost[g];
-                const bool after = c > lb_c || (c == lb_c && (long long)g > lb_i);
-                if (after && (c < bc || (c == bc && (long long)g < bi))) { bc = c; bi = g; }
+                const long long gg = (long long)(g + P.g_base);
+                const bool after = c > lb_c || (c == lb_c && gg > lb_i);
+                if (after && (c < bc || (c == bc && gg < bi))) { bc = c; bi = gg; }
             }
         }
         for (int off = 32; off >= 1; off >>= 1) {

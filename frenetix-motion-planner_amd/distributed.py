@@ -1,0 +1,140 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed over RCCL (backend "nccl").
+
+The reference has no collective at all -- its only parallelism is multiprocessing fan-out of candidate chunks
+(reactive_planner.py:197-224) and of agent batches (simulation.py:449-470, agent_batch.py:186-189), with
+results pickled back through Queues.  Candidates are independent given the shared inputs and agents are
+independent given the frozen predictions, so the MI355X-native form is:
+
+  * every rank receives the same (small) shared inputs,
+  * candidate sharding: rank r evaluates the contiguous global range shard_range(C, r, W) -- contiguous so
+    that the (cost, global index) tie-break of the stable sort (trajectories.py:560) is preserved,
+  * agent sharding: rank r evaluates agents a with a % W == r in one batched launch,
+  * ONE all-gather per plan step of each rank's k best collision-free survivors (cost f64, global index i64)
+    -- 16*k bytes per rank per agent, latency-bound over xGMI --
+  * every rank then takes the same lexicographic (cost, index) minimum.
+
+k > 1 survivors are exchanged so the host-side road-boundary walk (planner.py:362-390) can step past a
+rejected winner without another evaluation.
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """(begin, count) of rank's contiguous share of n items; the first n % world ranks get one more."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("bad rank/world")
+    base, rem = divmod(int(n), world)
+    begin = rank * base + min(rank, rem)
+    return begin, base + (1 if rank < rem else 0)
+
+
+def agents_of_rank(n_agents: int, rank: int, world: int) -> List[int]:
+    return list(range(rank, n_agents, world))
+
+
+def merge_survivors(cost: np.ndarray, index: np.ndarray):
+    """Lexicographic (cost, index) minimum over gathered survivors; index < 0 marks an empty slot.
+    Returns (best_cost, best_index, order) with order = all valid survivors sorted."""
+    cost = np.asarray(cost, dtype=np.float64).reshape(-1)
+    index = np.asarray(index, dtype=np.int64).reshape(-1)
+    ok = index >= 0
+    if not ok.any():
+        return 0.0, -1, np.zeros(0, np.int64)
+    c, i = cost[ok], index[ok]
+    order = np.lexsort((i, c))
+    return float(c[order[0]]), int(i[order[0]]), i[order]
+
+
+class ShardedEvaluator:
+    """Candidate-sharded plan step.  `engine` is a FrenetEngine (or anything with plan_step / topk /
+    topk_to_device / set_stream); `group` a torch.distributed process group (None = default group, or
+    no distribution at all when torch.distributed is not initialised)."""
+
+    def __init__(self, engine, k: int = 8, group=None):
+        import torch
+        import torch.distributed as dist
+        self.engine, self.k, self.group = engine, int(k), group
+        self.dist = dist if dist.is_available() and dist.is_initialized() else None
+        self.rank = self.dist.get_rank(group) if self.dist else 0
+        self.world = self.dist.get_world_size(group) if self.dist else 1
+        backend = self.dist.get_backend(group) if self.dist else None
+        self.on_device = bool(self.dist) and backend == "nccl" and torch.cuda.is_available()
+        self.torch = torch
+        if self.on_device:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            # the engine enqueues on torch's current stream so RCCL sees the survivors in stream order
+            engine.set_stream(torch.cuda.current_stream().cuda_stream)
+            self._cost = torch.empty(self.k, dtype=torch.float64, device=dev)
+            self._idx = torch.empty(self.k, dtype=torch.int64, device=dev)
+            self._gcost = torch.empty(self.world * self.k, dtype=torch.float64, device=dev)
+            self._gidx = torch.empty(self.world * self.k, dtype=torch.int64, device=dev)
+
+    def shard(self, inputs):
+        begin, count = shard_range(inputs.n_candidates_global, self.rank, self.world)
+        inputs.shard = (begin, count) if self.world > 1 else None
+        return inputs
+
+    def plan_step(self, inputs) -> dict:
+        """Evaluate this rank's shard, exchange survivors, return the global winner (same on all ranks)."""
+        self.shard(inputs)
+        if self.world == 1:
+            res = self.engine.plan_step(inputs)
+            res["global_best_index"], res["global_best_cost"] = res["best_index"], res["best_cost"]
+            return res
+        if self.on_device:
+            self.engine.upload(inputs)
+            self.engine.evaluate()
+            self.engine.topk_to_device(self.k, self._cost.data_ptr(), self._idx.data_ptr())
+            self.dist.all_gather_into_tensor(self._gcost, self._cost, group=self.group)
+            self.dist.all_gather_into_tensor(self._gidx, self._idx, group=self.group)
+            res = self.engine.finish()[0]
+            gc, gi = self._gcost.cpu().numpy(), self._gidx.cpu().numpy()
+        else:
+            res = self.engine.plan_step(inputs)
+            c, i = self.engine.topk(self.k)
+            tc = self.torch.from_numpy(np.ascontiguousarray(c[0]))
+            ti = self.torch.from_numpy(np.ascontiguousarray(i[0]))
+            gcl = [self.torch.empty_like(tc) for _ in range(self.world)]
+            gil = [self.torch.empty_like(ti) for _ in range(self.world)]
+            self.dist.all_gather(gcl, tc, group=self.group)
+            self.dist.all_gather(gil, ti, group=self.group)
+            gc = self.torch.cat(gcl).numpy()
+            gi = self.torch.cat(gil).numpy()
+        best_c, best_i, order = merge_survivors(gc, gi)
+        res["global_best_cost"], res["global_best_index"], res["survivors"] = best_c, best_i, order
+        return res
+
+    def plan_agents(self, agent_inputs: Sequence) -> List[Optional[dict]]:
+        """Agent sharding: rank r evaluates agents r, r+W, ... in one batched launch; winners are
+        all-gathered so every rank knows every agent's (cost, index).  Returns a list over ALL agents of
+        dicts {best_cost, best_index} (plus the full local result for the rank's own agents)."""
+        n = len(agent_inputs)
+        mine = agents_of_rank(n, self.rank, self.world)
+        local = self.engine.plan_batch([agent_inputs[a] for a in mine]) if mine else []
+        per = (n + self.world - 1) // self.world
+        buf = np.full((per, 3), -1.0)
+        for j, a in enumerate(mine):
+            buf[j] = (a, local[j]["best_cost"], local[j]["best_index"])
+        if self.world == 1:
+            gathered = buf
+        else:
+            t = self.torch.from_numpy(buf)
+            if self.on_device:
+                t = t.cuda()
+                g = self.torch.empty((self.world * per, 3), dtype=t.dtype, device=t.device)
+                self.dist.all_gather_into_tensor(g, t, group=self.group)
+                gathered = g.cpu().numpy()
+            else:
+                gl = [self.torch.empty_like(t) for _ in range(self.world)]
+                self.dist.all_gather(gl, t, group=self.group)
+                gathered = self.torch.cat(gl).numpy()
+        out: List[Optional[dict]] = [None] * n
+        for row in gathered:
+            a = int(row[0])
+            if a >= 0:
+                out[a] = dict(best_cost=float(row[1]), best_index=int(row[2]))
+        for j, a in enumerate(mine):
+            out[a] = dict(local[j], **out[a])
+        return out

@@ -116,6 +116,8 @@ class PlanInputs:
     # packed predictions (pack_predictions) and distance_to_obstacles positions
     obstacles: Optional[dict] = None
     dto_pos: Optional[np.ndarray] = None
+    # candidate shard of the global grid handled by this engine (multi-GPU); None = everything
+    shard: Optional[tuple] = None
 
     def __post_init__(self):
         self.x0_lon = _f64(self.x0_lon)
@@ -150,10 +152,19 @@ class PlanInputs:
         return self.N + 1
 
     @property
-    def n_candidates(self) -> int:
+    def n_candidates_global(self) -> int:
         if self.sampling_matrix is not None:
             return int(self.sampling_matrix.shape[0])
         return int(len(self.t_samp) * len(self.v_samp) * len(self.d_samp))
+
+    @property
+    def n_candidates(self) -> int:
+        """candidates evaluated by this engine (the shard, or the whole grid)"""
+        return int(self.shard[1]) if self.shard is not None else self.n_candidates_global
+
+    @property
+    def shard_begin(self) -> int:
+        return int(self.shard[0]) if self.shard is not None else 0
 
     @property
     def mode(self) -> int:
@@ -208,4 +219,11 @@ class PlanInputs:
         p.obs_pos, p.obs_cov_inv, p.obs_npred = _ptr(o["pos"]), _ptr(o["cov_inv"]), _ptr(o["npred"], C.c_int32)
         p.obs_hull, p.obs_nhull = _ptr(o["hull"]), _ptr(o["nhull"], C.c_int32)
         p.n_dto, p.dto_pos = len(self._dto), _ptr(self._dto)
+        if self.shard is not None:
+            b, n = int(self.shard[0]), int(self.shard[1])
+            if b < 0 or n < 1 or b + n > self.n_candidates_global:
+                raise ValueError(f"shard [{b}, {b + n}) outside the grid of {self.n_candidates_global} candidates")
+            p.shard_begin, p.shard_count = b, n
+        else:
+            p.shard_begin, p.shard_count = 0, 0
         return p

@@ -112,6 +112,11 @@ typedef struct FxProblem {
      * when sampling_matrix != NULL; then nT/nV/nD are ignored and C = n_rows. */
     const double *sampling_matrix;
     int64_t n_rows;
+    /* candidate shard [shard_begin, shard_begin + shard_count) of the global grid evaluated by this
+     * context (multi-GPU candidate sharding); shard_count == 0 means the whole grid.
+     * Per-candidate outputs are indexed locally (0..shard_count), best_index / top-k stay global so
+     * that the (cost, index) tie-break is the same on every rank. */
+    int64_t shard_begin, shard_count;
 
     /* reference path: utils_coordinate_system.py:189-207 (ref_pos/ref_theta/ref_curv/ref_curv_d),
      * plus vertices and vertex normals for the projection (DESIGN.md "projection"). */

@@ -565,6 +565,7 @@ static int cmp_costidx(const void *a, const void *b) {
 }
 
 int64_t fxo_num_candidates(const FxProblem *p) {
+    if (p->shard_count > 0) return p->shard_count;
     return p->sampling_matrix ? p->n_rows : (int64_t)p->nT * p->nV * p->nD;
 }
 
@@ -590,13 +591,14 @@ int32_t fxo_plan_step(const FxProblem *p, double *coeff_lon, double *coeff_lat, 
     res->best_index = -1;
     res->best_cost = 0.0;
 
-    for (int64_t g = 0; g < C; g++) {
+    const int64_t g0 = p->shard_count > 0 ? p->shard_begin : 0;
+    for (int64_t g = 0; g < C; g++) { /* g: local index; g0 + g: index in the global grid */
         double *pl = planes ? planes + (size_t)g * FX_NUM_PLANES * S : pl_local;
         memset(pl, 0, sizeof(double) * FX_NUM_PLANES * S);
         Cand cd;
         double raw[FX_NUM_COSTS], total = 0.0;
         double mg = 1e300;
-        uint32_t f = eval_candidate(p, g, &cd, pl, raw, &total, &mg);
+        uint32_t f = eval_candidate(p, g0 + g, &cd, pl, raw, &total, &mg);
         if ((f & FX_FLAG_SELECTABLE) && (p->mode & FX_MODE_COLLISION) && p->K > 0) {
             if (ego_collides(p, pl + FX_PL_X * S, pl + FX_PL_Y * S, pl + FX_PL_THETA * S, &mg)) f |= FX_FLAG_COLLISION;
         }
@@ -626,7 +628,7 @@ int32_t fxo_plan_step(const FxProblem *p, double *coeff_lon, double *coeff_lat, 
         uint32_t f = flags[ci[j].i];
         if (!(f & FX_FLAG_SELECTABLE)) continue;
         if (f & FX_FLAG_COLLISION) { res->n_collisions++; continue; }
-        res->best_index = ci[j].i;
+        res->best_index = g0 + ci[j].i; /* global id */
         res->best_cost = ci[j].c;
         break;
     }
