@@ -17,9 +17,10 @@
 
 #include "fx_device.h"
 
-extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, int max_blocks, int M_max, bool bundle,
-                                     bool obst, bool extra, hipStream_t stream);
+extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, int max_blocks, size_t lds_bytes, int G,
+                                     bool bundle, bool obst, bool extra, int wpe, hipStream_t stream);
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, hipStream_t stream);
+extern "C" hipError_t fx_launch_math_test(int n, const double *x, double *at, double *sn, double *cs, hipStream_t stream);
 extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int k, double *out_cost, long long *out_idx,
                                      hipStream_t stream);
 
@@ -89,7 +90,9 @@ struct FxContext {
     int n_agents = 0;
     std::vector<FxAgentSlot> slots;
     bool uploaded = false, evaluated = false;
-    int max_blocks_step = 0, M_max_step = 0;
+    int max_blocks_step = 0, M_max_step = 0, S_max_step = 0;
+    int G_step = 1, wpe_step = 2;          // lanes per candidate / occupancy target of the current step
+    int G_force = 0, wpe_force = 0;        // fx_set_tuning overrides (0 = automatic)
     bool any_bundle = false, any_obst = false, any_extra = false;
     float last_ms = 0.f, last_eval_ms = 0.f;
     int64_t dev_bytes = 0;
@@ -228,7 +231,7 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     const int S = max_steps + 1;
     // every agent's leading dimension is rounded up to 64 candidates
     c->total_ld = (int64_t)align_up((size_t)max_candidates_total, 64) + 64 * (int64_t)max_agents;
-    c->max_blocks_total = c->total_ld / FX_BLOCK + max_agents + 1;
+    c->max_blocks_total = c->total_ld / (FX_BLOCK / 8) + max_agents + 1;  // G = 8: 32 candidates per workgroup
     c->in_bytes = (size_t)max_agents * input_bytes_for(0, S, max_ref_knots, max_obstacles, c->max_pred, false) +
                   align_up(sizeof(double) * 13 * (size_t)max_candidates_total, 256) + 4096;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_in), c->in_bytes, hipHostMallocDefault));
@@ -277,6 +280,18 @@ int32_t fx_destroy(FxContext *c) {
     return FX_OK;
 }
 
+int32_t fx_set_tuning(FxContext *c, int32_t lanes_per_candidate, int32_t waves_per_simd) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (lanes_per_candidate != 0 && lanes_per_candidate != 1 && lanes_per_candidate != 2 && lanes_per_candidate != 4 &&
+        lanes_per_candidate != 8)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "lanes_per_candidate must be 0 (auto), 1, 2, 4 or 8");
+    if (waves_per_simd != 0 && (waves_per_simd < 2 || waves_per_simd > 4))
+        return set_err(FX_ERR_INVALID_ARGUMENT, "waves_per_simd must be 0 (auto), 2, 3 or 4");
+    c->G_force = lanes_per_candidate;
+    c->wpe_force = waves_per_simd;
+    return FX_OK;
+}
+
 int32_t fx_set_stream(FxContext *c, void *hip_stream) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
@@ -292,11 +307,37 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     HIP_TRY(hipSetDevice(c->device));
     c->uploaded = c->evaluated = false;
     Arena ar{c->h_in, c->d_in, 0, c->in_bytes};
+    // lanes per candidate: split the horizon over G lanes while the step has too few candidates to give every
+    // SIMD of the chip (256 CUs x 4) a few waves; windowed (Simpson) costs need the whole horizon in one lane
+    {
+        int64_t waves1 = 0;
+        bool extra_any = false;
+        for (int a = 0; a < n_agents; a++) {
+            const FxProblem *p = &probs[a];
+            const int64_t Cg = p->shard_count > 0 ? p->shard_count : (p->sampling_matrix ? p->n_rows : (int64_t)p->nT * p->nV * p->nD);
+            waves1 += (Cg + 63) / 64;
+            for (int n = 0; n < p->n_cost && p->cost_id; n++) {
+                const int id = p->cost_id[n];
+                extra_any |= id == FX_COST_ACCELERATION || id == FX_COST_JERK || id == FX_COST_ORIENTATION_OFFSET ||
+                             id == FX_COST_PATH_LENGTH || id == FX_COST_DISTANCE_TO_OBSTACLES;
+            }
+        }
+        int G = 1;
+        if (waves1 < 3072) G = 2;
+        if (waves1 < 1536) G = 4;
+        if (waves1 < 384) G = 8;
+        if (c->G_force) G = c->G_force;
+        if (extra_any) G = 1;
+        c->G_step = G;
+        c->wpe_step = c->wpe_force ? c->wpe_force : (G > 1 ? 4 : 2);
+    }
+    const int CPB = FX_BLOCK / c->G_step;
     int64_t cand_off = 0, block_off = 0;
     size_t planes_need = 0;
     c->any_bundle = c->any_obst = c->any_extra = false;
     c->max_blocks_step = 0;
     c->M_max_step = 0;
+    c->S_max_step = 0;
     for (int a = 0; a < n_agents; a++) {
         const FxProblem *p = &probs[a];
         int rc = validate(p);
@@ -312,7 +353,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         if (p->M > c->max_knots) return set_err(FX_ERR_CAPACITY, "M=%d reference knots exceed capacity %d", p->M, c->max_knots);
         if (p->K > c->max_obs || (p->K > 0 && p->P > c->max_pred))
             return set_err(FX_ERR_CAPACITY, "obstacles K=%d P=%d exceed capacity %d x %d", p->K, p->P, c->max_obs, c->max_pred);
-        if ((size_t)p->M * FX_REF_FIELDS * sizeof(double) > 160 * 1024 - 1024)
+        if (((size_t)p->M * FX_REF_FIELDS + 5 * (size_t)S) * sizeof(double) > 160 * 1024 - 1024)
             return set_err(FX_ERR_CAPACITY, "reference with %d knots does not fit the 160 KiB LDS", p->M);
         const int64_t ld = (int64_t)align_up((size_t)std::max<int64_t>(C, 1), 64);
         if (cand_off + ld > c->total_ld) return set_err(FX_ERR_CAPACITY, "candidates exceed context capacity %lld", (long long)c->max_cand);
@@ -374,7 +415,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         d.costmap = c->d_costmap + (size_t)FX_NUM_COSTS * cand_off;  // [n_cost][ld] inside this agent's slab
         d.coeffs = c->d_coeffs + (size_t)12 * cand_off;
         d.traj_len = c->d_trajlen + cand_off;
-        d.n_blocks = (int)((C + FX_BLOCK - 1) / FX_BLOCK);
+        d.n_blocks = (int)((C + CPB - 1) / CPB);
         d.part_cost = c->d_part_cost + block_off;
         d.part_idx = c->d_part_idx + block_off;
         d.counters = c->d_counters + (size_t)a * FX_CNT_COUNT;
@@ -387,6 +428,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         c->any_extra |= extra;
         c->max_blocks_step = std::max(c->max_blocks_step, d.n_blocks);
         c->M_max_step = std::max(c->M_max_step, p->M);
+        c->S_max_step = std::max(c->S_max_step, S);
         FxAgentSlot &sl = c->slots[a];
         sl.C = C; sl.ld = ld; sl.cand_off = cand_off; sl.S = S; sl.n_cost = p->n_cost; sl.n_blocks = d.n_blocks; sl.mode = d.mode;
         cand_off += ld;
@@ -416,8 +458,9 @@ int32_t fx_evaluate(FxContext *c) {
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * FX_CNT_COUNT * c->n_agents, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (c->max_blocks_step > 0)
-        HIP_TRY(fx_launch_eval(c->d_probs, c->n_agents, c->max_blocks_step, c->M_max_step, c->any_bundle, c->any_obst,
-                               c->any_extra, c->stream));
+        HIP_TRY(fx_launch_eval(c->d_probs, c->n_agents, c->max_blocks_step,
+                               sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + 5 * (size_t)c->S_max_step), c->G_step,
+                               c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, c->stream));
     HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
     HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -608,6 +651,21 @@ int32_t fx_build_obstacle_hulls(int32_t n_pred, const double *pos, const double 
         o[5] = 0.5 * (hi2 - lo2);
     }
     *n_hull = n_pred - 1;
+    return FX_OK;
+}
+
+// self-test hook: atan / sin / cos of the device math kernels for n host values (synchronous)
+int32_t fx_math_selftest(int32_t n, const double *x, double *atan_out, double *sin_out, double *cos_out) {
+    if (n < 1 || !x || !atan_out || !sin_out || !cos_out) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_math_selftest: bad argument");
+    double *d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(double) * 4 * n));
+    HIP_TRY(hipMemcpy(d, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(fx_launch_math_test(n, d, d + n, d + 2 * n, d + 3 * n, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(atan_out, d + n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sin_out, d + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cos_out, d + 3 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d));
     return FX_OK;
 }
 

@@ -27,6 +27,15 @@ def build_obstacle_hulls(n_pred, pos, yaw, length, width) -> np.ndarray:
     return out[:n.value]
 
 
+def math_selftest(x: np.ndarray):
+    """(atan, sin, cos) of the device math kernels for the values in x."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    outs = [np.zeros_like(x) for _ in range(3)]
+    check(lib().fx_math_selftest(x.size, x.ctypes.data_as(C.POINTER(C.c_double)),
+                                 *[o.ctypes.data_as(C.POINTER(C.c_double)) for o in outs]))
+    return outs
+
+
 def device_count() -> int:
     n = C.c_int32(0)
     lib().fx_device_count(C.byref(n))
@@ -64,6 +73,10 @@ class FrenetEngine:
     def set_stream(self, hip_stream_ptr: int):
         """Run on an external HIP stream (e.g. torch.cuda.current_stream().cuda_stream)."""
         check(lib().fx_set_stream(self._ctx, C.c_void_p(hip_stream_ptr)))
+
+    def set_tuning(self, lanes_per_candidate: int = 0, waves_per_simd: int = 0):
+        """Override the automatic work decomposition (0 = automatic); results are unaffected."""
+        check(lib().fx_set_tuning(self._ctx, int(lanes_per_candidate), int(waves_per_simd)))
 
     # -- plan step, split so callers can overlap host work (upload/evaluate enqueue only) --
     def upload(self, inputs):

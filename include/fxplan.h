@@ -175,6 +175,9 @@ int32_t fx_create(FxContext **out, int32_t device, int64_t max_candidates, int32
                   int32_t max_ref_knots, int32_t max_obstacles, int32_t max_pred_steps);
 int32_t fx_destroy(FxContext *ctx);
 int32_t fx_set_stream(FxContext *ctx, void *hip_stream);
+/* tuning override (0 = automatic): lanes that share one candidate's horizon (1, 2, 4, 8) and the occupancy
+ * target in waves per SIMD (2..4) of the evaluation kernel.  Results do not depend on either. */
+int32_t fx_set_tuning(FxContext *ctx, int32_t lanes_per_candidate, int32_t waves_per_simd);
 
 /* ---- staging: copy the shared inputs of a plan step to the device (borrowed for the call).
  *      Replaces handler.generate_trajectories(matrix, low_vel_mode) + the functor registration
@@ -236,6 +239,8 @@ int32_t fx_device_views(FxContext *ctx, int32_t agent, void **cost, void **flags
 int64_t fx_device_bytes(const FxContext *ctx);
 double fx_last_kernel_ms(const FxContext *ctx);
 double fx_last_eval_kernel_ms(const FxContext *ctx);
+/* device self-test of the kernel's elementary functions (atan, sin, cos) on n host values */
+int32_t fx_math_selftest(int32_t n, const double *x, double *atan_out, double *sin_out, double *cos_out);
 
 #ifdef __cplusplus
 }

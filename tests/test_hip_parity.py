@@ -156,6 +156,41 @@ def test_synthetic_cases_vs_oracle(eng, name):
         assert out["collision"].sum() > 0
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8])
+@pytest.mark.parametrize("wpe", [2, 3, 4])
+@pytest.mark.parametrize("name", ["dense_debug_obs", "dense_prod_obs", "dense_lowvel", "dense_horizon5", "ragged_tail",
+                                  "single_candidate"])
+def test_work_decomposition_does_not_change_results(eng, name, lanes, wpe):
+    """Every (lanes per candidate, occupancy target) specialisation against the oracle."""
+    from oracle import oracle
+    kw = CASES[name]
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
+    eng.set_tuning(lanes, wpe)
+    try:
+        res = eng.plan_step(inp)
+        compare(eng, inp, out, res)
+    finally:
+        eng.set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("lanes", [2, 4, 8])
+@pytest.mark.parametrize("name", ["short_ref_hv_l1_debug", "arc_standstill_l1_debug", "arc_slow_brake_l1_kd",
+                                  "arc_hv_l2_debug_obs5", "scurve_hv_l2_kd"])
+def test_split_horizon_on_golden_cases(eng, name, lanes):
+    """Projection-domain exits, standstill heading carry and first-violation semantics across chunk borders."""
+    from oracle import oracle
+    fx = load_golden(name)
+    inp = inputs_from_fixture(fx, hip_hulls())
+    out = oracle.plan_step(inputs_from_fixture(fx, oracle.build_obstacle_hulls))
+    eng.set_tuning(lanes, 0)
+    try:
+        res = eng.plan_step(inp)
+        compare(eng, inp, out, res)
+    finally:
+        eng.set_tuning(0, 0)
+
+
 def test_sampling_matrix_mode_matches_ranges(eng):
     kw = dict(ref_kind="arc", v0=10.0, grid=(5, 9, 11), n_obstacles=4)
     a = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
