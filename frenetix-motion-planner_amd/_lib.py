@@ -64,7 +64,7 @@ def lib():
                             C.c_int32),
         "fx_destroy": ([vp], C.c_int32),
         "fx_set_stream": ([vp, vp], C.c_int32),
-        "fx_set_tuning": ([vp, C.c_int32, C.c_int32], C.c_int32),
+        "fx_set_tuning": ([vp, C.c_int32, C.c_int32, C.c_int32], C.c_int32),
         "fx_math_selftest": ([C.c_int32, pd, pd, pd, pd], C.c_int32),
         "fx_upload": ([vp, PP], C.c_int32),
         "fx_upload_batch": ([vp, C.c_int32, PP], C.c_int32),

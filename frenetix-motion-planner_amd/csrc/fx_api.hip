@@ -19,6 +19,8 @@
 
 extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, int max_blocks, size_t lds_bytes, int G,
                                      bool bundle, bool obst, bool extra, int wpe, hipStream_t stream);
+extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, size_t lds_bytes, int G,
+                                          bool bundle, bool obst, int wpe, hipStream_t stream);
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, hipStream_t stream);
 extern "C" hipError_t fx_launch_math_test(int n, const double *x, double *at, double *sn, double *cs, hipStream_t stream);
 extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int k, double *out_cost, long long *out_idx,
@@ -93,6 +95,9 @@ struct FxContext {
     int max_blocks_step = 0, M_max_step = 0, S_max_step = 0;
     int G_step = 1, wpe_step = 2;          // lanes per candidate / occupancy target of the current step
     int G_force = 0, wpe_force = 0;        // fx_set_tuning overrides (0 = automatic)
+    int variant_force = 0;                 // 0 auto, 1 generic kernel, 2 grid kernel
+    bool use_grid = false;                 // current step runs fx_eval_grid_kernel
+    size_t lds_step = 0;
     bool any_bundle = false, any_obst = false, any_extra = false;
     float last_ms = 0.f, last_eval_ms = 0.f;
     int64_t dev_bytes = 0;
@@ -280,15 +285,17 @@ int32_t fx_destroy(FxContext *c) {
     return FX_OK;
 }
 
-int32_t fx_set_tuning(FxContext *c, int32_t lanes_per_candidate, int32_t waves_per_simd) {
+int32_t fx_set_tuning(FxContext *c, int32_t lanes_per_candidate, int32_t waves_per_simd, int32_t kernel_variant) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     if (lanes_per_candidate != 0 && lanes_per_candidate != 1 && lanes_per_candidate != 2 && lanes_per_candidate != 4 &&
         lanes_per_candidate != 8)
         return set_err(FX_ERR_INVALID_ARGUMENT, "lanes_per_candidate must be 0 (auto), 1, 2, 4 or 8");
     if (waves_per_simd != 0 && (waves_per_simd < 2 || waves_per_simd > 4))
         return set_err(FX_ERR_INVALID_ARGUMENT, "waves_per_simd must be 0 (auto), 2, 3 or 4");
+    if (kernel_variant < 0 || kernel_variant > 2) return set_err(FX_ERR_INVALID_ARGUMENT, "kernel_variant must be 0 (auto), 1 (generic) or 2 (grid)");
     c->G_force = lanes_per_candidate;
     c->wpe_force = waves_per_simd;
+    c->variant_force = kernel_variant;
     return FX_OK;
 }
 
@@ -329,7 +336,24 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         if (c->G_force) G = c->G_force;
         if (extra_any) G = 1;
         c->G_step = G;
-        c->wpe_step = c->wpe_force ? c->wpe_force : (G > 1 ? 4 : 2);
+        c->wpe_step = c->wpe_force ? c->wpe_force : 2;
+        // grid kernel: sampling ranges, no windowed costs, and the longitudinal rows of a workgroup fit in LDS
+        const int cpb = FX_BLOCK / G;
+        bool grid_ok = !extra_any;
+        size_t lds_need = 0;
+        for (int a = 0; a < n_agents && grid_ok; a++) {
+            const FxProblem *p = &probs[a];
+            if (p->sampling_matrix || p->nD < 1) { grid_ok = false; break; }
+            const size_t n_pairs = (size_t)(cpb + p->nD - 2) / p->nD + 1;
+            const size_t S = (size_t)p->N + 1;
+            const size_t bytes = sizeof(double) * (((size_t)p->M * FX_REF_FIELDS + 5 * S + 1) & ~(size_t)1) + 128 * n_pairs * S;
+            lds_need = std::max(lds_need, bytes);
+        }
+        if (lds_need > 78 * 1024) grid_ok = false;   // keep 2 workgroups per CU (160 KiB LDS)
+        if (c->variant_force == 1) grid_ok = false;
+        if (c->variant_force == 2 && !grid_ok) return set_err(FX_ERR_INVALID_ARGUMENT, "grid kernel forced but not applicable");
+        c->use_grid = grid_ok;
+        c->lds_step = lds_need;
     }
     const int CPB = FX_BLOCK / c->G_step;
     int64_t cand_off = 0, block_off = 0;
@@ -458,9 +482,15 @@ int32_t fx_evaluate(FxContext *c) {
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * FX_CNT_COUNT * c->n_agents, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (c->max_blocks_step > 0)
-        HIP_TRY(fx_launch_eval(c->d_probs, c->n_agents, c->max_blocks_step,
-                               sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + 5 * (size_t)c->S_max_step), c->G_step,
-                               c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, c->stream));
+    {
+        if (c->use_grid)
+            HIP_TRY(fx_launch_eval_grid(c->d_probs, c->n_agents, c->max_blocks_step, c->lds_step, c->G_step, c->any_bundle,
+                                        c->any_obst, c->wpe_step, c->stream));
+        else
+            HIP_TRY(fx_launch_eval(c->d_probs, c->n_agents, c->max_blocks_step,
+                                   sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + 5 * (size_t)c->S_max_step),
+                                   c->G_step, c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, c->stream));
+    }
     HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
     HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));

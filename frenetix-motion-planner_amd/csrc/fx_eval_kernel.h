@@ -142,6 +142,193 @@ __device__ __forceinline__ uint32_t group_min(uint32_t v) {
     return v;
 }
 
+
+// Per-lane results of the horizon walk, handed to the shared epilogue.
+struct WalkResult {
+    bool neg, acc_viol, collided;
+    uint32_t step_reasons;  // dbg: OR of all violated checks
+    uint32_t first_key;     // !dbg: (step << 4 | reason) of the first violated check, 0xffffffff if none
+    int fail_step;          // first step of this lane's chunk outside the projection domain, INT_MAX if none
+    double sum_abs_d, sum_voff, pred, dto, d_end, v_end;
+    double cl3, cl4, ct3, ct4, ct5;
+    Simpson sim_acc, sim_jerk, sim_orient, sim_path;
+};
+
+// Combine the G lanes of a candidate, assemble the flag word exactly as check_feasibility does, form the weighted
+// cost, write the per-candidate outputs and contribute to the workgroup's counters and (cost, index) arg-min.
+template <int G, bool BUNDLE, bool OBST, bool EXTRA>
+__device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult &W, int64_t g, bool active, int part,
+                                                 int i_begin, int i_end, bool bundle, bool do_collision, bool dbg, bool D,
+                                                 double *red_cost, long long *red_idx, unsigned int *red_cnt) {
+    const int tid = threadIdx.x;
+    const int S = P.S, K = P.K, Pn = P.P;
+    const int64_t ld = P.ld;
+    const double dt = P.dt;
+    double *__restrict__ planes = P.planes;
+    const double *__restrict__ obs_pos = P.obs_pos;
+    const double *__restrict__ obs_cov_inv = P.obs_cov_inv;
+    const int32_t *__restrict__ obs_npred = P.obs_npred;
+    bool neg = W.neg, acc_viol = W.acc_viol, collided = W.collided;
+    uint32_t step_reasons = W.step_reasons, first_key = W.first_key;
+    int fail_step = W.fail_step;
+    double sum_abs_d = W.sum_abs_d, sum_voff = W.sum_voff, pred = W.pred, dto = W.dto, d_end = W.d_end, v_end = W.v_end;
+    const double cl3 = W.cl3, cl4 = W.cl4, ct3 = W.ct3, ct4 = W.ct4, ct5 = W.ct5;
+    Simpson &sim_acc = W.sim_acc, &sim_jerk = W.sim_jerk, &sim_orient = W.sim_orient, &sim_path = W.sim_path;
+
+    // ---- combine the G parts of a candidate ----
+    uint32_t bits = (neg ? 1u : 0u) | (acc_viol ? 2u : 0u) | (collided ? 4u : 0u);
+    if (G > 1) {
+        bits = group_or<G>(bits);
+        step_reasons = group_or<G>(step_reasons);
+        first_key = group_min<G>(first_key);
+        const uint32_t fail_all = group_min<G>((uint32_t)fail_step);
+        if (fail_all != 0x7fffffffu && (int)fail_all < i_begin) {
+            // an earlier part left the projection domain: every later (x, y) is 0 (the reference's loop breaks, :547)
+            if (bundle && active) {
+                const int64_t ps = (int64_t)S * ld;
+                for (int i = i_begin; i < i_end; i++) {
+                    double *__restrict__ row = planes + (int64_t)i * ld + g;
+                    row[FX_PL_X * ps] = 0.0;
+                    row[FX_PL_Y * ps] = 0.0;
+                }
+            }
+            if (OBST) {
+                pred = 0.0;
+                for (int i = max(i_begin, 1); i < i_end; i++)
+                    for (int k = 0; k < K; k++)
+                        if (i < obs_npred[k]) {
+                            const double *__restrict__ mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
+                            const double *__restrict__ iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
+                            const double e0 = 0.0 - mu[0], e1 = 0.0 - mu[1];
+                            const double r0 = e0 * iv[0] + e1 * iv[2], r1 = e0 * iv[1] + e1 * iv[3];
+                            const double m = r0 * e0 + r1 * e1;
+                            pred += 1.0 / (m * m);
+                        }
+            }
+        }
+        fail_step = (int)fail_all;
+        sum_abs_d = group_sum<G>(sum_abs_d);
+        sum_voff = group_sum<G>(sum_voff);
+        if (OBST) pred = group_sum<G>(pred);
+        d_end = group_sum<G>(d_end);  // only the part that owns step S-1 holds a non-zero value
+        v_end = group_sum<G>(v_end);
+    }
+    neg = bits & 1u; acc_viol = bits & 2u; collided = bits & 4u;
+    if (!dbg) step_reasons = first_key == 0xffffffffu ? 0u : (1u << (first_key & 15u));
+    const bool proj_ok = fail_step == 0x7fffffff;
+    const bool leader = part == 0;
+
+    // ---- flags: return-list membership and reasons exactly as check_feasibility assembles them ----
+    uint32_t flags = FX_FLAG_VALID | FX_FLAG_FEASIBLE;
+    uint32_t reasons = 0;
+    bool done = false;
+    if (neg) {
+        flags &= ~FX_FLAG_VALID;
+        reasons |= 1u << 10;
+        if (!dbg) done = true;  // dropped: `continue` at :353-354
+    }
+    if (!done && !D) {
+        if (acc_viol) { flags &= ~FX_FLAG_FEASIBLE; reasons |= 1u << 1; flags |= FX_FLAG_RETURNED; done = true; }
+        else if (neg) { flags &= ~FX_FLAG_FEASIBLE; reasons |= 1u << 2; flags |= FX_FLAG_RETURNED; done = true; }
+    }
+    if (!done) {
+        reasons |= step_reasons;
+        if (step_reasons) flags &= ~FX_FLAG_FEASIBLE;
+        if ((flags & FX_FLAG_FEASIBLE) || D) {
+            if (!proj_ok) { flags &= ~FX_FLAG_VALID; reasons |= 1u << 9; }
+            flags |= FX_FLAG_RETURNED;
+        }
+    }
+    bool costed, selectable;
+    if (D) {
+        costed = (flags & FX_FLAG_RETURNED) != 0;
+        selectable = costed && (flags & FX_FLAG_FEASIBLE);
+    } else {
+        costed = (flags & FX_FLAG_RETURNED) && (flags & FX_FLAG_VALID) && (flags & FX_FLAG_FEASIBLE);
+        selectable = costed;
+    }
+    if (costed) flags |= FX_FLAG_COSTED;
+    if (selectable) flags |= FX_FLAG_SELECTABLE;
+    if (selectable && do_collision && collided) flags |= FX_FLAG_COLLISION;
+    flags |= reasons << FX_REASON_SHIFT;
+
+    // ---- weighted cost sum in name-sorted order (cost_function.py:78-91) ----
+    double total = 0.0;
+    {
+        const double tt = dt, tt2 = tt * tt, tt3 = tt2 * tt, tt4 = tt3 * tt, tt5 = tt4 * tt;
+        const int n_cost = P.n_cost;
+        double sum = -0.0;
+        for (int n = 0; n < n_cost; n++) {
+            double c = 0.0;
+            switch (P.cost_id[n]) {
+            case FX_COST_DISTANCE_TO_REFERENCE_PATH: c = ((0.0 + sum_abs_d) + fabs(d_end) * 5) / S; break;
+            case FX_COST_LATERAL_JERK:  // squared_jerk_integral(dt) (polynomial_trajectory.py:172-191, cost :54)
+                c = (36 * ct3 * ct3 * tt + 144 * ct3 * ct4 * tt2 + 240 * ct3 * ct5 * tt3 + 192 * ct4 * ct4 * tt3 +
+                     720 * ct4 * ct5 * tt4 + 720 * ct5 * ct5 * tt5);
+                break;
+            case FX_COST_LONGITUDINAL_JERK:
+                c = (36 * cl3 * cl3 * tt + 144 * cl3 * cl4 * tt2 + 240 * cl3 * 0.0 * tt3 + 192 * cl4 * cl4 * tt3 +
+                     720 * cl4 * 0.0 * tt4 + 720 * 0.0 * 0.0 * tt5);
+                break;
+            case FX_COST_VELOCITY_OFFSET: {
+                const double e = v_end - P.v_des;
+                c = (0.0 + sum_voff) + fabs(e * e);
+                break;
+            }
+            case FX_COST_PREDICTION: c = OBST ? pred : 0.0; break;
+            case FX_COST_ACCELERATION: c = EXTRA ? sim_acc.finish(S, dt, P.simpson_corr) : 0.0; break;
+            case FX_COST_PATH_LENGTH: c = EXTRA ? sim_path.finish(S, dt, P.simpson_corr) : 0.0; break;
+            case FX_COST_JERK: c = EXTRA ? sim_jerk.finish(S - 1, dt, P.simpson_corr) : 0.0; break;
+            case FX_COST_ORIENTATION_OFFSET: c = EXTRA ? sim_orient.finish(S - 1, dt, P.simpson_corr) : 0.0; break;
+            case FX_COST_DISTANCE_TO_OBSTACLES: c = EXTRA ? dto : 0.0; break;
+            default: break;
+            }
+            if ((P.mode & FX_MODE_WRITE_COSTMAP) && active && leader) P.costmap[(int64_t)n * ld + g] = costed ? c : 0.0;
+            sum += P.cost_w[n] * c;
+        }
+        total = 0.0 + sum;
+    }
+    if (active && leader) {
+        P.cost[g] = costed ? total : 0.0;
+        P.flags[g] = flags;
+    }
+
+    // ---- workgroup reductions (candidate leaders only): counters and the (cost, index) arg-min partial ----
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool own = active && leader;
+    {
+        const bool ret = own && (flags & FX_FLAG_RETURNED);
+        const int n_ret = wave_count(ret);
+        const int n_feas = wave_count(ret && (flags & FX_FLAG_VALID) && (flags & FX_FLAG_FEASIBLE));
+        if (lane == 0) {
+            if (n_ret) atomicAdd(&red_cnt[0], (unsigned)n_ret);
+            if (n_feas) atomicAdd(&red_cnt[1], (unsigned)n_feas);
+        }
+        for (int r = 0; r < FX_NUM_REASONS; r++) {
+            const int n = wave_count(own && ((reasons >> r) & 1u));
+            if (lane == 0 && n) atomicAdd(&red_cnt[2 + r], (unsigned)n);
+        }
+    }
+    const bool eligible = own && selectable && !(flags & FX_FLAG_COLLISION) && total == total;
+    double bc = eligible ? total : INFINITY;
+    long long bi = eligible ? (long long)(g + P.g_base) : 0x7fffffffffffffffLL;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oc = __shfl_xor(bc, off);
+        const long long oi = __shfl_xor(bi, off);
+        if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+    }
+    if (lane == 0) { red_cost[wave] = bc; red_idx[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < FX_BLOCK / 64; w++)
+            if (red_cost[w] < bc || (red_cost[w] == bc && red_idx[w] < bi)) { bc = red_cost[w]; bi = red_idx[w]; }
+        P.part_cost[blockIdx.x] = bc;
+        P.part_idx[blockIdx.x] = bi;
+    }
+    if (tid < 2 + FX_NUM_REASONS && red_cnt[tid]) atomicAdd(&P.counters[tid], (unsigned long long)red_cnt[tid]);
+}
+
 }  // namespace fxk
 
 // ---------------------------------------------------------------------------------------------------
@@ -157,7 +344,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     using namespace fxk;
     static_assert(!EXTRA || G == 1, "windowed costs need the whole horizon in one lane");
     constexpr int CPB = FX_BLOCK / G;  // candidates per workgroup
-    extern __shared__ double lds_dyn[];  // [M][8] knots, then [5][S] time powers
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];  // [M][8] knots, then [5][S] time powers
     __shared__ double red_cost[FX_BLOCK / 64];
     __shared__ long long red_idx[FX_BLOCK / 64];
     __shared__ unsigned int red_cnt[2 + FX_NUM_REASONS];
@@ -314,7 +501,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
                     }
                     double d_j, dv_j, da_j;
                     if (j < traj_len) lat_at(j, s_j, d_j, dv_j, da_j); else { d_j = d_last; dv_j = 0.0; da_j = 0.0; }
-                    const double dp_j = dv_j / sv_j;
+                    const double dp_j = div_rcp(dv_j, sv_j, 1.0 / sv_j);
                     int lo = 0, hi = M;
                     while (lo < hi) { int mid = (lo + hi) >> 1; if (knots[mid].pos > s_j) hi = mid; else lo = mid + 1; }
                     const int j1 = lo == M ? 0 : lo, j0 = j1 == 0 ? M - 1 : j1 - 1;
@@ -384,7 +571,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
             const double r_sv = 1.0 / sv_i;
             dp = moving ? div_rcp(dv_i, sv_i, r_sv) : 0.;
             double ddot = da_i - dp * sa_i;
-            dpp = moving ? ddot / (sv_i * sv_i) : 0.;
+            const double sv2 = sv_i * sv_i, r_sv2 = 1.0 / sv2;
+            dpp = moving ? div_rcp(ddot, sv2, r_sv2) : 0.;
         } else {
             dp = dv_i;
             dpp = da_i;
@@ -553,156 +741,13 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
         kap_prev = kap;
     }
 
-    // ---- combine the G parts of a candidate ----
-    uint32_t bits = (neg ? 1u : 0u) | (acc_viol ? 2u : 0u) | (collided ? 4u : 0u);
-    if (G > 1) {
-        bits = group_or<G>(bits);
-        step_reasons = group_or<G>(step_reasons);
-        first_key = group_min<G>(first_key);
-        const uint32_t fail_all = group_min<G>((uint32_t)fail_step);
-        if (fail_all != 0x7fffffffu && (int)fail_all < i_begin) {
-            // an earlier part left the projection domain: every later (x, y) is 0 (the reference's loop breaks, :547)
-            if (bundle && active) {
-                const int64_t ps = (int64_t)S * ld;
-                for (int i = i_begin; i < i_end; i++) {
-                    double *__restrict__ row = planes + (int64_t)i * ld + g;
-                    row[FX_PL_X * ps] = 0.0;
-                    row[FX_PL_Y * ps] = 0.0;
-                }
-            }
-            if (OBST) {
-                pred = 0.0;
-                for (int i = max(i_begin, 1); i < i_end; i++)
-                    for (int k = 0; k < K; k++)
-                        if (i < obs_npred[k]) {
-                            const double *__restrict__ mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
-                            const double *__restrict__ iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
-                            const double e0 = 0.0 - mu[0], e1 = 0.0 - mu[1];
-                            const double r0 = e0 * iv[0] + e1 * iv[2], r1 = e0 * iv[1] + e1 * iv[3];
-                            const double m = r0 * e0 + r1 * e1;
-                            pred += 1.0 / (m * m);
-                        }
-            }
-        }
-        fail_step = (int)fail_all;
-        sum_abs_d = group_sum<G>(sum_abs_d);
-        sum_voff = group_sum<G>(sum_voff);
-        if (OBST) pred = group_sum<G>(pred);
-        d_end = group_sum<G>(d_end);  // only the part that owns step S-1 holds a non-zero value
-        v_end = group_sum<G>(v_end);
-    }
-    neg = bits & 1u; acc_viol = bits & 2u; collided = bits & 4u;
-    if (!dbg) step_reasons = first_key == 0xffffffffu ? 0u : (1u << (first_key & 15u));
-    const bool proj_ok = fail_step == 0x7fffffff;
-    const bool leader = part == 0;
-
-    // ---- flags: return-list membership and reasons exactly as check_feasibility assembles them ----
-    uint32_t flags = FX_FLAG_VALID | FX_FLAG_FEASIBLE;
-    uint32_t reasons = 0;
-    bool done = false;
-    if (neg) {
-        flags &= ~FX_FLAG_VALID;
-        reasons |= 1u << 10;
-        if (!dbg) done = true;  // dropped: `continue` at :353-354
-    }
-    if (!done && !D) {
-        if (acc_viol) { flags &= ~FX_FLAG_FEASIBLE; reasons |= 1u << 1; flags |= FX_FLAG_RETURNED; done = true; }
-        else if (neg) { flags &= ~FX_FLAG_FEASIBLE; reasons |= 1u << 2; flags |= FX_FLAG_RETURNED; done = true; }
-    }
-    if (!done) {
-        reasons |= step_reasons;
-        if (step_reasons) flags &= ~FX_FLAG_FEASIBLE;
-        if ((flags & FX_FLAG_FEASIBLE) || D) {
-            if (!proj_ok) { flags &= ~FX_FLAG_VALID; reasons |= 1u << 9; }
-            flags |= FX_FLAG_RETURNED;
-        }
-    }
-    bool costed, selectable;
-    if (D) {
-        costed = (flags & FX_FLAG_RETURNED) != 0;
-        selectable = costed && (flags & FX_FLAG_FEASIBLE);
-    } else {
-        costed = (flags & FX_FLAG_RETURNED) && (flags & FX_FLAG_VALID) && (flags & FX_FLAG_FEASIBLE);
-        selectable = costed;
-    }
-    if (costed) flags |= FX_FLAG_COSTED;
-    if (selectable) flags |= FX_FLAG_SELECTABLE;
-    if (selectable && do_collision && collided) flags |= FX_FLAG_COLLISION;
-    flags |= reasons << FX_REASON_SHIFT;
-
-    // ---- weighted cost sum in name-sorted order (cost_function.py:78-91) ----
-    double total = 0.0;
-    {
-        const double tt = dt, tt2 = tt * tt, tt3 = tt2 * tt, tt4 = tt3 * tt, tt5 = tt4 * tt;
-        const int n_cost = P.n_cost;
-        double sum = -0.0;
-        for (int n = 0; n < n_cost; n++) {
-            double c = 0.0;
-            switch (P.cost_id[n]) {
-            case FX_COST_DISTANCE_TO_REFERENCE_PATH: c = ((0.0 + sum_abs_d) + fabs(d_end) * 5) / S; break;
-            case FX_COST_LATERAL_JERK:  // squared_jerk_integral(dt) (polynomial_trajectory.py:172-191, cost :54)
-                c = (36 * ct3 * ct3 * tt + 144 * ct3 * ct4 * tt2 + 240 * ct3 * ct5 * tt3 + 192 * ct4 * ct4 * tt3 +
-                     720 * ct4 * ct5 * tt4 + 720 * ct5 * ct5 * tt5);
-                break;
-            case FX_COST_LONGITUDINAL_JERK:
-                c = (36 * cl3 * cl3 * tt + 144 * cl3 * cl4 * tt2 + 240 * cl3 * 0.0 * tt3 + 192 * cl4 * cl4 * tt3 +
-                     720 * cl4 * 0.0 * tt4 + 720 * 0.0 * 0.0 * tt5);
-                break;
-            case FX_COST_VELOCITY_OFFSET: {
-                const double e = v_end - P.v_des;
-                c = (0.0 + sum_voff) + fabs(e * e);
-                break;
-            }
-            case FX_COST_PREDICTION: c = OBST ? pred : 0.0; break;
-            case FX_COST_ACCELERATION: c = EXTRA ? sim_acc.finish(S, dt, P.simpson_corr) : 0.0; break;
-            case FX_COST_PATH_LENGTH: c = EXTRA ? sim_path.finish(S, dt, P.simpson_corr) : 0.0; break;
-            case FX_COST_JERK: c = EXTRA ? sim_jerk.finish(S - 1, dt, P.simpson_corr) : 0.0; break;
-            case FX_COST_ORIENTATION_OFFSET: c = EXTRA ? sim_orient.finish(S - 1, dt, P.simpson_corr) : 0.0; break;
-            case FX_COST_DISTANCE_TO_OBSTACLES: c = EXTRA ? dto : 0.0; break;
-            default: break;
-            }
-            if ((P.mode & FX_MODE_WRITE_COSTMAP) && active && leader) P.costmap[(int64_t)n * ld + g] = costed ? c : 0.0;
-            sum += P.cost_w[n] * c;
-        }
-        total = 0.0 + sum;
-    }
-    if (active && leader) {
-        P.cost[g] = costed ? total : 0.0;
-        P.flags[g] = flags;
-    }
-
-    // ---- workgroup reductions (candidate leaders only): counters and the (cost, index) arg-min partial ----
-    const int lane = tid & 63, wave = tid >> 6;
-    const bool own = active && leader;
-    {
-        const bool ret = own && (flags & FX_FLAG_RETURNED);
-        const int n_ret = wave_count(ret);
-        const int n_feas = wave_count(ret && (flags & FX_FLAG_VALID) && (flags & FX_FLAG_FEASIBLE));
-        if (lane == 0) {
-            if (n_ret) atomicAdd(&red_cnt[0], (unsigned)n_ret);
-            if (n_feas) atomicAdd(&red_cnt[1], (unsigned)n_feas);
-        }
-        for (int r = 0; r < FX_NUM_REASONS; r++) {
-            const int n = wave_count(own && ((reasons >> r) & 1u));
-            if (lane == 0 && n) atomicAdd(&red_cnt[2 + r], (unsigned)n);
-        }
-    }
-    const bool eligible = own && selectable && !(flags & FX_FLAG_COLLISION) && total == total;
-    double bc = eligible ? total : INFINITY;
-    long long bi = eligible ? (long long)(g + P.g_base) : 0x7fffffffffffffffLL;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double oc = __shfl_xor(bc, off);
-        const long long oi = __shfl_xor(bi, off);
-        if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
-    }
-    if (lane == 0) { red_cost[wave] = bc; red_idx[wave] = bi; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < FX_BLOCK / 64; w++)
-            if (red_cost[w] < bc || (red_cost[w] == bc && red_idx[w] < bi)) { bc = red_cost[w]; bi = red_idx[w]; }
-        P.part_cost[blockIdx.x] = bc;
-        P.part_idx[blockIdx.x] = bi;
-    }
-    if (tid < 2 + FX_NUM_REASONS && red_cnt[tid]) atomicAdd(&P.counters[tid], (unsigned long long)red_cnt[tid]);
+    // ---- combine parts, flags, cost, outputs, workgroup reductions ----
+    WalkResult W;
+    W.neg = neg; W.acc_viol = acc_viol; W.collided = collided;
+    W.step_reasons = step_reasons; W.first_key = first_key; W.fail_step = fail_step;
+    W.sum_abs_d = sum_abs_d; W.sum_voff = sum_voff; W.pred = pred; W.dto = dto; W.d_end = d_end; W.v_end = v_end;
+    W.cl3 = cl3; W.cl4 = cl4; W.ct3 = ct3; W.ct4 = ct4; W.ct5 = ct5;
+    if (EXTRA) { W.sim_acc = sim_acc; W.sim_jerk = sim_jerk; W.sim_orient = sim_orient; W.sim_path = sim_path; }
+    finish_candidate<G, BUNDLE, OBST, EXTRA>(P, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D, red_cost,
+                                             red_idx, red_cnt);
 }

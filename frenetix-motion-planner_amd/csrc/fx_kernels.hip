@@ -22,6 +22,7 @@
 // reference term by term (the CPU oracle does the same), so GPU and oracle differ only in libm (OCML vs glibc)
 // and in the order of the long cost sums (the device accumulates in step order, NumPy pairwise).
 #include "fx_eval_kernel.h"
+#include "fx_eval_grid_kernel.h"
 
 using fxk::wave_count;
 
@@ -169,6 +170,44 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
         if (obst) FX_LAUNCH(1, false, true, true, 2);
         FX_LAUNCH(1, false, false, true, 2);
     }
+    switch (G) {
+    case 8: FX_W(8);
+    case 4: FX_W(4);
+    case 2: FX_W(2);
+    default: FX_W(1);
+    }
+#undef FX_W
+#undef FX_BO
+#undef FX_LAUNCH
+}
+
+// Grid (t x v x d) specialisation with the shared longitudinal table; lds_bytes includes the rows.
+extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, size_t lds_bytes, int G,
+                                          bool bundle, bool obst, int wpe, hipStream_t stream) {
+    dim3 grid(max_blocks, n_agents), block(FX_BLOCK);
+#define FX_LAUNCH(Gv, B, O, W)                                                                                     \
+    do {                                                                                                          \
+        if (lds_bytes > 48 * 1024) {                                                                              \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fx_eval_grid_kernel<Gv, B, O, W>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);      \
+            if (e_ != hipSuccess) return e_;                                                                      \
+        }                                                                                                         \
+        hipLaunchKernelGGL((fx_eval_grid_kernel<Gv, B, O, W>), grid, block, lds_bytes, stream, d_probs);           \
+        return hipGetLastError();                                                                                 \
+    } while (0)
+#define FX_BO(Gv, W)                                           \
+    do {                                                       \
+        if (bundle && obst) FX_LAUNCH(Gv, true, true, W);      \
+        if (bundle) FX_LAUNCH(Gv, true, false, W);             \
+        if (obst) FX_LAUNCH(Gv, false, true, W);               \
+        FX_LAUNCH(Gv, false, false, W);                        \
+    } while (0)
+#define FX_W(Gv)                          \
+    do {                                  \
+        if (wpe >= 4) FX_BO(Gv, 4);       \
+        if (wpe == 3) FX_BO(Gv, 3);       \
+        FX_BO(Gv, 2);                     \
+    } while (0)
     switch (G) {
     case 8: FX_W(8);
     case 4: FX_W(4);

@@ -74,9 +74,10 @@ class FrenetEngine:
         """Run on an external HIP stream (e.g. torch.cuda.current_stream().cuda_stream)."""
         check(lib().fx_set_stream(self._ctx, C.c_void_p(hip_stream_ptr)))
 
-    def set_tuning(self, lanes_per_candidate: int = 0, waves_per_simd: int = 0):
-        """Override the automatic work decomposition (0 = automatic); results are unaffected."""
-        check(lib().fx_set_tuning(self._ctx, int(lanes_per_candidate), int(waves_per_simd)))
+    def set_tuning(self, lanes_per_candidate: int = 0, waves_per_simd: int = 0, kernel_variant: int = 0):
+        """Override the automatic work decomposition (0 = automatic; kernel_variant 1 = generic, 2 = grid);
+        results are unaffected."""
+        check(lib().fx_set_tuning(self._ctx, int(lanes_per_candidate), int(waves_per_simd), int(kernel_variant)))
 
     # -- plan step, split so callers can overlap host work (upload/evaluate enqueue only) --
     def upload(self, inputs):

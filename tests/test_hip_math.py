@@ -12,8 +12,8 @@ def ulp_err(got, ref):
 def test_atan_sin_cos_accuracy():
     from frenetix_motion_planner_amd.engine import math_selftest
     rng = np.random.default_rng(11)
-    x = np.concatenate([rng.uniform(-64, 64, 200_000), rng.normal(size=100_000) * 1e-3, rng.normal(size=50_000) * 1e3,
-                        np.array([0.0, -0.0, 0.4375, 0.6875, 1.1875, 2.4375, 1e-300, 1e300, -1e300, np.pi / 2, np.pi]),
+    x = np.concatenate([np.array([0.0, -0.0, 0.4375, 0.6875, 1.1875, 2.4375, 1e-300, 1e300, -1e300, np.pi / 2, np.pi]),
+                        rng.uniform(-64, 64, 200_000), rng.normal(size=100_000) * 1e-3, rng.normal(size=50_000) * 1e3,
                         np.linspace(-7, 7, 20_001)])
     at, sn, cs = math_selftest(x)
     assert ulp_err(at, np.arctan(x)).max() <= 1.0

@@ -156,39 +156,68 @@ def test_synthetic_cases_vs_oracle(eng, name):
         assert out["collision"].sum() > 0
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("lanes", [1, 2, 4, 8])
 @pytest.mark.parametrize("wpe", [2, 3, 4])
 @pytest.mark.parametrize("name", ["dense_debug_obs", "dense_prod_obs", "dense_lowvel", "dense_horizon5", "ragged_tail",
                                   "single_candidate"])
-def test_work_decomposition_does_not_change_results(eng, name, lanes, wpe):
-    """Every (lanes per candidate, occupancy target) specialisation against the oracle."""
+def test_work_decomposition_does_not_change_results(eng, name, lanes, wpe, variant):
+    """Every (kernel variant, lanes per candidate, occupancy target) specialisation against the oracle."""
     from oracle import oracle
     kw = CASES[name]
     inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
     out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
-    eng.set_tuning(lanes, wpe)
+    eng.set_tuning(lanes, wpe, variant)
     try:
-        res = eng.plan_step(inp)
+        try:
+            res = eng.plan_step(inp)
+        except ValueError as e:
+            if "not applicable" in str(e):
+                pytest.skip("grid kernel not applicable to this case (LDS budget)")
+            raise
         compare(eng, inp, out, res)
     finally:
-        eng.set_tuning(0, 0)
+        eng.set_tuning(0, 0, 0)
 
 
-@pytest.mark.parametrize("lanes", [2, 4, 8])
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8])
 @pytest.mark.parametrize("name", ["short_ref_hv_l1_debug", "arc_standstill_l1_debug", "arc_slow_brake_l1_kd",
-                                  "arc_hv_l2_debug_obs5", "scurve_hv_l2_kd"])
-def test_split_horizon_on_golden_cases(eng, name, lanes):
+                                  "arc_hv_l2_debug_obs5", "scurve_hv_l2_kd", "arc_lv_l1_debug"])
+def test_split_horizon_on_golden_cases(eng, name, lanes, variant):
     """Projection-domain exits, standstill heading carry and first-violation semantics across chunk borders."""
     from oracle import oracle
     fx = load_golden(name)
     inp = inputs_from_fixture(fx, hip_hulls())
     out = oracle.plan_step(inputs_from_fixture(fx, oracle.build_obstacle_hulls))
-    eng.set_tuning(lanes, 0)
+    eng.set_tuning(lanes, 0, variant)
     try:
-        res = eng.plan_step(inp)
+        try:
+            res = eng.plan_step(inp)
+        except ValueError as e:
+            if "not applicable" in str(e):
+                pytest.skip("grid kernel not applicable to this case (LDS budget)")
+            raise
         compare(eng, inp, out, res)
     finally:
-        eng.set_tuning(0, 0)
+        eng.set_tuning(0, 0, 0)
+
+
+def test_generic_and_grid_kernels_agree_bitwise(eng):
+    kw = dict(ref_kind="scurve", kappa=0.02, v0=9.0, grid=(7, 9, 33), n_obstacles=6, draw_traj_set=True, kinematic_debug=True)
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    outs = []
+    try:
+        for variant in (1, 2):
+            eng.set_tuning(1, 0, variant)
+            res = eng.plan_step(inp)
+            outs.append((res, *eng.costs(), eng.bundle(), eng.costmap()))
+    finally:
+        eng.set_tuning(0, 0, 0)
+    a, b = outs
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert a[0]["best_index"] == b[0]["best_index"] and a[0]["reason_hist"] == b[0]["reason_hist"]
 
 
 def test_sampling_matrix_mode_matches_ranges(eng):

@@ -14,9 +14,10 @@ def run(label, steps=60, **kw):
     inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
     out = {}
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
-        for G in (1, 2, 4, 8):
+        for variant in (1, 2):
+          for G in (1, 2, 4, 8):
             for w in (2, 3, 4):
-                eng.set_tuning(G, w)
+                eng.set_tuning(G, w, variant)
                 eng.upload(inp)
                 for _ in range(5):
                     eng.evaluate(); eng.finish()
@@ -24,7 +25,7 @@ def run(label, steps=60, **kw):
                 for _ in range(steps):
                     eng.evaluate(); eng.finish()
                     ts.append(eng.last_eval_kernel_ms)
-                out[f"G{G}_w{w}"] = round(float(np.median(ts)) * 1e3, 1)
+                out[f"{'gen' if variant == 1 else 'grid'}_G{G}_w{w}"] = round(float(np.median(ts)) * 1e3, 1)
     print(label, inp.n_candidates, json.dumps(out))
 
 
