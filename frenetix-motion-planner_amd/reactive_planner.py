@@ -1,0 +1,386 @@
+"""ReactivePlannerHip -- the planner front-end over the HIP engine; same surface as the reference's
+`ReactivePlannerPython` / `ReactivePlannerCpp` (frenetix_motion_planner/reactive_planner.py:32-130,
+reactive_planner_cpp.py:32-441, base class planner.py:48-710) for the hot path.
+
+What is mirrored: update_externals() and the setters, the sampling-level escalation loop of plan(), the
+Frenet initial state (_compute_initial_states, planner.py:567-635), the velocity sampling range
+(set_desired_velocity, :292-310), the cost-ordered walk with the dynamic-obstacle collision check (GPU) and an
+optional host-side road-boundary callback (planner.py:362-390), standstill fallback
+(reactive_planner.py:114-118,579-626), output packaging (_compute_trajectory_pair, planner.py:394-447 with
+shift_orientation :536-542) and the counters `_infeasible_count_kinematics`, `infeasible_kinematics_percentage`,
+`infeasible_count_collision`, `all_traj`, `optimal_trajectory`, `trajectory_pair`, `x_cl`.
+
+What is not: CommonRoad containers (scenario, planning problem, DynamicObstacle, Trajectory) -- not installed
+here and outside the hot path; states are plain dataclasses with the same field names.  Risk/harm logging,
+occlusion module, behaviour planner hooks, SQLite/CSV logging are out of scope.
+"""
+import logging
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _abi
+from .coordinate_system import CoordinateSystem, interpolate_angle
+from .problem import DEFAULT_COST_WEIGHTS, PlanInputs, VehicleParams, pack_predictions
+from .sampling import SamplingHandler, v_sampling_bounds
+from .trajectories import (CartesianSample, CurviLinearSample, PlanStepResult, PolynomialView, StandstillSample,
+                           TrajectorySample)
+
+
+@dataclass
+class ReactivePlannerState:
+    """frenetix_motion_planner/state.py:16-75: rear-axle KS state + acceleration and yaw rate."""
+    time_step: int = 0
+    position: np.ndarray = field(default_factory=lambda: np.zeros(2))
+    orientation: float = 0.0
+    velocity: float = 0.0
+    acceleration: float = 0.0
+    yaw_rate: float = 0.0
+    steering_angle: float = 0.0
+
+    def shift_positions_to_center(self, wb_rear_axle: float) -> "ReactivePlannerState":
+        o = self.orientation
+        return ReactivePlannerState(self.time_step, np.asarray(self.position) + wb_rear_axle * np.array([np.cos(o), np.sin(o)]),
+                                    o, self.velocity, self.acceleration, self.yaw_rate, self.steering_angle)
+
+
+@dataclass
+class PlannerConfig:
+    """configurations/frenetix_motion_planner/{planning,cost,debug}.yaml defaults the hot path reads."""
+    dt: float = 0.1
+    planning_horizon: float = 3.0
+    low_vel_mode_threshold: float = 2.0
+    replanning_frequency: int = 3
+    t_min: float = 1.1
+    d_min: float = -3.0
+    d_max: float = 3.0
+    d_ego_pos: bool = False
+    sampling_min: int = 2
+    sampling_max: int = 3
+    emergency_mode: str = "stopping"
+    cost_weights: Dict[str, float] = field(default_factory=lambda: dict(DEFAULT_COST_WEIGHTS))
+    draw_traj_set: bool = True       # debug.yaml:8
+    kinematic_debug: bool = True     # debug.yaml:20
+    save_all_traj: bool = False
+    survivors: int = 16              # top-k kept for the host-side road-boundary walk
+
+
+class ReactivePlannerHip:
+    def __init__(self, config: Optional[PlannerConfig] = None, vehicle: Optional[VehicleParams] = None, engine=None,
+                 msg_logger=None, device: int = 0,
+                 road_boundary_check: Optional[Callable[[TrajectorySample], float]] = None):
+        self.config = config or PlannerConfig()
+        self.vehicle_params = vehicle or VehicleParams()
+        self.horizon = self.config.planning_horizon
+        self.dT = self.config.dt
+        self.N = int(self.config.planning_horizon / self.config.dt)
+        assert self.dT > 0 and self.N > 0 and self.horizon > 0  # planner.py:544-548
+        self._low_vel_mode_threshold = self.config.low_vel_mode_threshold
+        self.msg_logger = msg_logger or logging.getLogger("Message_logger")
+        self._device = device
+        self._engine = engine
+        self.road_boundary_check = road_boundary_check
+
+        self.x_0: Optional[ReactivePlannerState] = None
+        self.x_cl: Optional[Tuple[List, List]] = None
+        self.reference_path = None
+        self.coordinate_system: Optional[CoordinateSystem] = None
+        self.set_new_ref_path = None
+        self._LOW_VEL_MODE = False
+        self.predictions = None
+        self.use_prediction = False
+        self.desired_velocity = None
+        self.cost_weights = dict(self.config.cost_weights)
+        self._sampling_min, self._sampling_max = self.config.sampling_min, self.config.sampling_max
+        self.sampling_handler = SamplingHandler(dt=self.dT, max_sampling_number=self.config.sampling_max,
+                                                t_min=self.config.t_min, horizon=self.horizon,
+                                                delta_d_max=self.config.d_max, delta_d_min=self.config.d_min,
+                                                d_ego_pos=self.config.d_ego_pos)
+        self._draw_traj_set = self.config.draw_traj_set
+        self._kinematic_debug = self.config.kinematic_debug
+        self.save_all_traj = self.config.save_all_traj
+
+        self._collision_counter = 0
+        self._total_count = 0
+        self._infeasible_count_kinematics = None
+        self.infeasible_kinematics_percentage = None
+        self.all_traj = None
+        self.optimal_trajectory = None
+        self.trajectory_pair = None
+        self.ego_vehicle_history = []
+        self.last_step: Optional[PlanStepResult] = None
+        self.planning_time = None
+        self._packed_predictions = None
+
+    # ------------------------------------------------------------------ engine
+    @property
+    def engine(self):
+        if self._engine is None:
+            from .engine import FrenetEngine
+            lvl = max(self._sampling_max - 1, 0)
+            n = 2 ** (lvl + 1) + 1
+            cap = 16 * (n + 1) * (n + 1)
+            self._engine = FrenetEngine(max_candidates=max(cap, 4096), max_steps=self.N, max_ref_knots=4096,
+                                        max_obstacles=64, max_pred_steps=max(64, self.N + 2), device=self._device)
+        return self._engine
+
+    @property
+    def infeasible_count_collision(self):
+        return self._collision_counter
+
+    # ------------------------------------------------------------------ externals (planner.py:172-217)
+    def update_externals(self, reference_path: np.ndarray = None, x_0: ReactivePlannerState = None, x_cl=None,
+                         cost_weights=None, desired_velocity: float = None, predictions=None, **ignored):
+        if reference_path is not None:
+            self.reference_path = reference_path
+            self.set_reference_and_coordinate_system(reference_path)
+        if x_0 is not None:
+            self.set_x_0(x_0)
+            self.set_x_cl(x_cl)
+        if cost_weights is not None:
+            self.set_cost_function(cost_weights)
+        if desired_velocity is not None:
+            self.set_desired_velocity(desired_velocity, x_0.velocity if x_0 is not None else self.x_0.velocity)
+        if predictions is not None:
+            self.set_predictions(predictions)
+        if self.sampling_handler.d_ego_pos:
+            self.sampling_handler.set_d_sampling(self.x_cl[1][0])
+
+    def set_reference_and_coordinate_system(self, reference_path: np.ndarray):
+        self.coordinate_system = CoordinateSystem(reference_path)
+        self.set_new_ref_path = True
+
+    def set_x_0(self, x_0: ReactivePlannerState):
+        self.x_0 = x_0
+        self._LOW_VEL_MODE = bool(x_0.velocity < self._low_vel_mode_threshold)
+
+    def set_x_cl(self, x_cl):
+        if self.x_cl is not None and not self.set_new_ref_path and x_cl is not None:
+            self.x_cl = x_cl
+        else:
+            self.x_cl = self._compute_initial_states(self.x_0)
+            self.set_new_ref_path = False
+
+    def set_cost_function(self, cost_weights):
+        self.cost_weights = dict(cost_weights)
+
+    def set_predictions(self, predictions: dict):
+        self.use_prediction = True
+        self.predictions = predictions
+        self._packed_predictions = None
+
+    def set_sampling_parameters(self, t_min: float, horizon: float, delta_d_min: float, delta_d_max: float):
+        self.sampling_handler.update_static_params(t_min, horizon, delta_d_min, delta_d_max)
+
+    def set_desired_velocity(self, desired_velocity: float, current_speed: float = None, stopping: bool = False,
+                             v_limit: float = 36):
+        self.desired_velocity = desired_velocity
+        min_v, max_v = v_sampling_bounds(current_speed, self.vehicle_params.a_max, self.horizon, self.vehicle_params.v_max,
+                                         v_limit)
+        self.sampling_handler.set_v_sampling(min_v, max_v)
+
+    # ------------------------------------------------------------------ initial Frenet state (planner.py:567-635)
+    def _compute_initial_states(self, x_0: ReactivePlannerState):
+        cs = self.coordinate_system
+        try:
+            s, d = cs.convert_to_curvilinear_coords(x_0.position[0], x_0.position[1])
+        except ValueError:
+            raise ValueError("Initial state could not be transformed.")
+        s_idx = int(np.argmax(cs.ref_pos > s)) - 1
+        s_lambda = (s - cs.ref_pos[s_idx]) / (cs.ref_pos[s_idx + 1] - cs.ref_pos[s_idx])
+        ref_theta = np.unwrap(cs.ref_theta)
+        theta_cl = x_0.orientation - interpolate_angle(s, cs.ref_pos[s_idx], cs.ref_pos[s_idx + 1], ref_theta[s_idx],
+                                                       ref_theta[s_idx + 1])
+        kr = (cs.ref_curv[s_idx + 1] - cs.ref_curv[s_idx]) * s_lambda + cs.ref_curv[s_idx]
+        kr_d = (cs.ref_curv_d[s_idx + 1] - cs.ref_curv_d[s_idx]) * s_lambda + cs.ref_curv_d[s_idx]
+        kappa_0 = np.tan(x_0.steering_angle) / self.vehicle_params.wheelbase
+        d_p = (1 - kr * d) * np.tan(theta_cl)
+        d_pp = -(kr_d * d + kr * d_p) * np.tan(theta_cl) + ((1 - kr * d) / (math.cos(theta_cl) ** 2)) * (
+            kappa_0 * (1 - kr * d) / math.cos(theta_cl) - kr)
+        s_velocity = x_0.velocity * math.cos(theta_cl) / (1 - kr * d)
+        if s_velocity < 0:
+            raise Exception("Initial state or reference incorrect! Curvilinear velocity is negative which indicates"
+                            "that the ego vehicle is not driving in the same direction as specified by the reference")
+        s_acceleration = x_0.acceleration
+        s_acceleration -= (s_velocity ** 2 / math.cos(theta_cl)) * (
+            (1 - kr * d) * np.tan(theta_cl) * (kappa_0 * (1 - kr * d) / (math.cos(theta_cl)) - kr) - (kr_d * d + kr * d_p))
+        s_acceleration /= ((1 - kr * d) / (math.cos(theta_cl)))
+        if self._LOW_VEL_MODE:
+            d_velocity, d_acceleration = d_p, d_pp
+        else:
+            d_velocity = x_0.velocity * math.sin(theta_cl)
+            d_acceleration = s_acceleration * d_p + s_velocity ** 2 * d_pp
+        return [float(s), float(s_velocity), float(s_acceleration)], [float(d), float(d_velocity), float(d_acceleration)]
+
+    # ------------------------------------------------------------------ plan (reactive_planner.py:67-130)
+    def _inputs_for_level(self, samp_level: int) -> PlanInputs:
+        from .engine import build_obstacle_hulls
+        x_lon, x_lat = self.x_cl
+        t, v, d = self.sampling_handler.ordered_ranges(samp_level, x_lat[0])
+        if self._packed_predictions is None:
+            self._packed_predictions = pack_predictions(self.predictions if self.use_prediction else None, self.N + 1,
+                                                        build_obstacle_hulls)
+        weights = {k: w for k, w in self.cost_weights.items() if w != 0}
+        if not self._packed_predictions["K"]:
+            # prediction_costs over an empty predictions dict is 0 for every candidate
+            pass
+        return PlanInputs(N=self.N, dt=self.dT, low_vel_mode=self._LOW_VEL_MODE, x0_lon=x_lon, x0_lat=x_lat,
+                          x0_orientation=self.x_0.orientation, v_des=self.desired_velocity, vehicle=self.vehicle_params,
+                          coordinate_system=self.coordinate_system, t_samp=t, v_samp=v, d_samp=d, cost_weights=weights,
+                          draw_traj_set=self._draw_traj_set, kinematic_debug=self._kinematic_debug, write_bundle=True,
+                          write_costmap=True, collision=self.use_prediction, obstacles=self._packed_predictions)
+
+    def plan(self):
+        if self.x_cl is None:
+            raise RuntimeError("x_cl should have been set prior to plan()")  # reactive_planner_cpp.py:308-309
+        if self.desired_velocity is None:
+            raise RuntimeError("desired velocity not set (update_externals(desired_velocity=...))")
+        optimal_trajectory = None
+        t0 = time.time()
+        samp_level = self._sampling_min
+        while optimal_trajectory is None and samp_level < self._sampling_max:
+            optimal_trajectory = self._get_optimal_trajectory(self._inputs_for_level(samp_level), samp_level)
+            samp_level += 1
+        self.planning_time = time.time() - t0
+
+        self.trajectory_pair = self._compute_trajectory_pair(optimal_trajectory) if optimal_trajectory is not None else None
+        if self.trajectory_pair is not None:
+            self.ego_vehicle_history.append(self.trajectory_pair[0])
+        if optimal_trajectory is None and self.x_0.velocity <= 0.1:
+            self.msg_logger.warning('Planning standstill for the current scenario')
+            optimal_trajectory = self._compute_standstill_trajectory()
+        if optimal_trajectory is not None and hasattr(optimal_trajectory, "materialise"):
+            optimal_trajectory.materialise()  # survives the next step's overwrite of the device bundle
+        self.optimal_trajectory = optimal_trajectory
+        return self.trajectory_pair
+
+    def _get_optimal_trajectory(self, inputs: PlanInputs, samp_lvl: int):
+        """reactive_planner.py:184-272: feasibility, costs, stable sort, collision walk -- one fused launch."""
+        if self.last_step is not None:
+            self.last_step.invalidate()
+        res = self.engine.plan_step(inputs)
+        step = PlanStepResult(self.engine, inputs, res)
+        self.last_step = step
+        self._total_count = res["n_candidates"]
+        hist = list(res["reason_hist"]) if self._kinematic_debug else [0] * 11
+        hist[0] = res["n_infeasible"]  # reactive_planner.py:233-234
+        self._infeasible_count_kinematics = hist
+        self.infeasible_kinematics_percentage = res["feasible_percentage"]
+        self._collision_counter = res["n_collisions"]
+        if self._draw_traj_set or self.save_all_traj:
+            self.all_traj = _LazySortedList(step)
+        best = step.best
+        if best is None or self.road_boundary_check is None:
+            return best
+        # host-side walk over the GPU's survivors for checks that stay on the host (planner.py:362-390)
+        _, idx = self.engine.topk(self.config.survivors)
+        for g in idx[0]:
+            if g < 0:
+                break
+            cand = step.sample(int(g) - inputs.shard_begin)
+            harm = self.road_boundary_check(cand)
+            cand.boundary_harm = harm
+            cand._coll_detected = False
+            if harm == 0:
+                return cand
+        return None
+
+    # ------------------------------------------------------------------ standstill (reactive_planner.py:579-626)
+    def _compute_standstill_trajectory(self) -> StandstillSample:
+        x_0 = self.x_0
+        x_0_lon, x_0_lat = self.x_cl
+        cs = self.coordinate_system
+        N = self.N
+        kappa_0 = np.tan(x_0.steering_angle) / self.vehicle_params.wheelbase
+        a = np.repeat(0.0, N)
+        a[1] = -x_0.velocity / self.dT
+        cart = CartesianSample(np.repeat(x_0.position[0], N), np.repeat(x_0.position[1], N), np.repeat(x_0.orientation, N),
+                               np.repeat(0.0, N), a, np.repeat(kappa_0, N), np.repeat(0.0, N), current_time_step=N)
+        s_idx = int(np.argmax(cs.ref_pos > x_0_lon[0])) - 1
+        ref_theta = np.unwrap(cs.ref_theta)
+        theta_cl = x_0.orientation - interpolate_angle(x_0_lon[0], cs.ref_pos[s_idx], cs.ref_pos[s_idx + 1],
+                                                       ref_theta[s_idx], ref_theta[s_idx + 1])
+        curv = CurviLinearSample(np.repeat(x_0_lon[0], N), np.repeat(x_0_lat[0], N), np.repeat(theta_cl, N),
+                                 dd=np.repeat(x_0_lat[1], N), ddd=np.repeat(x_0_lat[2], N), ss=np.repeat(x_0_lon[1], N),
+                                 sss=np.repeat(x_0_lon[2], N), current_time_step=N)
+        T = self.horizon
+        lon = _quartic(x_0_lon[0], x_0_lon[1], x_0_lon[2], T, 0.0, 0.0)
+        lat = _quintic(x_0_lat[0], x_0_lat[1], x_0_lat[2], x_0_lat[0], 0.0, 0.0, T)
+        names = sorted(n for n, w in self.cost_weights.items() if w != 0)
+        return StandstillSample(self.horizon, self.dT, cart, curv, PolynomialView(lon, T), PolynomialView(lat, T), names)
+
+    # ------------------------------------------------------------------ output packaging (planner.py:394-447)
+    def _compute_trajectory_pair(self, trajectory) -> tuple:
+        cart_list, cl_list, lon_list, lat_list = [], [], [], []
+        c, k = trajectory.cartesian, trajectory.curvilinear
+        for i in range(len(c.x)):
+            yaw_rate = (c.theta[i] - c.theta[i - 1]) / self.dT if i > 0 else self.x_0.yaw_rate
+            cart_list.append(ReactivePlannerState(
+                time_step=self.x_0.time_step + i, position=np.array([c.x[i], c.y[i]]), orientation=float(c.theta[i]),
+                velocity=float(c.v[i]), acceleration=float(c.a[i]), yaw_rate=float(yaw_rate),
+                steering_angle=float(np.arctan2(self.vehicle_params.wheelbase * c.kappa[i], 1.0))))
+            cl_list.append(dict(time_step=self.x_0.time_step + i, position=np.array([k.s[i], k.d[i]]), velocity=float(c.v[i]),
+                                acceleration=float(c.a[i]), orientation=float(c.theta[i]), yaw_rate=float(c.kappa[i])))
+            lon_list.append([float(k.s[i]), float(k.s_dot[i]), float(k.s_ddot[i])])
+            lat_list.append([float(k.d[i]), float(k.d_dot[i]), float(k.d_ddot[i])])
+        self.shift_orientation(cart_list, interval_start=self.x_0.orientation - np.pi, interval_end=self.x_0.orientation + np.pi)
+        return cart_list, cl_list, lon_list, lat_list
+
+    @staticmethod
+    def shift_orientation(state_list, interval_start=-np.pi, interval_end=np.pi):
+        for state in state_list:
+            while state.orientation < interval_start:
+                state.orientation += 2 * np.pi
+            while state.orientation > interval_end:
+                state.orientation -= 2 * np.pi
+        return state_list
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+
+class _LazySortedList:
+    """`all_traj` (reactive_planner.py:245-247): every returned trajectory in stable cost order, created on
+    demand instead of as 10^4..10^6 Python objects."""
+
+    def __init__(self, step: PlanStepResult):
+        self._step = step
+        self._ids = None
+
+    def _order(self):
+        if self._ids is None:
+            self._ids = self._step.sorted_ids(_abi.FX_FLAG_COSTED)
+        return self._ids
+
+    def __len__(self):
+        return len(self._order())
+
+    def __getitem__(self, j):
+        ids = self._order()
+        if isinstance(j, slice):
+            return [self._step.sample(int(g)) for g in ids[j]]
+        return self._step.sample(int(ids[j]))
+
+    def __iter__(self):
+        for g in self._order():
+            yield self._step.sample(int(g))
+
+
+def _quartic(xs, vxs, axs, T, vxe, axe):
+    b1 = vxe - vxs - axs * T
+    b2 = axe - axs
+    return np.array([xs, vxs, .5 * axs, (3.0 * b1 - T * b2) / (3.0 * T * T), (T * b2 - 2.0 * b1) / (4.0 * T * T * T), 0.0])
+
+
+def _quintic(xs, vxs, axs, xe, vxe, axe, T):
+    T2, T3, T4, T5 = T * T, T ** 3, T ** 4, T ** 5
+    b0 = xe - xs - vxs * T - .5 * axs * T2
+    b1 = vxe - vxs - axs * T
+    b2 = axe - axs
+    return np.array([xs, vxs, .5 * axs, (10.0 * b0 - 4.0 * b1 * T + .5 * b2 * T2) / T3,
+                     (-15.0 * b0 + 7.0 * b1 * T - b2 * T2) / T4, (6.0 * b0 - 3.0 * b1 * T + .5 * b2 * T2) / T5])

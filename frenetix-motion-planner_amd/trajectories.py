@@ -1,0 +1,249 @@
+"""Result types of a plan step -- the attribute surface of the reference's trajectory objects, backed by the
+engine's structure-of-arrays TrajectoryBundle in HBM.
+
+Reference types mirrored (read/written by planner.py:371-437, reactive_planner_cpp.py:355-357,456,470-482,
+logging_helpers.py, visualization.py):
+  frenetix_motion_planner/trajectories.py:56-197   CartesianSample   x, y, theta, v, a, kappa, kappa_dot
+  frenetix_motion_planner/trajectories.py:200-334  CurviLinearSample s, d, theta, s_dot, s_ddot, d_dot, d_ddot
+  frenetix_motion_planner/trajectories.py:337-477  TrajectorySample  + the frenetix.TrajectorySample extras
+  frenetix_motion_planner/trajectories.py:480-602  TrajectoryBundle
+
+A TrajectorySample here is a *view*: the flag word and total cost come from the arrays the engine always
+reads back; the 14 planes, the per-name cost map and the polynomial coefficients of a candidate are gathered
+from device memory on first access and then cached, so the object stays valid after the next plan step
+overwrites the device buffers (the reference keeps `optimal_trajectory` alive across steps,
+reactive_planner_cpp.py:430,437 / frenet_interface.py:277).
+"""
+from typing import List, Optional
+
+import numpy as np
+
+from . import _abi
+
+_FEAS_KEYS = {  # frenetix feasabilityMap keys (reactive_planner_cpp.py:470-482) -> reason bit
+    "Curvature Constraint": 5, "Yaw rate Constraint": 6, "Curvature Rate Constraint": 7, "Acceleration Constraint": 8,
+}
+
+
+class _Sample:
+    def __init__(self, current_time_step: int):
+        self.current_time_step = current_time_step
+
+    def length(self) -> int:
+        return self.current_time_step
+
+
+class CartesianSample(_Sample):
+    def __init__(self, x, y, theta, v, a, kappa, kappa_dot, current_time_step):
+        super().__init__(current_time_step)
+        self.x, self.y, self.theta, self.v, self.a, self.kappa, self.kappa_dot = x, y, theta, v, a, kappa, kappa_dot
+
+    def length(self) -> int:
+        return len(self.x)
+
+
+class CurviLinearSample(_Sample):
+    def __init__(self, s, d, theta, dd=None, ddd=None, ss=None, sss=None, current_time_step=0):
+        super().__init__(current_time_step)
+        self.s, self.d, self.theta = s, d, theta
+        self.d_dot, self.d_ddot, self.s_dot, self.s_ddot = dd, ddd, ss, sss
+
+    def length(self) -> int:
+        return len(self.s)
+
+
+class PolynomialView:
+    """coeffs / delta_tau of polynomial_trajectory.py:17-272 (read-only)."""
+
+    def __init__(self, coeffs: np.ndarray, delta_tau: float):
+        self.coeffs = coeffs
+        self.delta_tau = delta_tau
+        self.tau_0 = 0
+
+    def squared_jerk_integral(self, t):
+        c = self.coeffs
+        t2 = t * t
+        t3 = t2 * t
+        t4 = t3 * t
+        t5 = t4 * t
+        return (36 * c[3] * c[3] * t + 144 * c[3] * c[4] * t2 + 240 * c[3] * c[5] * t3 + 192 * c[4] * c[4] * t3 +
+                720 * c[4] * c[5] * t4 + 720 * c[5] * c[5] * t5)
+
+
+class TrajectorySample:
+    def __init__(self, step: "PlanStepResult", index: int):
+        self._step = step
+        self.uniqueId = int(index)
+        flags = int(step.flags[index])
+        self._flags = flags
+        self.feasible = bool(flags & _abi.FX_FLAG_FEASIBLE)
+        self.valid = bool(flags & _abi.FX_FLAG_VALID)
+        self._cost = float(step.cost[index])
+        self.dt = step.inputs.dt
+        self.horizon = step.inputs.N * step.inputs.dt
+        # writable from Python (planner.py:325-326,381-382)
+        self._ego_risk = None
+        self._obst_risk = None
+        self.boundary_harm = None
+        self._coll_detected = bool(flags & _abi.FX_FLAG_COLLISION) if (flags & _abi.FX_FLAG_SELECTABLE) else None
+        self.harm_occ_module = None
+        self._planes = None
+        self._costmap = None
+        self._coeffs = None
+
+    # ---- cheap attributes ----
+    @property
+    def cost(self) -> float:
+        return self._cost
+
+    @property
+    def reasons(self) -> int:
+        """bit r set <=> infeasibility reason r (reactive_planner.py:352-545)"""
+        return (self._flags >> _abi.FX_REASON_SHIFT) & 0x7FF
+
+    @property
+    def feasabilityMap(self) -> dict:
+        r = self.reasons
+        return {k: float((r >> b) & 1) for k, b in _FEAS_KEYS.items()}
+
+    @property
+    def sampling_parameters(self) -> np.ndarray:
+        return self._step.inputs.candidate_params(self.uniqueId + self._step.inputs.shard_begin)
+
+    # ---- lazily gathered from the device bundle ----
+    def _need_planes(self):
+        if self._planes is None:
+            self._planes = self._step.fetch_sample(self.uniqueId)
+        return self._planes
+
+    def materialise(self):
+        """Pull everything this sample can ever need off the device (call before the next plan step)."""
+        self._need_planes()
+        _ = self.costMap
+        _ = self.trajectory_long
+        return self
+
+    @property
+    def cartesian(self) -> CartesianSample:
+        p = self._need_planes()
+        return CartesianSample(p[0], p[1], p[2], p[3], p[4], p[5], p[6], current_time_step=self.actual_traj_length)
+
+    @property
+    def curvilinear(self) -> CurviLinearSample:
+        p = self._need_planes()
+        return CurviLinearSample(p[7], p[8], p[9], ss=p[10], sss=p[11], dd=p[12], ddd=p[13],
+                                 current_time_step=self.actual_traj_length)
+
+    @property
+    def costMap(self) -> dict:
+        if self._costmap is None:
+            raw = self._step.fetch_costmap_row(self.uniqueId)
+            names = self._step.inputs.cost_names
+            w = self._step.inputs.cost_weights
+            self._costmap = {n: (float(raw[k]), float(w[n] * raw[k])) for k, n in enumerate(names)}
+        return self._costmap
+
+    def _need_coeffs(self):
+        if self._coeffs is None:
+            self._coeffs = self._step.fetch_coeffs(self.uniqueId)
+        return self._coeffs
+
+    @property
+    def trajectory_long(self) -> PolynomialView:
+        lon, _, _ = self._need_coeffs()
+        return PolynomialView(lon, float(self.sampling_parameters[1] - self.sampling_parameters[0]))
+
+    @property
+    def trajectory_lat(self) -> PolynomialView:
+        _, lat, _ = self._need_coeffs()
+        return PolynomialView(lat, float(self.sampling_parameters[1] - self.sampling_parameters[0]))
+
+    @property
+    def actual_traj_length(self) -> int:
+        return int(self._need_coeffs()[2])
+
+    def length(self) -> int:
+        return self._step.inputs.n_samples
+
+    def __repr__(self):
+        return (f"TrajectorySample(uniqueId={self.uniqueId}, cost={self._cost:.6g}, feasible={self.feasible}, "
+                f"valid={self.valid})")
+
+
+class StandstillSample:
+    """_compute_standstill_trajectory (reactive_planner.py:579-626): plain arrays of length N (not N+1)."""
+
+    def __init__(self, horizon, dt, cartesian, curvilinear, trajectory_long, trajectory_lat, cost_names):
+        self.horizon, self.dt = horizon, dt
+        self.cartesian, self.curvilinear = cartesian, curvilinear
+        self.trajectory_long, self.trajectory_lat = trajectory_long, trajectory_lat
+        self.uniqueId = 0
+        self.feasible = None
+        self.valid = None
+        self.cost = 0
+        self.costMap = {n: (0, 0) for n in cost_names}
+        self.feasabilityMap = {k: 0.0 for k in _FEAS_KEYS}
+        self._ego_risk = self._obst_risk = self.boundary_harm = self._coll_detected = None
+        self.actual_traj_length = None
+        self.harm_occ_module = None
+
+
+class PlanStepResult:
+    """Everything one evaluated plan step produced; hands out TrajectorySample views."""
+
+    def __init__(self, engine, inputs, result: dict, agent: int = 0):
+        self.engine, self.inputs, self.result, self.agent = engine, inputs, result, agent
+        self.cost, self.flags = engine.costs(agent)
+        self._stale = False
+        self._samples = {}
+
+    def invalidate(self):
+        """The engine is about to run another step: device buffers will be overwritten."""
+        self._stale = True
+
+    def _check(self):
+        if self._stale:
+            raise RuntimeError("this plan step's device data has been overwritten; materialise() samples you keep")
+
+    def fetch_sample(self, index):
+        self._check()
+        return self.engine.sample(index, self.agent)
+
+    def fetch_costmap_row(self, index):
+        self._check()
+        if not hasattr(self, "_cm"):
+            self._cm = self.engine.costmap(self.agent)
+        return self._cm[index]
+
+    def fetch_coeffs(self, index):
+        self._check()
+        return self.engine.coeffs(index, self.agent)
+
+    def sample(self, index: int) -> TrajectorySample:
+        if index not in self._samples:
+            self._samples[index] = TrajectorySample(self, index)
+        return self._samples[index]
+
+    # ---- views the planner needs ----
+    @property
+    def n_candidates(self) -> int:
+        return len(self.cost)
+
+    def mask(self, bit) -> np.ndarray:
+        return (self.flags & bit) != 0
+
+    def sorted_ids(self, pool_bit=_abi.FX_FLAG_COSTED) -> np.ndarray:
+        """ids of the pool in stable cost order (TrajectoryBundle.sort, trajectories.py:524-561)."""
+        ids = np.nonzero(self.mask(pool_bit))[0]
+        return ids[np.argsort(self.cost[ids], kind="stable")]
+
+    def sorted_trajectories(self, pool_bit=_abi.FX_FLAG_COSTED, limit: Optional[int] = None) -> List[TrajectorySample]:
+        ids = self.sorted_ids(pool_bit)
+        if limit is not None:
+            ids = ids[:limit]
+        return [self.sample(int(g)) for g in ids]
+
+    @property
+    def best(self) -> Optional[TrajectorySample]:
+        g = self.result["best_index"] - self.inputs.shard_begin
+        return self.sample(int(g)) if self.result["best_index"] >= 0 else None

@@ -1,0 +1,181 @@
+"""Host-side logic that runs without a GPU: sampling order, coordinate system, initial state, packing,
+frenetix-shaped surface, sharding arithmetic."""
+import sys
+
+import numpy as np
+import pytest
+
+from frenetix_motion_planner_amd import (CoordinateSystem, PlanInputs, SamplingHandler, VehicleParams, _abi,
+                                         generate_sampling_matrix, pack_predictions, synthetic)
+from frenetix_motion_planner_amd.coordinate_system import simpson_even_correction, time_power_table
+from frenetix_motion_planner_amd.distributed import agents_of_rank, merge_survivors, shard_range
+from tests.fixtures import golden_names, load_golden
+
+
+def test_sampling_iteration_order_matches_reference_goldens():
+    # G1: ordered ranges as the reference's SamplingHandler iterates its sets (stored in every fixture)
+    seen = 0
+    for name in golden_names():
+        fx = load_golden(name)
+        import json
+        kw = json.loads(str(fx["kw"]))
+        if "level" not in kw:
+            continue
+        inp = synthetic.make_inputs(**kw)
+        assert np.array_equal(inp.t_samp, fx["t_order"]) and np.array_equal(inp.v_samp, fx["v_order"])
+        assert np.array_equal(inp.d_samp, fx["d_order"])
+        seen += 1
+    assert seen >= 10
+
+
+def test_sampling_level_sizes():
+    sh = SamplingHandler(dt=0.1, max_sampling_number=5, t_min=1.1, horizon=3.0, delta_d_min=-3, delta_d_max=3, d_ego_pos=False)
+    sh.set_v_sampling(0.001, 15.75)
+    # L0 2x3x3 -> 24/48; L1 4x5x5 -> 120/180; L2 7x9x9 -> 630/800; L3 10x17x17 -> 3060/3564
+    want = {0: (24, 48), 1: (120, 180), 2: (630, 800), 3: (3060, 3564), 4: (11220, 12716)}
+    for lvl, (py, cpp) in want.items():
+        t, v, d = sh.ordered_ranges(lvl, 0.2)
+        assert len(t) * len(v) * len(d) == py
+        t, v, d = sh.ordered_ranges(lvl, 0.2, cpp_style=True, ss0=10.0, t_full=3.0)
+        assert len(t) * len(v) * len(d) == cpp
+    m = generate_sampling_matrix(t0_range=0.0, t1_range=t, s0_range=1.0, ss0_range=10.0, sss0_range=0.0, ss1_range=v,
+                                 sss1_range=0.0, d0_range=0.2, dd0_range=0.0, ddd0_range=0.0, d1_range=d, dd1_range=0.0,
+                                 ddd1_range=0.0)
+    assert m.shape == (len(t) * len(v) * len(d), 13)
+    # row order = itertools.product order: d fastest
+    assert np.array_equal(m[:len(d), 10], d) and np.all(m[:len(d), 5] == v[0])
+
+
+def test_time_grid_and_traj_len_quirk():
+    tp = time_power_table(0.1, 31)
+    assert tp.shape == (5, 31) and tp[0, 3] == 0.3 and tp[1, 3] == 0.09
+    # len(np.arange(0, T+dt, dt)) == ceil((T+dt)/dt): 13 for T=1.1 (one sample past T), 30 for 2.9
+    for T in np.round(np.arange(1.1, 3.0, 0.1), 2):
+        assert len(np.arange(0, T + 0.1, 0.1)) == int(np.ceil((T + 0.1) / 0.1))
+    assert int(np.ceil((1.1 + 0.1) / 0.1)) == 13
+    a, b, e = simpson_even_correction(0.1)
+    assert abs(a - 5 * 0.1 / 12) < 1e-15 and abs(b - 2 * 0.1 / 3) < 1e-15 and abs(e - 0.1 / 12) < 1e-15
+
+
+@pytest.mark.parametrize("kind", ["straight", "arc", "scurve"])
+def test_coordinate_system_roundtrip(kind):
+    cs = CoordinateSystem(synthetic.reference_polyline(kind, 300, 0.5, 0.02))
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        s = rng.uniform(cs.ref_pos[2], cs.ref_pos[-3])
+        d = rng.uniform(-3, 3)
+        xy = cs.convert_to_cartesian_coords(s, d)
+        sd = cs.convert_to_curvilinear_coords(*xy)
+        assert abs(sd[0] - s) < 1e-8 and abs(sd[1] - d) < 1e-8
+    assert cs.convert_to_cartesian_coords(cs.ref_pos[-1] + 1.0, 0.0) is None
+    with pytest.raises(ValueError):
+        CoordinateSystem(np.zeros((2, 2)))
+
+
+def test_initial_state_roundtrip():
+    """_compute_initial_states (planner.py:567-635): a state built from known Frenet values maps back."""
+    from frenetix_motion_planner_amd.reactive_planner import PlannerConfig, ReactivePlannerHip, ReactivePlannerState
+    rp = ReactivePlannerHip(PlannerConfig(), VehicleParams(), engine=object())
+    ref = synthetic.reference_polyline("arc", 400, 0.5, 0.01)
+    rp.set_reference_and_coordinate_system(ref)
+    cs = rp.coordinate_system
+    s, d = 25.3, 0.4
+    xy = cs.convert_to_cartesian_coords(s, d)
+    k = cs.segment_of(s)
+    theta = float(cs.ref_theta[k] + (cs.ref_theta[k + 1] - cs.ref_theta[k]) * (s - cs.ref_pos[k]) / (cs.ref_pos[k + 1] - cs.ref_pos[k]))
+    x0 = ReactivePlannerState(position=xy, orientation=theta, velocity=8.0, acceleration=0.5, steering_angle=0.0)
+    rp.set_x_0(x0)
+    lon, lat = rp._compute_initial_states(x0)
+    assert abs(lon[0] - s) < 1e-8 and abs(lat[0] - d) < 1e-8
+    assert abs(lat[1]) < 1e-6              # heading along the reference -> no lateral velocity
+    assert abs(lon[1] - 8.0 / (1 - 0.01 * d)) < 0.02
+    assert not rp._LOW_VEL_MODE
+    rp.set_x_0(ReactivePlannerState(position=xy, orientation=theta, velocity=1.0))
+    assert rp._LOW_VEL_MODE
+
+
+def test_plan_inputs_packing_and_validation():
+    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(3, 4, 5), n_obstacles=2)
+    st = inp.as_struct()
+    assert st.N == 30 and st.nT * st.nV * st.nD == inp.n_candidates and st.M == 400
+    assert [st.cost_id[i] for i in range(st.n_cost)] == sorted(_abi.COST_ID[n] for n in inp.cost_names)
+    assert inp.cost_names == sorted(inp.cost_names)
+    p = inp.candidate_params(7)
+    assert p.shape == (13,) and p[10] in inp.d_samp
+    with pytest.raises(NotImplementedError):
+        synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(2, 2, 2), cost_weights={"lane_center_offset": 1.0})
+    inp.shard = (5, 10)
+    st = inp.as_struct()
+    assert (st.shard_begin, st.shard_count) == (5, 10) and inp.n_candidates == 10
+    inp.shard = (0, 10 ** 9)
+    with pytest.raises(ValueError):
+        inp.as_struct()
+    # predictions packing keeps dict order and inverts covariances like np.linalg.inv
+    preds = {7: dict(pos_list=np.ones((4, 2)), cov_list=np.tile(np.diag([0.1, 0.4]), (4, 1, 1)), orientation_list=np.zeros(4),
+                     shape=dict(length=4.5, width=2.0)),
+             3: dict(pos_list=np.zeros((2, 2)), cov_list=np.tile(np.eye(2), (2, 1, 1)), orientation_list=np.zeros(2),
+                     shape=dict(length=4.5, width=2.0))}
+    o = pack_predictions(preds, 31, lambda n, pos, yaw, L, W: np.zeros((max(n - 1, 0) if n > 2 else 0, 6)))
+    assert o["K"] == 2 and o["P"] == 4 and list(o["npred"]) == [4, 2] and list(o["nhull"]) == [3, 0]
+    assert np.allclose(o["cov_inv"][0, 0], [10.0, 0, 0, 2.5])
+
+
+def test_frenetix_surface_is_complete():
+    """Every name reactive_planner_cpp.py uses on `frenetix` resolves after install()."""
+    from frenetix_motion_planner_amd import frenetix_compat
+    saved = {k: v for k, v in sys.modules.items() if k == "frenetix" or k.startswith("frenetix.")}
+    try:
+        fx = frenetix_compat.install(force=True)
+        import frenetix
+        import frenetix.trajectory_functions.cost_functions as cf
+        import frenetix.trajectory_functions.feasability_functions as ff
+        assert frenetix is fx
+        for name in ("TrajectoryHandler", "CoordinateSystemWrapper", "PoseWithCovariance", "PredictedObject",
+                     "CartesianPlannerState", "CurvilinearPlannerState", "PlannerState", "SamplingConfiguration",
+                     "compute_initial_state", "TrajectorySample"):
+            assert hasattr(frenetix, name), name
+        assert hasattr(frenetix._frenetix, "setup_logger") and hasattr(frenetix.trajectory_functions, "FillCoordinates")
+        for name in ("CheckYawRateConstraint", "CheckAccelerationConstraint", "CheckCurvatureConstraint",
+                     "CheckCurvatureRateConstraint"):
+            assert hasattr(ff, name)
+        for name in ("CalculateAccelerationCost", "CalculateJerkCost", "CalculateLateralJerkCost",
+                     "CalculateLongitudinalJerkCost", "CalculateOrientationOffsetCost", "CalculateLaneCenterOffsetCost",
+                     "CalculateDistanceToReferencePathCost", "CalculateCollisionProbabilityFast",
+                     "CalculateDistanceToObstacleCost", "CalculateVelocityOffsetCost"):
+            assert hasattr(cf, name)
+        h = frenetix.TrajectoryHandler(dt=0.1)
+        for m in ("add_feasability_function", "add_cost_function", "add_function", "generate_trajectories",
+                  "generate_stopping_trajectories", "reset_Trajectories", "evaluate_all_current_functions",
+                  "evaluate_all_current_functions_concurrent", "get_sorted_trajectories"):
+            assert callable(getattr(h, m))
+        with pytest.raises(ValueError):
+            h.generate_stopping_trajectories(None, None, 1.0, 0.0, False)
+        with pytest.raises(ValueError):
+            h.generate_trajectories(np.zeros((3, 5)), False)
+        # data types
+        pwc = frenetix.PoseWithCovariance(np.array([1.0, 2.0, 0.0]), np.array([0, 0, np.sin(0.4), np.cos(0.4)]), np.eye(6))
+        assert abs(pwc.yaw - 0.8) < 1e-12
+        cs = frenetix.CoordinateSystemWrapper(synthetic.reference_polyline("arc", 100, 0.5, 0.01))
+        st = frenetix.compute_initial_state(coordinate_system=cs,
+                                            x_0=frenetix.CartesianPlannerState(cs.reference[20], cs.ref_theta[20], 5.0, 0.0, 0.0),
+                                            wheelbase=2.5789, low_velocity_mode=False)
+        assert abs(st.x0_lon[0] - cs.ref_pos[20]) < 1e-6 and abs(st.x0_lat[0]) < 1e-6
+    finally:
+        for k in [k for k in sys.modules if k == "frenetix" or k.startswith("frenetix.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_shard_arithmetic_and_merge():
+    for n, w in ((50388, 8), (7, 3), (5, 8), (1, 1)):
+        cover = []
+        for r in range(w):
+            b, c = shard_range(n, r, w)
+            cover.extend(range(b, b + c))
+        assert cover == list(range(n))
+    assert agents_of_rank(6, 1, 4) == [1, 5]
+    c = np.array([[3.0, 5.0], [3.0, np.inf], [2.5, 9.0]])
+    i = np.array([[40, 7], [12, -1], [99, 100]])
+    bc, bi, order = merge_survivors(c, i)
+    assert (bc, bi) == (2.5, 99) and list(order) == [99, 12, 40, 7, 100]
+    assert merge_survivors(np.zeros(2), np.array([-1, -1]))[1] == -1
