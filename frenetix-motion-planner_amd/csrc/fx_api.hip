@@ -19,9 +19,10 @@
 
 extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, int max_blocks, size_t lds_bytes, int G,
                                      bool bundle, bool obst, bool extra, int wpe, hipStream_t stream);
-extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, size_t lds_bytes, int G,
-                                          bool bundle, bool obst, int wpe, hipStream_t stream);
-extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, hipStream_t stream);
+extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, int block_size,
+                                          size_t lds_bytes, int G, bool bundle, bool obst, int wpe, hipStream_t stream);
+extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
+                                       unsigned long long seq, hipStream_t stream);
 extern "C" hipError_t fx_launch_math_test(int n, const double *x, double *at, double *sn, double *cs, hipStream_t stream);
 extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int k, double *out_cost, long long *out_idx,
                                      hipStream_t stream);
@@ -81,7 +82,10 @@ struct FxContext {
     double *d_part_cost = nullptr;
     int64_t *d_part_idx = nullptr;
     unsigned long long *d_counters = nullptr;  // [max_agents][FX_CNT_COUNT]
-    unsigned long long *h_counters = nullptr;  // pinned
+    unsigned long long *h_counters = nullptr;  // pinned + mapped: [max_agents][FX_CNT_COUNT + 1], last word = sequence
+    unsigned long long *h_counters_dev = nullptr;  // device address of the same block
+    unsigned long long seq = 0;
+    bool in_flight = false;                // work enqueued whose completion the host has not observed yet
     double *d_topk_cost = nullptr;
     long long *d_topk_idx = nullptr;
     double *h_topk_cost = nullptr;
@@ -96,10 +100,13 @@ struct FxContext {
     int G_step = 1, wpe_step = 2;          // lanes per candidate / occupancy target of the current step
     int G_force = 0, wpe_force = 0;        // fx_set_tuning overrides (0 = automatic)
     int variant_force = 0;                 // 0 auto, 1 generic kernel, 2 grid kernel
+    int block_force = 0;                   // grid-kernel workgroup size override (0 auto)
+    int block_step = FX_BLOCK;
     bool use_grid = false;                 // current step runs fx_eval_grid_kernel
     size_t lds_step = 0;
     bool any_bundle = false, any_obst = false, any_extra = false;
     float last_ms = 0.f, last_eval_ms = 0.f;
+    bool timing = true, times_valid = false;
     int64_t dev_bytes = 0;
 };
 
@@ -148,6 +155,15 @@ struct Arena {
         return hp;
     }
 };
+
+int fetch_times(FxContext *c) {
+    if (c->times_valid) return FX_OK;
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    HIP_TRY(hipEventElapsedTime(&c->last_eval_ms, c->ev0, c->ev_mid));
+    c->times_valid = true;
+    return FX_OK;
+}
 
 int ensure_planes(FxContext *c, size_t bytes) {
     if (bytes <= c->planes_bytes) return FX_OK;
@@ -236,7 +252,7 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     const int S = max_steps + 1;
     // every agent's leading dimension is rounded up to 64 candidates
     c->total_ld = (int64_t)align_up((size_t)max_candidates_total, 64) + 64 * (int64_t)max_agents;
-    c->max_blocks_total = c->total_ld / (FX_BLOCK / 8) + max_agents + 1;  // G = 8: 32 candidates per workgroup
+    c->max_blocks_total = c->total_ld / 8 + max_agents + 1;  // 64-lane workgroups at G = 8: 8 candidates each
     c->in_bytes = (size_t)max_agents * input_bytes_for(0, S, max_ref_knots, max_obstacles, c->max_pred, false) +
                   align_up(sizeof(double) * 13 * (size_t)max_candidates_total, 256) + 4096;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_in), c->in_bytes, hipHostMallocDefault));
@@ -253,8 +269,11 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     if ((rc = dev_alloc(c, &c->d_part_cost, c->max_blocks_total))) return rc;
     if ((rc = dev_alloc(c, &c->d_part_idx, c->max_blocks_total))) return rc;
     if ((rc = dev_alloc(c, &c->d_counters, (size_t)max_agents * FX_CNT_COUNT))) return rc;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), sizeof(unsigned long long) * max_agents * FX_CNT_COUNT,
-                          hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), sizeof(unsigned long long) * max_agents * (FX_CNT_COUNT + 1),
+                          hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_counters, 0, sizeof(unsigned long long) * max_agents * (FX_CNT_COUNT + 1));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_counters_dev), c->h_counters, 0));
+    HIP_TRY(hipMemset(c->d_counters, 0, sizeof(unsigned long long) * max_agents * FX_CNT_COUNT));
     if ((rc = dev_alloc(c, &c->d_topk_cost, (size_t)max_agents * 64))) return rc;
     if ((rc = dev_alloc(c, &c->d_topk_idx, (size_t)max_agents * 64))) return rc;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_topk_cost), sizeof(double) * max_agents * 64, hipHostMallocDefault));
@@ -285,6 +304,14 @@ int32_t fx_destroy(FxContext *c) {
     return FX_OK;
 }
 
+int32_t fx_set_block_size(FxContext *c, int32_t block_size) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (block_size != 0 && block_size != 64 && block_size != 128 && block_size != 256)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "block_size must be 0 (auto), 64, 128 or 256");
+    c->block_force = block_size;
+    return FX_OK;
+}
+
 int32_t fx_set_tuning(FxContext *c, int32_t lanes_per_candidate, int32_t waves_per_simd, int32_t kernel_variant) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     if (lanes_per_candidate != 0 && lanes_per_candidate != 1 && lanes_per_candidate != 2 && lanes_per_candidate != 4 &&
@@ -312,6 +339,10 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     if (!c || !probs) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_upload: NULL argument");
     if (n_agents < 1 || n_agents > c->max_agents) return set_err(FX_ERR_CAPACITY, "n_agents=%d exceeds capacity %d", n_agents, c->max_agents);
     HIP_TRY(hipSetDevice(c->device));
+    if (c->in_flight) {  // the pinned staging block is about to be rewritten: earlier copies must have landed
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->in_flight = false;
+    }
     c->uploaded = c->evaluated = false;
     Arena ar{c->h_in, c->d_in, 0, c->in_bytes};
     // lanes per candidate: split the horizon over G lanes while the step has too few candidates to give every
@@ -329,33 +360,52 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                              id == FX_COST_PATH_LENGTH || id == FX_COST_DISTANCE_TO_OBSTACLES;
             }
         }
+        // measured on MI355X (tools/quick.py): one lane per candidate once the grid gives >= 3 waves per SIMD,
+        // two lanes per candidate below that, four for tiny grids (a single wave's 31-step chain is pure latency)
         int G = 1;
         if (waves1 < 3072) G = 2;
-        if (waves1 < 1536) G = 4;
-        if (waves1 < 384) G = 8;
+        if (waves1 < 200) G = 4;
         if (c->G_force) G = c->G_force;
         if (extra_any) G = 1;
         c->G_step = G;
         c->wpe_step = c->wpe_force ? c->wpe_force : 2;
-        // grid kernel: sampling ranges, no windowed costs, and the longitudinal rows of a workgroup fit in LDS
-        const int cpb = FX_BLOCK / G;
+        // grid kernel: sampling ranges, no windowed costs, and the longitudinal rows of a workgroup fit in LDS.
+        // Workgroup size: the smallest of 64/128/256 lanes whose LDS footprint still lets a CU hold the target
+        // number of waves (small workgroups balance small grids at wave granularity).
         bool grid_ok = !extra_any;
+        for (int a = 0; a < n_agents && grid_ok; a++)
+            if (probs[a].sampling_matrix || probs[a].nD < 1) grid_ok = false;
         size_t lds_need = 0;
-        for (int a = 0; a < n_agents && grid_ok; a++) {
-            const FxProblem *p = &probs[a];
-            if (p->sampling_matrix || p->nD < 1) { grid_ok = false; break; }
-            const size_t n_pairs = (size_t)(cpb + p->nD - 2) / p->nD + 1;
-            const size_t S = (size_t)p->N + 1;
-            const size_t bytes = sizeof(double) * (((size_t)p->M * FX_REF_FIELDS + 5 * S + 1) & ~(size_t)1) + 128 * n_pairs * S;
-            lds_need = std::max(lds_need, bytes);
+        int block = FX_BLOCK;
+        if (grid_ok) {
+            auto lds_for = [&](int blk) {
+                size_t need = 0;
+                for (int a = 0; a < n_agents; a++) {
+                    const FxProblem *p = &probs[a];
+                    const size_t n_pairs = (size_t)(blk / G + p->nD - 2) / p->nD + 1;
+                    const size_t S = (size_t)p->N + 1;
+                    need = std::max(need, sizeof(double) * ((5 * S + 1) & ~(size_t)1) + 128 * n_pairs * S);
+                }
+                return need;
+            };
+            const int want_waves = 4 * c->wpe_step;
+            block = 0;
+            for (int blk : {256, 128, 64}) {
+                const size_t need = lds_for(blk);
+                const int by_lds = (int)((160 * 1024) / (need + 256));
+                if (by_lds * (blk / 64) >= want_waves) { block = blk; lds_need = need; break; }
+            }
+            if (c->block_force) { block = c->block_force; lds_need = lds_for(block); }
+            if (!block) { block = FX_BLOCK; lds_need = lds_for(block); }
+            if (lds_need > 78 * 1024) grid_ok = false;   // at least two workgroups per CU
         }
-        if (lds_need > 78 * 1024) grid_ok = false;   // keep 2 workgroups per CU (160 KiB LDS)
         if (c->variant_force == 1) grid_ok = false;
         if (c->variant_force == 2 && !grid_ok) return set_err(FX_ERR_INVALID_ARGUMENT, "grid kernel forced but not applicable");
         c->use_grid = grid_ok;
         c->lds_step = lds_need;
+        c->block_step = grid_ok ? block : FX_BLOCK;
     }
-    const int CPB = FX_BLOCK / c->G_step;
+    const int CPB = c->block_step / c->G_step;
     int64_t cand_off = 0, block_off = 0;
     size_t planes_need = 0;
     c->any_bundle = c->any_obst = c->any_extra = false;
@@ -470,6 +520,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, ar.off, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_probs, c->h_probs, sizeof(DevProblem) * n_agents, hipMemcpyHostToDevice, c->stream));
     c->uploaded = true;
+    c->in_flight = true;
     return FX_OK;
 }
 
@@ -479,35 +530,49 @@ int32_t fx_evaluate(FxContext *c) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     if (!c->uploaded) return set_err(FX_ERR_NOT_READY, "fx_evaluate before fx_upload");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * FX_CNT_COUNT * c->n_agents, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (c->max_blocks_step > 0)
     {
         if (c->use_grid)
-            HIP_TRY(fx_launch_eval_grid(c->d_probs, c->n_agents, c->max_blocks_step, c->lds_step, c->G_step, c->any_bundle,
-                                        c->any_obst, c->wpe_step, c->stream));
+            HIP_TRY(fx_launch_eval_grid(c->d_probs, c->n_agents, c->max_blocks_step, c->block_step, c->lds_step, c->G_step,
+                                        c->any_bundle, c->any_obst, c->wpe_step, c->stream));
         else
             HIP_TRY(fx_launch_eval(c->d_probs, c->n_agents, c->max_blocks_step,
                                    sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + 5 * (size_t)c->S_max_step),
                                    c->G_step, c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, c->stream));
     }
     HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
-    HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->stream));
+    c->seq++;
+    HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(unsigned long long) * FX_CNT_COUNT * c->n_agents,
-                           hipMemcpyDeviceToHost, c->stream));
     c->evaluated = true;
+    c->in_flight = true;
+    c->times_valid = false;
     return FX_OK;
 }
 
 int32_t fx_finish_batch(FxContext *c, FxResult *res) {
     if (!c || !res) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_finish: NULL argument");
     if (!c->evaluated) return set_err(FX_ERR_NOT_READY, "fx_finish before fx_evaluate");
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
-    HIP_TRY(hipEventElapsedTime(&c->last_eval_ms, c->ev0, c->ev_mid));
+    {   // poll the sequence words the selection kernel publishes; fall back to a stream sync (which also surfaces
+        // a faulted kernel) if they do not arrive
+        bool done = false;
+        for (long spin = 0; spin < 20000000L && !done; spin++) {
+            done = true;
+            for (int a = 0; a < c->n_agents; a++) {
+                const volatile unsigned long long *sq = c->h_counters + (size_t)a * (FX_CNT_COUNT + 1) + FX_CNT_COUNT;
+                if (__atomic_load_n(sq, __ATOMIC_ACQUIRE) != c->seq) { done = false; break; }
+            }
+        }
+        if (!done) HIP_TRY(hipStreamSynchronize(c->stream));
+        c->in_flight = false;
+    }
+    if (c->timing) {
+        int rc = fetch_times(c);
+        if (rc) return rc;
+    }
     for (int a = 0; a < c->n_agents; a++) {
-        const unsigned long long *cn = c->h_counters + (size_t)a * FX_CNT_COUNT;
+        const unsigned long long *cn = c->h_counters + (size_t)a * (FX_CNT_COUNT + 1);
         FxResult &r = res[a];
         memset(&r, 0, sizeof(r));
         r.n_candidates = c->slots[a].C;
@@ -521,7 +586,7 @@ int32_t fx_finish_batch(FxContext *c, FxResult *res) {
         r.best_cost = r.best_index < 0 ? 0.0 : bc;
         r.n_collisions = (int64_t)cn[FX_CNT_COLLISIONS];
         r.feasible_percentage = r.n_returned ? 100.0 * ((double)r.n_feasible / (double)r.n_returned) : 0.0;
-        r.kernel_ms = c->last_ms;
+        r.kernel_ms = c->timing ? c->last_ms : -1.0;
     }
     return FX_OK;
 }
@@ -700,8 +765,21 @@ int32_t fx_math_selftest(int32_t n, const double *x, double *atan_out, double *s
 }
 
 int64_t fx_device_bytes(const FxContext *c) { return c ? c->dev_bytes : 0; }
-double fx_last_kernel_ms(const FxContext *c) { return c ? (double)c->last_ms : 0.0; }
-double fx_last_eval_kernel_ms(const FxContext *c) { return c ? (double)c->last_eval_ms : 0.0; }
+double fx_last_kernel_ms(const FxContext *cc) {
+    FxContext *c = const_cast<FxContext *>(cc);
+    if (!c || !c->evaluated || fetch_times(c)) return 0.0;
+    return (double)c->last_ms;
+}
+double fx_last_eval_kernel_ms(const FxContext *cc) {
+    FxContext *c = const_cast<FxContext *>(cc);
+    if (!c || !c->evaluated || fetch_times(c)) return 0.0;
+    return (double)c->last_eval_ms;
+}
+int32_t fx_set_timing(FxContext *c, int32_t enabled) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    c->timing = enabled != 0;
+    return FX_OK;
+}
 
 // device pointers of agent 0's outputs, for callers that keep working on the GPU (torch tensors via
 // from_blob-style wrapping or RCCL sends): cost f64[ld], flags u32[ld], planes f64[14][S][ld]

@@ -61,3 +61,12 @@ enum {
     FX_CNT_RETURNED = 0, FX_CNT_FEASIBLE, FX_CNT_HIST0, /* 11 entries */
     FX_CNT_BEST_IDX = FX_CNT_HIST0 + FX_NUM_REASONS, FX_CNT_BEST_COST, FX_CNT_COLLISIONS, FX_CNT_COUNT
 };
+
+// Pointers stored inside DevProblem are loaded from memory, so the compiler only knows them as generic ("flat")
+// pointers: every access would be a flat_load/flat_store and wave-uniform reads could not become scalar loads.
+// They all point into hipMalloc'ed memory -- say so.
+#define FX_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ FX_GLOBAL T *as_global(T *p) {
+    return (FX_GLOBAL T *)p;
+}

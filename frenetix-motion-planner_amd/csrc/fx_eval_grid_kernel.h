@@ -40,12 +40,15 @@ enum : uint32_t { LON_NEG = 1u, LON_ACC = 2u, LON_MOVING = 4u, LON_INDOMAIN = 8u
 
 }  // namespace fxk
 
-// rows_per_block_max: pairs a workgroup may span (host guarantees (CPB + nD - 2) / nD + 1 <= rows budget)
+// Workgroup size is a launch parameter (64, 128 or 256 lanes): small grids run wave-sized workgroups so that the
+// dispatcher balances the chip at wave granularity and nothing is staged that a single wave does not need; the
+// host guarantees that the rows of a workgroup ((CPB + nD - 2) / nD + 1 pairs) fit its dynamic LDS.
 template <int G, bool BUNDLE, bool OBST, int WPE>
 __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevProblem *__restrict__ probs) {
     using namespace fxk;
-    constexpr int CPB = FX_BLOCK / G;
-    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];  // [M][8] knots | [5][S] time powers | rows[n_pairs][S]
+    const int BLK = blockDim.x;
+    const int CPB = BLK / G;
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];  // [5][S] time powers | rows[n_pairs][S]
     __shared__ double red_cost[FX_BLOCK / 64];
     __shared__ long long red_idx[FX_BLOCK / 64];
     __shared__ unsigned int red_cnt[2 + FX_NUM_REASONS];
@@ -63,17 +66,21 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     const int M = P.M, S = P.S;
     const int nD = P.nD, nV = P.nV;
     {
-        const double *__restrict__ src = P.ref;
-        for (int i = tid; i < M * FX_REF_FIELDS; i += FX_BLOCK) lds_dyn[i] = src[i];
-        const double *__restrict__ tsrc = P.tpow;
-        for (int i = tid; i < 5 * S; i += FX_BLOCK) lds_dyn[M * FX_REF_FIELDS + i] = tsrc[i];
+        const FX_GLOBAL double *__restrict__ tsrc = as_global(P.tpow);
+        for (int i = tid; i < 5 * S; i += BLK) lds_dyn[i] = tsrc[i];
     }
     if (tid < 2 + FX_NUM_REASONS) red_cnt[tid] = 0;
     __syncthreads();
-    const Knot *__restrict__ knots = reinterpret_cast<const Knot *>(lds_dyn);
-    const double *__restrict__ tp = lds_dyn + M * FX_REF_FIELDS;
-    // rows start at the next 16-byte boundary (M*8 + 5*S doubles is a multiple of 8 B; round to 2 doubles)
-    LonRow *__restrict__ rows = reinterpret_cast<LonRow *>(lds_dyn + ((M * FX_REF_FIELDS + 5 * S + 1) & ~1));
+    // the knots are only touched by the prologue (one lookup per (pair, step) item): read them through L1/L2
+    const FX_GLOBAL double *__restrict__ kn = as_global(P.ref);
+    auto knot_at = [&](int k) {
+        const FX_GLOBAL double *q = kn + (int64_t)k * FX_REF_FIELDS;
+        Knot r;
+        r.pos = q[0]; r.theta = q[1]; r.curv = q[2]; r.curv_d = q[3]; r.x = q[4]; r.y = q[5]; r.nx = q[6]; r.ny = q[7];
+        return r;
+    };
+    const double *__restrict__ tp = lds_dyn;
+    LonRow *__restrict__ rows = reinterpret_cast<LonRow *>(lds_dyn + ((5 * S + 1) & ~1));  // 16-byte aligned
 
     const double dt = P.dt;
     const bool low_vel = P.low_vel_mode != 0;
@@ -81,7 +88,9 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     const bool dbg = D || (P.mode & FX_MODE_KINEMATIC_DEBUG) != 0;
     const bool do_collision = OBST && (P.mode & FX_MODE_COLLISION) != 0;
     const bool bundle = BUNDLE && (P.mode & FX_MODE_WRITE_BUNDLE) != 0;
-    const double a_max = P.veh.a_max, kappa_max = P.veh.kappa_max;
+    const double a_max = P.veh.a_max, kappa_max = P.veh.kappa_max, v_switch = P.veh.v_switch, v_des = P.v_des;
+    const double av_switch = a_max * v_switch;
+    const double wb = P.veh.wb_rear_axle, half_len = P.veh.length / 2, half_wid = P.veh.width / 2;
     const int64_t ld = P.ld;
     const double r_dt = 1.0 / dt;
     const double s0 = P.x0_lon[0], ss0 = P.x0_lon[1], sss0 = P.x0_lon[2];
@@ -91,12 +100,12 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     const int64_t pair0 = (c0 + gbase) / nD;
     const int64_t c_last = min(c0 + CPB, C) - 1;
     const int n_pairs = (int)((c_last + gbase) / nD - pair0) + 1;
-    const double rp_first = knots[0].pos, rp_last = knots[M - 1].pos;
-    for (int item = tid; item < n_pairs * S; item += FX_BLOCK) {
+    const double rp_first = kn[0], rp_last = kn[(int64_t)(M - 1) * FX_REF_FIELDS];
+    for (int item = tid; item < n_pairs * S; item += BLK) {
         const int pl = item / S, i = item - pl * S;
         const int64_t pair = pair0 + pl;
         const int it = (int)(pair / nV), iv = (int)(pair - (int64_t)it * nV);
-        const double T = P.t_samp[it], v1 = P.v_samp[iv];
+        const double T = P.t_samp[it], v1 = as_global(P.v_samp)[iv];
         // longitudinal quartic (polynomial_trajectory.py:452-488)
         const double b1 = v1 - ss0 - sss0 * T, b2 = 0.0 - sss0, T2 = T * T;
         const double cl0 = s0, cl1 = ss0, cl2 = .5 * sss0;
@@ -127,12 +136,12 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
         int lo = 0, hi = M;
         while (lo < hi) {
             int mid = (lo + hi) >> 1;
-            if (knots[mid].pos > s_i) hi = mid; else lo = mid + 1;
+            if (kn[(int64_t)mid * FX_REF_FIELDS] > s_i) hi = mid; else lo = mid + 1;
         }
         const int ub = lo;
         const int i1 = ub == M ? 0 : ub;
         const int i0 = i1 == 0 ? M - 1 : i1 - 1;
-        const Knot k0 = knots[i0], k1 = knots[i1];
+        const Knot k0 = knot_at(i0), k1 = knot_at(i1);
         const double seg = k1.pos - k0.pos, r_seg = 1.0 / seg;
         const double s_lambda = div_rcp(s_i - k0.pos, seg, r_seg);
         r.th_ref = wrap_pm_2pi(div_rcp((k1.theta - k0.theta) * (s_i - k0.pos), seg, r_seg) + k0.theta);
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
             r.flags |= LON_INDOMAIN;
             int kk = ub - 1;
             kk = kk < 0 ? 0 : (kk > M - 2 ? M - 2 : kk);
-            const Knot q0 = kk == i0 ? k0 : knots[kk], q1 = kk == i0 ? k1 : knots[kk + 1];
+            const Knot q0 = kk == i0 ? k0 : knot_at(kk), q1 = kk == i0 ? k1 : knot_at(kk + 1);
             const double lam = kk == i0 ? s_lambda : (s_i - q0.pos) / (q1.pos - q0.pos);
             r.px = q0.x + lam * (q1.x - q0.x);
             r.py = q0.y + lam * (q1.y - q0.y);
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     const int64_t pair = gg / nD;
     const int id = (int)(gg - pair * nD);
     const int it = (int)(pair / nV), iv = (int)(pair - (int64_t)it * nV);
-    const double T = P.t_samp[it], v1 = P.v_samp[iv], d1 = P.d_samp[id];
+    const double T = P.t_samp[it], v1 = P.v_samp[iv], d1 = as_global(P.d_samp)[id];
     const double d0 = P.x0_lat[0], dd0 = P.x0_lat[1], ddd0 = P.x0_lat[2];
     const LonRow *__restrict__ my = rows + (int)(pair - pair0) * S;
     double cl3, cl4;
@@ -196,10 +205,10 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     traj_len = traj_len > S ? S : (traj_len < 1 ? 1 : traj_len);
 
     if (bundle && active && part == 0) {
-        double *__restrict__ co = P.coeffs + g;
+        FX_GLOBAL double *__restrict__ co = as_global(P.coeffs) + g;
         co[0 * ld] = s0; co[1 * ld] = ss0; co[2 * ld] = .5 * sss0; co[3 * ld] = cl3; co[4 * ld] = cl4; co[5 * ld] = 0.0;
         co[6 * ld] = ct0; co[7 * ld] = ct1; co[8 * ld] = ct2; co[9 * ld] = ct3; co[10 * ld] = ct4; co[11 * ld] = ct5;
-        P.traj_len[g] = traj_len;
+        as_global(P.traj_len)[g] = traj_len;
     }
 
     auto lat_at = [&](int i, double u_lowvel, double &d, double &dv, double &da) {
@@ -239,14 +248,14 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     bool collided = false;
     double bx_prev = 0.0, by_prev = 0.0, ux_prev = 0.0, uy_prev = 0.0;
     const int K = P.K, Pn = P.P;
-    const double *__restrict__ obs_pos = P.obs_pos;
-    const double *__restrict__ obs_cov_inv = P.obs_cov_inv;
-    const double *__restrict__ obs_hull = P.obs_hull;
-    const int32_t *__restrict__ obs_npred = P.obs_npred;
-    const int32_t *__restrict__ obs_nhull = P.obs_nhull;
+    const FX_GLOBAL double *__restrict__ obs_pos = as_global(P.obs_pos);
+    const FX_GLOBAL double *__restrict__ obs_cov_inv = as_global(P.obs_cov_inv);
+    const FX_GLOBAL double *__restrict__ obs_hull = as_global(P.obs_hull);
+    const FX_GLOBAL int32_t *__restrict__ obs_npred = as_global(P.obs_npred);
+    const FX_GLOBAL int32_t *__restrict__ obs_nhull = as_global(P.obs_nhull);
     int max_nhull = 0;
     if (do_collision) for (int k = 0; k < K; k++) max_nhull = max(max_nhull, obs_nhull[k]);
-    double *__restrict__ planes = P.planes;
+    FX_GLOBAL double *__restrict__ planes = as_global(P.planes);
 
 #pragma unroll 1
     for (int i = i_first; i < i_end; i++) {
@@ -304,8 +313,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
             if (fabs(np_round5(yaw_rate)) > kappa_max * v_i) hit |= 1u << 6;
             const double kap_rate = i > 0 ? div_rcp(kap - kap_prev, dt, r_dt) : 0.;
             if (fabs(kap_rate) > 0.4) hit |= 1u << 7;
-            const double v_switch = P.veh.v_switch;
-            const double a_hi = v_i > v_switch ? a_max * v_switch / v_i : a_max;
+            const double a_hi = v_i > v_switch ? av_switch / v_i : a_max;
             if (!(-a_max <= a_i && a_i <= a_hi)) hit |= 1u << 8;
             if (dbg) step_reasons |= hit;
             else if (hit && first_key == 0xffffffffu) first_key = ((uint32_t)i << 4) | (uint32_t)(__ffs((int)hit) - 1);
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
         }
 
         if (bundle && active && emit) {
-            double *__restrict__ row = planes + (int64_t)i * ld + g;
+            FX_GLOBAL double *__restrict__ row = planes + (int64_t)i * ld + g;
             const int64_t ps = (int64_t)S * ld;
             row[FX_PL_X * ps] = x_i;
             row[FX_PL_Y * ps] = y_i;
@@ -342,15 +350,15 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
 
         if (emit) {
             sum_abs_d += fabs(d_i);
-            if (i >= half && i < S - 1) sum_voff += fabs(v_i - P.v_des);
+            if (i >= half && i < S - 1) sum_voff += fabs(v_i - v_des);
             if (i == S - 1) { d_end = d_i; v_end = v_i; }
         }
         if (OBST) {
             if (emit && i >= 1) {
                 for (int k = 0; k < K; k++) {
                     if (i < obs_npred[k]) {
-                        const double *__restrict__ mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
-                        const double *__restrict__ iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
+                        const FX_GLOBAL double *__restrict__ mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
+                        const FX_GLOBAL double *__restrict__ iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
                         const double e0 = x_i - mu[0], e1 = y_i - mu[1];
                         const double r0 = e0 * iv[0] + e1 * iv[2], r1 = e0 * iv[1] + e1 * iv[3];
                         const double m = r0 * e0 + r1 * e1;
@@ -363,14 +371,12 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
                 if (need && i >= 1) {
                     double su, cu;
                     fxm::sincos(th_gl, &su, &cu);
-                    const double wb = P.veh.wb_rear_axle;
                     const double bx = x_i + wb * cu, by = y_i + wb * su;
                     if (emit && i >= 2) {
-                        const Obb hull = obb_hull(bx_prev, by_prev, ux_prev, uy_prev, bx, by, cu, su, P.veh.length / 2,
-                                                  P.veh.width / 2);
+                        const Obb hull = obb_hull(bx_prev, by_prev, ux_prev, uy_prev, bx, by, cu, su, half_len, half_wid);
                         for (int k = 0; k < K; k++) {
                             if (i - 2 < obs_nhull[k]) {
-                                const double *__restrict__ oh = obs_hull + ((int64_t)k * (Pn - 1) + (i - 2)) * 6;
+                                const FX_GLOBAL double *__restrict__ oh = obs_hull + ((int64_t)k * (Pn - 1) + (i - 2)) * 6;
                                 collided |= obb_overlap(hull, oh);
                             }
                         }

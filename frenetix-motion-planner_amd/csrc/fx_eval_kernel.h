@@ -108,7 +108,8 @@ __device__ __forceinline__ Obb obb_hull(double c0x, double c0y, double u0x, doub
 }
 
 // separating-axis test; b = (cx, cy, ex, ey, h1, h2)
-__device__ __forceinline__ bool obb_overlap(const Obb &a, const double *__restrict__ b) {
+template <typename PtrT>
+__device__ __forceinline__ bool obb_overlap(const Obb &a, PtrT b) {
     double tx = b[0] - a.cx, ty = b[1] - a.cy;
     double c = a.ex * b[2] + a.ey * b[3];
     double s = a.ex * b[3] - a.ey * b[2];
@@ -164,10 +165,10 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
     const int S = P.S, K = P.K, Pn = P.P;
     const int64_t ld = P.ld;
     const double dt = P.dt;
-    double *__restrict__ planes = P.planes;
-    const double *__restrict__ obs_pos = P.obs_pos;
-    const double *__restrict__ obs_cov_inv = P.obs_cov_inv;
-    const int32_t *__restrict__ obs_npred = P.obs_npred;
+    FX_GLOBAL double *__restrict__ planes = as_global(P.planes);
+    const FX_GLOBAL double *__restrict__ obs_pos = as_global(P.obs_pos);
+    const FX_GLOBAL double *__restrict__ obs_cov_inv = as_global(P.obs_cov_inv);
+    const FX_GLOBAL int32_t *__restrict__ obs_npred = as_global(P.obs_npred);
     bool neg = W.neg, acc_viol = W.acc_viol, collided = W.collided;
     uint32_t step_reasons = W.step_reasons, first_key = W.first_key;
     int fail_step = W.fail_step;
@@ -187,7 +188,7 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
             if (bundle && active) {
                 const int64_t ps = (int64_t)S * ld;
                 for (int i = i_begin; i < i_end; i++) {
-                    double *__restrict__ row = planes + (int64_t)i * ld + g;
+                    FX_GLOBAL double *__restrict__ row = planes + (int64_t)i * ld + g;
                     row[FX_PL_X * ps] = 0.0;
                     row[FX_PL_Y * ps] = 0.0;
                 }
@@ -197,8 +198,8 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
                 for (int i = max(i_begin, 1); i < i_end; i++)
                     for (int k = 0; k < K; k++)
                         if (i < obs_npred[k]) {
-                            const double *__restrict__ mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
-                            const double *__restrict__ iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
+                            const FX_GLOBAL double *__restrict__ mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
+                            const FX_GLOBAL double *__restrict__ iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
                             const double e0 = 0.0 - mu[0], e1 = 0.0 - mu[1];
                             const double r0 = e0 * iv[0] + e1 * iv[2], r1 = e0 * iv[1] + e1 * iv[3];
                             const double m = r0 * e0 + r1 * e1;
@@ -283,14 +284,14 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
             case FX_COST_DISTANCE_TO_OBSTACLES: c = EXTRA ? dto : 0.0; break;
             default: break;
             }
-            if ((P.mode & FX_MODE_WRITE_COSTMAP) && active && leader) P.costmap[(int64_t)n * ld + g] = costed ? c : 0.0;
+            if ((P.mode & FX_MODE_WRITE_COSTMAP) && active && leader) as_global(P.costmap)[(int64_t)n * ld + g] = costed ? c : 0.0;
             sum += P.cost_w[n] * c;
         }
         total = 0.0 + sum;
     }
     if (active && leader) {
-        P.cost[g] = costed ? total : 0.0;
-        P.flags[g] = flags;
+        as_global(P.cost)[g] = costed ? total : 0.0;
+        as_global(P.flags)[g] = flags;
     }
 
     // ---- workgroup reductions (candidate leaders only): counters and the (cost, index) arg-min partial ----
@@ -321,10 +322,10 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
     if (lane == 0) { red_cost[wave] = bc; red_idx[wave] = bi; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < FX_BLOCK / 64; w++)
+        for (int w = 1; w < (int)blockDim.x / 64; w++)
             if (red_cost[w] < bc || (red_cost[w] == bc && red_idx[w] < bi)) { bc = red_cost[w]; bi = red_idx[w]; }
-        P.part_cost[blockIdx.x] = bc;
-        P.part_idx[blockIdx.x] = bi;
+        as_global(P.part_cost)[blockIdx.x] = bc;
+        as_global(P.part_idx)[blockIdx.x] = bi;
     }
     if (tid < 2 + FX_NUM_REASONS && red_cnt[tid]) atomicAdd(&P.counters[tid], (unsigned long long)red_cnt[tid]);
 }
@@ -360,9 +361,9 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
 
     const int M = P.M, S = P.S;
     {
-        const double *__restrict__ src = P.ref;
+        const FX_GLOBAL double *__restrict__ src = as_global(P.ref);
         for (int i = tid; i < M * FX_REF_FIELDS; i += FX_BLOCK) lds_dyn[i] = src[i];
-        const double *__restrict__ tsrc = P.tpow;
+        const FX_GLOBAL double *__restrict__ tsrc = as_global(P.tpow);
         for (int i = tid; i < 5 * S; i += FX_BLOCK) lds_dyn[M * FX_REF_FIELDS + i] = tsrc[i];
     }
     if (tid < 2 + FX_NUM_REASONS) red_cnt[tid] = 0;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     // ---- candidate parameters (reactive_planner.py:149-171 / sampling matrix row) ----
     double T, s0, ss0, sss0, v1, a1, d0, dd0, ddd0, d1, dd1, ddd1;
     if (P.has_matrix) {
-        const double *__restrict__ r = P.matrix + 13 * (g + P.g_base);
+        const FX_GLOBAL double *__restrict__ r = as_global(P.matrix) + 13 * (g + P.g_base);
         T = r[1] - r[0];
         s0 = r[2]; ss0 = r[3]; sss0 = r[4]; v1 = r[5]; a1 = r[6];
         d0 = r[7]; dd0 = r[8]; ddd0 = r[9]; d1 = r[10]; dd1 = r[11]; ddd1 = r[12];
@@ -395,9 +396,9 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
         const int id = (int)(gg - q * nD);
         const int it = (int)(q / nV);
         const int iv = (int)(q - (int64_t)it * nV);
-        T = P.t_samp[it];
-        v1 = P.v_samp[iv];
-        d1 = P.d_samp[id];
+        T = as_global(P.t_samp)[it];
+        v1 = as_global(P.v_samp)[iv];
+        d1 = as_global(P.d_samp)[id];
         s0 = P.x0_lon[0]; ss0 = P.x0_lon[1]; sss0 = P.x0_lon[2];
         d0 = P.x0_lat[0]; dd0 = P.x0_lat[1]; ddd0 = P.x0_lat[2];
         a1 = 0.0; dd1 = 0.0; ddd1 = 0.0;
@@ -441,10 +442,10 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     traj_len = traj_len > S ? S : (traj_len < 1 ? 1 : traj_len);
 
     if (bundle && active && part == 0) {
-        double *__restrict__ co = P.coeffs + g;
+        FX_GLOBAL double *__restrict__ co = as_global(P.coeffs) + g;
         co[0 * ld] = cl0; co[1 * ld] = cl1; co[2 * ld] = cl2; co[3 * ld] = cl3; co[4 * ld] = cl4; co[5 * ld] = 0.0;
         co[6 * ld] = ct0; co[7 * ld] = ct1; co[8 * ld] = ct2; co[9 * ld] = ct3; co[10 * ld] = ct4; co[11 * ld] = ct5;
-        P.traj_len[g] = traj_len;
+        as_global(P.traj_len)[g] = traj_len;
     }
 
     // polynomial samples on the rounded time grid (reactive_planner.py:313-316,326-341); i < traj_len
@@ -527,16 +528,16 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     bool collided = false;
     double bx_prev = 0.0, by_prev = 0.0, ux_prev = 0.0, uy_prev = 0.0;
     const int K = P.K, Pn = P.P, n_dto = EXTRA ? P.n_dto : 0;
-    const double *__restrict__ obs_pos = P.obs_pos;
-    const double *__restrict__ obs_cov_inv = P.obs_cov_inv;
-    const double *__restrict__ obs_hull = P.obs_hull;
-    const int32_t *__restrict__ obs_npred = P.obs_npred;
-    const int32_t *__restrict__ obs_nhull = P.obs_nhull;
-    const double *__restrict__ dto_pos = P.dto_pos;
+    const FX_GLOBAL double *__restrict__ obs_pos = as_global(P.obs_pos);
+    const FX_GLOBAL double *__restrict__ obs_cov_inv = as_global(P.obs_cov_inv);
+    const FX_GLOBAL double *__restrict__ obs_hull = as_global(P.obs_hull);
+    const FX_GLOBAL int32_t *__restrict__ obs_npred = as_global(P.obs_npred);
+    const FX_GLOBAL int32_t *__restrict__ obs_nhull = as_global(P.obs_nhull);
+    const FX_GLOBAL double *__restrict__ dto_pos = as_global(P.dto_pos);
     int max_nhull = 0;
     if (do_collision) for (int k = 0; k < K; k++) max_nhull = max(max_nhull, obs_nhull[k]);
 
-    double *__restrict__ planes = P.planes;
+    FX_GLOBAL double *__restrict__ planes = as_global(P.planes);
 
 #pragma unroll 1
     for (int i = i_first; i < i_end; i++) {
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
 
         // -- SoA bundle (trajectories.py:56-334) --
         if (bundle && active && emit) {
-            double *__restrict__ row = planes + (int64_t)i * ld + g;
+            FX_GLOBAL double *__restrict__ row = planes + (int64_t)i * ld + g;
             const int64_t ps = (int64_t)S * ld;
             row[FX_PL_X * ps] = x_i;
             row[FX_PL_Y * ps] = y_i;
@@ -704,8 +705,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
             if (emit && i >= 1) {  // ego step i pairs with prediction i-1 (collision_probability.py:283-292)
                 for (int k = 0; k < K; k++) {
                     if (i < obs_npred[k]) {
-                        const double *__restrict__ mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
-                        const double *__restrict__ iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
+                        const FX_GLOBAL double *__restrict__ mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
+                        const FX_GLOBAL double *__restrict__ iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
                         const double e0 = x_i - mu[0], e1 = y_i - mu[1];
                         const double r0 = e0 * iv[0] + e1 * iv[2], r1 = e0 * iv[1] + e1 * iv[3];
                         const double m = r0 * e0 + r1 * e1;
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
                                                   P.veh.width / 2);
                         for (int k = 0; k < K; k++) {
                             if (i - 2 < obs_nhull[k]) {
-                                const double *__restrict__ oh = obs_hull + ((int64_t)k * (Pn - 1) + (i - 2)) * 6;
+                                const FX_GLOBAL double *__restrict__ oh = obs_hull + ((int64_t)k * (Pn - 1) + (i - 2)) * 6;
                                 collided |= obb_overlap(hull, oh);
                             }
                         }

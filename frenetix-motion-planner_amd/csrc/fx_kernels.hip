@@ -31,7 +31,8 @@ using fxk::wave_count;
 // counts the colliding candidates that the reference's cost-ordered walk would have visited before it
 // (planner.py:336-357 `_collision_counter`).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void fx_select_kernel(const DevProblem *__restrict__ probs) {
+__global__ __launch_bounds__(1024) void fx_select_kernel(const DevProblem *__restrict__ probs, unsigned long long *host_result,
+                                                         unsigned long long seq) {
     __shared__ double sc[16];
     __shared__ long long si[16];
     __shared__ unsigned int scnt;
@@ -40,8 +41,8 @@ __global__ __launch_bounds__(1024) void fx_select_kernel(const DevProblem *__res
     double bc = INFINITY;
     long long bi = 0x7fffffffffffffffLL;
     for (int b = tid; b < P.n_blocks; b += 1024) {
-        const double c = P.part_cost[b];
-        const long long ix = P.part_idx[b];
+        const double c = as_global(P.part_cost)[b];
+        const long long ix = as_global(P.part_idx)[b];
         if (c < bc || (c == bc && ix < bi)) { bc = c; bi = ix; }
     }
 #pragma unroll
@@ -61,9 +62,9 @@ __global__ __launch_bounds__(1024) void fx_select_kernel(const DevProblem *__res
     unsigned int cnt = 0;
     if (P.mode & FX_MODE_COLLISION) {
         for (int64_t g = tid; g < P.C; g += 1024) {
-            const uint32_t f = P.flags[g];
+            const uint32_t f = as_global(P.flags)[g];
             if ((f & FX_FLAG_SELECTABLE) && (f & FX_FLAG_COLLISION)) {
-                const double c = P.cost[g];
+                const double c = as_global(P.cost)[g];
                 if (none || c < bc || (c == bc && g + P.g_base < bi)) cnt++;
             }
         }
@@ -71,10 +72,22 @@ __global__ __launch_bounds__(1024) void fx_select_kernel(const DevProblem *__res
         if (lane == 0 && cnt) atomicAdd(&scnt, cnt);
     }
     __syncthreads();
+    // Publish the step's result straight into pinned host memory (the host polls the sequence word instead of
+    // paying for a D2H copy and a stream synchronisation) and leave the device counters zeroed for the next step.
+    unsigned long long *out = host_result + (size_t)blockIdx.x * (FX_CNT_COUNT + 1);
+    if (tid < FX_CNT_BEST_IDX) {
+        out[tid] = P.counters[tid];
+        P.counters[tid] = 0ULL;
+    }
     if (tid == 0) {
-        P.counters[FX_CNT_BEST_IDX] = none ? ~0ULL : (unsigned long long)bi;
-        P.counters[FX_CNT_BEST_COST] = none ? 0ULL : (unsigned long long)__double_as_longlong(bc);
-        P.counters[FX_CNT_COLLISIONS] = scnt;
+        out[FX_CNT_BEST_IDX] = none ? ~0ULL : (unsigned long long)bi;
+        out[FX_CNT_BEST_COST] = none ? 0ULL : (unsigned long long)__double_as_longlong(bc);
+        out[FX_CNT_COLLISIONS] = scnt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&out[FX_CNT_COUNT], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -95,9 +108,9 @@ __global__ __launch_bounds__(1024) void fx_topk_kernel(const DevProblem *__restr
         double bc = INFINITY;
         long long bi = 0x7fffffffffffffffLL;
         for (int64_t g = tid; g < P.C; g += 1024) {
-            const uint32_t f = P.flags[g];
+            const uint32_t f = as_global(P.flags)[g];
             if ((f & FX_FLAG_SELECTABLE) && !(f & FX_FLAG_COLLISION)) {
-                const double c = P.cost[g];
+                const double c = as_global(P.cost)[g];
                 const long long gg = (long long)(g + P.g_base);
                 const bool after = c > lb_c || (c == lb_c && gg > lb_i);
                 if (after && (c < bc || (c == bc && gg < bi))) { bc = c; bi = gg; }
@@ -182,9 +195,9 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
 }
 
 // Grid (t x v x d) specialisation with the shared longitudinal table; lds_bytes includes the rows.
-extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, size_t lds_bytes, int G,
-                                          bool bundle, bool obst, int wpe, hipStream_t stream) {
-    dim3 grid(max_blocks, n_agents), block(FX_BLOCK);
+extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, int block_size,
+                                          size_t lds_bytes, int G, bool bundle, bool obst, int wpe, hipStream_t stream) {
+    dim3 grid(max_blocks, n_agents), block(block_size);
 #define FX_LAUNCH(Gv, B, O, W)                                                                                     \
     do {                                                                                                          \
         if (lds_bytes > 48 * 1024) {                                                                              \
@@ -219,8 +232,9 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
 #undef FX_LAUNCH
 }
 
-extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, hipStream_t stream) {
-    hipLaunchKernelGGL(fx_select_kernel, dim3(n_agents), dim3(1024), 0, stream, d_probs);
+extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
+                                       unsigned long long seq, hipStream_t stream) {
+    hipLaunchKernelGGL(fx_select_kernel, dim3(n_agents), dim3(1024), 0, stream, d_probs, host_result, seq);
     return hipGetLastError();
 }
 

@@ -179,6 +179,8 @@ int32_t fx_set_stream(FxContext *ctx, void *hip_stream);
  * target in waves per SIMD (2..4) of the evaluation kernel, and the kernel variant (1 = generic per-candidate
  * kernel, 2 = grid kernel with the per-(t,v) longitudinal table).  Results do not depend on any of them. */
 int32_t fx_set_tuning(FxContext *ctx, int32_t lanes_per_candidate, int32_t waves_per_simd, int32_t kernel_variant);
+/* workgroup size of the grid kernel: 0 (auto), 64, 128 or 256 lanes */
+int32_t fx_set_block_size(FxContext *ctx, int32_t block_size);
 
 /* ---- staging: copy the shared inputs of a plan step to the device (borrowed for the call).
  *      Replaces handler.generate_trajectories(matrix, low_vel_mode) + the functor registration
@@ -240,6 +242,9 @@ int32_t fx_device_views(FxContext *ctx, int32_t agent, void **cost, void **flags
 int64_t fx_device_bytes(const FxContext *ctx);
 double fx_last_kernel_ms(const FxContext *ctx);
 double fx_last_eval_kernel_ms(const FxContext *ctx);
+/* per-step HIP-event timing on (default) / off: when off fx_finish only polls the result block the selection
+ * kernel publishes into pinned host memory and FxResult.kernel_ms is -1 */
+int32_t fx_set_timing(FxContext *ctx, int32_t enabled);
 /* device self-test of the kernel's elementary functions (atan, sin, cos) on n host values */
 int32_t fx_math_selftest(int32_t n, const double *x, double *atan_out, double *sin_out, double *cos_out);
 

@@ -2,13 +2,15 @@
 """Probe: fixed vs per-step cost of the evaluation kernel (GPU box)."""
 import json, sys
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from frenetix_motion_planner_amd import synthetic
 from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
 
+VARIANT = int(os.environ.get('FXV', '2'))
 def t(inp, G, w, steps=40):
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N, max_ref_knots=2048) as eng:
-        eng.set_tuning(G, w); eng.upload(inp)
+        eng.set_tuning(G, w, VARIANT); eng.upload(inp)
         for _ in range(5): eng.evaluate(); eng.finish()
         ts = []
         for _ in range(steps):

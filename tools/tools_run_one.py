@@ -2,7 +2,8 @@
 """Run one configuration a few times (for rocprofv3 --pmc / --kernel-trace on the GPU box).
 usage: tools_run_one.py G WPE VARIANT modeA|modeB n_obst [nt nv nd] [steps]"""
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from frenetix_motion_planner_amd import synthetic
 from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
 G, w, var, mode, nobs = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])

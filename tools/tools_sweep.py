@@ -5,7 +5,8 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from frenetix_motion_planner_amd import synthetic  # noqa: E402
 from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls  # noqa: E402
 
@@ -14,10 +15,11 @@ def run(label, steps=60, **kw):
     inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
     out = {}
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
-        for variant in (1, 2):
-          for G in (1, 2, 4, 8):
+        for blk in (64, 128, 256):
+          for G in (1, 2, 4):
             for w in (2, 3, 4):
-                eng.set_tuning(G, w, variant)
+                variant = 2
+                eng.set_tuning(G, w, variant, blk)
                 eng.upload(inp)
                 for _ in range(5):
                     eng.evaluate(); eng.finish()
@@ -25,7 +27,7 @@ def run(label, steps=60, **kw):
                 for _ in range(steps):
                     eng.evaluate(); eng.finish()
                     ts.append(eng.last_eval_kernel_ms)
-                out[f"{'gen' if variant == 1 else 'grid'}_G{G}_w{w}"] = round(float(np.median(ts)) * 1e3, 1)
+                out[f"b{blk}_G{G}_w{w}"] = round(float(np.median(ts)) * 1e3, 1)
     print(label, inp.n_candidates, json.dumps(out))
 
 
