@@ -20,7 +20,8 @@
 extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, int max_blocks, size_t lds_bytes, int G,
                                      bool bundle, bool obst, bool extra, int wpe, hipStream_t stream);
 extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, int block_size,
-                                          size_t lds_bytes, int G, bool bundle, bool obst, int wpe, hipStream_t stream);
+                                          size_t lds_bytes, int G, bool bundle, bool obst, int wpe, bool wsplit,
+                                          hipStream_t stream);
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
                                        unsigned long long seq, hipStream_t stream);
 extern "C" hipError_t fx_launch_math_test(int n, const double *x, double *at, double *sn, double *cs, hipStream_t stream);
@@ -101,6 +102,8 @@ struct FxContext {
     int G_force = 0, wpe_force = 0;        // fx_set_tuning overrides (0 = automatic)
     int variant_force = 0;                 // 0 auto, 1 generic kernel, 2 grid kernel
     int block_force = 0;                   // grid-kernel workgroup size override (0 auto)
+    int wsplit_force = 0;                  // 0 auto, 1 lane split, 2 wave split
+    bool wsplit_step = false;
     int block_step = FX_BLOCK;
     bool use_grid = false;                 // current step runs fx_eval_grid_kernel
     size_t lds_step = 0;
@@ -304,6 +307,13 @@ int32_t fx_destroy(FxContext *c) {
     return FX_OK;
 }
 
+int32_t fx_set_part_mapping(FxContext *c, int32_t mapping) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (mapping < 0 || mapping > 2) return set_err(FX_ERR_INVALID_ARGUMENT, "mapping must be 0 (auto), 1 (lane split) or 2 (wave split)");
+    c->wsplit_force = mapping;
+    return FX_OK;
+}
+
 int32_t fx_set_block_size(FxContext *c, int32_t block_size) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     if (block_size != 0 && block_size != 64 && block_size != 128 && block_size != 256)
@@ -384,7 +394,8 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                     const FxProblem *p = &probs[a];
                     const size_t n_pairs = (size_t)(blk / G + p->nD - 2) / p->nD + 1;
                     const size_t S = (size_t)p->N + 1;
-                    need = std::max(need, sizeof(double) * ((5 * S + 1) & ~(size_t)1) + 128 * n_pairs * S);
+                    need = std::max(need, sizeof(double) * ((5 * S + 1) & ~(size_t)1) + 128 * n_pairs * S +
+                                              (G > 1 ? (size_t)56 * blk : 0));  // + wave-split exchange block
                 }
                 return need;
             };
@@ -404,6 +415,10 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         c->use_grid = grid_ok;
         c->lds_step = lds_need;
         c->block_step = grid_ok ? block : FX_BLOCK;
+        // wave split needs whole waves per part (CPB % 64 == 0) and G in {2, 4}
+        const bool ws_possible = grid_ok && (G == 2 || G == 4) && (c->block_step / G) % 64 == 0;
+        c->wsplit_step = ws_possible && c->wsplit_force != 1;
+        if (c->wsplit_force == 2 && !ws_possible && G > 1) return set_err(FX_ERR_INVALID_ARGUMENT, "wave split forced but not applicable");
     }
     const int CPB = c->block_step / c->G_step;
     int64_t cand_off = 0, block_off = 0;
@@ -535,7 +550,7 @@ int32_t fx_evaluate(FxContext *c) {
     {
         if (c->use_grid)
             HIP_TRY(fx_launch_eval_grid(c->d_probs, c->n_agents, c->max_blocks_step, c->block_step, c->lds_step, c->G_step,
-                                        c->any_bundle, c->any_obst, c->wpe_step, c->stream));
+                                        c->any_bundle, c->any_obst, c->wpe_step, c->wsplit_step, c->stream));
         else
             HIP_TRY(fx_launch_eval(c->d_probs, c->n_agents, c->max_blocks_step,
                                    sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + 5 * (size_t)c->S_max_step),

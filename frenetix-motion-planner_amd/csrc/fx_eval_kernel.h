@@ -144,6 +144,12 @@ __device__ __forceinline__ uint32_t group_min(uint32_t v) {
 }
 
 
+}  // namespace fxk
+
+#include "fx_walk.h"
+
+namespace fxk {
+
 // Per-lane results of the horizon walk, handed to the shared epilogue.
 struct WalkResult {
     bool neg, acc_viol, collided;
@@ -157,10 +163,15 @@ struct WalkResult {
 
 // Combine the G lanes of a candidate, assemble the flag word exactly as check_feasibility does, form the weighted
 // cost, write the per-candidate outputs and contribute to the workgroup's counters and (cost, index) arg-min.
-template <int G, bool BUNDLE, bool OBST, bool EXTRA>
+//
+// The G parts of a candidate are either G adjacent lanes (WSPLIT = false: combined with wave shuffles) or the same
+// lane of G different lane-groups of the workgroup (WSPLIT = true: part = tid / CPB, combined through the LDS block
+// `xch` of G * CPB * 56 bytes).  The second form keeps every store of the walk a contiguous row segment per wave.
+template <int G, bool BUNDLE, bool OBST, bool EXTRA, bool WSPLIT = false>
 __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult &W, int64_t g, bool active, int part,
                                                  int i_begin, int i_end, bool bundle, bool do_collision, bool dbg, bool D,
-                                                 double *red_cost, long long *red_idx, unsigned int *red_cnt) {
+                                                 double *red_cost, long long *red_idx, unsigned int *red_cnt,
+                                                 double *xch = nullptr, int CPB = 0, int cand_local = 0) {
     const int tid = threadIdx.x;
     const int S = P.S, K = P.K, Pn = P.P;
     const int64_t ld = P.ld;
@@ -179,10 +190,21 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
     // ---- combine the G parts of a candidate ----
     uint32_t bits = (neg ? 1u : 0u) | (acc_viol ? 2u : 0u) | (collided ? 4u : 0u);
     if (G > 1) {
-        bits = group_or<G>(bits);
-        step_reasons = group_or<G>(step_reasons);
-        first_key = group_min<G>(first_key);
-        const uint32_t fail_all = group_min<G>((uint32_t)fail_step);
+        uint32_t fail_all;
+        uint32_t *xu = reinterpret_cast<uint32_t *>(xch + 5 * G * CPB);  // [4][G*CPB] after the five double planes
+        const int slot = part * CPB + cand_local, n_slot = G * CPB;
+        if (!WSPLIT) {
+            bits = group_or<G>(bits);
+            step_reasons = group_or<G>(step_reasons);
+            first_key = group_min<G>(first_key);
+            fail_all = group_min<G>((uint32_t)fail_step);
+        } else {
+            xu[slot] = (uint32_t)fail_step;
+            __syncthreads();
+            fail_all = 0x7fffffffu;
+#pragma unroll
+            for (int q = 0; q < G; q++) { const uint32_t f = xu[q * CPB + cand_local]; fail_all = f < fail_all ? f : fail_all; }
+        }
         if (fail_all != 0x7fffffffu && (int)fail_all < i_begin) {
             // an earlier part left the projection domain: every later (x, y) is 0 (the reference's loop breaks, :547)
             if (bundle && active) {
@@ -201,18 +223,56 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
                             const FX_GLOBAL double *__restrict__ mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
                             const FX_GLOBAL double *__restrict__ iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
                             const double e0 = 0.0 - mu[0], e1 = 0.0 - mu[1];
-                            const double r0 = e0 * iv[0] + e1 * iv[2], r1 = e0 * iv[1] + e1 * iv[3];
-                            const double m = r0 * e0 + r1 * e1;
-                            pred += 1.0 / (m * m);
+                            const double r0 = fma(e1, iv[2], e0 * iv[0]), r1 = fma(e1, iv[3], e0 * iv[1]);
+                            const double m = fma(r1, e1, r0 * e0);
+                            const double mm = m * m;
+                            pred += mm > 0.0 ? rcp_nr(mm) : 1.0 / mm;
                         }
             }
         }
         fail_step = (int)fail_all;
-        sum_abs_d = group_sum<G>(sum_abs_d);
-        sum_voff = group_sum<G>(sum_voff);
-        if (OBST) pred = group_sum<G>(pred);
-        d_end = group_sum<G>(d_end);  // only the part that owns step S-1 holds a non-zero value
-        v_end = group_sum<G>(v_end);
+        if (!WSPLIT) {
+            sum_abs_d = group_sum<G>(sum_abs_d);
+            sum_voff = group_sum<G>(sum_voff);
+            if (OBST) pred = group_sum<G>(pred);
+            d_end = group_sum<G>(d_end);  // only the part that owns step S-1 holds a non-zero value
+            v_end = group_sum<G>(v_end);
+        } else {
+            xch[0 * n_slot + slot] = sum_abs_d;
+            xch[1 * n_slot + slot] = sum_voff;
+            xch[2 * n_slot + slot] = pred;
+            xch[3 * n_slot + slot] = d_end;
+            xch[4 * n_slot + slot] = v_end;
+            xu[1 * n_slot + slot] = bits;
+            xu[2 * n_slot + slot] = step_reasons;
+            xu[3 * n_slot + slot] = first_key;
+            __syncthreads();
+            if (part == 0) {
+                // same association as the xor-shuffle tree: ((p0 + p1) + (p2 + p3)) + ...
+                auto tree = [&](int plane) {
+                    double v[G];
+#pragma unroll
+                    for (int q = 0; q < G; q++) v[q] = xch[plane * n_slot + q * CPB + cand_local];
+#pragma unroll
+                    for (int w = 1; w < G; w <<= 1)
+#pragma unroll
+                        for (int q = 0; q < G; q += 2 * w) v[q] += v[q + w];
+                    return v[0];
+                };
+                sum_abs_d = tree(0);
+                sum_voff = tree(1);
+                if (OBST) pred = tree(2);
+                d_end = tree(3);
+                v_end = tree(4);
+#pragma unroll
+                for (int q = 1; q < G; q++) {
+                    bits |= xu[1 * n_slot + q * CPB + cand_local];
+                    step_reasons |= xu[2 * n_slot + q * CPB + cand_local];
+                    const uint32_t fk = xu[3 * n_slot + q * CPB + cand_local];
+                    first_key = fk < first_key ? fk : first_key;
+                }
+            }
+        }
     }
     neg = bits & 1u; acc_viol = bits & 2u; collided = bits & 4u;
     if (!dbg) step_reasons = first_key == 0xffffffffu ? 0u : (1u << (first_key & 15u));
@@ -333,6 +393,7 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
 }  // namespace fxk
 
 // ---------------------------------------------------------------------------------------------------
+// Generic kernel: arbitrary sampling-matrix rows (or ranges), every lane derives its own longitudinal row.
 // grid = (ceil(maxC / (256/G)), n_agents), block = 256, dynamic LDS = M*64 B + 5*S*8 B.
 //   G      : lanes per candidate (1, 2, 4, 8)
 //   BUNDLE : write the 14-plane SoA TrajectoryBundle + coefficients (FX_MODE_WRITE_BUNDLE)
@@ -378,9 +439,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     const bool do_collision = OBST && (P.mode & FX_MODE_COLLISION) != 0;
     // a batch launch is specialised for the union of its agents' modes; each agent still honours its own
     const bool bundle = BUNDLE && (P.mode & FX_MODE_WRITE_BUNDLE) != 0;
-    const double a_max = P.veh.a_max, kappa_max = P.veh.kappa_max;
+    const double a_max = P.veh.a_max;
     const int64_t ld = P.ld;
-    const double r_dt = 1.0 / dt;
 
     // ---- candidate parameters (reactive_planner.py:149-171 / sampling matrix row) ----
     double T, s0, ss0, sss0, v1, a1, d0, dd0, ddd0, d1, dd1, ddd1;
@@ -424,18 +484,14 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
         if (s_lon_goal <= 0) s_lon_goal = T;
         tau = s_lon_goal;
     }
-    double ct0, ct1, ct2, ct3, ct4, ct5;
+    LatPoly L;
     {
         double T2 = tau * tau, T3 = T2 * tau, T4 = T3 * tau, T5 = T4 * tau;
         double b0 = d1 - d0 - dd0 * tau - .5 * ddd0 * T2;
         double b1 = dd1 - dd0 - ddd0 * tau;
         double b2 = ddd1 - ddd0;
-        ct0 = d0;
-        ct1 = dd0;
-        ct2 = .5 * ddd0;
-        ct3 = (10.0 * b0 - 4.0 * b1 * tau + .5 * b2 * T2) / T3;
-        ct4 = (-15.0 * b0 + 7.0 * b1 * tau - b2 * T2) / T4;
-        ct5 = (6.0 * b0 - 3.0 * b1 * tau + .5 * b2 * T2) / T5;
+        L.set(d0, dd0, .5 * ddd0, (10.0 * b0 - 4.0 * b1 * tau + .5 * b2 * T2) / T3,
+              (-15.0 * b0 + 7.0 * b1 * tau - b2 * T2) / T4, (6.0 * b0 - 3.0 * b1 * tau + .5 * b2 * T2) / T5);
     }
     // len(np.arange(0, T+dt, dt)) (reactive_planner.py:296,303), clamped to the horizon
     int traj_len = (int)ceil((T + dt) / dt);
@@ -444,24 +500,27 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     if (bundle && active && part == 0) {
         FX_GLOBAL double *__restrict__ co = as_global(P.coeffs) + g;
         co[0 * ld] = cl0; co[1 * ld] = cl1; co[2 * ld] = cl2; co[3 * ld] = cl3; co[4 * ld] = cl4; co[5 * ld] = 0.0;
-        co[6 * ld] = ct0; co[7 * ld] = ct1; co[8 * ld] = ct2; co[9 * ld] = ct3; co[10 * ld] = ct4; co[11 * ld] = ct5;
+        co[6 * ld] = L.c0; co[7 * ld] = L.c1; co[8 * ld] = L.c2; co[9 * ld] = L.c3; co[10 * ld] = L.c4; co[11 * ld] = L.c5;
         as_global(P.traj_len)[g] = traj_len;
     }
 
-    // polynomial samples on the rounded time grid (reactive_planner.py:313-316,326-341); i < traj_len
-    auto lon_at = [&](int i, double &s, double &sv, double &sa) {
-        const double t1 = tp[i], t2 = tp[S + i], t3 = tp[2 * S + i], t4 = tp[3 * S + i];
-        s = cl0 + cl1 * t1 + cl2 * t2 + cl3 * t3 + cl4 * t4;
-        sv = cl1 + 2. * cl2 * t1 + 3. * cl3 * t2 + 4. * cl4 * t3;
-        sa = 2 * cl2 + 6 * cl3 * t1 + 12 * cl4 * t2;
+    const double rp_first = knots[0].pos, rp_last = knots[M - 1].pos;
+    auto row_at = [&](int i) {
+        return make_lon_row(i, S, M, dt, a_max, cl0, cl1, cl2, cl3, cl4, traj_len, tp, rp_first, rp_last,
+                            [&](int k) { return knots[k]; }, [&](int k) { return knots[k].pos; });
     };
-    auto lat_at = [&](int i, double s_i, double &d, double &dv, double &da) {
-        double u1 = tp[i], u2 = tp[S + i], u3 = tp[2 * S + i], u4 = tp[3 * S + i], u5 = tp[4 * S + i];
-        if (low_vel) { u1 = s_i - cl0; u2 = u1 * u1; u3 = u2 * u1; u4 = u2 * u2; u5 = u4 * u1; }  // s[0] == cl0 (t[0] = 0)
-        d = ct0 + ct1 * u1 + ct2 * u2 + ct3 * u3 + ct4 * u4 + ct5 * u5;
-        dv = ct1 + 2. * ct2 * u1 + 3. * ct3 * u2 + 4. * ct4 * u3 + 5. * ct5 * u4;
-        da = 2 * ct2 + 6 * ct3 * u1 + 12 * ct4 * u2 + 20 * ct5 * u3;
+    auto lat_eval = [&](int i, double u_lowvel, double &d, double &dv, double &da) {
+        double u1, u2, u3, u4, u5;
+        if (low_vel) { u1 = u_lowvel; u2 = u1 * u1; u3 = u2 * u1; u4 = u2 * u2; u5 = u4 * u1; }
+        else { u1 = tp[i]; u2 = tp[S + i]; u3 = tp[2 * S + i]; u4 = tp[3 * S + i]; u5 = tp[4 * S + i]; }
+        L.eval(u1, u2, u3, u4, u5, d, dv, da);
     };
+    // lateral value the extension holds: d[traj_len-1] (reactive_planner.py:344)
+    double d_ext, dv_u, da_u;
+    {
+        const LonRow rl = row_at(traj_len - 1);
+        lat_eval(traj_len - 1, rl.u1, d_ext, dv_u, da_u);
+    }
 
     // ---- this lane's chunk of the horizon ----
     const int CH = G == 1 ? S : (S + G - 1) / G;
@@ -469,285 +528,79 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     const int i_end = min(S, i_begin + CH);
     const int i_first = (G > 1 && part > 0) ? i_begin - 1 : i_begin;  // carry-in step re-evaluated, not emitted
 
-    // ---- streaming state, including the carry-in for a chunk that starts past step 0 ----
-    double s_prev = 0.0, sv_last = 0.0, d_last = 0.0;
-    double th_prev = P.x0_orientation, kap_prev = 0.0;
-    if (G > 1 && i_first > 0 && i_first < S) {
-        if (i_first >= traj_len) {
-            // chunk starts inside the horizon extension: re-run s[i] = s[i-1] + dt * s_dot_end from traj_len-1
-            double sa_u;
-            lon_at(traj_len - 1, s_prev, sv_last, sa_u);
-            double dv_u, da_u;
-            lat_at(traj_len - 1, s_prev, d_last, dv_u, da_u);
-            for (int j = traj_len; j < i_first; j++) s_prev = s_prev + dt * sv_last;
-        }
-        // theta_gl[i_first-1] is only consumed when step i_first keeps the previous heading (standstill in
-        // high-speed mode): scan back to the last moving step (reactive_planner.py:447)
-        if (!low_vel) {
-            double s_c, sv_c, sa_c;
-            if (i_first < traj_len) lon_at(i_first, s_c, sv_c, sa_c); else sv_c = sv_last;
-            if (!(fabs(sv_c) >= FX_EPS && sv_c > 0.001)) {
-                int j = i_first - 1;
-                double s_j = 0.0, sv_j = 0.0, sa_j = 0.0;
-                for (; j >= 0; j--) {
-                    if (j < traj_len) lon_at(j, s_j, sv_j, sa_j);
-                    else { sv_j = sv_last; }
-                    if (fabs(sv_j) >= FX_EPS && sv_j > 0.001) break;
-                }
-                if (j >= 0) {
-                    if (j >= traj_len) {  // moving extension step: position from the recurrence
-                        double sa_u, sv_u;
-                        lon_at(traj_len - 1, s_j, sv_u, sa_u);
-                        for (int q = traj_len; q <= j; q++) s_j = s_j + dt * sv_last;
-                    }
-                    double d_j, dv_j, da_j;
-                    if (j < traj_len) lat_at(j, s_j, d_j, dv_j, da_j); else { d_j = d_last; dv_j = 0.0; da_j = 0.0; }
-                    const double dp_j = div_rcp(dv_j, sv_j, 1.0 / sv_j);
-                    int lo = 0, hi = M;
-                    while (lo < hi) { int mid = (lo + hi) >> 1; if (knots[mid].pos > s_j) hi = mid; else lo = mid + 1; }
-                    const int j1 = lo == M ? 0 : lo, j0 = j1 == 0 ? M - 1 : j1 - 1;
-                    const double segj = knots[j1].pos - knots[j0].pos;
-                    const double th_ref_j = wrap_pm_2pi((knots[j1].theta - knots[j0].theta) * (s_j - knots[j0].pos) / segj + knots[j0].theta);
-                    th_prev = fxm::atan(dp_j) + th_ref_j;
-                }
-            }
-        }
-    }
-
-    const double rp_first = knots[0].pos, rp_last = knots[M - 1].pos;
-    bool neg = false, acc_viol = false;
-    uint32_t step_reasons = 0;       // dbg: OR of all violated checks; else: key (step << 4 | reason) of the first
-    uint32_t first_key = 0xffffffffu;
-    int fail_step = 0x7fffffff;      // first step of this chunk whose (s, d) is outside the projection domain
-    int ub = -1;                     // first knot index with pos > s (upper bound), carried between steps
-    double sum_abs_d = 0.0, sum_voff = 0.0, pred = 0.0, dto = 0.0, d_end = 0.0, v_end = 0.0;
-    const int half = S / 2;
-    Simpson sim_acc, sim_jerk, sim_orient, sim_path;
-    double a_prev = 0.0, thcl_prev = 0.0;
-    if (EXTRA) { sim_acc.init(); sim_jerk.init(); sim_orient.init(); sim_path.init(); }
-    bool collided = false;
-    double bx_prev = 0.0, by_prev = 0.0, ux_prev = 0.0, uy_prev = 0.0;
-    const int K = P.K, Pn = P.P, n_dto = EXTRA ? P.n_dto : 0;
+    StepConst K;
+    K.dt = dt; K.r_dt = 1.0 / dt; K.kappa_max = P.veh.kappa_max; K.a_max = a_max; K.v_switch = P.veh.v_switch;
+    K.av_switch = a_max * P.veh.v_switch; K.v_des = P.v_des; K.wb = P.veh.wb_rear_axle; K.half_len = P.veh.length / 2;
+    K.half_wid = P.veh.width / 2; K.S = S; K.half = S / 2; K.K = P.K; K.Pn = P.P; K.low_vel = low_vel; K.dbg = dbg;
+    K.do_collision = do_collision;
     const FX_GLOBAL double *__restrict__ obs_pos = as_global(P.obs_pos);
     const FX_GLOBAL double *__restrict__ obs_cov_inv = as_global(P.obs_cov_inv);
     const FX_GLOBAL double *__restrict__ obs_hull = as_global(P.obs_hull);
     const FX_GLOBAL int32_t *__restrict__ obs_npred = as_global(P.obs_npred);
     const FX_GLOBAL int32_t *__restrict__ obs_nhull = as_global(P.obs_nhull);
-    const FX_GLOBAL double *__restrict__ dto_pos = as_global(P.dto_pos);
-    int max_nhull = 0;
-    if (do_collision) for (int k = 0; k < K; k++) max_nhull = max(max_nhull, obs_nhull[k]);
+    K.max_nhull = 0;
+    if (do_collision) for (int k = 0; k < K.K; k++) K.max_nhull = max(K.max_nhull, obs_nhull[k]);
 
+    StepCarry Cy;
+    Cy.th_prev = P.x0_orientation; Cy.kap_prev = 0.0; Cy.bx_prev = Cy.by_prev = Cy.ux_prev = Cy.uy_prev = 0.0;
+    if (G > 1 && !low_vel && i_first > 0 && i_first < S) {
+        // the carry-in step keeps the previous heading when it stands still: scan back to the last moving step (:447)
+        if (!(row_at(i_first).flags & LON_MOVING)) {
+            for (int j = i_first - 1; j >= 0; j--) {
+                const LonRow rj = row_at(j);
+                if (rj.flags & LON_MOVING) {
+                    double d_j, dv_j = 0.0, da_j;
+                    if (j < traj_len) lat_eval(j, rj.u1, d_j, dv_j, da_j);
+                    Cy.th_prev = heading_of_moving_step(rj, dv_j);
+                    break;
+                }
+            }
+        }
+    }
+    StepAcc A;
+    A.neg = A.acc_viol = A.collided = false;
+    A.step_reasons = 0; A.first_key = 0xffffffffu; A.fail_step = 0x7fffffff;
+    A.sum_abs_d = A.sum_voff = A.pred = A.d_end = A.v_end = 0.0;
+    StepOut O;
+    Simpson sim_acc, sim_jerk, sim_orient, sim_path;
+    double a_prev = 0.0, thcl_prev = 0.0, dto = 0.0;
+    if (EXTRA) { sim_acc.init(); sim_jerk.init(); sim_orient.init(); sim_path.init(); }
+    const int n_dto = EXTRA ? P.n_dto : 0;
+    const FX_GLOBAL double *__restrict__ dto_pos = as_global(P.dto_pos);
     FX_GLOBAL double *__restrict__ planes = as_global(P.planes);
+    const int64_t ps = (int64_t)S * ld;
 
 #pragma unroll 1
     for (int i = i_first; i < i_end; i++) {
         const bool emit = i >= i_begin;  // false only for the carry-in step of parts > 0
-        // -- polynomials on the rounded time grid, horizon extension (reactive_planner.py:313-346) --
-        double s_i, sv_i, sa_i, d_i, dv_i, da_i;
-        if (i < traj_len) {
-            lon_at(i, s_i, sv_i, sa_i);
-            sv_last = sv_i;
-            lat_at(i, s_i, d_i, dv_i, da_i);
-            d_last = d_i;
-        } else {
-            s_i = s_prev + dt * sv_last;
-            sv_i = sv_last;
-            sa_i = 0.0;
-            d_i = d_last;
-            dv_i = 0.0;
-            da_i = 0.0;
-        }
-        s_prev = s_i;
-        // -- validity, clamp, pre-filter (reactive_planner.py:350-355, :375) --
-        if (emit) {
-            neg |= sv_i < -FX_EPS;
-            acc_viol |= fabs(sa_i) > a_max;
-        }
-        if (fabs(sv_i) < FX_EPS) sv_i = 0.0;
-
-        // -- d', d'' (reactive_planner.py:392-412) --
-        double dp, dpp;
-        const bool moving = sv_i > 0.001;
-        if (!low_vel) {
-            const double r_sv = 1.0 / sv_i;
-            dp = moving ? div_rcp(dv_i, sv_i, r_sv) : 0.;
-            double ddot = da_i - dp * sa_i;
-            const double sv2 = sv_i * sv_i, r_sv2 = 1.0 / sv2;
-            dpp = moving ? div_rcp(ddot, sv2, r_sv2) : 0.;
-        } else {
-            dp = dv_i;
-            dpp = da_i;
-        }
-        // -- reference segment: np.argmax(ref_pos > s) - 1 with Python's negative-index wrap (:415-420) --
-        if (ub < 0) {
-            int lo = 0, hi = M;
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (knots[mid].pos > s_i) hi = mid; else lo = mid + 1;
-            }
-            ub = lo;
-        } else {
-            while (ub < M && knots[ub].pos <= s_i) ub++;
-            while (ub > 0 && knots[ub - 1].pos > s_i) ub--;
-        }
-        const int i1 = ub == M ? 0 : ub;
-        const int i0 = i1 == 0 ? M - 1 : i1 - 1;
-        const Knot k0 = knots[i0], k1 = knots[i1];
-        const double seg = k1.pos - k0.pos, r_seg = 1.0 / seg;
-        const double s_lambda = div_rcp(s_i - k0.pos, seg, r_seg);
-        // interpolate_angle (utils_coordinate_system.py:137-155)
-        const double th_ref = wrap_pm_2pi(div_rcp((k1.theta - k0.theta) * (s_i - k0.pos), seg, r_seg) + k0.theta);
-        double th_cl, th_gl, cosTheta, tanTheta, secTheta;
-        if (moving || low_vel) {
-            // theta_cl = arctan2(d', 1): cos and tan of it follow algebraically (|error| <= 2 ulp, same as libm's)
-            th_cl = fxm::atan(dp);
-            th_gl = th_cl + th_ref;
-            secTheta = sqrt(1.0 + dp * dp);
-            cosTheta = 1.0 / secTheta;
-            tanTheta = dp;
-        } else {  // standstill at high-speed mode keeps the previous global heading (:447-454)
-            th_gl = th_prev;  // x_0.orientation at i == 0
-            th_cl = th_gl - th_ref;
-            double sinTheta;
-            fxm::sincos(th_cl, &sinTheta, &cosTheta);
-            secTheta = 1.0 / cosTheta;
-            tanTheta = sinTheta * secTheta;
-        }
-        const double k_r = (k1.curv - k0.curv) * s_lambda + k0.curv;
-        const double k_r_d = (k1.curv_d - k0.curv_d) * s_lambda + k0.curv_d;
-        // -- global curvature, velocity, acceleration (:463-478) --
-        const double oneKrD = (1 - k_r * d_i);
-        const double cok = cosTheta / oneKrD;
-        const double okc = oneKrD * secTheta;  // (1 - k_r d) / cos(theta)
-        const double kap = (dpp + (k_r * dp + k_r_d * d_i) * tanTheta) * cosTheta * (cok * cok) + cok * k_r;
-        const double v_i = sv_i * okc;
-        const double a_i = sa_i * okc +
-                           ((sv_i * sv_i) * secTheta) *
-                               (oneKrD * tanTheta * (kap * okc - k_r) - (k_r_d * d_i + k_r * dp));
-        // -- constraints (:480-533): bit r = reason r --
-        if (emit) {
-            uint32_t hit = 0;
-            if (v_i < -FX_EPS) hit |= 1u << 4;
-            if (fabs(kap) > kappa_max) hit |= 1u << 5;
-            const double yaw_rate = i > 0 ? div_rcp(th_gl - th_prev, dt, r_dt) : 0.;
-            if (fabs(np_round5(yaw_rate)) > kappa_max * v_i) hit |= 1u << 6;
-            const double kap_rate = i > 0 ? div_rcp(kap - kap_prev, dt, r_dt) : 0.;
-            if (fabs(kap_rate) > 0.4) hit |= 1u << 7;
-            const double v_switch = P.veh.v_switch;
-            const double a_hi = v_i > v_switch ? a_max * v_switch / v_i : a_max;
-            if (!(-a_max <= a_i && a_i <= a_hi)) hit |= 1u << 8;
-            if (dbg) step_reasons |= hit;
-            else if (hit && first_key == 0xffffffffu) first_key = ((uint32_t)i << 4) | (uint32_t)(__ffs((int)hit) - 1);
-        }
-        const double kap_dot = i > 0 ? kap - kap_prev : 0.0;  // np.append([0], np.diff(kappa_gl)) (:552)
-
-        // -- (s, d) -> (x, y) (:537-547; normative projection) --
-        double x_i = 0.0, y_i = 0.0;
-        if (!(s_i >= rp_first && s_i <= rp_last)) {
-            if (emit && fail_step == 0x7fffffff) fail_step = i;
-        } else if (fail_step == 0x7fffffff) {
-            int kk = ub - 1;
-            kk = kk < 0 ? 0 : (kk > M - 2 ? M - 2 : kk);
-            // kk == i0 unless the knot lookup wrapped (s outside the reference): same segment, same lambda
-            const Knot q0 = kk == i0 ? k0 : knots[kk], q1 = kk == i0 ? k1 : knots[kk + 1];
-            const double lam = kk == i0 ? s_lambda : (s_i - q0.pos) / (q1.pos - q0.pos);
-            const double px = q0.x + lam * (q1.x - q0.x), py = q0.y + lam * (q1.y - q0.y);
-            const double nx = q0.nx + lam * (q1.nx - q0.nx), ny = q0.ny + lam * (q1.ny - q0.ny);
-            const double nn = sqrt(nx * nx + ny * ny), r_nn = 1.0 / nn;
-            x_i = px + d_i * div_rcp(nx, nn, r_nn);
-            y_i = py + d_i * div_rcp(ny, nn, r_nn);
-        }
-
-        // -- SoA bundle (trajectories.py:56-334) --
-        if (bundle && active && emit) {
-            FX_GLOBAL double *__restrict__ row = planes + (int64_t)i * ld + g;
-            const int64_t ps = (int64_t)S * ld;
-            row[FX_PL_X * ps] = x_i;
-            row[FX_PL_Y * ps] = y_i;
-            row[FX_PL_THETA * ps] = th_gl;
-            row[FX_PL_V * ps] = v_i;
-            row[FX_PL_A * ps] = a_i;
-            row[FX_PL_KAPPA * ps] = kap;
-            row[FX_PL_KAPPA_DOT * ps] = kap_dot;
-            row[FX_PL_S * ps] = s_i;
-            row[FX_PL_D * ps] = d_i;
-            row[FX_PL_THETA_CL * ps] = th_cl;
-            row[FX_PL_S_DOT * ps] = sv_i;
-            row[FX_PL_S_DDOT * ps] = sa_i;
-            row[FX_PL_D_DOT * ps] = dv_i;
-            row[FX_PL_D_DDOT * ps] = da_i;
-        }
-
-        // -- partial costs, streamed --
-        if (emit) {
-            sum_abs_d += fabs(d_i);                                               // partial_cost_functions.py:166-167
-            if (i >= half && i < S - 1) sum_voff += fabs(v_i - P.v_des);          // :125-127
-            if (i == S - 1) { d_end = d_i; v_end = v_i; }
-        }
+        const LonRow r = row_at(i);
+        walk_step<OBST>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit, planes + (int64_t)i * ld + g, ps, Cy, A,
+                        O, obs_pos, obs_cov_inv, obs_hull, obs_npred, obs_nhull);
         if (EXTRA) {
-            sim_acc.push(a_i * a_i, S);                                 // :29-31
-            sim_path.push(v_i, S);                                      // :194-195
+            sim_acc.push(O.a * O.a, S);                                 // partial_cost_functions.py:29-31
+            sim_path.push(O.v, S);                                      // :194-195
             if (i > 0) {
-                const double j = (a_i - a_prev) / dt;                   // :41-44
-                const double w = (th_cl - thcl_prev) / dt;              // :146-149
+                const double j = (O.a - a_prev) / dt;                   // :41-44
+                const double w = (O.th_cl - thcl_prev) / dt;            // :146-149
                 sim_jerk.push(j * j, S - 1);
                 sim_orient.push(w * w, S - 1);
             }
-            a_prev = a_i;
-            thcl_prev = th_cl;
+            a_prev = O.a;
+            thcl_prev = O.th_cl;
             for (int o = 0; o < n_dto; o++) {                           // :177-184
-                const double ex = x_i - dto_pos[2 * o], ey = y_i - dto_pos[2 * o + 1];
+                const double ex = O.x - dto_pos[2 * o], ey = O.y - dto_pos[2 * o + 1];
                 const double dist = sqrt(ex * ex + ey * ey);
                 dto += 1.0 / (dist * dist);
             }
         }
-        if (OBST) {
-            if (emit && i >= 1) {  // ego step i pairs with prediction i-1 (collision_probability.py:283-292)
-                for (int k = 0; k < K; k++) {
-                    if (i < obs_npred[k]) {
-                        const FX_GLOBAL double *__restrict__ mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
-                        const FX_GLOBAL double *__restrict__ iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
-                        const double e0 = x_i - mu[0], e1 = y_i - mu[1];
-                        const double r0 = e0 * iv[0] + e1 * iv[2], r1 = e0 * iv[1] + e1 * iv[3];
-                        const double m = r0 * e0 + r1 * e1;
-                        pred += 1.0 / (m * m);
-                    }
-                }
-            }
-            if (do_collision) {
-                // ego box: centre = rear axle + wb_rear_axle along heading (state.py:30-39), heading theta_gl;
-                // needed while some obstacle hull exists at time index i-1 (this step's pair) or later
-                const bool need = (i >= 2 ? i - 2 : 0) < max_nhull;
-                if (need && i >= 1) {
-                    double su, cu;
-                    fxm::sincos(th_gl, &su, &cu);
-                    const double wb = P.veh.wb_rear_axle;
-                    const double bx = x_i + wb * cu, by = y_i + wb * su;
-                    if (emit && i >= 2) {
-                        // OBB-sum hull of ego boxes (i-1, i) lives at time index i-1 and meets obstacle hull i-2
-                        const Obb hull = obb_hull(bx_prev, by_prev, ux_prev, uy_prev, bx, by, cu, su, P.veh.length / 2,
-                                                  P.veh.width / 2);
-                        for (int k = 0; k < K; k++) {
-                            if (i - 2 < obs_nhull[k]) {
-                                const FX_GLOBAL double *__restrict__ oh = obs_hull + ((int64_t)k * (Pn - 1) + (i - 2)) * 6;
-                                collided |= obb_overlap(hull, oh);
-                            }
-                        }
-                    }
-                    bx_prev = bx; by_prev = by; ux_prev = cu; uy_prev = su;
-                }
-            }
-        }
-        th_prev = th_gl;
-        kap_prev = kap;
     }
 
     // ---- combine parts, flags, cost, outputs, workgroup reductions ----
     WalkResult W;
-    W.neg = neg; W.acc_viol = acc_viol; W.collided = collided;
-    W.step_reasons = step_reasons; W.first_key = first_key; W.fail_step = fail_step;
-    W.sum_abs_d = sum_abs_d; W.sum_voff = sum_voff; W.pred = pred; W.dto = dto; W.d_end = d_end; W.v_end = v_end;
-    W.cl3 = cl3; W.cl4 = cl4; W.ct3 = ct3; W.ct4 = ct4; W.ct5 = ct5;
+    W.neg = A.neg; W.acc_viol = A.acc_viol; W.collided = A.collided;
+    W.step_reasons = A.step_reasons; W.first_key = A.first_key; W.fail_step = A.fail_step;
+    W.sum_abs_d = A.sum_abs_d; W.sum_voff = A.sum_voff; W.pred = A.pred; W.dto = dto; W.d_end = A.d_end; W.v_end = A.v_end;
+    W.cl3 = cl3; W.cl4 = cl4; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
     if (EXTRA) { W.sim_acc = sim_acc; W.sim_jerk = sim_jerk; W.sim_orient = sim_orient; W.sim_path = sim_path; }
     finish_candidate<G, BUNDLE, OBST, EXTRA>(P, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D, red_cost,
                                              red_idx, red_cnt);

@@ -196,36 +196,43 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
 
 // Grid (t x v x d) specialisation with the shared longitudinal table; lds_bytes includes the rows.
 extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, int block_size,
-                                          size_t lds_bytes, int G, bool bundle, bool obst, int wpe, hipStream_t stream) {
+                                          size_t lds_bytes, int G, bool bundle, bool obst, int wpe, bool wsplit,
+                                          hipStream_t stream) {
     dim3 grid(max_blocks, n_agents), block(block_size);
-#define FX_LAUNCH(Gv, B, O, W)                                                                                     \
+#define FX_LAUNCH(Gv, B, O, W, WS)                                                                                 \
     do {                                                                                                          \
         if (lds_bytes > 48 * 1024) {                                                                              \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fx_eval_grid_kernel<Gv, B, O, W>), \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fx_eval_grid_kernel<Gv, B, O, W, WS>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);      \
             if (e_ != hipSuccess) return e_;                                                                      \
         }                                                                                                         \
-        hipLaunchKernelGGL((fx_eval_grid_kernel<Gv, B, O, W>), grid, block, lds_bytes, stream, d_probs);           \
+        hipLaunchKernelGGL((fx_eval_grid_kernel<Gv, B, O, W, WS>), grid, block, lds_bytes, stream, d_probs);       \
         return hipGetLastError();                                                                                 \
     } while (0)
-#define FX_BO(Gv, W)                                           \
-    do {                                                       \
-        if (bundle && obst) FX_LAUNCH(Gv, true, true, W);      \
-        if (bundle) FX_LAUNCH(Gv, true, false, W);             \
-        if (obst) FX_LAUNCH(Gv, false, true, W);               \
-        FX_LAUNCH(Gv, false, false, W);                        \
+#define FX_BO(Gv, W, WS)                                           \
+    do {                                                           \
+        if (bundle && obst) FX_LAUNCH(Gv, true, true, W, WS);      \
+        if (bundle) FX_LAUNCH(Gv, true, false, W, WS);             \
+        if (obst) FX_LAUNCH(Gv, false, true, W, WS);               \
+        FX_LAUNCH(Gv, false, false, W, WS);                        \
     } while (0)
-#define FX_W(Gv)                          \
-    do {                                  \
-        if (wpe >= 4) FX_BO(Gv, 4);       \
-        if (wpe == 3) FX_BO(Gv, 3);       \
-        FX_BO(Gv, 2);                     \
+#define FX_W(Gv, WS)                          \
+    do {                                      \
+        if (wpe >= 4) FX_BO(Gv, 4, WS);       \
+        if (wpe == 3) FX_BO(Gv, 3, WS);       \
+        FX_BO(Gv, 2, WS);                     \
     } while (0)
+    if (wsplit && G > 1) {
+        switch (G) {
+        case 4: FX_W(4, true);
+        default: FX_W(2, true);
+        }
+    }
     switch (G) {
-    case 8: FX_W(8);
-    case 4: FX_W(4);
-    case 2: FX_W(2);
-    default: FX_W(1);
+    case 8: FX_W(8, false);
+    case 4: FX_W(4, false);
+    case 2: FX_W(2, false);
+    default: FX_W(1, false);
     }
 #undef FX_W
 #undef FX_BO

@@ -33,6 +33,18 @@ __device__ __forceinline__ double atan(double x) {
     return copysign(r, x);
 }
 
+// atan(x) for |x| < 7/16: the id = -1 branch of fdlibm (no reduction, no division); identical to atan() there
+__device__ __forceinline__ double atan_small(double x) {
+    const double z = x * x, w = z * z;
+    const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02),
+                                                    6.66107313738753120669e-02), 9.09088713343650656196e-02),
+                                     1.42857142725034663711e-01), 3.33333333333329318027e-01);
+    const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02),
+                                             -7.69187620504482999495e-02), -1.11111104054623557880e-01),
+                              -1.99999999998764832476e-01);
+    return x - x * (s1 + s2);
+}
+
 // sin and cos of x for |x| up to ~1e6 (two-constant Cody-Waite with FMA; fdlibm k_sin / k_cos kernels)
 __device__ __forceinline__ void sincos(double x, double *sn, double *cs) {
     const double n = rint(x * 6.36619772367581382433e-01);

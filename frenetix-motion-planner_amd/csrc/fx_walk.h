@@ -1,0 +1,325 @@
+// fx_walk.h -- the per-candidate, per-step arithmetic shared by both evaluation kernels.
+//
+// A step consumes the longitudinal quantities of (candidate, step) -- a `LonRow`, either read from the
+// workgroup's shared table (grid kernel) or derived by the lane itself (generic kernel) -- and does the
+// lateral polynomial, the Frenet->Cartesian kinematics (reactive_planner.py:389-478), the five constraints
+// (:480-533), the projection, the plane stores, the streamed partial costs and the obstacle stage.  Both kernels
+// call the same inlined function, so they agree bit for bit by construction.
+//
+// Instruction diet (the walk is FP64-issue-bound):
+//   * lateral polynomial with explicit FMAs and pre-multiplied derivative coefficients (15 instead of 37 ops),
+//   * 1/sqrt(1+d'^2) from v_rsq_f64 + two coupled Newton steps gives cos and sec without sqrt + division,
+//   * divisions as v_rcp_f64 + two Newton steps + one residual correction (8 ops, no div_scale/fmas/fixup),
+//   * atan: wave-uniform fast path when every lane has |d'| < 7/16 (no range reduction, no division),
+//   * the standstill branch (heading carried, real sin/cos) only runs when some lane of the wave needs it.
+#pragma once
+
+#include "fx_device.h"
+#include "fx_math.h"
+
+namespace fxk {
+
+struct alignas(16) LonRow {  // longitudinal quantities of one (pair, step); 128 B
+    double s, sv, sa;        // s, clamped s_dot, s_ddot
+    double th_ref, k_r, k_r_d;
+    double px, py, nhx, nhy;  // foot point and unit normal (0 outside the projection domain)
+    double r_sv, sv2, r_sv2;  // 1/s_dot, s_dot^2, 1/s_dot^2 (only meaningful when moving)
+    double u1;                // s - s[0] (LOW_VEL_MODE lateral parameter)
+    uint32_t flags;           // LON_* bits
+    uint32_t pad0;
+    double pad1;
+};
+static_assert(sizeof(LonRow) == 128, "LonRow must be 128 bytes");
+
+enum : uint32_t { LON_NEG = 1u, LON_ACC = 2u, LON_MOVING = 4u, LON_INDOMAIN = 8u };
+
+// 1/d for normal, finite d: hardware estimate + two Newton steps (full double precision)
+__device__ __forceinline__ double rcp_nr(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+}
+
+// n / d with one residual correction on the quotient (correctly rounded for the operands of this kernel)
+__device__ __forceinline__ double fdiv(double n, double d) {
+    const double r = rcp_nr(d);
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+
+// sqrt(x) and 1/sqrt(x) together: v_rsq_f64 + two coupled (Goldschmidt) Newton steps
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &sq, double &rsq) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    // final residual on sqrt
+    g = fma(fma(-g, g, x), h, g);
+    sq = g;
+    rsq = h + h;
+}
+
+// Longitudinal quantities of (T, v1) at step i: quartic sample or horizon extension (reactive_planner.py:313-322),
+// validity / pre-filter predicates (:350-355,375), reference-segment lookup with Python's negative-index wrap
+// (:415-420), interpolate_angle (utils_coordinate_system.py:137-155), reference curvature (:457-460) and the
+// projection foot point + unit normal.  `knot(k)` returns knot k, `kpos(k)` its arclength.
+template <typename KnotFn, typename PosFn>
+__device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, double a_max, double cl0, double cl1, double cl2,
+                                               double cl3, double cl4, int traj_len, const double *tp, double rp_first,
+                                               double rp_last, KnotFn knot, PosFn kpos) {
+    const int ie = i < traj_len ? i : traj_len - 1;  // sample that is evaluated (the last one feeds the extension)
+    const double t1 = tp[ie], t2 = tp[S + ie], t3 = tp[2 * S + ie], t4 = tp[3 * S + ie];
+    double s_i = cl0 + cl1 * t1 + cl2 * t2 + cl3 * t3 + cl4 * t4;
+    double sv_i = cl1 + 2. * cl2 * t1 + 3. * cl3 * t2 + 4. * cl4 * t3;
+    double sa_i = 2 * cl2 + 6 * cl3 * t1 + 12 * cl4 * t2;
+    if (i >= traj_len) {  // s[i] = s[i-1] + dt * s_dot_end, one rounding per step as in the reference loop
+        for (int j = traj_len; j <= i; j++) s_i = s_i + dt * sv_i;
+        sa_i = 0.0;
+    }
+    LonRow r;
+    r.flags = (sv_i < -FX_EPS ? LON_NEG : 0u) | (fabs(sa_i) > a_max ? LON_ACC : 0u);
+    if (fabs(sv_i) < FX_EPS) sv_i = 0.0;
+    if (sv_i > 0.001) r.flags |= LON_MOVING;
+    r.s = s_i; r.sv = sv_i; r.sa = sa_i;
+    r.u1 = s_i - cl0;
+    r.r_sv = 1.0 / sv_i;
+    r.sv2 = sv_i * sv_i;
+    r.r_sv2 = 1.0 / r.sv2;
+    int lo = 0, hi = M;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (kpos(mid) > s_i) hi = mid; else lo = mid + 1;
+    }
+    const int ub = lo;
+    const int i1 = ub == M ? 0 : ub;
+    const int i0 = i1 == 0 ? M - 1 : i1 - 1;
+    const Knot k0 = knot(i0), k1 = knot(i1);
+    const double seg = k1.pos - k0.pos, r_seg = 1.0 / seg;
+    const double s_lambda = div_rcp(s_i - k0.pos, seg, r_seg);
+    r.th_ref = wrap_pm_2pi(div_rcp((k1.theta - k0.theta) * (s_i - k0.pos), seg, r_seg) + k0.theta);
+    r.k_r = (k1.curv - k0.curv) * s_lambda + k0.curv;
+    r.k_r_d = (k1.curv_d - k0.curv_d) * s_lambda + k0.curv_d;
+    r.px = r.py = r.nhx = r.nhy = 0.0;
+    if (s_i >= rp_first && s_i <= rp_last) {
+        r.flags |= LON_INDOMAIN;
+        int kk = ub - 1;
+        kk = kk < 0 ? 0 : (kk > M - 2 ? M - 2 : kk);
+        // kk == i0 unless the lookup wrapped (s outside the reference): same segment, same lambda
+        const Knot q0 = kk == i0 ? k0 : knot(kk), q1 = kk == i0 ? k1 : knot(kk + 1);
+        const double lam = kk == i0 ? s_lambda : (s_i - q0.pos) / (q1.pos - q0.pos);
+        r.px = q0.x + lam * (q1.x - q0.x);
+        r.py = q0.y + lam * (q1.y - q0.y);
+        const double nx = q0.nx + lam * (q1.nx - q0.nx), ny = q0.ny + lam * (q1.ny - q0.ny);
+        const double nn = sqrt(nx * nx + ny * ny), r_nn = 1.0 / nn;
+        r.nhx = div_rcp(nx, nn, r_nn);
+        r.nhy = div_rcp(ny, nn, r_nn);
+    }
+    r.pad0 = 0; r.pad1 = 0.0;
+    return r;
+}
+
+// heading of a *moving* step j from its row: atan(d'/1) + theta_ref, exactly as walk_step computes it
+__device__ __forceinline__ double heading_of_moving_step(const LonRow &r, double dv_j) {
+    const double q = dv_j * r.r_sv;
+    const double dp = fma(fma(-r.sv, q, dv_j), r.r_sv, q);
+    return fxm::atan(dp) + r.th_ref;
+}
+
+// lateral quintic with the derivative coefficients pre-multiplied: (2.*c2)*t etc. are the reference's own
+// products (polynomial_trajectory.py:251-257), the sums are fused left to right
+struct LatPoly {
+    double c0, c1, c2, c3, c4, c5;
+    double v2, v3, v4, v5;      // 2 c2, 3 c3, 4 c4, 5 c5
+    double a2, a3, a4, a5;      // 2 c2, 6 c3, 12 c4, 20 c5
+    __device__ __forceinline__ void set(double k0, double k1, double k2, double k3, double k4, double k5) {
+        c0 = k0; c1 = k1; c2 = k2; c3 = k3; c4 = k4; c5 = k5;
+        v2 = 2. * k2; v3 = 3. * k3; v4 = 4. * k4; v5 = 5. * k5;
+        a2 = 2 * k2; a3 = 6 * k3; a4 = 12 * k4; a5 = 20 * k5;
+    }
+    __device__ __forceinline__ void eval(double u1, double u2, double u3, double u4, double u5, double &d, double &dv,
+                                         double &da) const {
+        d = fma(c5, u5, fma(c4, u4, fma(c3, u3, fma(c2, u2, fma(c1, u1, c0)))));
+        dv = fma(v5, u4, fma(v4, u3, fma(v3, u2, fma(v2, u1, c1))));
+        da = fma(a5, u3, fma(a4, u2, fma(a3, u1, a2)));
+    }
+};
+
+struct StepConst {  // wave-uniform constants of the walk
+    double dt, r_dt, kappa_max, a_max, v_switch, av_switch, v_des, wb, half_len, half_wid;
+    int S, half, K, Pn, max_nhull;
+    bool low_vel, dbg, do_collision;
+};
+
+struct StepCarry {  // per-lane state carried from step to step
+    double th_prev, kap_prev;
+    double bx_prev, by_prev, ux_prev, uy_prev;
+};
+
+struct StepAcc {  // per-lane accumulators over the emitted steps
+    bool neg, acc_viol, collided;
+    uint32_t step_reasons, first_key;
+    int fail_step;
+    double sum_abs_d, sum_voff, pred, d_end, v_end;
+};
+
+struct StepOut {  // per-step values the windowed (EXTRA) costs of the generic kernel need
+    double a, v, th_cl, x, y;
+};
+
+// One step of one candidate.  `planes_i` = address of plane 0 at (step i, this candidate); ps = plane stride.
+template <bool OBST, typename PlanePtr, typename ObsD, typename ObsI>
+__device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, const LatPoly &L, const double *tp, int i,
+                                          int traj_len, double d_ext, bool emit, bool store, PlanePtr planes_i, int64_t ps,
+                                          StepCarry &C, StepAcc &A, StepOut &O, ObsD obs_pos, ObsD obs_cov_inv, ObsD obs_hull,
+                                          ObsI obs_npred, ObsI obs_nhull) {
+    const int S = K.S;
+    const double s_i = r.s, sv_i = r.sv, sa_i = r.sa;
+    // -- lateral polynomial (reactive_planner.py:326-346) --
+    double d_i, dv_i, da_i;
+    if (i < traj_len) {
+        double u1, u2, u3, u4, u5;
+        if (K.low_vel) { u1 = r.u1; u2 = u1 * u1; u3 = u2 * u1; u4 = u2 * u2; u5 = u4 * u1; }
+        else { u1 = tp[i]; u2 = tp[S + i]; u3 = tp[2 * S + i]; u4 = tp[3 * S + i]; u5 = tp[4 * S + i]; }
+        L.eval(u1, u2, u3, u4, u5, d_i, dv_i, da_i);
+    } else {
+        d_i = d_ext; dv_i = 0.0; da_i = 0.0;
+    }
+    if (emit) {
+        A.neg |= (r.flags & LON_NEG) != 0;
+        A.acc_viol |= (r.flags & LON_ACC) != 0;
+    }
+    // -- d', d'' (:392-412) --
+    const bool moving = (r.flags & LON_MOVING) != 0;
+    double dp, dpp;
+    if (!K.low_vel) {
+        const double q = dv_i * r.r_sv;
+        dp = moving ? fma(fma(-sv_i, q, dv_i), r.r_sv, q) : 0.;
+        const double ddot = da_i - dp * sa_i;
+        const double q2 = ddot * r.r_sv2;
+        dpp = moving ? fma(fma(-r.sv2, q2, ddot), r.r_sv2, q2) : 0.;
+    } else {
+        dp = dv_i;
+        dpp = da_i;
+    }
+    const double th_ref = r.th_ref, k_r = r.k_r, k_r_d = r.k_r_d;
+    // -- theta_cl = arctan2(d', 1); cos = 1/sqrt(1+d'^2), tan = d' (:423-433) --
+    double secTheta, cosTheta;
+    sqrt_rsqrt(fma(dp, dp, 1.0), secTheta, cosTheta);
+    double tanTheta = dp;
+    double th_cl = __all(fabs(dp) < 0.4375) ? fxm::atan_small(dp) : fxm::atan(dp);
+    double th_gl = th_cl + th_ref;
+    const bool still = !(moving || K.low_vel);
+    if (__any(still)) {  // standstill at high-speed mode keeps the previous global heading (:447-454)
+        const double th_gl_s = C.th_prev;  // x_0.orientation at i == 0
+        const double th_cl_s = th_gl_s - th_ref;
+        double sn, cs;
+        fxm::sincos(th_cl_s, &sn, &cs);
+        const double sec_s = rcp_nr(cs);
+        if (still) { th_gl = th_gl_s; th_cl = th_cl_s; cosTheta = cs; secTheta = sec_s; tanTheta = sn * sec_s; }
+    }
+    // -- global curvature, velocity, acceleration (:463-478) --
+    const double oneKrD = fma(-k_r, d_i, 1.0);
+    const double cok = cosTheta * rcp_nr(oneKrD);   // cos / (1 - k_r d)
+    const double okc = oneKrD * secTheta;           // (1 - k_r d) / cos
+    const double kap = fma(fma(fma(k_r, dp, k_r_d * d_i), tanTheta, dpp) * cosTheta, cok * cok, cok * k_r);
+    const double v_i = sv_i * okc;
+    const double a_i = fma(sa_i, okc, (r.sv2 * secTheta) * (oneKrD * tanTheta * fma(kap, okc, -k_r) - fma(k_r, dp, k_r_d * d_i)));
+    // -- constraints (:480-533): bit r = reason r --
+    if (emit) {
+        uint32_t hit = 0;
+        if (v_i < -FX_EPS) hit |= 1u << 4;
+        if (!(fabs(kap) <= K.kappa_max)) hit |= 1u << 5;  // also catches a NaN curvature
+        const double yaw_rate = i > 0 ? div_rcp(th_gl - C.th_prev, K.dt, K.r_dt) : 0.;
+        if (fabs(np_round5(yaw_rate)) > K.kappa_max * v_i) hit |= 1u << 6;
+        const double kap_rate = i > 0 ? div_rcp(kap - C.kap_prev, K.dt, K.r_dt) : 0.;
+        if (fabs(kap_rate) > 0.4) hit |= 1u << 7;
+        // a <= a_max * v_switch / v  <=>  a * v <= a_max * v_switch for v > v_switch > 0: no division
+        const bool over = v_i > K.v_switch ? !(a_i * v_i <= K.av_switch) : !(a_i <= K.a_max);
+        if (!(-K.a_max <= a_i) || over) hit |= 1u << 8;
+        if (K.dbg) A.step_reasons |= hit;
+        else if (hit && A.first_key == 0xffffffffu) A.first_key = ((uint32_t)i << 4) | (uint32_t)(__ffs((int)hit) - 1);
+    }
+    const double kap_dot = i > 0 ? kap - C.kap_prev : 0.0;  // np.append([0], np.diff(kappa_gl)) (:552)
+
+    // -- (s, d) -> (x, y): foot point + d * unit normal, 0 from the first step outside the domain on (:537-547) --
+    double x_i = 0.0, y_i = 0.0;
+    if (!(r.flags & LON_INDOMAIN)) {
+        if (emit && A.fail_step == 0x7fffffff) A.fail_step = i;
+    } else if (A.fail_step == 0x7fffffff) {
+        x_i = fma(d_i, r.nhx, r.px);
+        y_i = fma(d_i, r.nhy, r.py);
+    }
+
+    // -- SoA bundle (trajectories.py:56-334) --
+    if (store) {
+        planes_i[FX_PL_X * ps] = x_i;
+        planes_i[FX_PL_Y * ps] = y_i;
+        planes_i[FX_PL_THETA * ps] = th_gl;
+        planes_i[FX_PL_V * ps] = v_i;
+        planes_i[FX_PL_A * ps] = a_i;
+        planes_i[FX_PL_KAPPA * ps] = kap;
+        planes_i[FX_PL_KAPPA_DOT * ps] = kap_dot;
+        planes_i[FX_PL_S * ps] = s_i;
+        planes_i[FX_PL_D * ps] = d_i;
+        planes_i[FX_PL_THETA_CL * ps] = th_cl;
+        planes_i[FX_PL_S_DOT * ps] = sv_i;
+        planes_i[FX_PL_S_DDOT * ps] = sa_i;
+        planes_i[FX_PL_D_DOT * ps] = dv_i;
+        planes_i[FX_PL_D_DDOT * ps] = da_i;
+    }
+
+    // -- partial costs, streamed --
+    if (emit) {
+        A.sum_abs_d += fabs(d_i);                                               // partial_cost_functions.py:166-167
+        if (i >= K.half && i < S - 1) A.sum_voff += fabs(v_i - K.v_des);        // :125-127
+        if (i == S - 1) { A.d_end = d_i; A.v_end = v_i; }
+    }
+    if (OBST) {
+        const int nK = K.K, Pn = K.Pn;
+        if (emit && i >= 1) {  // ego step i pairs with prediction i-1 (collision_probability.py:283-292)
+            for (int k = 0; k < nK; k++) {
+                if (i < obs_npred[k]) {
+                    const auto mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
+                    const auto iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
+                    const double e0 = x_i - mu[0], e1 = y_i - mu[1];
+                    const double r0 = fma(e1, iv[2], e0 * iv[0]), r1 = fma(e1, iv[3], e0 * iv[1]);
+                    const double m = fma(r1, e1, r0 * e0);
+                    const double mm = m * m;
+                    A.pred += mm > 0.0 ? rcp_nr(mm) : 1.0 / mm;
+                }
+            }
+        }
+        if (K.do_collision) {
+            // ego box: centre = rear axle + wb_rear_axle along heading (state.py:30-39), heading theta_gl; needed
+            // while some obstacle hull exists at time index i-1 (this step's pair) or later
+            const bool need = (i >= 2 ? i - 2 : 0) < K.max_nhull;
+            if (need && i >= 1) {
+                double su, cu;
+                fxm::sincos(th_gl, &su, &cu);
+                const double bx = fma(K.wb, cu, x_i), by = fma(K.wb, su, y_i);
+                if (emit && i >= 2) {
+                    // OBB-sum hull of ego boxes (i-1, i) lives at time index i-1 and meets obstacle hull i-2
+                    const Obb hull = obb_hull(C.bx_prev, C.by_prev, C.ux_prev, C.uy_prev, bx, by, cu, su, K.half_len, K.half_wid);
+                    for (int k = 0; k < nK; k++) {
+                        if (i - 2 < obs_nhull[k]) {
+                            const auto oh = obs_hull + ((int64_t)k * (Pn - 1) + (i - 2)) * 6;
+                            A.collided |= obb_overlap(hull, oh);
+                        }
+                    }
+                }
+                C.bx_prev = bx; C.by_prev = by; C.ux_prev = cu; C.uy_prev = su;
+            }
+        }
+    }
+    C.th_prev = th_gl;
+    C.kap_prev = kap;
+    O.a = a_i; O.v = v_i; O.th_cl = th_cl; O.x = x_i; O.y = y_i;
+}
+
+}  // namespace fxk

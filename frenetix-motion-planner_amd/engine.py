@@ -75,11 +75,12 @@ class FrenetEngine:
         check(lib().fx_set_stream(self._ctx, C.c_void_p(hip_stream_ptr)))
 
     def set_tuning(self, lanes_per_candidate: int = 0, waves_per_simd: int = 0, kernel_variant: int = 0,
-                   block_size: int = 0):
+                   block_size: int = 0, mapping: int = 0):
         """Override the automatic work decomposition (0 = automatic; kernel_variant 1 = generic, 2 = grid;
         block_size 64/128/256 lanes for the grid kernel); results are unaffected."""
         check(lib().fx_set_tuning(self._ctx, int(lanes_per_candidate), int(waves_per_simd), int(kernel_variant)))
         check(lib().fx_set_block_size(self._ctx, int(block_size)))
+        check(lib().fx_set_part_mapping(self._ctx, int(mapping)))
 
     def set_timing(self, enabled: bool):
         """HIP-event timing of every step (default on; off shaves the event queries from fx_finish)."""

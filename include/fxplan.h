@@ -179,6 +179,9 @@ int32_t fx_set_stream(FxContext *ctx, void *hip_stream);
  * target in waves per SIMD (2..4) of the evaluation kernel, and the kernel variant (1 = generic per-candidate
  * kernel, 2 = grid kernel with the per-(t,v) longitudinal table).  Results do not depend on any of them. */
 int32_t fx_set_tuning(FxContext *ctx, int32_t lanes_per_candidate, int32_t waves_per_simd, int32_t kernel_variant);
+/* how the parts of a split horizon map to lanes: 0 auto, 1 adjacent lanes (shuffle combine), 2 lane-groups of the
+ * workgroup ("wave split", LDS combine; keeps every plane store a contiguous row segment per wave) */
+int32_t fx_set_part_mapping(FxContext *ctx, int32_t mapping);
 /* workgroup size of the grid kernel: 0 (auto), 64, 128 or 256 lanes */
 int32_t fx_set_block_size(FxContext *ctx, int32_t block_size);
 

@@ -180,6 +180,49 @@ def test_work_decomposition_does_not_change_results(eng, name, lanes, wpe, varia
         eng.set_tuning(0, 0, 0)
 
 
+@pytest.mark.parametrize("lanes", [2, 4])
+@pytest.mark.parametrize("wpe", [2, 4])
+@pytest.mark.parametrize("name", ["dense_debug_obs", "dense_prod_obs", "dense_lowvel", "dense_horizon5", "ragged_tail",
+                                  "single_candidate", "dense_prod_scurve"])
+def test_wave_split_mapping(eng, name, lanes, wpe):
+    """Parts of a candidate on different lane-groups of the workgroup (LDS combine) against the oracle."""
+    from oracle import oracle
+    kw = CASES[name]
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
+    eng.set_tuning(lanes, wpe, 2, 256, 2)
+    try:
+        try:
+            res = eng.plan_step(inp)
+        except ValueError as e:
+            if "not applicable" in str(e):
+                pytest.skip("grid kernel / wave split not applicable to this case")
+            raise
+        compare(eng, inp, out, res)
+    finally:
+        eng.set_tuning(0, 0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("lanes", [2, 4])
+@pytest.mark.parametrize("name", ["short_ref_hv_l1_debug", "arc_standstill_l1_debug", "arc_slow_brake_l1_kd", "scurve_hv_l2_kd"])
+def test_wave_split_on_golden_cases(eng, name, lanes):
+    from oracle import oracle
+    fx = load_golden(name)
+    inp = inputs_from_fixture(fx, hip_hulls())
+    out = oracle.plan_step(inputs_from_fixture(fx, oracle.build_obstacle_hulls))
+    eng.set_tuning(lanes, 0, 2, 256, 2)
+    try:
+        try:
+            res = eng.plan_step(inp)
+        except ValueError as e:
+            if "not applicable" in str(e):
+                pytest.skip("grid kernel / wave split not applicable to this case")
+            raise
+        compare(eng, inp, out, res)
+    finally:
+        eng.set_tuning(0, 0, 0, 0, 0)
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("lanes", [1, 2, 4, 8])
 @pytest.mark.parametrize("name", ["short_ref_hv_l1_debug", "arc_standstill_l1_debug", "arc_slow_brake_l1_kd",

@@ -10,16 +10,17 @@ def run(label, tunings, steps=60, **kw):
     inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
     out = {}
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
-        for (G, w, var, blk) in tunings:
-            eng.set_tuning(G, w, var, blk); eng.upload(inp)
+        for tn in tunings:
+            G, w, var, blk = tn[:4]; mp = tn[4] if len(tn) > 4 else 0
+            eng.set_tuning(G, w, var, blk, mp); eng.upload(inp)
             for _ in range(5): eng.evaluate(); eng.finish()
             ts = []
             for _ in range(steps):
                 eng.evaluate(); eng.finish(); ts.append(eng.last_eval_kernel_ms)
-            out[f"G{G}w{w}v{var}b{blk}"] = round(float(np.median(ts)) * 1e3, 1)
+            out[f"G{G}w{w}v{var}b{blk}m{mp}"] = round(float(np.median(ts)) * 1e3, 1)
     print(label, inp.n_candidates, json.dumps(out), flush=True)
 
-T = [(0, 0, 0, 0), (1, 2, 2, 256), (2, 2, 2, 256), (2, 3, 2, 256), (4, 2, 2, 256), (1, 4, 2, 256)]
+T = [(0, 0, 0, 0), (1, 2, 2, 256), (2, 2, 2, 256, 1), (2, 2, 2, 256, 2), (4, 2, 2, 256, 2), (4, 3, 2, 256, 2), (4, 4, 2, 256, 2), (1, 4, 2, 256)]
 run("config2_modeB", T, ref_kind="arc", v0=10.0, grid=(19, 51, 51))
 run("config2_modeA", T, ref_kind="arc", v0=10.0, grid=(19, 51, 51), write_bundle=False, write_costmap=False)
 run("config3_modeB", T, ref_kind="arc", v0=10.0, grid=(19, 51, 51), n_obstacles=20)
