@@ -131,6 +131,7 @@ size_t input_bytes_for(int64_t cand, int S, int M, int K, int Pn, bool matrix) {
     b += align_up(sizeof(double) * 2 * (size_t)K * Pn, 256);
     b += align_up(sizeof(double) * 4 * (size_t)K * Pn, 256);
     b += align_up(sizeof(double) * 6 * (size_t)K * (Pn > 0 ? Pn : 1), 256);
+    b += align_up(sizeof(double) * 12 * (size_t)K * S, 256) + 2 * align_up(sizeof(unsigned long long) * S, 256);
     b += 2 * align_up(sizeof(int32_t) * (size_t)K, 256);
     b += align_up(sizeof(double) * 2 * (size_t)K, 256);           // dto positions (<= K)
     return b + 4096;
@@ -202,6 +203,7 @@ int validate(const FxProblem *p) {
         if (p->cost_id[n] < 0 || p->cost_id[n] >= FX_NUM_COSTS) return set_err(FX_ERR_INVALID_ARGUMENT, "unknown cost id %d", p->cost_id[n]);
         if (n && p->cost_id[n] <= p->cost_id[n - 1]) return set_err(FX_ERR_INVALID_ARGUMENT, "cost ids must be strictly ascending");
     }
+    if (p->K > 64) return set_err(FX_ERR_CAPACITY, "at most 64 obstacles per agent (K=%d)", p->K);
     if (p->K < 0 || p->P < 0 || (p->K > 0 && (p->P < 2 || !p->obs_pos || !p->obs_cov_inv || !p->obs_npred)))
         return set_err(FX_ERR_INVALID_ARGUMENT, "obstacle arrays inconsistent (K=%d, P=%d)", p->K, p->P);
     if ((p->mode & FX_MODE_COLLISION) && p->K > 0 && (!p->obs_hull || !p->obs_nhull))
@@ -378,7 +380,9 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         if (c->G_force) G = c->G_force;
         if (extra_any) G = 1;
         c->G_step = G;
-        c->wpe_step = c->wpe_force ? c->wpe_force : 2;
+        // large grids: 4 waves per SIMD (128 VGPRs, a few spills) beats 2 at full VGPR budget; small grids are
+        // latency-bound with 1-2 waves per SIMD anyway and run faster unspilled
+        c->wpe_step = c->wpe_force ? c->wpe_force : (waves1 >= 3072 ? 4 : 2);
         // grid kernel: sampling ranges, no windowed costs, and the longitudinal rows of a workgroup fit in LDS.
         // Workgroup size: the smallest of 64/128/256 lanes whose LDS footprint still lets a CU hold the target
         // number of waves (small workgroups balance small grids at wave granularity).
@@ -488,11 +492,40 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             d.obs_pos = ar.put(p->obs_pos, (size_t)2 * p->K * p->P, &ok);
             d.obs_cov_inv = ar.put(p->obs_cov_inv, (size_t)4 * p->K * p->P, &ok);
             d.obs_npred = ar.put(p->obs_npred, p->K, &ok);
-            if (p->obs_hull && p->obs_nhull) {
+            const bool have_hull = p->obs_hull && p->obs_nhull;
+            if (have_hull) {
                 d.obs_hull = ar.put(p->obs_hull, (size_t)6 * p->K * (p->P - 1), &ok);
                 d.obs_nhull = ar.put(p->obs_nhull, p->K, &ok);
             } else {
                 d.mode &= ~FX_MODE_COLLISION;
+            }
+            {   // step-major packed records + per-step obstacle masks
+                const double *dev = nullptr;
+                double *rec = ar.host_slot<double>((size_t)S * p->K * 12, &dev, &ok);
+                const unsigned long long *dpm = nullptr, *dhm = nullptr;
+                unsigned long long *pm = ar.host_slot<unsigned long long>(S, &dpm, &ok);
+                unsigned long long *hm = ar.host_slot<unsigned long long>(S, &dhm, &ok);
+                if (rec && pm && hm) {
+                    for (int i = 0; i < S; i++) {
+                        pm[i] = hm[i] = 0ULL;
+                        for (int k = 0; k < p->K; k++) {
+                            double *q = rec + ((size_t)i * p->K + k) * 12;
+                            for (int e = 0; e < 12; e++) q[e] = 0.0;
+                            if (i >= 1 && i < p->obs_npred[k] && i - 1 < p->P) {
+                                const double *mu = p->obs_pos + ((size_t)k * p->P + (i - 1)) * 2;
+                                const double *iv = p->obs_cov_inv + ((size_t)k * p->P + (i - 1)) * 4;
+                                q[0] = mu[0]; q[1] = mu[1]; q[2] = iv[0]; q[3] = iv[1]; q[4] = iv[2]; q[5] = iv[3];
+                                pm[i] |= 1ULL << k;
+                            }
+                            if (have_hull && i >= 2 && i - 2 < p->obs_nhull[k]) {
+                                const double *oh = p->obs_hull + ((size_t)k * (p->P - 1) + (i - 2)) * 6;
+                                for (int e = 0; e < 6; e++) q[6 + e] = oh[e];
+                                hm[i] |= 1ULL << k;
+                            }
+                        }
+                    }
+                }
+                d.obs_rec = dev; d.obs_pmask = dpm; d.obs_hmask = dhm;
             }
         } else {
             d.mode &= ~FX_MODE_COLLISION;

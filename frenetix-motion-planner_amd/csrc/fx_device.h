@@ -41,6 +41,11 @@ struct DevProblem {
     const int32_t *obs_npred;  // [K]
     const double *obs_hull;    // [K][P-1][6]
     const int32_t *obs_nhull;  // [K]
+    // step-major packed obstacle records for the walk: rec[S][K][12] = {mu_x, mu_y, iv00, iv01, iv10, iv11 of
+    // prediction i-1 ; hull (cx, cy, ex, ey, h1, h2) of hull i-2}; pmask/hmask[S]: bit k set <=> obstacle k has a
+    // prediction / a hull that ego step i meets.  One contiguous 96-byte record per (step, obstacle).
+    const double *obs_rec;
+    const unsigned long long *obs_pmask, *obs_hmask;
     const double *dto_pos;     // [n_dto][2]
     // ---- outputs (device) ----
     double *cost;              // [ld]

@@ -159,15 +159,11 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     StepConst K;
     K.dt = dt; K.r_dt = 1.0 / dt; K.kappa_max = P.veh.kappa_max; K.a_max = a_max; K.v_switch = P.veh.v_switch;
     K.av_switch = a_max * P.veh.v_switch; K.v_des = P.v_des; K.wb = P.veh.wb_rear_axle; K.half_len = P.veh.length / 2;
-    K.half_wid = P.veh.width / 2; K.S = S; K.half = S / 2; K.K = P.K; K.Pn = P.P; K.low_vel = low_vel; K.dbg = dbg;
+    K.half_wid = P.veh.width / 2; K.S = S; K.half = S / 2; K.K = P.K; K.low_vel = low_vel; K.dbg = dbg;
     K.do_collision = do_collision;
-    const FX_GLOBAL double *__restrict__ obs_pos = as_global(P.obs_pos);
-    const FX_GLOBAL double *__restrict__ obs_cov_inv = as_global(P.obs_cov_inv);
-    const FX_GLOBAL double *__restrict__ obs_hull = as_global(P.obs_hull);
-    const FX_GLOBAL int32_t *__restrict__ obs_npred = as_global(P.obs_npred);
-    const FX_GLOBAL int32_t *__restrict__ obs_nhull = as_global(P.obs_nhull);
-    K.max_nhull = 0;
-    if (do_collision) for (int k = 0; k < K.K; k++) K.max_nhull = max(K.max_nhull, obs_nhull[k]);
+    const FX_GLOBAL double *__restrict__ obs_rec = as_global(P.obs_rec);
+    const FX_GLOBAL unsigned long long *__restrict__ obs_pmask = as_global(P.obs_pmask);
+    const FX_GLOBAL unsigned long long *__restrict__ obs_hmask = as_global(P.obs_hmask);
 
     StepCarry Cy;
     Cy.th_prev = P.x0_orientation; Cy.kap_prev = 0.0; Cy.bx_prev = Cy.by_prev = Cy.ux_prev = Cy.uy_prev = 0.0;
@@ -193,8 +189,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     for (int i = i_first; i < i_end; i++) {
         const bool emit = i >= i_begin;
         const LonRow r = my[i];
-        walk_step<OBST>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit, planes + (int64_t)i * ld + g, ps, Cy, A,
-                        O, obs_pos, obs_cov_inv, obs_hull, obs_npred, obs_nhull);
+        walk_step<OBST, (G == 1 || WSPLIT)>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit,
+                                            planes + (int64_t)i * ld + g, ps, Cy, A, O, obs_rec, obs_pmask, obs_hmask);
     }
 
     WalkResult W;

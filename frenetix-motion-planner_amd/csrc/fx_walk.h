@@ -152,7 +152,7 @@ struct LatPoly {
 
 struct StepConst {  // wave-uniform constants of the walk
     double dt, r_dt, kappa_max, a_max, v_switch, av_switch, v_des, wb, half_len, half_wid;
-    int S, half, K, Pn, max_nhull;
+    int S, half, K;
     bool low_vel, dbg, do_collision;
 };
 
@@ -173,11 +173,12 @@ struct StepOut {  // per-step values the windowed (EXTRA) costs of the generic k
 };
 
 // One step of one candidate.  `planes_i` = address of plane 0 at (step i, this candidate); ps = plane stride.
-template <bool OBST, typename PlanePtr, typename ObsD, typename ObsI>
+// USTEP: the step index is wave-uniform (one lane per candidate, or parts on different waves), so the obstacle
+// records of the step come in through scalar loads; otherwise every lane reads its own step's records.
+template <bool OBST, bool USTEP, typename PlanePtr, typename ObsD, typename ObsM>
 __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, const LatPoly &L, const double *tp, int i,
                                           int traj_len, double d_ext, bool emit, bool store, PlanePtr planes_i, int64_t ps,
-                                          StepCarry &C, StepAcc &A, StepOut &O, ObsD obs_pos, ObsD obs_cov_inv, ObsD obs_hull,
-                                          ObsI obs_npred, ObsI obs_nhull) {
+                                          StepCarry &C, StepAcc &A, StepOut &O, ObsD obs_rec, ObsM obs_pmask, ObsM obs_hmask) {
     const int S = K.S;
     const double s_i = r.s, sv_i = r.sv, sa_i = r.sa;
     // -- lateral polynomial (reactive_planner.py:326-346) --
@@ -280,37 +281,44 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
         if (i >= K.half && i < S - 1) A.sum_voff += fabs(v_i - K.v_des);        // :125-127
         if (i == S - 1) { A.d_end = d_i; A.v_end = v_i; }
     }
-    if (OBST) {
-        const int nK = K.K, Pn = K.Pn;
-        if (emit && i >= 1) {  // ego step i pairs with prediction i-1 (collision_probability.py:283-292)
-            for (int k = 0; k < nK; k++) {
-                if (i < obs_npred[k]) {
-                    const auto mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
-                    const auto iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
-                    const double e0 = x_i - mu[0], e1 = y_i - mu[1];
-                    const double r0 = fma(e1, iv[2], e0 * iv[0]), r1 = fma(e1, iv[3], e0 * iv[1]);
-                    const double m = fma(r1, e1, r0 * e0);
-                    const double mm = m * m;
-                    A.pred += mm > 0.0 ? rcp_nr(mm) : 1.0 / mm;
-                }
-            }
+    if (OBST && K.K > 0) {  // a batched launch may mix agents with and without obstacles
+        const int nK = K.K;
+        const int iu = USTEP ? __builtin_amdgcn_readfirstlane(i) : i;
+        const auto rec_i = obs_rec + (int64_t)iu * nK * 12;
+        // -- prediction cost: ego step i pairs with prediction i-1 (collision_probability.py:283-292) --
+        unsigned long long pm = emit ? obs_pmask[iu] : 0ULL;
+        if (USTEP) pm = __builtin_amdgcn_readfirstlane((unsigned)(pm & 0xffffffffu)) |
+                        ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(pm >> 32)) << 32);
+        if (USTEP && !emit) pm = 0ULL;  // emit is wave-uniform whenever the step index is
+        while (pm) {
+            const int k = __builtin_ctzll(pm);
+            pm &= pm - 1;
+            const auto q = rec_i + k * 12;
+            const double e0 = x_i - q[0], e1 = y_i - q[1];
+            const double r0 = fma(e1, q[4], e0 * q[2]), r1 = fma(e1, q[5], e0 * q[3]);
+            const double m = fma(r1, e1, r0 * e0);
+            const double mm = m * m;
+            A.pred += mm > 0.0 ? rcp_nr(mm) : 1.0 / mm;
         }
         if (K.do_collision) {
-            // ego box: centre = rear axle + wb_rear_axle along heading (state.py:30-39), heading theta_gl; needed
-            // while some obstacle hull exists at time index i-1 (this step's pair) or later
-            const bool need = (i >= 2 ? i - 2 : 0) < K.max_nhull;
-            if (need && i >= 1) {
+            // ego box: centre = rear axle + wb_rear_axle along heading (state.py:30-39), heading theta_gl; it is needed
+            // when this step closes a hull that meets an obstacle hull, or opens the next step's
+            const unsigned long long hm_now = obs_hmask[iu];
+            const unsigned long long hm_next = iu + 1 < S ? obs_hmask[iu + 1] : 0ULL;
+            if ((hm_now | hm_next) != 0ULL && i >= 1) {
                 double su, cu;
                 fxm::sincos(th_gl, &su, &cu);
                 const double bx = fma(K.wb, cu, x_i), by = fma(K.wb, su, y_i);
-                if (emit && i >= 2) {
+                unsigned long long hm = emit ? hm_now : 0ULL;
+                if (USTEP) hm = __builtin_amdgcn_readfirstlane((unsigned)(hm & 0xffffffffu)) |
+                                ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(hm >> 32)) << 32);
+                if (hm) {
                     // OBB-sum hull of ego boxes (i-1, i) lives at time index i-1 and meets obstacle hull i-2
                     const Obb hull = obb_hull(C.bx_prev, C.by_prev, C.ux_prev, C.uy_prev, bx, by, cu, su, K.half_len, K.half_wid);
-                    for (int k = 0; k < nK; k++) {
-                        if (i - 2 < obs_nhull[k]) {
-                            const auto oh = obs_hull + ((int64_t)k * (Pn - 1) + (i - 2)) * 6;
-                            A.collided |= obb_overlap(hull, oh);
-                        }
+                    while (hm) {
+                        const int k = __builtin_ctzll(hm);
+                        hm &= hm - 1;
+                        A.collided |= obb_overlap(hull, rec_i + k * 12 + 6);
                     }
                 }
                 C.bx_prev = bx; C.by_prev = by; C.ux_prev = cu; C.uy_prev = su;
