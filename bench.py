@@ -128,19 +128,8 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        # inputs are resident: upload happened once; a step re-runs evaluation + selection (+ exchange)
-        if world == 1:
-            eng.evaluate()
-            return eng.finish()[0]
-        eng.evaluate()
-        eng.topk_to_device(ev.k, ev._cost.data_ptr(), ev._idx.data_ptr())
-        dist.all_gather_into_tensor(ev._gcost, ev._cost)
-        dist.all_gather_into_tensor(ev._gidx, ev._idx)
-        res = eng.finish()[0]
-        from frenetix_motion_planner_amd.distributed import merge_survivors
-        bc, bi, _ = merge_survivors(ev._gcost.cpu().numpy(), ev._gidx.cpu().numpy())
-        res["global_best_cost"], res["global_best_index"] = bc, bi
-        return res
+        # inputs are resident: upload happened once; a step re-runs evaluation + selection (+ survivor exchange)
+        return ev.step_enqueued()
 
     eng.upload(inp)
     for _ in range(args.warmup):

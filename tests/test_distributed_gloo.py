@@ -110,3 +110,94 @@ def test_candidate_and_agent_sharding_world2():
                                     n_obstacles=a % 3, seed=a)
         ref = oracle.plan_step(inp, want_planes=False)["result"]
         assert bi == ref["best_index"] and bc == ref["best_cost"]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Same sharded path with the REAL engine: two ranks share cuda:0 (RCCL refuses two ranks on one device, so the
+# exchange runs over gloo on host tensors -- the ShardedEvaluator's non-NCCL branch); GPU box only.
+# ---------------------------------------------------------------------------------------------------------
+def _gpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator
+    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        kw = dict(ref_kind="arc", v0=10.0, grid=(9, 21, 21), n_obstacles=8)
+        with FrenetEngine(max_candidates=8192, max_agents=4, device=0) as eng:
+            ev = ShardedEvaluator(eng, k=8)
+            inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
+            res = ev.plan_step(inp)
+            agents = [synthetic.make_inputs(hull_builder=build_obstacle_hulls, ref_kind="arc", v0=6.0 + 2 * a, grid=(3, 5, 7),
+                                            n_obstacles=a % 3, seed=a) for a in range(5)]
+            ares = ev.plan_agents(agents)
+            q.put((rank, res["global_best_index"], res["global_best_cost"], list(res["survivors"][:8]), inp.shard,
+                   [(r["best_index"], r["best_cost"]) for r in ares]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_sharded_path_with_real_engine_world2():
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    kw = dict(ref_kind="arc", v0=10.0, grid=(9, 21, 21), n_obstacles=8)
+    inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
+    with FrenetEngine(max_candidates=8192, max_agents=4, device=0) as eng:
+        full = eng.plan_step(inp)
+        tc, ti = eng.topk(8)
+        singles = [eng.plan_step(synthetic.make_inputs(hull_builder=build_obstacle_hulls, ref_kind="arc", v0=6.0 + 2 * a,
+                                                       grid=(3, 5, 7), n_obstacles=a % 3, seed=a)) for a in range(5)]
+    for rank, bi, bc, surv, shard, ares in got:
+        assert bi == full["best_index"] and bc == full["best_cost"]
+        assert surv[:4] == list(ti[0][:4])   # merged survivors == single-GPU top-k
+        for a, (abi, abc) in enumerate(ares):
+            assert abi == singles[a]["best_index"] and abc == singles[a]["best_cost"]
+    C = inp.n_candidates_global
+    assert got[0][4] == (0, (C + 1) // 2) and got[1][4] == ((C + 1) // 2, C // 2)
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_path_single_rank():
+    """The device-side exchange (top-k written straight into torch tensors on torch's stream + RCCL all-gather)
+    with a one-rank nccl group: everything bench.py --gpus N does per step except having N > 1 peers."""
+    import torch
+    import torch.distributed as dist
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator
+    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(9, 21, 21), n_obstacles=8, hull_builder=build_obstacle_hulls)
+        with FrenetEngine(max_candidates=8192, device=0) as eng:
+            ref = eng.plan_step(inp)
+            tc, ti = eng.topk(8)
+            ev = ShardedEvaluator(eng, k=8, force_exchange=True)
+            assert ev.on_device
+            res = ev.plan_step(inp)
+            assert res["global_best_index"] == ref["best_index"] and res["global_best_cost"] == ref["best_cost"]
+            assert list(res["survivors"]) == [int(x) for x in ti[0] if x >= 0]
+            eng.upload(inp)
+            for _ in range(3):
+                res2 = ev.step_enqueued()
+            assert res2["global_best_index"] == ref["best_index"]
+    finally:
+        dist.destroy_process_group()
