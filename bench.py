@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["config2", "config3"], default="config2")
     ap.add_argument("--select-only", action="store_true", help="Mode A: no SoA bundle write")
-    ap.add_argument("--topk", type=int, default=8)
+    ap.add_argument("--topk", type=int, default=1, help="survivors per GPU in the exchange (1: the winner, no top-k kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

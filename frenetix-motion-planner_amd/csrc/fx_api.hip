@@ -23,10 +23,12 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
                                           size_t lds_bytes, int G, bool bundle, bool obst, int wpe, bool wsplit,
                                           hipStream_t stream);
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
-                                       unsigned long long seq, hipStream_t stream);
+                                       unsigned long long seq, double *dev_winner, hipStream_t stream);
 extern "C" hipError_t fx_launch_math_test(int n, const double *x, double *at, double *sn, double *cs, hipStream_t stream);
-extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int k, double *out_cost, long long *out_idx,
-                                     hipStream_t stream);
+extern "C" hipError_t fx_launch_publish(const double *src, int n, double *host_dst, unsigned long long *host_seq,
+                                        unsigned long long seq, hipStream_t stream);
+extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int k, double *scr_cost, long long *scr_idx,
+                                     double *out_cost, long long *out_idx, hipStream_t stream);
 
 namespace {
 
@@ -50,6 +52,8 @@ int set_err(int code, const char *fmt, ...) {
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
+
+#define FX_PUB_MAX 16384  // doubles: 8 ranks x 64 survivors x 2 x 16 agents
 
 struct FxAgentSlot {
     int64_t C = 0, ld = 0, cand_off = 0;  // cand_off: offset of this agent in the per-candidate arrays
@@ -86,9 +90,15 @@ struct FxContext {
     unsigned long long *h_counters = nullptr;  // pinned + mapped: [max_agents][FX_CNT_COUNT + 1], last word = sequence
     unsigned long long *h_counters_dev = nullptr;  // device address of the same block
     unsigned long long seq = 0;
+    double *h_pub = nullptr, *h_pub_dev = nullptr;   // pinned + mapped [FX_PUB_MAX + 1]: published buffer, last word = sequence
+    unsigned long long pub_seq = 0;
+    int pub_n = 0;
+    double *dev_winner = nullptr;          // caller-owned device buffer [n_agents][2] the selection kernel also fills
     bool in_flight = false;                // work enqueued whose completion the host has not observed yet
     double *d_topk_cost = nullptr;
     long long *d_topk_idx = nullptr;
+    double *d_topk_scr_cost = nullptr;     // [max_agents][64 slices][64]
+    long long *d_topk_scr_idx = nullptr;
     double *h_topk_cost = nullptr;
     long long *h_topk_idx = nullptr;
     int64_t total_ld = 0;  // capacity of per-candidate arrays (elements)
@@ -279,8 +289,13 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     memset(c->h_counters, 0, sizeof(unsigned long long) * max_agents * (FX_CNT_COUNT + 1));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_counters_dev), c->h_counters, 0));
     HIP_TRY(hipMemset(c->d_counters, 0, sizeof(unsigned long long) * max_agents * FX_CNT_COUNT));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_pub), sizeof(double) * (FX_PUB_MAX + 1), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_pub, 0, sizeof(double) * (FX_PUB_MAX + 1));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_pub_dev), c->h_pub, 0));
     if ((rc = dev_alloc(c, &c->d_topk_cost, (size_t)max_agents * 64))) return rc;
     if ((rc = dev_alloc(c, &c->d_topk_idx, (size_t)max_agents * 64))) return rc;
+    if ((rc = dev_alloc(c, &c->d_topk_scr_cost, (size_t)max_agents * 64 * 64))) return rc;
+    if ((rc = dev_alloc(c, &c->d_topk_scr_idx, (size_t)max_agents * 64 * 64))) return rc;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_topk_cost), sizeof(double) * max_agents * 64, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_topk_idx), sizeof(long long) * max_agents * 64, hipHostMallocDefault));
     c->slots.resize(max_agents);
@@ -297,15 +312,47 @@ int32_t fx_destroy(FxContext *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_in, c->d_probs, c->d_cost, c->d_flags, c->d_costmap, c->d_coeffs, c->d_trajlen, c->d_planes,
-                   c->d_part_cost, c->d_part_idx, c->d_counters, c->d_topk_cost, c->d_topk_idx};
+                   c->d_part_cost, c->d_part_idx, c->d_counters, c->d_topk_cost, c->d_topk_idx, c->d_topk_scr_cost,
+                   c->d_topk_scr_idx};
     for (void *p : dev) if (p) (void)hipFree(p);
-    void *host[] = {c->h_in, c->h_probs, c->h_counters, c->h_topk_cost, c->h_topk_idx};
+    void *host[] = {c->h_in, c->h_probs, c->h_counters, c->h_topk_cost, c->h_topk_idx, c->h_pub};
     for (void *p : host) if (p) (void)hipHostFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return FX_OK;
+}
+
+// Publish n doubles of a device buffer (e.g. the all-gathered survivors) to the host through pinned memory;
+// enqueued on the context stream.  fx_wait_published copies them out once they have arrived.
+int32_t fx_publish(FxContext *c, const void *d_src, int32_t n) {
+    if (!c || !d_src) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_publish: NULL argument");
+    if (n < 1 || n > FX_PUB_MAX) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_publish: n=%d outside [1,%d]", n, FX_PUB_MAX);
+    HIP_TRY(hipSetDevice(c->device));
+    c->pub_seq++;
+    c->pub_n = n;
+    HIP_TRY(fx_launch_publish(reinterpret_cast<const double *>(d_src), n, c->h_pub_dev,
+                              reinterpret_cast<unsigned long long *>(c->h_pub_dev + FX_PUB_MAX), c->pub_seq, c->stream));
+    c->in_flight = true;
+    return FX_OK;
+}
+
+int32_t fx_wait_published(FxContext *c, double *out) {
+    if (!c || !out) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_wait_published: NULL argument");
+    if (c->pub_n < 1) return set_err(FX_ERR_NOT_READY, "nothing published");
+    const volatile unsigned long long *sq = reinterpret_cast<const unsigned long long *>(c->h_pub + FX_PUB_MAX);
+    bool done = false;
+    for (long spin = 0; spin < 20000000L && !done; spin++) done = __atomic_load_n(sq, __ATOMIC_ACQUIRE) == c->pub_seq;
+    if (!done) HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_pub, sizeof(double) * c->pub_n);
+    return FX_OK;
+}
+
+int32_t fx_set_winner_buffer(FxContext *c, void *d_winner) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    c->dev_winner = reinterpret_cast<double *>(d_winner);
     return FX_OK;
 }
 
@@ -591,7 +638,7 @@ int32_t fx_evaluate(FxContext *c) {
     }
     HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
     c->seq++;
-    HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, c->stream));
+    HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, c->dev_winner, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->evaluated = true;
     c->in_flight = true;
@@ -730,8 +777,9 @@ int32_t fx_topk_to_device(FxContext *c, int32_t k, void *d_cost, void *d_index) 
     if (!c->evaluated) return set_err(FX_ERR_NOT_READY, "no evaluated plan step");
     if (k < 1 || k > 64) return set_err(FX_ERR_INVALID_ARGUMENT, "k=%d outside [1,64]", k);
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(fx_launch_topk(c->d_probs, c->n_agents, k, reinterpret_cast<double *>(d_cost), reinterpret_cast<long long *>(d_index),
-                           c->stream));
+    HIP_TRY(fx_launch_topk(c->d_probs, c->n_agents, k, c->d_topk_scr_cost, c->d_topk_scr_idx, reinterpret_cast<double *>(d_cost),
+                           reinterpret_cast<long long *>(d_index), c->stream));
+    c->in_flight = true;
     return FX_OK;
 }
 

@@ -32,7 +32,7 @@ using fxk::wave_count;
 // (planner.py:336-357 `_collision_counter`).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void fx_select_kernel(const DevProblem *__restrict__ probs, unsigned long long *host_result,
-                                                         unsigned long long seq) {
+                                                         unsigned long long seq, double *dev_winner) {
     __shared__ double sc[16];
     __shared__ long long si[16];
     __shared__ unsigned int scnt;
@@ -79,6 +79,10 @@ __global__ __launch_bounds__(1024) void fx_select_kernel(const DevProblem *__res
         out[tid] = P.counters[tid];
         P.counters[tid] = 0ULL;
     }
+    if (tid == 0 && dev_winner) {  // (cost, index bits) of the winner, device-resident for the multi-GPU exchange
+        dev_winner[2 * blockIdx.x] = none ? INFINITY : bc;
+        reinterpret_cast<long long *>(dev_winner)[2 * blockIdx.x + 1] = none ? -1 : bi;
+    }
     if (tid == 0) {
         out[FX_CNT_BEST_IDX] = none ? ~0ULL : (unsigned long long)bi;
         out[FX_CNT_BEST_COST] = none ? 0ULL : (unsigned long long)__double_as_longlong(bc);
@@ -92,47 +96,107 @@ __global__ __launch_bounds__(1024) void fx_select_kernel(const DevProblem *__res
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Top-k: the k best selectable collision-free candidates in (cost, index) order, one workgroup per agent.
-// k successive arg-min passes with a strict lower bound; k <= 64, C up to millions is fine for the
-// occasional host-side walk, the per-step fast path only needs fx_select_kernel.
+// Top-k: the k best selectable collision-free candidates in (cost, index) order (k <= 64).
+// Two small launches: FX_TOPK_SLICES workgroups per agent each extract the k best of a contiguous slice
+// (k rounds of arg-min with a strict lower bound, over 1/64 of the candidates), then one workgroup per agent
+// merges the 64 x k survivors.  Only the multi-GPU exchange and the host-side road-boundary walk need it.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void fx_topk_kernel(const DevProblem *__restrict__ probs, int k, double *out_cost,
-                                                       long long *out_idx) {
-    __shared__ double sc[16];
-    __shared__ long long si[16];
-    const DevProblem &P = probs[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define FX_TOPK_SLICES 64
+
+__device__ __forceinline__ void block_argmin(double &bc, long long &bi, double *sc, long long *si) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oc = __shfl_xor(bc, off);
+        const long long oi = __shfl_xor(bi, off);
+        if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { sc[wave] = bc; si[wave] = bi; }
+    __syncthreads();
+    bc = sc[0]; bi = si[0];
+    for (int w = 1; w < nw; w++)
+        if (sc[w] < bc || (sc[w] == bc && si[w] < bi)) { bc = sc[w]; bi = si[w]; }
+}
+
+__global__ __launch_bounds__(256) void fx_topk_slice_kernel(const DevProblem *__restrict__ probs, int k, double *scr_cost,
+                                                            long long *scr_idx) {
+    __shared__ double sc[4];
+    __shared__ long long si[4];
+    const DevProblem &P = probs[blockIdx.y];
+    const int tid = threadIdx.x;
+    const int64_t per = (P.C + FX_TOPK_SLICES - 1) / FX_TOPK_SLICES;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = min(P.C, lo + per);
+    const FX_GLOBAL uint32_t *__restrict__ flags = as_global(P.flags);
+    const FX_GLOBAL double *__restrict__ cost = as_global(P.cost);
+    const long long NONE = 0x7fffffffffffffffLL;
     double lb_c = -INFINITY;
     long long lb_i = -1;
+    const size_t out = ((size_t)blockIdx.y * FX_TOPK_SLICES + blockIdx.x) * k;
     for (int r = 0; r < k; r++) {
         double bc = INFINITY;
-        long long bi = 0x7fffffffffffffffLL;
-        for (int64_t g = tid; g < P.C; g += 1024) {
-            const uint32_t f = as_global(P.flags)[g];
+        long long bi = NONE;
+        for (int64_t g = lo + tid; g < hi; g += 256) {
+            const uint32_t f = flags[g];
             if ((f & FX_FLAG_SELECTABLE) && !(f & FX_FLAG_COLLISION)) {
-                const double c = as_global(P.cost)[g];
+                const double c = cost[g];
                 const long long gg = (long long)(g + P.g_base);
                 const bool after = c > lb_c || (c == lb_c && gg > lb_i);
                 if (after && (c < bc || (c == bc && gg < bi))) { bc = c; bi = gg; }
             }
         }
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double oc = __shfl_xor(bc, off);
-            const long long oi = __shfl_xor(bi, off);
-            if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
-        }
-        __syncthreads();
-        if (lane == 0) { sc[wave] = bc; si[wave] = bi; }
-        __syncthreads();
-        bc = sc[0]; bi = si[0];
-        for (int w = 1; w < 16; w++)
-            if (sc[w] < bc || (sc[w] == bc && si[w] < bi)) { bc = sc[w]; bi = si[w]; }
-        if (tid == 0) {
-            out_cost[(int64_t)blockIdx.x * k + r] = bi == 0x7fffffffffffffffLL ? INFINITY : bc;
-            out_idx[(int64_t)blockIdx.x * k + r] = bi == 0x7fffffffffffffffLL ? -1 : bi;
-        }
-        if (bi == 0x7fffffffffffffffLL) { lb_c = INFINITY; lb_i = 0x7fffffffffffffffLL; } else { lb_c = bc; lb_i = bi; }
+        block_argmin(bc, bi, sc, si);
+        const bool none = bi == NONE;
+        if (tid == 0) { scr_cost[out + r] = none ? INFINITY : bc; scr_idx[out + r] = none ? -1 : bi; }
+        if (none) { lb_c = INFINITY; lb_i = NONE; } else { lb_c = bc; lb_i = bi; }
     }
+}
+
+__global__ __launch_bounds__(256) void fx_topk_merge_kernel(int k, const double *__restrict__ scr_cost,
+                                                            const long long *__restrict__ scr_idx, double *out_cost,
+                                                            long long *out_idx) {
+    __shared__ double sc[4];
+    __shared__ long long si[4];
+    const int tid = threadIdx.x;
+    const int n = FX_TOPK_SLICES * k;
+    const size_t base = (size_t)blockIdx.x * n;
+    const long long NONE = 0x7fffffffffffffffLL;
+    double lb_c = -INFINITY;
+    long long lb_i = -1;
+    for (int r = 0; r < k; r++) {
+        double bc = INFINITY;
+        long long bi = NONE;
+        for (int e = tid; e < n; e += 256) {
+            const long long gg = scr_idx[base + e];
+            if (gg >= 0) {
+                const double c = scr_cost[base + e];
+                const bool after = c > lb_c || (c == lb_c && gg > lb_i);
+                if (after && (c < bc || (c == bc && gg < bi))) { bc = c; bi = gg; }
+            }
+        }
+        block_argmin(bc, bi, sc, si);
+        const bool none = bi == NONE;
+        if (tid == 0) { out_cost[(size_t)blockIdx.x * k + r] = none ? INFINITY : bc; out_idx[(size_t)blockIdx.x * k + r] = none ? -1 : bi; }
+        if (none) { lb_c = INFINITY; lb_i = NONE; } else { lb_c = bc; lb_i = bi; }
+    }
+}
+
+// Copy a small device buffer (the all-gathered survivors) into pinned host memory and publish a sequence word:
+// the host polls instead of paying for a D2H copy + stream synchronisation.
+__global__ __launch_bounds__(256) void fx_publish_kernel(const double *__restrict__ src, int n, double *host_dst,
+                                                         unsigned long long *host_seq, unsigned long long seq) {
+    for (int i = threadIdx.x; i < n; i += 256) host_dst[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+extern "C" hipError_t fx_launch_publish(const double *src, int n, double *host_dst, unsigned long long *host_seq,
+                                        unsigned long long seq, hipStream_t stream) {
+    hipLaunchKernelGGL(fx_publish_kernel, dim3(1), dim3(256), 0, stream, src, n, host_dst, host_seq, seq);
+    return hipGetLastError();
 }
 
 // element-wise check of the fx_math kernels (tests/test_hip_math.py)
@@ -240,13 +304,14 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
 }
 
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
-                                       unsigned long long seq, hipStream_t stream) {
-    hipLaunchKernelGGL(fx_select_kernel, dim3(n_agents), dim3(1024), 0, stream, d_probs, host_result, seq);
+                                       unsigned long long seq, double *dev_winner, hipStream_t stream) {
+    hipLaunchKernelGGL(fx_select_kernel, dim3(n_agents), dim3(1024), 0, stream, d_probs, host_result, seq, dev_winner);
     return hipGetLastError();
 }
 
-extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int k, double *out_cost, long long *out_idx,
-                                     hipStream_t stream) {
-    hipLaunchKernelGGL(fx_topk_kernel, dim3(n_agents), dim3(1024), 0, stream, d_probs, k, out_cost, out_idx);
+extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int k, double *scr_cost, long long *scr_idx,
+                                     double *out_cost, long long *out_idx, hipStream_t stream) {
+    hipLaunchKernelGGL(fx_topk_slice_kernel, dim3(FX_TOPK_SLICES, n_agents), dim3(256), 0, stream, d_probs, k, scr_cost, scr_idx);
+    hipLaunchKernelGGL(fx_topk_merge_kernel, dim3(n_agents), dim3(256), 0, stream, k, scr_cost, scr_idx, out_cost, out_idx);
     return hipGetLastError();
 }

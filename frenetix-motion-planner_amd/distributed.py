@@ -67,10 +67,11 @@ class ShardedEvaluator:
             dev = torch.device("cuda", torch.cuda.current_device())
             # the engine enqueues on torch's current stream so RCCL sees the survivors in stream order
             engine.set_stream(torch.cuda.current_stream().cuda_stream)
-            self._cost = torch.empty(self.k, dtype=torch.float64, device=dev)
-            self._idx = torch.empty(self.k, dtype=torch.int64, device=dev)
-            self._gcost = torch.empty(self.world * self.k, dtype=torch.float64, device=dev)
-            self._gidx = torch.empty(self.world * self.k, dtype=torch.int64, device=dev)
+            # one buffer per rank: [cost f64 x k | index i64 x k] so the exchange is a single all-gather of 16*k bytes
+            self._surv = torch.empty(2 * self.k, dtype=torch.float64, device=dev)
+            self._gath = torch.empty(self.world * 2 * self.k, dtype=torch.float64, device=dev)
+            if self.k == 1:  # the selection kernel itself leaves (cost, index) in the exchange buffer: no top-k launch
+                engine.set_winner_buffer(self._surv.data_ptr())
 
     def shard(self, inputs):
         begin, count = shard_range(inputs.n_candidates_global, self.rank, self.world)
@@ -85,13 +86,22 @@ class ShardedEvaluator:
             res["global_best_index"], res["global_best_cost"] = res["best_index"], res["best_cost"]
             return res
         self.engine.evaluate()
-        self.engine.topk_to_device(self.k, self._cost.data_ptr(), self._idx.data_ptr())
-        self.dist.all_gather_into_tensor(self._gcost, self._cost, group=self.group)
-        self.dist.all_gather_into_tensor(self._gidx, self._idx, group=self.group)
+        gc, gi = self._exchange_on_device()
         res = self.engine.finish()[0]
-        best_c, best_i, order = merge_survivors(self._gcost.cpu().numpy(), self._gidx.cpu().numpy())
+        best_c, best_i, order = merge_survivors(gc, gi)
         res["global_best_cost"], res["global_best_index"], res["survivors"] = best_c, best_i, order
         return res
+
+    def _exchange_on_device(self):
+        """top-k straight into the torch buffer (torch's stream), ONE RCCL all-gather, one D2H of W*16*k bytes."""
+        k = self.k
+        if k > 1:
+            self.engine.topk_to_device(k, self._surv.data_ptr(), self._surv.data_ptr() + 8 * k)
+        self.dist.all_gather_into_tensor(self._gath, self._surv, group=self.group)
+        # the engine copies the gathered block into pinned host memory on the same stream and the host polls for it
+        self.engine.publish(self._gath.data_ptr(), self.world * 2 * k)
+        g = self.engine.wait_published().reshape(self.world, 2, k)
+        return g[:, 0, :].copy(), g[:, 1, :].copy().view(np.int64)
 
     def plan_step(self, inputs) -> dict:
         """Evaluate this rank's shard, exchange survivors, return the global winner (same on all ranks)."""
@@ -103,11 +113,8 @@ class ShardedEvaluator:
         if self.on_device:
             self.engine.upload(inputs)
             self.engine.evaluate()
-            self.engine.topk_to_device(self.k, self._cost.data_ptr(), self._idx.data_ptr())
-            self.dist.all_gather_into_tensor(self._gcost, self._cost, group=self.group)
-            self.dist.all_gather_into_tensor(self._gidx, self._idx, group=self.group)
+            gc, gi = self._exchange_on_device()
             res = self.engine.finish()[0]
-            gc, gi = self._gcost.cpu().numpy(), self._gidx.cpu().numpy()
         else:
             res = self.engine.plan_step(inputs)
             c, i = self.engine.topk(self.k)

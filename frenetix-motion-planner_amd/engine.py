@@ -82,6 +82,20 @@ class FrenetEngine:
         check(lib().fx_set_block_size(self._ctx, int(block_size)))
         check(lib().fx_set_part_mapping(self._ctx, int(mapping)))
 
+    def set_winner_buffer(self, d_ptr: int):
+        """Device buffer [n_agents][2] (cost f64, global index i64) every step's winner is also written to."""
+        check(lib().fx_set_winner_buffer(self._ctx, C.c_void_p(d_ptr)))
+
+    def publish(self, d_ptr: int, n: int):
+        """Enqueue the copy of n doubles at device address d_ptr into the pinned publication block."""
+        check(lib().fx_publish(self._ctx, C.c_void_p(d_ptr), int(n)))
+        self._pub_n = int(n)
+
+    def wait_published(self) -> np.ndarray:
+        out = np.empty(self._pub_n)
+        check(lib().fx_wait_published(self._ctx, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     def set_timing(self, enabled: bool):
         """HIP-event timing of every step (default on; off shaves the event queries from fx_finish)."""
         check(lib().fx_set_timing(self._ctx, int(bool(enabled))))

@@ -179,6 +179,13 @@ int32_t fx_set_stream(FxContext *ctx, void *hip_stream);
  * target in waves per SIMD (2..4) of the evaluation kernel, and the kernel variant (1 = generic per-candidate
  * kernel, 2 = grid kernel with the per-(t,v) longitudinal table).  Results do not depend on any of them. */
 int32_t fx_set_tuning(FxContext *ctx, int32_t lanes_per_candidate, int32_t waves_per_simd, int32_t kernel_variant);
+/* device buffer [n_agents][2] = (cost f64, global index i64) that every evaluated step also leaves its winner in,
+ * so a k = 1 survivor exchange needs no extra kernel (NULL to disable); e.g. a torch tensor's data_ptr() */
+int32_t fx_set_winner_buffer(FxContext *ctx, void *d_winner);
+/* publish n doubles of a small device buffer (the all-gathered survivors) to the host through pinned memory on the
+ * context stream, and wait for / copy them out: avoids a D2H copy + stream synchronisation per step */
+int32_t fx_publish(FxContext *ctx, const void *d_src, int32_t n);
+int32_t fx_wait_published(FxContext *ctx, double *out);
 /* how the parts of a split horizon map to lanes: 0 auto, 1 adjacent lanes (shuffle combine), 2 lane-groups of the
  * workgroup ("wave split", LDS combine; keeps every plane store a contiguous row segment per wave) */
 int32_t fx_set_part_mapping(FxContext *ctx, int32_t mapping);

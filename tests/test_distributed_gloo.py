@@ -201,3 +201,27 @@ def test_rccl_exchange_path_single_rank():
             assert res2["global_best_index"] == ref["best_index"]
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_k1_uses_selection_result():
+    import torch
+    import torch.distributed as dist
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator
+    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(9, 21, 21), n_obstacles=8, hull_builder=build_obstacle_hulls)
+        with FrenetEngine(max_candidates=8192, device=0) as eng:
+            ref = eng.plan_step(inp)
+            ev = ShardedEvaluator(eng, k=1, force_exchange=True)
+            res = ev.plan_step(inp)
+            assert res["global_best_index"] == ref["best_index"] and res["global_best_cost"] == ref["best_cost"]
+            assert list(res["survivors"]) == [ref["best_index"]]
+            eng.set_winner_buffer(0)
+    finally:
+        dist.destroy_process_group()

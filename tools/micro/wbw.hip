@@ -37,6 +37,34 @@ __global__ void k_planes_work(double* __restrict__ out, long ld, int S, long C, 
     }
     if (!STORE && acc == 12345.678) out[g] = acc;
 }
+// nontemporal variant of the plane pattern
+__global__ void k_planes_nt(double* __restrict__ out, long ld, int S, long C) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= C) return;
+    double v = (double)g;
+    for (int i = 0; i < S; i++) {
+        double* row = out + (long)i * ld + g;
+        long ps = (long)S * ld;
+#pragma unroll
+        for (int p = 0; p < 14; p++) __builtin_nontemporal_store(v + p, row + p * ps);
+        v += 1.0;
+    }
+}
+template <bool NT>
+__global__ void k_planes_work2(double* __restrict__ out, long ld, int S, long C, int work, double seed) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= C) return;
+    double v = (double)g * 1e-9 + seed;
+    for (int i = 0; i < S; i++) {
+        double x = v, y = v * 0.5, z = v * 0.25, w = v * 0.125;
+        for (int k = 0; k < work; k++) { x = fma(x, 0.999999, 1e-9); y = fma(y, 0.999998, 2e-9); z = fma(z, 0.999997, 3e-9); w = fma(w, 0.999996, 4e-9); }
+        v = (x + y) + (z + w);
+        double* row = out + (long)i * ld + g;
+        long ps = (long)S * ld;
+#pragma unroll
+        for (int p = 0; p < 14; p++) { if (NT) __builtin_nontemporal_store(v + p, row + p * ps); else row[p * ps] = v + p; }
+    }
+}
 // horizon split over G adjacent lanes: lane = (candidate, part), part walks steps [part*CH, (part+1)*CH)
 template <int G>
 __global__ void k_planes_split(double* __restrict__ out, long ld, int S, long C) {
@@ -78,6 +106,9 @@ int main() {
     };
     timeit("plane pattern (256 thr)", [&] { hipLaunchKernelGGL(k_planes, dim3((C + 255) / 256), dim3(256), 0, 0, d, ld, S, C); });
     timeit("plane pattern (64 thr)", [&] { hipLaunchKernelGGL(k_planes, dim3((C + 63) / 64), dim3(64), 0, 0, d, ld, S, C); });
+    timeit("plane pattern NT (256 thr)", [&] { hipLaunchKernelGGL(k_planes_nt, dim3((C + 255) / 256), dim3(256), 0, 0, d, ld, S, C); });
+    timeit("work=20 c+s plain", [&] { hipLaunchKernelGGL(k_planes_work2<false>, dim3((C + 255) / 256), dim3(256), 0, 0, d, ld, S, C, 20, 1.0); });
+    timeit("work=20 c+s NT", [&] { hipLaunchKernelGGL(k_planes_work2<true>, dim3((C + 255) / 256), dim3(256), 0, 0, d, ld, S, C, 20, 1.0); });
     timeit("split G=2", [&] { hipLaunchKernelGGL(k_planes_split<2>, dim3((C * 2 + 255) / 256), dim3(256), 0, 0, d, ld, S, C); });
     timeit("split G=4", [&] { hipLaunchKernelGGL(k_planes_split<4>, dim3((C * 4 + 255) / 256), dim3(256), 0, 0, d, ld, S, C); });
     timeit("split G=8", [&] { hipLaunchKernelGGL(k_planes_split<8>, dim3((C * 8 + 255) / 256), dim3(256), 0, 0, d, ld, S, C); });
