@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--select-only", action="store_true", help="Mode A: no SoA bundle write")
     ap.add_argument("--topk", type=int, default=1, help="survivors per GPU in the exchange (1: the winner, no top-k kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timing", choices=["stream", "kernel"], default="kernel",
+                    help="HIP events around the evaluation kernel: attached to the kernel (hipExtLaunchKernel) or stream events")
     args = ap.parse_args()
 
     import torch
@@ -131,6 +133,7 @@ def main():
         # inputs are resident: upload happened once; a step re-runs evaluation + selection (+ survivor exchange)
         return ev.step_enqueued()
 
+    eng.set_timing(args.timing)
     eng.upload(inp)
     for _ in range(args.warmup):
         res = step()

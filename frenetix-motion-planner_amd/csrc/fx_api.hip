@@ -18,10 +18,11 @@
 #include "fx_device.h"
 
 extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, int max_blocks, size_t lds_bytes, int G,
-                                     bool bundle, bool obst, bool extra, int wpe, hipStream_t stream);
+                                     bool bundle, bool obst, bool extra, int wpe, hipEvent_t ev_start, hipEvent_t ev_stop,
+                                     hipStream_t stream);
 extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, int block_size,
                                           size_t lds_bytes, int G, bool bundle, bool obst, int wpe, bool wsplit,
-                                          hipStream_t stream);
+                                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t stream);
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
                                        unsigned long long seq, double *dev_winner, hipStream_t stream);
 extern "C" hipError_t fx_launch_math_test(int n, const double *x, double *at, double *sn, double *cs, hipStream_t stream);
@@ -65,7 +66,8 @@ struct FxContext {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // attached to the evaluation kernel itself (hipExtLaunchKernel)
     // capacities
     int64_t max_cand = 0;
     int32_t max_steps = 0, max_knots = 0, max_obs = 0, max_pred = 0, max_agents = 1;
@@ -119,7 +121,8 @@ struct FxContext {
     size_t lds_step = 0;
     bool any_bundle = false, any_obst = false, any_extra = false;
     float last_ms = 0.f, last_eval_ms = 0.f;
-    bool timing = true, times_valid = false;
+    int timing = FX_TIMING_STREAM;
+    bool times_valid = false, timed_step = false, eval_launched = false, attached_step = false;
     int64_t dev_bytes = 0;
 };
 
@@ -173,8 +176,10 @@ struct Arena {
 int fetch_times(FxContext *c) {
     if (c->times_valid) return FX_OK;
     HIP_TRY(hipEventSynchronize(c->ev1));
-    HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
-    HIP_TRY(hipEventElapsedTime(&c->last_eval_ms, c->ev0, c->ev_mid));
+    hipEvent_t start = c->attached_step ? c->ev_k0 : c->ev0;
+    HIP_TRY(hipEventElapsedTime(&c->last_ms, start, c->ev1));
+    if (c->eval_launched) HIP_TRY(hipEventElapsedTime(&c->last_eval_ms, start, c->ev_k1));
+    else c->last_eval_ms = 0.f;
     c->times_valid = true;
     return FX_OK;
 }
@@ -263,7 +268,8 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     c->own_stream = true;
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
-    HIP_TRY(hipEventCreate(&c->ev_mid));
+    HIP_TRY(hipEventCreate(&c->ev_k0));
+    HIP_TRY(hipEventCreate(&c->ev_k1));
     const int S = max_steps + 1;
     // every agent's leading dimension is rounded up to 64 candidates
     c->total_ld = (int64_t)align_up((size_t)max_candidates_total, 64) + 64 * (int64_t)max_agents;
@@ -319,7 +325,8 @@ int32_t fx_destroy(FxContext *c) {
     for (void *p : host) if (p) (void)hipHostFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
+    if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
+    if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FX_OK;
@@ -625,21 +632,31 @@ int32_t fx_evaluate(FxContext *c) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     if (!c->uploaded) return set_err(FX_ERR_NOT_READY, "fx_evaluate before fx_upload");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    if (c->max_blocks_step > 0)
+    // timing: the evaluation kernel carries its own start/stop events (hipExtLaunchKernel), so its duration is
+    // the kernel's, not launch latency; the step's device time runs from that start to after the selection kernel
+    // (FX_TIMING_KERNEL); FX_TIMING_STREAM brackets with stream events instead (cheaper on the host, includes the
+    // dispatch gap before the kernel)
+    const bool timed = c->timing != FX_TIMING_OFF;
+    const bool attached = c->timing == FX_TIMING_KERNEL;
+    hipEvent_t k0 = attached ? c->ev_k0 : nullptr, k1 = attached ? c->ev_k1 : nullptr;
+    c->eval_launched = c->max_blocks_step > 0;
+    c->attached_step = attached && c->eval_launched;
+    if (timed && !c->attached_step) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (c->eval_launched)
     {
         if (c->use_grid)
             HIP_TRY(fx_launch_eval_grid(c->d_probs, c->n_agents, c->max_blocks_step, c->block_step, c->lds_step, c->G_step,
-                                        c->any_bundle, c->any_obst, c->wpe_step, c->wsplit_step, c->stream));
+                                        c->any_bundle, c->any_obst, c->wpe_step, c->wsplit_step, k0, k1, c->stream));
         else
             HIP_TRY(fx_launch_eval(c->d_probs, c->n_agents, c->max_blocks_step,
                                    sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + 5 * (size_t)c->S_max_step),
-                                   c->G_step, c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, c->stream));
+                                   c->G_step, c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, k0, k1, c->stream));
     }
-    HIP_TRY(hipEventRecord(c->ev_mid, c->stream));
+    if (timed && !c->attached_step) HIP_TRY(hipEventRecord(c->ev_k1, c->stream));
     c->seq++;
     HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, c->dev_winner, c->stream));
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if (timed) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed_step = timed;
     c->evaluated = true;
     c->in_flight = true;
     c->times_valid = false;
@@ -662,7 +679,7 @@ int32_t fx_finish_batch(FxContext *c, FxResult *res) {
         if (!done) HIP_TRY(hipStreamSynchronize(c->stream));
         c->in_flight = false;
     }
-    if (c->timing) {
+    if (c->timed_step) {
         int rc = fetch_times(c);
         if (rc) return rc;
     }
@@ -681,7 +698,7 @@ int32_t fx_finish_batch(FxContext *c, FxResult *res) {
         r.best_cost = r.best_index < 0 ? 0.0 : bc;
         r.n_collisions = (int64_t)cn[FX_CNT_COLLISIONS];
         r.feasible_percentage = r.n_returned ? 100.0 * ((double)r.n_feasible / (double)r.n_returned) : 0.0;
-        r.kernel_ms = c->timing ? c->last_ms : -1.0;
+        r.kernel_ms = c->timed_step ? c->last_ms : -1.0;
     }
     return FX_OK;
 }
@@ -863,17 +880,18 @@ int32_t fx_math_selftest(int32_t n, const double *x, double *atan_out, double *s
 int64_t fx_device_bytes(const FxContext *c) { return c ? c->dev_bytes : 0; }
 double fx_last_kernel_ms(const FxContext *cc) {
     FxContext *c = const_cast<FxContext *>(cc);
-    if (!c || !c->evaluated || fetch_times(c)) return 0.0;
+    if (!c || !c->evaluated || !c->timed_step || fetch_times(c)) return 0.0;
     return (double)c->last_ms;
 }
 double fx_last_eval_kernel_ms(const FxContext *cc) {
     FxContext *c = const_cast<FxContext *>(cc);
-    if (!c || !c->evaluated || fetch_times(c)) return 0.0;
+    if (!c || !c->evaluated || !c->timed_step || fetch_times(c)) return 0.0;
     return (double)c->last_eval_ms;
 }
-int32_t fx_set_timing(FxContext *c, int32_t enabled) {
+int32_t fx_set_timing(FxContext *c, int32_t mode) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
-    c->timing = enabled != 0;
+    if (mode < FX_TIMING_OFF || mode > FX_TIMING_KERNEL) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_set_timing: unknown mode");
+    c->timing = mode;
     return FX_OK;
 }
 

@@ -21,6 +21,8 @@
 // FP64 throughout, compiled with -ffp-contract=off: the expression trees mirror the NumPy expressions of the
 // reference term by term (the CPU oracle does the same), so GPU and oracle differ only in libm (OCML vs glibc)
 // and in the order of the long cost sums (the device accumulates in step order, NumPy pairwise).
+#include <hip/hip_ext.h>
+
 #include "fx_eval_kernel.h"
 #include "fx_eval_grid_kernel.h"
 
@@ -216,7 +218,8 @@ extern "C" hipError_t fx_launch_math_test(int n, const double *x, double *at, do
 // ---- launchers (called from fx_api.hip) ----
 // Launch the evaluation kernel specialised for (G lanes per candidate, bundle, obstacles, extra costs, occupancy target).
 extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, int max_blocks, size_t lds_bytes, int G,
-                                     bool bundle, bool obst, bool extra, int wpe, hipStream_t stream) {
+                                     bool bundle, bool obst, bool extra, int wpe, hipEvent_t ev_start, hipEvent_t ev_stop,
+                                     hipStream_t stream) {
     dim3 grid(max_blocks, n_agents), block(FX_BLOCK);
 #define FX_LAUNCH(Gv, B, O, E, W)                                                                                \
     do {                                                                                                        \
@@ -225,7 +228,7 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);    \
             if (e_ != hipSuccess) return e_;                                                                    \
         }                                                                                                       \
-        hipLaunchKernelGGL((fx_eval_kernel<Gv, B, O, E, W>), grid, block, lds_bytes, stream, d_probs);          \
+        hipExtLaunchKernelGGL((fx_eval_kernel<Gv, B, O, E, W>), grid, block, lds_bytes, stream, ev_start, ev_stop, 0, d_probs); \
         return hipGetLastError();                                                                               \
     } while (0)
 #define FX_BO(Gv, W)                                                          \
@@ -261,7 +264,7 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
 // Grid (t x v x d) specialisation with the shared longitudinal table; lds_bytes includes the rows.
 extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, int block_size,
                                           size_t lds_bytes, int G, bool bundle, bool obst, int wpe, bool wsplit,
-                                          hipStream_t stream) {
+                                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t stream) {
     dim3 grid(max_blocks, n_agents), block(block_size);
 #define FX_LAUNCH(Gv, B, O, W, WS)                                                                                 \
     do {                                                                                                          \
@@ -270,7 +273,7 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);      \
             if (e_ != hipSuccess) return e_;                                                                      \
         }                                                                                                         \
-        hipLaunchKernelGGL((fx_eval_grid_kernel<Gv, B, O, W, WS>), grid, block, lds_bytes, stream, d_probs);       \
+        hipExtLaunchKernelGGL((fx_eval_grid_kernel<Gv, B, O, W, WS>), grid, block, lds_bytes, stream, ev_start, ev_stop, 0, d_probs); \
         return hipGetLastError();                                                                                 \
     } while (0)
 #define FX_BO(Gv, W, WS)                                           \

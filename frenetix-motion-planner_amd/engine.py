@@ -96,9 +96,14 @@ class FrenetEngine:
         check(lib().fx_wait_published(self._ctx, out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
-    def set_timing(self, enabled: bool):
-        """HIP-event timing of every step (default on; off shaves the event queries from fx_finish)."""
-        check(lib().fx_set_timing(self._ctx, int(bool(enabled))))
+    TIMING = {"off": 0, "stream": 1, "kernel": 2}
+
+    def set_timing(self, mode):
+        """HIP-event timing of every step: "off" / False, "stream" / True (default: stream events around the
+        kernels) or "kernel" (events attached to the evaluation kernel itself -- what a kernel trace reports)."""
+        if isinstance(mode, str):
+            mode = self.TIMING[mode]
+        check(lib().fx_set_timing(self._ctx, int(mode)))
 
     # -- plan step, split so callers can overlap host work (upload/evaluate enqueue only) --
     def upload(self, inputs):

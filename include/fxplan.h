@@ -252,9 +252,13 @@ int32_t fx_device_views(FxContext *ctx, int32_t agent, void **cost, void **flags
 int64_t fx_device_bytes(const FxContext *ctx);
 double fx_last_kernel_ms(const FxContext *ctx);
 double fx_last_eval_kernel_ms(const FxContext *ctx);
-/* per-step HIP-event timing on (default) / off: when off fx_finish only polls the result block the selection
- * kernel publishes into pinned host memory and FxResult.kernel_ms is -1 */
-int32_t fx_set_timing(FxContext *ctx, int32_t enabled);
+/* per-step HIP-event timing: FX_TIMING_OFF -- fx_finish only polls the result block the selection kernel
+ * publishes into pinned host memory and FxResult.kernel_ms is -1; FX_TIMING_STREAM (default) -- stream events
+ * around the kernels (the evaluation figure includes the dispatch gap in front of the kernel);
+ * FX_TIMING_KERNEL -- start/stop events attached to the evaluation kernel itself (hipExtLaunchKernel): the
+ * figure a kernel trace reports, at a few microseconds more host time per step */
+enum { FX_TIMING_OFF = 0, FX_TIMING_STREAM = 1, FX_TIMING_KERNEL = 2 };
+int32_t fx_set_timing(FxContext *ctx, int32_t mode);
 /* device self-test of the kernel's elementary functions (atan, sin, cos) on n host values */
 int32_t fx_math_selftest(int32_t n, const double *x, double *atan_out, double *sin_out, double *cos_out);
 
