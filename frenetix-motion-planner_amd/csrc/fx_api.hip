@@ -19,10 +19,10 @@
 
 extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, int max_blocks, size_t lds_bytes, int G,
                                      bool bundle, bool obst, bool extra, int wpe, hipEvent_t ev_start, hipEvent_t ev_stop,
-                                     hipStream_t stream);
+                                     FuseArgs fuse, hipStream_t stream);
 extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, int block_size,
                                           size_t lds_bytes, int G, bool bundle, bool obst, int wpe, bool wsplit,
-                                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t stream);
+                                          hipEvent_t ev_start, hipEvent_t ev_stop, FuseArgs fuse, hipStream_t stream);
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
                                        unsigned long long seq, double *dev_winner, hipStream_t stream);
 extern "C" hipError_t fx_launch_math_test(int n, const double *x, double *at, double *sn, double *cs, hipStream_t stream);
@@ -123,6 +123,7 @@ struct FxContext {
     float last_ms = 0.f, last_eval_ms = 0.f;
     int timing = FX_TIMING_STREAM;
     bool times_valid = false, timed_step = false, eval_launched = false, attached_step = false;
+    bool fuse_enabled = true, fusable_step = false, fused_step = false;
     int64_t dev_bytes = 0;
 };
 
@@ -175,9 +176,10 @@ struct Arena {
 
 int fetch_times(FxContext *c) {
     if (c->times_valid) return FX_OK;
-    HIP_TRY(hipEventSynchronize(c->ev1));
     hipEvent_t start = c->attached_step ? c->ev_k0 : c->ev0;
-    HIP_TRY(hipEventElapsedTime(&c->last_ms, start, c->ev1));
+    hipEvent_t end = c->fused_step ? c->ev_k1 : c->ev1;
+    HIP_TRY(hipEventSynchronize(end));
+    HIP_TRY(hipEventElapsedTime(&c->last_ms, start, end));
     if (c->eval_launched) HIP_TRY(hipEventElapsedTime(&c->last_eval_ms, start, c->ev_k1));
     else c->last_eval_ms = 0.f;
     c->times_valid = true;
@@ -482,6 +484,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     int64_t cand_off = 0, block_off = 0;
     size_t planes_need = 0;
     c->any_bundle = c->any_obst = c->any_extra = false;
+    c->fusable_step = true;
     c->max_blocks_step = 0;
     c->M_max_step = 0;
     c->S_max_step = 0;
@@ -601,6 +604,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             c->any_bundle = true;
         }
         c->any_obst |= p->K > 0;
+        if ((d.mode & FX_MODE_COLLISION) || d.n_blocks == 0) c->fusable_step = false;
         c->any_extra |= extra;
         c->max_blocks_step = std::max(c->max_blocks_step, d.n_blocks);
         c->M_max_step = std::max(c->M_max_step, p->M);
@@ -642,20 +646,26 @@ int32_t fx_evaluate(FxContext *c) {
     c->eval_launched = c->max_blocks_step > 0;
     c->attached_step = attached && c->eval_launched;
     if (timed && !c->attached_step) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    // one launch when no agent needs the collision-ordered count of the selection kernel: the evaluation kernel's
+    // last workgroup reduces and publishes (fx_eval_kernel.h, "fused selection")
+    c->seq++;
+    c->fused_step = c->fuse_enabled && c->fusable_step && c->eval_launched;
+    FuseArgs fuse{c->fused_step ? c->h_counters_dev : nullptr, c->seq, c->dev_winner};
     if (c->eval_launched)
     {
         if (c->use_grid)
             HIP_TRY(fx_launch_eval_grid(c->d_probs, c->n_agents, c->max_blocks_step, c->block_step, c->lds_step, c->G_step,
-                                        c->any_bundle, c->any_obst, c->wpe_step, c->wsplit_step, k0, k1, c->stream));
+                                        c->any_bundle, c->any_obst, c->wpe_step, c->wsplit_step, k0, k1, fuse, c->stream));
         else
             HIP_TRY(fx_launch_eval(c->d_probs, c->n_agents, c->max_blocks_step,
                                    sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + 5 * (size_t)c->S_max_step),
-                                   c->G_step, c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, k0, k1, c->stream));
+                                   c->G_step, c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, k0, k1, fuse, c->stream));
     }
     if (timed && !c->attached_step) HIP_TRY(hipEventRecord(c->ev_k1, c->stream));
-    c->seq++;
-    HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, c->dev_winner, c->stream));
-    if (timed) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if (!c->fused_step) {
+        HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, c->dev_winner, c->stream));
+        if (timed) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    }
     c->timed_step = timed;
     c->evaluated = true;
     c->in_flight = true;
@@ -887,6 +897,11 @@ double fx_last_eval_kernel_ms(const FxContext *cc) {
     FxContext *c = const_cast<FxContext *>(cc);
     if (!c || !c->evaluated || !c->timed_step || fetch_times(c)) return 0.0;
     return (double)c->last_eval_ms;
+}
+int32_t fx_set_fused_selection(FxContext *c, int32_t enabled) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    c->fuse_enabled = enabled != 0;
+    return FX_OK;
 }
 int32_t fx_set_timing(FxContext *c, int32_t mode) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");

@@ -67,6 +67,19 @@ enum {
     FX_CNT_BEST_IDX = FX_CNT_HIST0 + FX_NUM_REASONS, FX_CNT_BEST_COST, FX_CNT_COLLISIONS, FX_CNT_COUNT
 };
 
+// The device-side counters[] slot FX_CNT_BEST_IDX is free (the winner only exists in the published block): the
+// evaluation kernel's workgroups take completion tickets from it when the selection is fused into the kernel.
+#define FX_DCNT_TICKET FX_CNT_BEST_IDX
+
+// Fused selection (no agent asks for the collision stage): the LAST workgroup of an agent to finish reduces the
+// per-workgroup partials and publishes the step's result block, so the step is one launch.  host_result == nullptr:
+// a separate fx_select_kernel follows.
+struct FuseArgs {
+    unsigned long long *host_result;  // pinned + mapped [n_agents][FX_CNT_COUNT + 1]
+    unsigned long long seq;           // sequence word the host polls for
+    double *dev_winner;               // optional device copy of (cost, index) per agent
+};
+
 // Pointers stored inside DevProblem are loaded from memory, so the compiler only knows them as generic ("flat")
 // pointers: every access would be a flat_load/flat_store and wave-uniform reads could not become scalar loads.
 // They all point into hipMalloc'ed memory -- say so.

@@ -25,14 +25,15 @@
 // Workgroup size is a launch parameter (64, 128 or 256 lanes); the host guarantees that the rows of a workgroup
 // ((CPB + nD - 2) / nD + 1 pairs) fit its dynamic LDS.
 template <int G, bool BUNDLE, bool OBST, int WPE, bool WSPLIT>
-__global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevProblem *__restrict__ probs) {
+__global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevProblem *__restrict__ probs,
+                                                                         const FuseArgs fuse) {
     using namespace fxk;
     const int BLK = blockDim.x;
     const int CPB = BLK / G;
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];  // [5][S] time powers | rows[n_pairs][S]
     __shared__ double red_cost[FX_BLOCK / 64];
     __shared__ long long red_idx[FX_BLOCK / 64];
-    __shared__ unsigned int red_cnt[2 + FX_NUM_REASONS];
+    __shared__ unsigned int red_cnt[2 + FX_NUM_REASONS + 1];
 
     const DevProblem &P = probs[blockIdx.y];
     const int tid = threadIdx.x;
@@ -201,5 +202,5 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     // wave split: the exchange block sits behind the rows in dynamic LDS
     double *xch = reinterpret_cast<double *>(rows + (size_t)n_pairs_max * S);
     finish_candidate<G, BUNDLE, OBST, false, WSPLIT>(P, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D,
-                                                     red_cost, red_idx, red_cnt, xch, CPB, cand_local);
+                                                     red_cost, red_idx, red_cnt, fuse, xch, CPB, cand_local);
 }

@@ -171,7 +171,8 @@ template <int G, bool BUNDLE, bool OBST, bool EXTRA, bool WSPLIT = false>
 __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult &W, int64_t g, bool active, int part,
                                                  int i_begin, int i_end, bool bundle, bool do_collision, bool dbg, bool D,
                                                  double *red_cost, long long *red_idx, unsigned int *red_cnt,
-                                                 double *xch = nullptr, int CPB = 0, int cand_local = 0) {
+                                                 const FuseArgs &fuse, double *xch = nullptr, int CPB = 0,
+                                                 int cand_local = 0) {
     const int tid = threadIdx.x;
     const int S = P.S, K = P.K, Pn = P.P;
     const int64_t ld = P.ld;
@@ -384,10 +385,60 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
     if (tid == 0) {
         for (int w = 1; w < (int)blockDim.x / 64; w++)
             if (red_cost[w] < bc || (red_cost[w] == bc && red_idx[w] < bi)) { bc = red_cost[w]; bi = red_idx[w]; }
-        as_global(P.part_cost)[blockIdx.x] = bc;
-        as_global(P.part_idx)[blockIdx.x] = bi;
+        // agent-scope stores: visible to whichever XCD runs the reducing workgroup without an L2 write-back
+        __hip_atomic_store(as_global(P.part_cost) + blockIdx.x, bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(as_global(P.part_idx) + blockIdx.x, (int64_t)bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid < 2 + FX_NUM_REASONS && red_cnt[tid]) atomicAdd(&P.counters[tid], (unsigned long long)red_cnt[tid]);
+    if (fuse.host_result == nullptr) return;  // a selection kernel follows
+
+    // ---- fused selection: the last workgroup of this agent to arrive reduces and publishes ----
+    // Partials and counters above are agent-scope atomics; once they are acknowledged (vmcnt 0) they are performed,
+    // so a relaxed ticket is enough -- no L2 write-back in the way of the bundle's store stream.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long t = atomicAdd(&P.counters[FX_DCNT_TICKET], 1ULL);
+        red_cnt[2 + FX_NUM_REASONS] = (t == (unsigned long long)(P.n_blocks - 1));
+    }
+    __syncthreads();
+    if (!red_cnt[2 + FX_NUM_REASONS]) return;
+    bc = INFINITY;
+    bi = 0x7fffffffffffffffLL;
+    for (int b = tid; b < P.n_blocks; b += (int)blockDim.x) {
+        const double c = __hip_atomic_load(as_global(P.part_cost) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long ix = __hip_atomic_load(as_global(P.part_idx) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c < bc || (c == bc && ix < bi)) { bc = c; bi = ix; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oc = __shfl_xor(bc, off);
+        const long long oi = __shfl_xor(bi, off);
+        if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+    }
+    if (lane == 0) { red_cost[wave] = bc; red_idx[wave] = bi; }
+    unsigned long long *out = fuse.host_result + (size_t)blockIdx.y * (FX_CNT_COUNT + 1);
+    // counters: read and zero in one agent-scope exchange (the next step starts from a clean block)
+    if (tid < FX_CNT_BEST_IDX) out[tid] = atomicExch(&P.counters[tid], 0ULL);
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < (int)blockDim.x / 64; w++)
+            if (red_cost[w] < bc || (red_cost[w] == bc && red_idx[w] < bi)) { bc = red_cost[w]; bi = red_idx[w]; }
+        const bool none = bi == 0x7fffffffffffffffLL;
+        if (fuse.dev_winner) {
+            fuse.dev_winner[2 * blockIdx.y] = none ? INFINITY : bc;
+            reinterpret_cast<long long *>(fuse.dev_winner)[2 * blockIdx.y + 1] = none ? -1 : bi;
+        }
+        out[FX_CNT_BEST_IDX] = none ? ~0ULL : (unsigned long long)bi;
+        out[FX_CNT_BEST_COST] = none ? 0ULL : (unsigned long long)__double_as_longlong(bc);
+        out[FX_CNT_COLLISIONS] = 0ULL;
+        __hip_atomic_store(&P.counters[FX_DCNT_TICKET], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&out[FX_CNT_COUNT], fuse.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace fxk
@@ -402,14 +453,14 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
 //   WPE    : occupancy target in waves per SIMD handed to the register allocator
 // ---------------------------------------------------------------------------------------------------
 template <int G, bool BUNDLE, bool OBST, bool EXTRA, int WPE>
-__global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem *__restrict__ probs) {
+__global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem *__restrict__ probs, const FuseArgs fuse) {
     using namespace fxk;
     static_assert(!EXTRA || G == 1, "windowed costs need the whole horizon in one lane");
     constexpr int CPB = FX_BLOCK / G;  // candidates per workgroup
     extern __shared__ __attribute__((aligned(16))) double lds_dyn[];  // [M][8] knots, then [5][S] time powers
     __shared__ double red_cost[FX_BLOCK / 64];
     __shared__ long long red_idx[FX_BLOCK / 64];
-    __shared__ unsigned int red_cnt[2 + FX_NUM_REASONS];
+    __shared__ unsigned int red_cnt[2 + FX_NUM_REASONS + 1];  // counters, then the last-workgroup flag
 
     const DevProblem &P = probs[blockIdx.y];
     const int tid = threadIdx.x;
@@ -599,5 +650,5 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     W.cl3 = cl3; W.cl4 = cl4; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
     if (EXTRA) { W.sim_acc = sim_acc; W.sim_jerk = sim_jerk; W.sim_orient = sim_orient; W.sim_path = sim_path; }
     finish_candidate<G, BUNDLE, OBST, EXTRA>(P, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D, red_cost,
-                                             red_idx, red_cnt);
+                                             red_idx, red_cnt, fuse);
 }

@@ -219,7 +219,7 @@ extern "C" hipError_t fx_launch_math_test(int n, const double *x, double *at, do
 // Launch the evaluation kernel specialised for (G lanes per candidate, bundle, obstacles, extra costs, occupancy target).
 extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, int max_blocks, size_t lds_bytes, int G,
                                      bool bundle, bool obst, bool extra, int wpe, hipEvent_t ev_start, hipEvent_t ev_stop,
-                                     hipStream_t stream) {
+                                     FuseArgs fuse, hipStream_t stream) {
     dim3 grid(max_blocks, n_agents), block(FX_BLOCK);
 #define FX_LAUNCH(Gv, B, O, E, W)                                                                                \
     do {                                                                                                        \
@@ -228,7 +228,7 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);    \
             if (e_ != hipSuccess) return e_;                                                                    \
         }                                                                                                       \
-        hipExtLaunchKernelGGL((fx_eval_kernel<Gv, B, O, E, W>), grid, block, lds_bytes, stream, ev_start, ev_stop, 0, d_probs); \
+        hipExtLaunchKernelGGL((fx_eval_kernel<Gv, B, O, E, W>), grid, block, lds_bytes, stream, ev_start, ev_stop, 0, d_probs, fuse); \
         return hipGetLastError();                                                                               \
     } while (0)
 #define FX_BO(Gv, W)                                                          \
@@ -264,7 +264,7 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
 // Grid (t x v x d) specialisation with the shared longitudinal table; lds_bytes includes the rows.
 extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, int block_size,
                                           size_t lds_bytes, int G, bool bundle, bool obst, int wpe, bool wsplit,
-                                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t stream) {
+                                          hipEvent_t ev_start, hipEvent_t ev_stop, FuseArgs fuse, hipStream_t stream) {
     dim3 grid(max_blocks, n_agents), block(block_size);
 #define FX_LAUNCH(Gv, B, O, W, WS)                                                                                 \
     do {                                                                                                          \
@@ -273,7 +273,7 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);      \
             if (e_ != hipSuccess) return e_;                                                                      \
         }                                                                                                         \
-        hipExtLaunchKernelGGL((fx_eval_grid_kernel<Gv, B, O, W, WS>), grid, block, lds_bytes, stream, ev_start, ev_stop, 0, d_probs); \
+        hipExtLaunchKernelGGL((fx_eval_grid_kernel<Gv, B, O, W, WS>), grid, block, lds_bytes, stream, ev_start, ev_stop, 0, d_probs, fuse); \
         return hipGetLastError();                                                                                 \
     } while (0)
 #define FX_BO(Gv, W, WS)                                           \

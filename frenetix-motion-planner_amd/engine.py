@@ -96,6 +96,10 @@ class FrenetEngine:
         check(lib().fx_wait_published(self._ctx, out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    def set_fused_selection(self, enabled: bool):
+        """Selection fused into the evaluation kernel (default on; applies when no agent runs the collision stage)."""
+        check(lib().fx_set_fused_selection(self._ctx, int(bool(enabled))))
+
     TIMING = {"off": 0, "stream": 1, "kernel": 2}
 
     def set_timing(self, mode):

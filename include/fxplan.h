@@ -257,6 +257,10 @@ double fx_last_eval_kernel_ms(const FxContext *ctx);
  * around the kernels (the evaluation figure includes the dispatch gap in front of the kernel);
  * FX_TIMING_KERNEL -- start/stop events attached to the evaluation kernel itself (hipExtLaunchKernel): the
  * figure a kernel trace reports, at a few microseconds more host time per step */
+/* selection fused into the evaluation kernel (default on): when no agent of the step asks for FX_MODE_COLLISION the
+ * evaluation kernel's last workgroup reduces the partial arg-mins and publishes the result, so a plan step is a
+ * single launch; off = always run the separate selection kernel (same results; used by the parity tests) */
+int32_t fx_set_fused_selection(FxContext *ctx, int32_t enabled);
 enum { FX_TIMING_OFF = 0, FX_TIMING_STREAM = 1, FX_TIMING_KERNEL = 2 };
 int32_t fx_set_timing(FxContext *ctx, int32_t mode);
 /* device self-test of the kernel's elementary functions (atan, sin, cos) on n host values */

@@ -292,6 +292,57 @@ def test_select_only_mode_equals_bundle_mode(eng):
         eng.sample(0)
 
 
+RESULT_KEYS = ("best_index", "best_cost", "n_returned", "n_feasible", "n_infeasible", "n_collisions", "reason_hist",
+               "n_candidates", "feasible_percentage")
+
+
+@pytest.mark.parametrize("lanes", [0, 1, 4])
+@pytest.mark.parametrize("name", ["dense_debug_obs", "dense_lowvel", "ragged_tail", "single_candidate", "no_costs",
+                                  "dense_prod_obs"])
+def test_fused_selection_equals_selection_kernel(eng, name, lanes):
+    """The last-workgroup reduction inside the evaluation kernel and the separate selection kernel publish the
+    same result block; repeated steps start from clean counters (ticket and histogram reset)."""
+    kw = dict(CASES[name], collision=False)  # the collision-ordered count keeps the selection kernel
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    eng.set_tuning(lanes, 0, 0)
+    try:
+        eng.set_fused_selection(False)
+        ref = eng.plan_step(inp)
+        eng.set_fused_selection(True)
+        for _ in range(3):
+            got = eng.plan_step(inp)
+            for k in RESULT_KEYS:
+                assert got[k] == ref[k], k
+        # evaluate() re-enqueued on resident inputs, several in a row before one finish
+        eng.upload(inp)
+        for _ in range(4):
+            eng.evaluate()
+        got = eng.finish()[0]
+        for k in RESULT_KEYS:
+            assert got[k] == ref[k], k
+    finally:
+        eng.set_fused_selection(True)
+        eng.set_tuning(0, 0, 0)
+
+
+def test_fused_selection_batch(eng):
+    kws = [dict(ref_kind="arc", v0=10.0, grid=(5, 9, 11), seed=1),
+           dict(ref_kind="scurve", kappa=0.02, v0=6.0, grid=(4, 7, 9), seed=2, draw_traj_set=True, kinematic_debug=True),
+           dict(ref_kind="straight", v0=1.0, v_des=2.0, d0=0.0, grid=(1, 1, 1), seed=3),
+           dict(ref_kind="arc", n_knots=300, v0=15.0, grid=(6, 11, 9), seed=4, write_bundle=False)]
+    inps = [synthetic.make_inputs(**kw) for kw in kws]
+    eng.set_fused_selection(False)
+    try:
+        ref = eng.plan_batch(inps)
+    finally:
+        eng.set_fused_selection(True)
+    for _ in range(2):
+        got = eng.plan_batch(inps)
+        for a in range(len(inps)):
+            for k in RESULT_KEYS:
+                assert got[a][k] == ref[a][k], (a, k)
+
+
 def test_topk_is_sorted_prefix(eng):
     from oracle import oracle
     kw = dict(ref_kind="arc", v0=10.0, grid=(7, 13, 13), n_obstacles=10)
