@@ -71,6 +71,21 @@ def cpu_baseline(args, seconds=12.0):
             "cpu": _cpu_model(), "host_cores": os.cpu_count()}
 
 
+def pmc_traffic(args, world):
+    """HBM bytes per launch of the evaluation kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r1/final_config2_modeB_rocprof_summary.json; tools/collect_profiles.sh): WRITE_SIZE [KiB] x 1024 +
+    FETCH_SIZE [KiB] x 1024 x 2 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half of the bytes read).  PMC
+    counters cannot be collected from inside the timed run, so other workloads report null."""
+    if args.workload != "config2" or args.select_only or world != 1:
+        return None, None
+    path = os.path.join(ROOT, "profiles", "r1", "final_config2_modeB_rocprof_summary.json")
+    try:
+        pmc = json.load(open(path))["pmc_per_launch_mean"]
+        return pmc["WRITE_SIZE"] * 1024.0 + 2.0 * pmc["FETCH_SIZE"] * 1024.0, os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -92,6 +107,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timing", choices=["stream", "kernel"], default="kernel",
                     help="HIP events around the evaluation kernel: attached to the kernel (hipExtLaunchKernel) or stream events")
+    ap.add_argument("--timing-every", type=int, default=8,
+                    help="attach the events to every n-th launch of the timed region (they are read after it)")
     args = ap.parse_args()
 
     import torch
@@ -133,21 +150,22 @@ def main():
         # inputs are resident: upload happened once; a step re-runs evaluation + selection (+ survivor exchange)
         return ev.step_enqueued()
 
-    eng.set_timing(args.timing)
+    eng.set_timing(args.timing, every=args.timing_every)
     eng.upload(inp)
     for _ in range(args.warmup):
         res = step()
     barrier()
-    lat, kern, evalk = [], [], []
+    lat = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts = time.perf_counter()
         res = step()
         lat.append(time.perf_counter() - ts)
-        kern.append(eng.last_kernel_ms)
-        evalk.append(eng.last_eval_kernel_ms)
     barrier()
     elapsed = time.perf_counter() - t0
+    # HIP-event durations of the launches timed inside the region above (event ring, read only now)
+    n_timed = min(256, (args.steps + args.timing_every - 1) // args.timing_every)
+    evalk, kern = eng.kernel_times(n_timed)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -171,6 +189,7 @@ def main():
             per_cand = bundle_bytes_per_candidate(S)  # SURVEY 8(d) Mode-B figure: 3 472 B / candidate at 31 samples
         alg_bytes = per_cand * C_local
         achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args, world)
         out = {
             "metric": "candidate trajectories/sec (30-step horizon)",
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -189,9 +208,11 @@ def main():
             "winner": {"index": int(res.get("global_best_index", res["best_index"])),
                        "cost": float(res.get("global_best_cost", res["best_cost"])), "n_feasible_local": int(res["n_feasible"])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "fx_eval_kernel", "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_candidate": per_cand, "avg_launch_ms": eval_ms},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "fx_eval_grid_kernel (evaluation + fused selection)" if not inp.obstacles["K"] else "fx_eval_grid_kernel", "algorithmic_bytes_per_launch": alg_bytes,
+                         "bytes_per_candidate": per_cand, "avg_launch_ms": eval_ms,
+                         "launches_timed": int(len(evalk)), "timing": f"HIP events attached to every {args.timing_every}. launch "
+                         "of the timed region (hipExtLaunchKernel start/stop)" if args.timing == "kernel" else "stream events"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -66,8 +66,18 @@ struct FxContext {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // attached to the evaluation kernel itself (hipExtLaunchKernel)
+    // timing ring: per timed step (start, evaluation end, step end) events; elapsed times are read lazily, so a
+    // timed step never waits for its own events
+    struct TimeSlot {
+        hipEvent_t e0 = nullptr, e_eval = nullptr, e_end = nullptr;
+        bool eval_launched = false, fused = false, fetched = false;
+        float step_ms = 0.f, eval_ms = 0.f;
+    };
+    static constexpr int kTimeRing = 256;
+    TimeSlot ring[kTimeRing];
+    long long n_timed = 0;       // timed steps so far (slot = (n_timed - 1) % kTimeRing is the latest)
+    long long n_steps = 0;       // evaluations so far
+    int timing_every = 1;        // time every n-th step
     // capacities
     int64_t max_cand = 0;
     int32_t max_steps = 0, max_knots = 0, max_obs = 0, max_pred = 0, max_agents = 1;
@@ -120,9 +130,8 @@ struct FxContext {
     bool use_grid = false;                 // current step runs fx_eval_grid_kernel
     size_t lds_step = 0;
     bool any_bundle = false, any_obst = false, any_extra = false;
-    float last_ms = 0.f, last_eval_ms = 0.f;
-    int timing = FX_TIMING_STREAM;
-    bool times_valid = false, timed_step = false, eval_launched = false, attached_step = false;
+    int timing = FX_TIMING_OFF;
+    bool timed_step = false, eval_launched = false;
     bool fuse_enabled = true, fusable_step = false, fused_step = false;
     int64_t dev_bytes = 0;
 };
@@ -174,15 +183,15 @@ struct Arena {
     }
 };
 
-int fetch_times(FxContext *c) {
-    if (c->times_valid) return FX_OK;
-    hipEvent_t start = c->attached_step ? c->ev_k0 : c->ev0;
-    hipEvent_t end = c->fused_step ? c->ev_k1 : c->ev1;
+// elapsed times of one ring slot (waits for the slot's last event if it is still pending)
+int fetch_slot(FxContext *c, FxContext::TimeSlot &t) {
+    if (t.fetched) return FX_OK;
+    hipEvent_t end = t.fused ? t.e_eval : t.e_end;
     HIP_TRY(hipEventSynchronize(end));
-    HIP_TRY(hipEventElapsedTime(&c->last_ms, start, end));
-    if (c->eval_launched) HIP_TRY(hipEventElapsedTime(&c->last_eval_ms, start, c->ev_k1));
-    else c->last_eval_ms = 0.f;
-    c->times_valid = true;
+    HIP_TRY(hipEventElapsedTime(&t.step_ms, t.e0, end));
+    if (t.eval_launched) HIP_TRY(hipEventElapsedTime(&t.eval_ms, t.e0, t.e_eval));
+    else t.eval_ms = 0.f;
+    t.fetched = true;
     return FX_OK;
 }
 
@@ -268,10 +277,11 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     *out = c;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
-    HIP_TRY(hipEventCreate(&c->ev0));
-    HIP_TRY(hipEventCreate(&c->ev1));
-    HIP_TRY(hipEventCreate(&c->ev_k0));
-    HIP_TRY(hipEventCreate(&c->ev_k1));
+    for (auto &t : c->ring) {
+        HIP_TRY(hipEventCreate(&t.e0));
+        HIP_TRY(hipEventCreate(&t.e_eval));
+        HIP_TRY(hipEventCreate(&t.e_end));
+    }
     const int S = max_steps + 1;
     // every agent's leading dimension is rounded up to 64 candidates
     c->total_ld = (int64_t)align_up((size_t)max_candidates_total, 64) + 64 * (int64_t)max_agents;
@@ -325,10 +335,11 @@ int32_t fx_destroy(FxContext *c) {
     for (void *p : dev) if (p) (void)hipFree(p);
     void *host[] = {c->h_in, c->h_probs, c->h_counters, c->h_topk_cost, c->h_topk_idx, c->h_pub};
     for (void *p : host) if (p) (void)hipHostFree(p);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
-    if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+    for (auto &t : c->ring) {
+        if (t.e0) (void)hipEventDestroy(t.e0);
+        if (t.e_eval) (void)hipEventDestroy(t.e_eval);
+        if (t.e_end) (void)hipEventDestroy(t.e_end);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FX_OK;
@@ -454,7 +465,8 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                     const FxProblem *p = &probs[a];
                     const size_t n_pairs = (size_t)(blk / G + p->nD - 2) / p->nD + 1;
                     const size_t S = (size_t)p->N + 1;
-                    need = std::max(need, sizeof(double) * ((5 * S + 1) & ~(size_t)1) + 128 * n_pairs * S +
+                    need = std::max(need, sizeof(double) * (((5 * S + 1) & ~(size_t)1) + (((size_t)p->M + 1) & ~(size_t)1)) +
+                                              128 * n_pairs * S +
                                               (G > 1 ? (size_t)56 * blk : 0));  // + wave-split exchange block
                 }
                 return need;
@@ -636,16 +648,22 @@ int32_t fx_evaluate(FxContext *c) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     if (!c->uploaded) return set_err(FX_ERR_NOT_READY, "fx_evaluate before fx_upload");
     HIP_TRY(hipSetDevice(c->device));
-    // timing: the evaluation kernel carries its own start/stop events (hipExtLaunchKernel), so its duration is
-    // the kernel's, not launch latency; the step's device time runs from that start to after the selection kernel
-    // (FX_TIMING_KERNEL); FX_TIMING_STREAM brackets with stream events instead (cheaper on the host, includes the
-    // dispatch gap before the kernel)
-    const bool timed = c->timing != FX_TIMING_OFF;
-    const bool attached = c->timing == FX_TIMING_KERNEL;
-    hipEvent_t k0 = attached ? c->ev_k0 : nullptr, k1 = attached ? c->ev_k1 : nullptr;
+    // timing (every timing_every-th step): FX_TIMING_KERNEL attaches start/stop events to the evaluation kernel
+    // itself (hipExtLaunchKernel), so its duration is the kernel's, not launch latency; FX_TIMING_STREAM brackets
+    // with stream events instead (includes the dispatch gap before the kernel).  Events live in a ring and are
+    // only read on request.
+    const bool timed = c->timing != FX_TIMING_OFF && (c->n_steps % c->timing_every) == 0;
+    c->n_steps++;
     c->eval_launched = c->max_blocks_step > 0;
-    c->attached_step = attached && c->eval_launched;
-    if (timed && !c->attached_step) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    const bool attached = timed && c->timing == FX_TIMING_KERNEL && c->eval_launched;
+    FxContext::TimeSlot *ts = nullptr;
+    if (timed) {
+        ts = &c->ring[c->n_timed % FxContext::kTimeRing];
+        ts->fetched = false;
+        ts->eval_launched = c->eval_launched;
+    }
+    hipEvent_t k0 = attached ? ts->e0 : nullptr, k1 = attached ? ts->e_eval : nullptr;
+    if (timed && !attached) HIP_TRY(hipEventRecord(ts->e0, c->stream));
     // one launch when no agent needs the collision-ordered count of the selection kernel: the evaluation kernel's
     // last workgroup reduces and publishes (fx_eval_kernel.h, "fused selection")
     c->seq++;
@@ -661,15 +679,15 @@ int32_t fx_evaluate(FxContext *c) {
                                    sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + 5 * (size_t)c->S_max_step),
                                    c->G_step, c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, k0, k1, fuse, c->stream));
     }
-    if (timed && !c->attached_step) HIP_TRY(hipEventRecord(c->ev_k1, c->stream));
+    if (timed && !attached) HIP_TRY(hipEventRecord(ts->e_eval, c->stream));
     if (!c->fused_step) {
         HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, c->dev_winner, c->stream));
-        if (timed) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        if (timed) HIP_TRY(hipEventRecord(ts->e_end, c->stream));
     }
+    if (timed) { ts->fused = c->fused_step; c->n_timed++; }
     c->timed_step = timed;
     c->evaluated = true;
     c->in_flight = true;
-    c->times_valid = false;
     return FX_OK;
 }
 
@@ -689,9 +707,16 @@ int32_t fx_finish_batch(FxContext *c, FxResult *res) {
         if (!done) HIP_TRY(hipStreamSynchronize(c->stream));
         c->in_flight = false;
     }
+    // device time of this step: only if its events have already completed (a timed step never waits for them here;
+    // fx_last_kernel_ms / fx_read_kernel_times do)
+    double step_ms = -1.0;
     if (c->timed_step) {
-        int rc = fetch_times(c);
-        if (rc) return rc;
+        FxContext::TimeSlot &t = c->ring[(c->n_timed - 1) % FxContext::kTimeRing];
+        if (t.fetched || hipEventQuery(t.fused ? t.e_eval : t.e_end) == hipSuccess) {
+            int rc = fetch_slot(c, t);
+            if (rc) return rc;
+            step_ms = t.step_ms;
+        } else (void)hipGetLastError();  // hipErrorNotReady is not an error
     }
     for (int a = 0; a < c->n_agents; a++) {
         const unsigned long long *cn = c->h_counters + (size_t)a * (FX_CNT_COUNT + 1);
@@ -708,7 +733,7 @@ int32_t fx_finish_batch(FxContext *c, FxResult *res) {
         r.best_cost = r.best_index < 0 ? 0.0 : bc;
         r.n_collisions = (int64_t)cn[FX_CNT_COLLISIONS];
         r.feasible_percentage = r.n_returned ? 100.0 * ((double)r.n_feasible / (double)r.n_returned) : 0.0;
-        r.kernel_ms = c->timed_step ? c->last_ms : -1.0;
+        r.kernel_ms = step_ms;
     }
     return FX_OK;
 }
@@ -890,13 +915,34 @@ int32_t fx_math_selftest(int32_t n, const double *x, double *atan_out, double *s
 int64_t fx_device_bytes(const FxContext *c) { return c ? c->dev_bytes : 0; }
 double fx_last_kernel_ms(const FxContext *cc) {
     FxContext *c = const_cast<FxContext *>(cc);
-    if (!c || !c->evaluated || !c->timed_step || fetch_times(c)) return 0.0;
-    return (double)c->last_ms;
+    if (!c || !c->evaluated || c->n_timed == 0) return 0.0;
+    FxContext::TimeSlot &t = c->ring[(c->n_timed - 1) % FxContext::kTimeRing];
+    return fetch_slot(c, t) ? 0.0 : (double)t.step_ms;
 }
 double fx_last_eval_kernel_ms(const FxContext *cc) {
     FxContext *c = const_cast<FxContext *>(cc);
-    if (!c || !c->evaluated || !c->timed_step || fetch_times(c)) return 0.0;
-    return (double)c->last_eval_ms;
+    if (!c || !c->evaluated || c->n_timed == 0) return 0.0;
+    FxContext::TimeSlot &t = c->ring[(c->n_timed - 1) % FxContext::kTimeRing];
+    return fetch_slot(c, t) ? 0.0 : (double)t.eval_ms;
+}
+int32_t fx_read_kernel_times(FxContext *c, int32_t max_n, double *eval_ms, double *step_ms, int32_t *n_out) {
+    if (!c || max_n < 0 || !n_out) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_read_kernel_times: bad argument");
+    const long long have = std::min<long long>(c->n_timed, FxContext::kTimeRing);
+    const int n = (int)std::min<long long>(have, max_n);
+    for (int k = 0; k < n; k++) {  // oldest of the returned window first
+        FxContext::TimeSlot &t = c->ring[(c->n_timed - n + k) % FxContext::kTimeRing];
+        int rc = fetch_slot(c, t);
+        if (rc) return rc;
+        if (eval_ms) eval_ms[k] = t.eval_ms;
+        if (step_ms) step_ms[k] = t.step_ms;
+    }
+    *n_out = n;
+    return FX_OK;
+}
+int32_t fx_set_timing_interval(FxContext *c, int32_t every) {
+    if (!c || every < 1) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_set_timing_interval: every=%d", every);
+    c->timing_every = every;
+    return FX_OK;
 }
 int32_t fx_set_fused_selection(FxContext *c, int32_t enabled) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");

@@ -61,6 +61,81 @@ struct DevProblem {
     int32_t n_blocks;
 };
 
+// The same fields held in registers: a kernel loads them all at entry (one batch of scalar loads, one latency).
+// The dynamically indexed arrays become pointers (the kernels stage cost ids / weights in LDS).
+struct ProblemRegs {
+    int32_t N, S;
+    uint32_t mode;
+    int32_t low_vel_mode;
+    double dt;
+    double x0_lon[3], x0_lat[3];
+    double x0_orientation, v_des;
+    FxVehicle veh;
+    int32_t nT, nV, nD;
+    int32_t has_matrix;
+    int64_t C, g_base, ld;
+    int32_t M, K, P;
+    int32_t n_cost, n_dto;
+    const int32_t *cost_id;
+    const double *cost_w;
+    const double *simpson_corr;
+    const double *tpow;
+    const double *t_samp, *v_samp, *d_samp;
+    const double *matrix;
+    const double *ref;
+    const double *obs_pos;
+    const double *obs_cov_inv;
+    const int32_t *obs_npred;
+    const double *obs_rec;
+    const unsigned long long *obs_pmask, *obs_hmask;
+    const double *dto_pos;
+    double *cost;
+    uint32_t *flags;
+    double *costmap;
+    double *planes;
+    double *coeffs;
+    int32_t *traj_len;
+    double *part_cost;
+    int64_t *part_idx;
+    unsigned long long *counters;
+    int32_t n_blocks;
+
+    __device__ __forceinline__ static ProblemRegs load(const DevProblem &g, const int32_t *cost_id, const double *cost_w) {
+        ProblemRegs r;
+        r.N = g.N; r.S = g.S; r.mode = g.mode; r.low_vel_mode = g.low_vel_mode; r.dt = g.dt;
+        r.x0_lon[0] = g.x0_lon[0]; r.x0_lon[1] = g.x0_lon[1]; r.x0_lon[2] = g.x0_lon[2];
+        r.x0_lat[0] = g.x0_lat[0]; r.x0_lat[1] = g.x0_lat[1]; r.x0_lat[2] = g.x0_lat[2];
+        r.x0_orientation = g.x0_orientation; r.v_des = g.v_des; r.veh = g.veh;
+        r.nT = g.nT; r.nV = g.nV; r.nD = g.nD; r.has_matrix = g.has_matrix;
+        r.C = g.C; r.g_base = g.g_base; r.ld = g.ld; r.M = g.M; r.K = g.K; r.P = g.P;
+        r.n_cost = g.n_cost; r.n_dto = g.n_dto;
+        r.cost_id = cost_id; r.cost_w = cost_w; r.simpson_corr = g.simpson_corr;
+        r.tpow = g.tpow; r.t_samp = g.t_samp; r.v_samp = g.v_samp; r.d_samp = g.d_samp; r.matrix = g.matrix;
+        r.ref = g.ref; r.obs_pos = g.obs_pos; r.obs_cov_inv = g.obs_cov_inv; r.obs_npred = g.obs_npred;
+        r.obs_rec = g.obs_rec; r.obs_pmask = g.obs_pmask; r.obs_hmask = g.obs_hmask; r.dto_pos = g.dto_pos;
+        r.cost = g.cost; r.flags = g.flags; r.costmap = g.costmap; r.planes = g.planes; r.coeffs = g.coeffs;
+        r.traj_len = g.traj_len; r.part_cost = g.part_cost; r.part_idx = g.part_idx; r.counters = g.counters;
+        r.n_blocks = g.n_blocks;
+        return r;
+    }
+};
+
+// Developer probe (-DFX_PROBE): per-wave cycle stamps at the phase boundaries of the evaluation kernels, read back
+// with fx_probe_read (tools/probe_phases.py).  Compiles to nothing in the product build.
+#ifdef FX_PROBE
+#define FX_PROBE_SLOTS 16
+#define FX_PROBE_WAVES (1 << 16)
+extern __device__ unsigned long long fx_probe_stamps[FX_PROBE_WAVES * FX_PROBE_SLOTS];
+#define FX_STAMP(k)                                                                                              \
+    do {                                                                                                         \
+        const unsigned w_ = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));                               \
+        if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && w_ < FX_PROBE_WAVES)                                   \
+            fx_probe_stamps[(size_t)w_ * FX_PROBE_SLOTS + (k)] = (k) == 0 || (k) == 15 ? wall_clock64() : clock64(); \
+    } while (0)
+#else
+#define FX_STAMP(k) do { } while (0)
+#endif
+
 // counters[] layout
 enum {
     FX_CNT_RETURNED = 0, FX_CNT_FEASIBLE, FX_CNT_HIST0, /* 11 entries */

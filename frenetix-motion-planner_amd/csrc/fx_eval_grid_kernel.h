@@ -35,10 +35,17 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     __shared__ long long red_idx[FX_BLOCK / 64];
     __shared__ unsigned int red_cnt[2 + FX_NUM_REASONS + 1];
 
-    const DevProblem &P = probs[blockIdx.y];
+    __shared__ int32_t sh_cost_id[FX_NUM_COSTS];
+    __shared__ double sh_cost_w[FX_NUM_COSTS];
+
+    // every field is fetched by scalar loads issued together at kernel entry (one latency) instead of one
+    // dependent s_load wherever a field is first used
+    const DevProblem &Pg = probs[blockIdx.y];
+    const ProblemRegs P = ProblemRegs::load(Pg, sh_cost_id, sh_cost_w);
     const int tid = threadIdx.x;
     const int64_t C = P.C;
     if ((int64_t)blockIdx.x * CPB >= C) return;
+    FX_STAMP(0);
     // parts of a candidate: adjacent lanes (lane split) or the same lane of G lane-groups (wave split, CPB % 64 == 0)
     const int part = G == 1 ? 0 : (WSPLIT ? tid / CPB : (tid & (G - 1)));
     const int cand_local = G == 1 ? tid : (WSPLIT ? tid - part * CPB : tid / G);
@@ -49,16 +56,40 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
 
     const int M = P.M, S = P.S;
     const int nD = P.nD, nV = P.nV;
+    // pairs of this workgroup; the sampling values of this lane's first table item and of its own candidate are
+    // requested now so that their latency overlaps phase 1
+    const int64_t gbase = P.g_base;
+    const int64_t pair0 = (c0 + gbase) / nD;
+    const int64_t c_last = min(c0 + CPB, C) - 1;
+    const int n_pairs = (int)((c_last + gbase) / nD - pair0) + 1;
+    const int n_pairs_max = (CPB + nD - 2) / nD + 1;  // what the host sized the row block for
+    double T_item0 = 0.0, v_item0 = 0.0;
+    if (tid < n_pairs * S) {
+        const int64_t pair = pair0 + tid / S;
+        const int it = (int)(pair / nV), iv = (int)(pair - (int64_t)it * nV);
+        T_item0 = as_global(P.t_samp)[it]; v_item0 = as_global(P.v_samp)[iv];
+    }
+    const int64_t gg = g + gbase;
+    const int64_t pair = gg / nD;
+    const int id = (int)(gg - pair * nD);
+    const int it = (int)(pair / nV), iv = (int)(pair - (int64_t)it * nV);
+    const double T = as_global(P.t_samp)[it], v1 = as_global(P.v_samp)[iv], d1 = as_global(P.d_samp)[id];
+    // ---- phase 1: one round of global loads -- time powers, knot arc lengths, cost ids / weights -> LDS ----
+    double *__restrict__ tpw = lds_dyn;                                // [5][S]
+    double *__restrict__ rpos = lds_dyn + ((5 * S + 1) & ~1);          // [M] arc length of the knots (binary search)
+    LonRow *__restrict__ rows = reinterpret_cast<LonRow *>(rpos + ((M + 1) & ~1));  // 16-byte aligned
+    // the knots themselves are only touched once per (pair, step) item: read them through L1/L2
+    const FX_GLOBAL double *__restrict__ kn = as_global(P.ref);
     {
         const FX_GLOBAL double *__restrict__ tsrc = as_global(P.tpow);
-        for (int i = tid; i < 5 * S; i += BLK) lds_dyn[i] = tsrc[i];
+        for (int i = tid; i < 5 * S; i += BLK) tpw[i] = tsrc[i];
+        for (int i = tid; i < M; i += BLK) rpos[i] = kn[(int64_t)i * FX_REF_FIELDS];
+        if (tid < P.n_cost) { sh_cost_id[tid] = Pg.cost_id[tid]; sh_cost_w[tid] = Pg.cost_w[tid]; }
     }
     if (tid < 2 + FX_NUM_REASONS) red_cnt[tid] = 0;
     __syncthreads();
-    // the knots are only touched by the prologue (one lookup per (pair, step) item): read them through L1/L2
-    const FX_GLOBAL double *__restrict__ kn = as_global(P.ref);
-    const double *__restrict__ tp = lds_dyn;
-    LonRow *__restrict__ rows = reinterpret_cast<LonRow *>(lds_dyn + ((5 * S + 1) & ~1));  // 16-byte aligned
+    const double *__restrict__ tp = tpw;
+    FX_STAMP(1);
 
     const double dt = P.dt;
     const bool low_vel = P.low_vel_mode != 0;
@@ -71,48 +102,44 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     const double s0 = P.x0_lon[0], ss0 = P.x0_lon[1], sss0 = P.x0_lon[2];
 
     // ---- prologue: longitudinal table of the pairs this workgroup touches ----
-    const int64_t gbase = P.g_base;
-    const int64_t pair0 = (c0 + gbase) / nD;
-    const int64_t c_last = min(c0 + CPB, C) - 1;
-    const int n_pairs = (int)((c_last + gbase) / nD - pair0) + 1;
-    const int n_pairs_max = (CPB + nD - 2) / nD + 1;  // what the host sized the row block for
-    const double rp_first = kn[0], rp_last = kn[(int64_t)(M - 1) * FX_REF_FIELDS];
+    const double rp_first = rpos[0], rp_last = rpos[M - 1];
+    const double guess_scale = fdiv((double)(M - 1), rp_last - rp_first);
     for (int item = tid; item < n_pairs * S; item += BLK) {
         const int pl = item / S, i = item - pl * S;
-        const int64_t pair = pair0 + pl;
-        const int it = (int)(pair / nV), iv = (int)(pair - (int64_t)it * nV);
-        const double T = as_global(P.t_samp)[it], v1 = as_global(P.v_samp)[iv];
+        double T, v1;
+        if (item == tid) { T = T_item0; v1 = v_item0; }  // fetched with phase 1
+        else {
+            const int64_t pair = pair0 + pl;
+            const int it = (int)(pair / nV), iv = (int)(pair - (int64_t)it * nV);
+            T = as_global(P.t_samp)[it]; v1 = as_global(P.v_samp)[iv];
+        }
         // longitudinal quartic (polynomial_trajectory.py:452-488)
         const double b1 = v1 - ss0 - sss0 * T, b2 = 0.0 - sss0, T2 = T * T;
-        const double cl3 = (3.0 * b1 - T * b2) / (3.0 * T2);
-        const double cl4 = (T * b2 - 2.0 * b1) / (4.0 * T2 * T);
+        const double cl3 = fdiv(3.0 * b1 - T * b2, 3.0 * T2);
+        const double cl4 = fdiv(T * b2 - 2.0 * b1, 4.0 * T2 * T);
         int traj_len = (int)ceil((T + dt) / dt);
         traj_len = traj_len > S ? S : (traj_len < 1 ? 1 : traj_len);
         rows[item] = make_lon_row(
-            i, S, M, dt, a_max, s0, ss0, .5 * sss0, cl3, cl4, traj_len, tp, rp_first, rp_last,
+            i, S, M, dt, a_max, s0, ss0, .5 * sss0, cl3, cl4, traj_len, tp, rp_first, rp_last, guess_scale,
             [&](int k) {
                 const FX_GLOBAL double *q = kn + (int64_t)k * FX_REF_FIELDS;
                 Knot kt;
                 kt.pos = q[0]; kt.theta = q[1]; kt.curv = q[2]; kt.curv_d = q[3]; kt.x = q[4]; kt.y = q[5]; kt.nx = q[6]; kt.ny = q[7];
                 return kt;
             },
-            [&](int k) { return kn[(int64_t)k * FX_REF_FIELDS]; });
+            [&](int k) { return rpos[k]; });
     }
     __syncthreads();
+    FX_STAMP(2);
 
     // ---- candidate: lateral quintic (reactive_planner.py:158-171) ----
-    const int64_t gg = g + gbase;
-    const int64_t pair = gg / nD;
-    const int id = (int)(gg - pair * nD);
-    const int it = (int)(pair / nV), iv = (int)(pair - (int64_t)it * nV);
-    const double T = as_global(P.t_samp)[it], v1 = as_global(P.v_samp)[iv], d1 = as_global(P.d_samp)[id];
     const double d0 = P.x0_lat[0], dd0 = P.x0_lat[1], ddd0 = P.x0_lat[2];
     const LonRow *__restrict__ my = rows + (int)(pair - pair0) * S;
     double cl3, cl4;
     {
         const double b1 = v1 - ss0 - sss0 * T, b2 = 0.0 - sss0, T2 = T * T;
-        cl3 = (3.0 * b1 - T * b2) / (3.0 * T2);
-        cl4 = (T * b2 - 2.0 * b1) / (4.0 * T2 * T);
+        cl3 = fdiv(3.0 * b1 - T * b2, 3.0 * T2);
+        cl4 = fdiv(T * b2 - 2.0 * b1, 4.0 * T2 * T);
     }
     double tau = T;
     if (low_vel) {
@@ -128,8 +155,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
         double b0 = d1 - d0 - dd0 * tau - .5 * ddd0 * T2;
         double b1 = 0.0 - dd0 - ddd0 * tau;
         double b2 = 0.0 - ddd0;
-        L.set(d0, dd0, .5 * ddd0, (10.0 * b0 - 4.0 * b1 * tau + .5 * b2 * T2) / T3,
-              (-15.0 * b0 + 7.0 * b1 * tau - b2 * T2) / T4, (6.0 * b0 - 3.0 * b1 * tau + .5 * b2 * T2) / T5);
+        L.set(d0, dd0, .5 * ddd0, fdiv(10.0 * b0 - 4.0 * b1 * tau + .5 * b2 * T2, T3),
+              fdiv(-15.0 * b0 + 7.0 * b1 * tau - b2 * T2, T4), fdiv(6.0 * b0 - 3.0 * b1 * tau + .5 * b2 * T2, T5));
     }
     int traj_len = (int)ceil((T + dt) / dt);
     traj_len = traj_len > S ? S : (traj_len < 1 ? 1 : traj_len);
@@ -186,6 +213,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     FX_GLOBAL double *__restrict__ planes = as_global(P.planes);
     const int64_t ps = (int64_t)S * ld;
 
+    FX_STAMP(3);
 #pragma unroll 1
     for (int i = i_first; i < i_end; i++) {
         const bool emit = i >= i_begin;
@@ -194,6 +222,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
                                             planes + (int64_t)i * ld + g, ps, Cy, A, O, obs_rec, obs_pmask, obs_hmask);
     }
 
+    FX_STAMP(4);
     WalkResult W;
     W.neg = A.neg; W.acc_viol = A.acc_viol; W.collided = A.collided;
     W.step_reasons = A.step_reasons; W.first_key = A.first_key; W.fail_step = A.fail_step;

@@ -123,6 +123,12 @@ __device__ __forceinline__ bool obb_overlap(const Obb &a, PtrT b) {
 
 __device__ __forceinline__ int wave_count(bool p) { return __popcll(__ballot(p)); }
 
+// m[lane K] = n (n wave-uniform): v_writelane_b32, one instruction
+template <int K>
+__device__ __forceinline__ void write_lane(unsigned int &m, int n) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(m) : "s"(n), "n"(K));
+}
+
 // reductions over the G adjacent lanes that share a candidate
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
@@ -168,7 +174,7 @@ struct WalkResult {
 // lane of G different lane-groups of the workgroup (WSPLIT = true: part = tid / CPB, combined through the LDS block
 // `xch` of G * CPB * 56 bytes).  The second form keeps every store of the walk a contiguous row segment per wave.
 template <int G, bool BUNDLE, bool OBST, bool EXTRA, bool WSPLIT = false>
-__device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult &W, int64_t g, bool active, int part,
+__device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResult &W, int64_t g, bool active, int part,
                                                  int i_begin, int i_end, bool bundle, bool do_collision, bool dbg, bool D,
                                                  double *red_cost, long long *red_idx, unsigned int *red_cnt,
                                                  const FuseArgs &fuse, double *xch = nullptr, int CPB = 0,
@@ -280,6 +286,7 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
     const bool proj_ok = fail_step == 0x7fffffff;
     const bool leader = part == 0;
 
+    FX_STAMP(5);
     // ---- flags: return-list membership and reasons exactly as check_feasibility assembles them ----
     uint32_t flags = FX_FLAG_VALID | FX_FLAG_FEASIBLE;
     uint32_t reasons = 0;
@@ -314,15 +321,22 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
     if (selectable && do_collision && collided) flags |= FX_FLAG_COLLISION;
     flags |= reasons << FX_REASON_SHIFT;
 
+    FX_STAMP(6);
     // ---- weighted cost sum in name-sorted order (cost_function.py:78-91) ----
     double total = 0.0;
     {
         const double tt = dt, tt2 = tt * tt, tt3 = tt2 * tt, tt4 = tt3 * tt, tt5 = tt4 * tt;
         const int n_cost = P.n_cost;
         double sum = -0.0;
+        // ids / weights come from LDS: fetch entry n+1 while term n is computed
+        int id_next = n_cost > 0 ? P.cost_id[0] : 0;
+        double w_next = n_cost > 0 ? P.cost_w[0] : 0.0;
         for (int n = 0; n < n_cost; n++) {
+            const int id = id_next;
+            const double w = w_next;
+            if (n + 1 < n_cost) { id_next = P.cost_id[n + 1]; w_next = P.cost_w[n + 1]; }
             double c = 0.0;
-            switch (P.cost_id[n]) {
+            switch (id) {
             case FX_COST_DISTANCE_TO_REFERENCE_PATH: c = ((0.0 + sum_abs_d) + fabs(d_end) * 5) / S; break;
             case FX_COST_LATERAL_JERK:  // squared_jerk_integral(dt) (polynomial_trajectory.py:172-191, cost :54)
                 c = (36 * ct3 * ct3 * tt + 144 * ct3 * ct4 * tt2 + 240 * ct3 * ct5 * tt3 + 192 * ct4 * ct4 * tt3 +
@@ -346,7 +360,7 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
             default: break;
             }
             if ((P.mode & FX_MODE_WRITE_COSTMAP) && active && leader) as_global(P.costmap)[(int64_t)n * ld + g] = costed ? c : 0.0;
-            sum += P.cost_w[n] * c;
+            sum += w * c;
         }
         total = 0.0 + sum;
     }
@@ -355,57 +369,70 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
         as_global(P.flags)[g] = flags;
     }
 
+    FX_STAMP(7);
     // ---- workgroup reductions (candidate leaders only): counters and the (cost, index) arg-min partial ----
     const int lane = tid & 63, wave = tid >> 6;
     const bool own = active && leader;
     {
+        // lane k of the wave collects counter k (scalar popcounts dropped into a lane each), one LDS atomic per wave
+        unsigned int mine = 0;
         const bool ret = own && (flags & FX_FLAG_RETURNED);
-        const int n_ret = wave_count(ret);
-        const int n_feas = wave_count(ret && (flags & FX_FLAG_VALID) && (flags & FX_FLAG_FEASIBLE));
-        if (lane == 0) {
-            if (n_ret) atomicAdd(&red_cnt[0], (unsigned)n_ret);
-            if (n_feas) atomicAdd(&red_cnt[1], (unsigned)n_feas);
-        }
-        for (int r = 0; r < FX_NUM_REASONS; r++) {
-            const int n = wave_count(own && ((reasons >> r) & 1u));
-            if (lane == 0 && n) atomicAdd(&red_cnt[2 + r], (unsigned)n);
-        }
+        write_lane<0>(mine, wave_count(ret));
+        write_lane<1>(mine, wave_count(ret && (flags & FX_FLAG_VALID) && (flags & FX_FLAG_FEASIBLE)));
+        static_assert(FX_NUM_REASONS == 11, "one write_lane per reason below");
+#define FX_REASON_LANE(r) write_lane<2 + r>(mine, wave_count(own && ((reasons >> r) & 1u)))
+        FX_REASON_LANE(0); FX_REASON_LANE(1); FX_REASON_LANE(2); FX_REASON_LANE(3); FX_REASON_LANE(4); FX_REASON_LANE(5);
+        FX_REASON_LANE(6); FX_REASON_LANE(7); FX_REASON_LANE(8); FX_REASON_LANE(9); FX_REASON_LANE(10);
+#undef FX_REASON_LANE
+        if (lane < 2 + FX_NUM_REASONS && mine) atomicAdd(&red_cnt[lane], mine);
     }
+    FX_STAMP(8);
     const bool eligible = own && selectable && !(flags & FX_FLAG_COLLISION) && total == total;
     double bc = eligible ? total : INFINITY;
     long long bi = eligible ? (long long)(g + P.g_base) : 0x7fffffffffffffffLL;
+    // wave arg-min: candidate indices grow with the lane, so the (cost, index) minimum is the LOWEST lane that
+    // holds the minimum cost -- a min-reduction of the cost alone plus one ballot
+    {
+        double m = bc;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double oc = __shfl_xor(bc, off);
-        const long long oi = __shfl_xor(bi, off);
-        if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+        for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off));
+        const unsigned long long hit = __ballot(eligible && bc == m);
+        const int src = hit ? __ffsll((long long)hit) - 1 : 0;
+        bc = m;
+        bi = hit ? __shfl(bi, src) : 0x7fffffffffffffffLL;
     }
     if (lane == 0) { red_cost[wave] = bc; red_idx[wave] = bi; }
+    FX_STAMP(9);
     __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < (int)blockDim.x / 64; w++)
-            if (red_cost[w] < bc || (red_cost[w] == bc && red_idx[w] < bi)) { bc = red_cost[w]; bi = red_idx[w]; }
+    // Only the first wave goes on (it owns the lanes that publish); the others are done.
+    if (wave != 0) return;
+    for (int w = 1; w < (int)blockDim.x / 64; w++)
+        if (red_cost[w] < bc || (red_cost[w] == bc && red_idx[w] < bi)) { bc = red_cost[w]; bi = red_idx[w]; }
+    if (lane == 0) {
         // agent-scope stores: visible to whichever XCD runs the reducing workgroup without an L2 write-back
         __hip_atomic_store(as_global(P.part_cost) + blockIdx.x, bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(as_global(P.part_idx) + blockIdx.x, (int64_t)bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid < 2 + FX_NUM_REASONS && red_cnt[tid]) atomicAdd(&P.counters[tid], (unsigned long long)red_cnt[tid]);
+    if (lane < 2 + FX_NUM_REASONS && red_cnt[lane]) atomicAdd(&P.counters[lane], (unsigned long long)red_cnt[lane]);
+    FX_STAMP(10);
     if (fuse.host_result == nullptr) return;  // a selection kernel follows
 
     // ---- fused selection: the last workgroup of this agent to arrive reduces and publishes ----
-    // Partials and counters above are agent-scope atomics; once they are acknowledged (vmcnt 0) they are performed,
-    // so a relaxed ticket is enough -- no L2 write-back in the way of the bundle's store stream.
+    // Partials and counters above are agent-scope atomics issued by THIS wave; once they are acknowledged
+    // (vmcnt 0) they are performed, so a relaxed ticket is enough -- no L2 write-back in the way of the bundle's
+    // store stream, no workgroup barrier.  (The other waves' cost / flag / plane stores may still be in flight
+    // when the result is published: every consumer of those is ordered behind the kernel on the stream.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long t = atomicAdd(&P.counters[FX_DCNT_TICKET], 1ULL);
-        red_cnt[2 + FX_NUM_REASONS] = (t == (unsigned long long)(P.n_blocks - 1));
-    }
-    __syncthreads();
-    if (!red_cnt[2 + FX_NUM_REASONS]) return;
+    FX_STAMP(11);
+    unsigned long long ticket = 0;
+    if (lane == 0) ticket = atomicAdd(&P.counters[FX_DCNT_TICKET], 1ULL);
+    ticket = __shfl(ticket, 0);
+    FX_STAMP(12);
+    FX_STAMP(15);
+    if (ticket != (unsigned long long)(P.n_blocks - 1)) return;
     bc = INFINITY;
     bi = 0x7fffffffffffffffLL;
-    for (int b = tid; b < P.n_blocks; b += (int)blockDim.x) {
+    for (int b = lane; b < P.n_blocks; b += 64) {
         const double c = __hip_atomic_load(as_global(P.part_cost) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long ix = __hip_atomic_load(as_global(P.part_idx) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c < bc || (c == bc && ix < bi)) { bc = c; bi = ix; }
@@ -416,14 +443,10 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
         const long long oi = __shfl_xor(bi, off);
         if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
     }
-    if (lane == 0) { red_cost[wave] = bc; red_idx[wave] = bi; }
     unsigned long long *out = fuse.host_result + (size_t)blockIdx.y * (FX_CNT_COUNT + 1);
     // counters: read and zero in one agent-scope exchange (the next step starts from a clean block)
-    if (tid < FX_CNT_BEST_IDX) out[tid] = atomicExch(&P.counters[tid], 0ULL);
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < (int)blockDim.x / 64; w++)
-            if (red_cost[w] < bc || (red_cost[w] == bc && red_idx[w] < bi)) { bc = red_cost[w]; bi = red_idx[w]; }
+    if (lane < FX_CNT_BEST_IDX) out[lane] = atomicExch(&P.counters[lane], 0ULL);
+    if (lane == 0) {
         const bool none = bi == 0x7fffffffffffffffLL;
         if (fuse.dev_winner) {
             fuse.dev_winner[2 * blockIdx.y] = none ? INFINITY : bc;
@@ -434,11 +457,9 @@ __device__ __forceinline__ void finish_candidate(const DevProblem &P, WalkResult
         out[FX_CNT_COLLISIONS] = 0ULL;
         __hip_atomic_store(&P.counters[FX_DCNT_TICKET], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence_system();
-        __hip_atomic_store(&out[FX_CNT_COUNT], fuse.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    // every lane's result words are out (vmcnt 0 is per wave) before lane 0 releases the sequence word
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(&out[FX_CNT_COUNT], fuse.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace fxk
@@ -462,7 +483,11 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     __shared__ long long red_idx[FX_BLOCK / 64];
     __shared__ unsigned int red_cnt[2 + FX_NUM_REASONS + 1];  // counters, then the last-workgroup flag
 
-    const DevProblem &P = probs[blockIdx.y];
+    __shared__ int32_t sh_cost_id[FX_NUM_COSTS];
+    __shared__ double sh_cost_w[FX_NUM_COSTS];
+
+    const DevProblem &Pg = probs[blockIdx.y];
+    const ProblemRegs P = ProblemRegs::load(Pg, sh_cost_id, sh_cost_w);  // one batch of scalar loads at entry
     const int tid = threadIdx.x;
     const int64_t C = P.C;
     if ((int64_t)blockIdx.x * CPB >= C) return;  // whole workgroup beyond this agent's grid
@@ -477,6 +502,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
         for (int i = tid; i < M * FX_REF_FIELDS; i += FX_BLOCK) lds_dyn[i] = src[i];
         const FX_GLOBAL double *__restrict__ tsrc = as_global(P.tpow);
         for (int i = tid; i < 5 * S; i += FX_BLOCK) lds_dyn[M * FX_REF_FIELDS + i] = tsrc[i];
+        if (tid < P.n_cost) { sh_cost_id[tid] = Pg.cost_id[tid]; sh_cost_w[tid] = Pg.cost_w[tid]; }
     }
     if (tid < 2 + FX_NUM_REASONS) red_cnt[tid] = 0;
     __syncthreads();
@@ -524,8 +550,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
         cl0 = s0;
         cl1 = ss0;
         cl2 = .5 * sss0;
-        cl3 = (3.0 * b1 - T * b2) / (3.0 * T2);
-        cl4 = (T * b2 - 2.0 * b1) / (4.0 * T2 * T);
+        cl3 = fdiv(3.0 * b1 - T * b2, 3.0 * T2);
+        cl4 = fdiv(T * b2 - 2.0 * b1, 4.0 * T2 * T);
     }
     // ---- lateral quintic over time (high speed) or arclength (LOW_VEL_MODE), reactive_planner.py:161-171 ----
     double tau = T;
@@ -541,8 +567,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
         double b0 = d1 - d0 - dd0 * tau - .5 * ddd0 * T2;
         double b1 = dd1 - dd0 - ddd0 * tau;
         double b2 = ddd1 - ddd0;
-        L.set(d0, dd0, .5 * ddd0, (10.0 * b0 - 4.0 * b1 * tau + .5 * b2 * T2) / T3,
-              (-15.0 * b0 + 7.0 * b1 * tau - b2 * T2) / T4, (6.0 * b0 - 3.0 * b1 * tau + .5 * b2 * T2) / T5);
+        L.set(d0, dd0, .5 * ddd0, fdiv(10.0 * b0 - 4.0 * b1 * tau + .5 * b2 * T2, T3),
+              fdiv(-15.0 * b0 + 7.0 * b1 * tau - b2 * T2, T4), fdiv(6.0 * b0 - 3.0 * b1 * tau + .5 * b2 * T2, T5));
     }
     // len(np.arange(0, T+dt, dt)) (reactive_planner.py:296,303), clamped to the horizon
     int traj_len = (int)ceil((T + dt) / dt);
@@ -556,8 +582,9 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     }
 
     const double rp_first = knots[0].pos, rp_last = knots[M - 1].pos;
+    const double guess_scale = fdiv((double)(M - 1), rp_last - rp_first);
     auto row_at = [&](int i) {
-        return make_lon_row(i, S, M, dt, a_max, cl0, cl1, cl2, cl3, cl4, traj_len, tp, rp_first, rp_last,
+        return make_lon_row(i, S, M, dt, a_max, cl0, cl1, cl2, cl3, cl4, traj_len, tp, rp_first, rp_last, guess_scale,
                             [&](int k) { return knots[k]; }, [&](int k) { return knots[k].pos; });
     };
     auto lat_eval = [&](int i, double u_lowvel, double &d, double &dv, double &da) {

@@ -28,6 +28,13 @@
 
 using fxk::wave_count;
 
+#ifdef FX_PROBE
+__device__ unsigned long long fx_probe_stamps[FX_PROBE_WAVES * FX_PROBE_SLOTS];
+extern "C" int fx_probe_read(unsigned long long *out, size_t n_words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fx_probe_stamps), n_words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // Selection kernel: one workgroup per agent.  Reduces the per-workgroup partials to the winner and
 // counts the colliding candidates that the reference's cost-ordered walk would have visited before it

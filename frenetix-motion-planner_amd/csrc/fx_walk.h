@@ -72,7 +72,7 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double &sq, double &rsq) {
 template <typename KnotFn, typename PosFn>
 __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, double a_max, double cl0, double cl1, double cl2,
                                                double cl3, double cl4, int traj_len, const double *tp, double rp_first,
-                                               double rp_last, KnotFn knot, PosFn kpos) {
+                                               double rp_last, double guess_scale, KnotFn knot, PosFn kpos) {
     const int ie = i < traj_len ? i : traj_len - 1;  // sample that is evaluated (the last one feeds the extension)
     const double t1 = tp[ie], t2 = tp[S + ie], t3 = tp[2 * S + ie], t4 = tp[3 * S + ie];
     double s_i = cl0 + cl1 * t1 + cl2 * t2 + cl3 * t3 + cl4 * t4;
@@ -88,10 +88,22 @@ __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, d
     if (sv_i > 0.001) r.flags |= LON_MOVING;
     r.s = s_i; r.sv = sv_i; r.sa = sa_i;
     r.u1 = s_i - cl0;
-    r.r_sv = 1.0 / sv_i;
+    // reciprocals are only consumed on moving steps (walk_step selects them away otherwise)
+    const bool mv = (r.flags & LON_MOVING) != 0;
+    r.r_sv = mv ? rcp_nr(sv_i) : 0.0;
     r.sv2 = sv_i * sv_i;
-    r.r_sv2 = 1.0 / r.sv2;
+    r.r_sv2 = mv ? rcp_nr(r.sv2) : 0.0;
+    // upper_bound(ref_pos, s): first try the segment a uniformly spaced reference would put s in (resampled
+    // reference paths are close to uniform), then bisect whatever interval that probe leaves
     int lo = 0, hi = M;
+    if (M >= 2 && s_i >= rp_first && s_i < rp_last) {
+        int kg = (int)((s_i - rp_first) * guess_scale);
+        kg = kg < 0 ? 0 : (kg > M - 2 ? M - 2 : kg);
+        const double p0 = kpos(kg), p1 = kpos(kg + 1);
+        if (p0 > s_i) hi = kg;
+        else if (p1 > s_i) { lo = kg + 1; hi = kg + 1; }
+        else lo = kg + 2 > M ? M : kg + 2;
+    }
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (kpos(mid) > s_i) hi = mid; else lo = mid + 1;
@@ -100,7 +112,7 @@ __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, d
     const int i1 = ub == M ? 0 : ub;
     const int i0 = i1 == 0 ? M - 1 : i1 - 1;
     const Knot k0 = knot(i0), k1 = knot(i1);
-    const double seg = k1.pos - k0.pos, r_seg = 1.0 / seg;
+    const double seg = k1.pos - k0.pos, r_seg = rcp_nr(seg);
     const double s_lambda = div_rcp(s_i - k0.pos, seg, r_seg);
     r.th_ref = wrap_pm_2pi(div_rcp((k1.theta - k0.theta) * (s_i - k0.pos), seg, r_seg) + k0.theta);
     r.k_r = (k1.curv - k0.curv) * s_lambda + k0.curv;
@@ -112,11 +124,12 @@ __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, d
         kk = kk < 0 ? 0 : (kk > M - 2 ? M - 2 : kk);
         // kk == i0 unless the lookup wrapped (s outside the reference): same segment, same lambda
         const Knot q0 = kk == i0 ? k0 : knot(kk), q1 = kk == i0 ? k1 : knot(kk + 1);
-        const double lam = kk == i0 ? s_lambda : (s_i - q0.pos) / (q1.pos - q0.pos);
+        const double lam = kk == i0 ? s_lambda : fdiv(s_i - q0.pos, q1.pos - q0.pos);
         r.px = q0.x + lam * (q1.x - q0.x);
         r.py = q0.y + lam * (q1.y - q0.y);
         const double nx = q0.nx + lam * (q1.nx - q0.nx), ny = q0.ny + lam * (q1.ny - q0.ny);
-        const double nn = sqrt(nx * nx + ny * ny), r_nn = 1.0 / nn;
+        double nn, r_nn;
+        sqrt_rsqrt(nx * nx + ny * ny, nn, r_nn);
         r.nhx = div_rcp(nx, nn, r_nn);
         r.nhy = div_rcp(ny, nn, r_nn);
     }

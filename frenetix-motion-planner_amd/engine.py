@@ -102,12 +102,23 @@ class FrenetEngine:
 
     TIMING = {"off": 0, "stream": 1, "kernel": 2}
 
-    def set_timing(self, mode):
-        """HIP-event timing of every step: "off" / False, "stream" / True (default: stream events around the
-        kernels) or "kernel" (events attached to the evaluation kernel itself -- what a kernel trace reports)."""
+    def set_timing(self, mode, every: int = 1):
+        """HIP-event timing of (every n-th) step: "off" / False (default), "stream" / True (stream events around the
+        kernels) or "kernel" (events attached to the evaluation kernel itself -- what a kernel trace reports).
+        Times are read lazily: `last_kernel_ms`, `last_eval_kernel_ms`, `kernel_times()`."""
         if isinstance(mode, str):
             mode = self.TIMING[mode]
         check(lib().fx_set_timing(self._ctx, int(mode)))
+        check(lib().fx_set_timing_interval(self._ctx, int(every)))
+
+    def kernel_times(self, max_n: int = 256):
+        """(evaluation-kernel ms, whole-step device ms) of the most recent timed steps, oldest first."""
+        ev = np.zeros(max_n, dtype=np.float64)
+        st = np.zeros(max_n, dtype=np.float64)
+        n = C.c_int32(0)
+        check(lib().fx_read_kernel_times(self._ctx, max_n, ev.ctypes.data_as(C.POINTER(C.c_double)),
+                                         st.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n)))
+        return ev[:n.value], st[:n.value]
 
     # -- plan step, split so callers can overlap host work (upload/evaluate enqueue only) --
     def upload(self, inputs):

@@ -158,7 +158,8 @@ typedef struct FxResult {
     int64_t n_collisions;      /* _collision_counter: colliding candidates walked before the winner */
     int64_t reason_hist[FX_NUM_REASONS]; /* infeasible_invalid_count_kinematics (queue_2 payload) */
     double feasible_percentage;/* infeasible_kinematics_percentage (is the feasible %, :235) */
-    double kernel_ms;          /* HIP-event time of the device work of this step */
+    double kernel_ms;          /* HIP-event time of the device work of this step; -1 when the step was not timed or
+                                * its events were still pending when fx_finish returned (fx_last_kernel_ms waits) */
 } FxResult;
 
 typedef struct FxContext FxContext;
@@ -252,17 +253,21 @@ int32_t fx_device_views(FxContext *ctx, int32_t agent, void **cost, void **flags
 int64_t fx_device_bytes(const FxContext *ctx);
 double fx_last_kernel_ms(const FxContext *ctx);
 double fx_last_eval_kernel_ms(const FxContext *ctx);
-/* per-step HIP-event timing: FX_TIMING_OFF -- fx_finish only polls the result block the selection kernel
- * publishes into pinned host memory and FxResult.kernel_ms is -1; FX_TIMING_STREAM (default) -- stream events
- * around the kernels (the evaluation figure includes the dispatch gap in front of the kernel);
- * FX_TIMING_KERNEL -- start/stop events attached to the evaluation kernel itself (hipExtLaunchKernel): the
- * figure a kernel trace reports, at a few microseconds more host time per step */
 /* selection fused into the evaluation kernel (default on): when no agent of the step asks for FX_MODE_COLLISION the
  * evaluation kernel's last workgroup reduces the partial arg-mins and publishes the result, so a plan step is a
  * single launch; off = always run the separate selection kernel (same results; used by the parity tests) */
 int32_t fx_set_fused_selection(FxContext *ctx, int32_t enabled);
+/* per-step HIP-event timing (default FX_TIMING_OFF: fx_finish only polls the result block the kernel publishes
+ * into pinned host memory).  FX_TIMING_STREAM -- stream events around the kernels (the evaluation figure includes
+ * the dispatch gap in front of the kernel); FX_TIMING_KERNEL -- start/stop events attached to the evaluation
+ * kernel itself (hipExtLaunchKernel): the figure a kernel trace reports, at a few microseconds more host time per
+ * timed launch.  Events live in a ring of 256 steps and are read on request only: fx_last_*_ms (latest timed
+ * step) and fx_read_kernel_times (the most recent <= max_n timed steps, oldest first; n_out = how many) wait for
+ * the events they read, fx_finish never does.  fx_set_timing_interval: time every n-th step only. */
 enum { FX_TIMING_OFF = 0, FX_TIMING_STREAM = 1, FX_TIMING_KERNEL = 2 };
 int32_t fx_set_timing(FxContext *ctx, int32_t mode);
+int32_t fx_set_timing_interval(FxContext *ctx, int32_t every);
+int32_t fx_read_kernel_times(FxContext *ctx, int32_t max_n, double *eval_ms, double *step_ms, int32_t *n_out);
 /* device self-test of the kernel's elementary functions (atan, sin, cos) on n host values */
 int32_t fx_math_selftest(int32_t n, const double *x, double *atan_out, double *sin_out, double *cos_out);
 

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Phase timing inside the evaluation kernel from per-wave cycle stamps (probe build, -DFX_PROBE):
+    hipcc ... -DFX_PROBE=9 -shared -o tools/probe_build/libfxplan_p9.so fx_kernels.hip fx_api.hip
+Stamps: 0 kernel entry (wall clock, 100 MHz) | 1 after phase 1 | 2 rows done | 3 walk start | 4 walk end |
+5 parts combined | 6 flags | 7 costs | 8 histogram | 9 wave arg-min | 10 partial + counters | 11 stores drained |
+12 ticket | 15 end (wall clock)."""
+import ctypes as C, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["FXPLAN_SO"] = os.path.join(ROOT, "tools", "probe_build", "libfxplan_p9.so")
+sys.path.insert(0, ROOT)
+import numpy as np
+from frenetix_motion_planner_amd import synthetic, _lib
+from frenetix_motion_planner_amd.engine import FrenetEngine
+
+SL = 16
+def run(label, G, mp, fused, **kw):
+    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, **kw)
+    with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
+        eng.set_timing("kernel"); eng.set_fused_selection(fused); eng.set_tuning(G, 2, 2, 256, mp); eng.upload(inp)
+        for _ in range(5): eng.evaluate(); eng.finish()
+        ms = eng.last_eval_kernel_ms
+        n_waves = -(-inp.n_candidates // (256 // G)) * 4
+        buf = np.zeros(n_waves * SL, dtype=np.uint64)
+        lib = _lib.lib()
+        lib.fx_probe_read.argtypes = [C.c_void_p, C.c_size_t]
+        assert lib.fx_probe_read(buf.ctypes.data, buf.size) == 0
+    st = buf.reshape(n_waves, SL).astype(np.int64)
+    t0 = st[:, 0].min()
+    wall = (st[:, 15].max() - t0) * 10e-3  # us (100 MHz)
+    cyc = st[:, 1:13] - st[:, 1:2]         # cycles relative to stamp 1
+    d = np.diff(st[:, 1:13], axis=1)       # per-phase cycles
+    names = ["rows", "lat_setup", "walk", "combine", "flags", "costs", "hist", "argmin", "partial", "drain", "ticket"]
+    tot = (st[:, 12] - st[:, 1])
+    clk = np.median(tot) / max(1e-9, (np.median(st[:, 15] - st[:, 0]) * 10e-3))  # cycles per us, rough
+    print(label, f"G{G}m{mp} fused={fused} kernel {ms*1e3:.1f} us; first entry -> last end {wall:.1f} us; entry spread "
+          f"{(st[:,0].max()-t0)*10e-3:.1f} us; ~{clk:.0f} cycles/us")
+    print("   median cycles per phase:", {n: int(np.median(d[:, i])) for i, n in enumerate(names)})
+    print("   p95    cycles per phase:", {n: int(np.percentile(d[:, i], 95)) for i, n in enumerate(names)})
+
+run("50k_B", 2, 2, True, grid=(19, 51, 51))
+run("50k_B", 2, 2, False, grid=(19, 51, 51))
+run("50k_A", 2, 2, True, grid=(19, 51, 51), write_bundle=False, write_costmap=False)
+run("50k_B", 1, 0, True, grid=(19, 51, 51))
+run("1M_A", 1, 0, True, grid=(19, 230, 229), write_bundle=False, write_costmap=False)

@@ -12,7 +12,7 @@ def run(label, tunings, steps=60, **kw):
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
         for tn in tunings:
             G, w, var, blk = tn[:4]; mp = tn[4] if len(tn) > 4 else 0
-            eng.set_tuning(G, w, var, blk, mp); eng.upload(inp)
+            eng.set_timing("kernel"); eng.set_tuning(G, w, var, blk, mp); eng.upload(inp)
             for _ in range(5): eng.evaluate(); eng.finish()
             ts = []
             for _ in range(steps):
@@ -27,3 +27,5 @@ run("config3_modeB", T, ref_kind="arc", v0=10.0, grid=(19, 51, 51), n_obstacles=
 run("config3_modeA", T, ref_kind="arc", v0=10.0, grid=(19, 51, 51), n_obstacles=20, write_bundle=False, write_costmap=False)
 run("1M_modeA_obs20", T, steps=10, ref_kind="arc", v0=10.0, grid=(19, 230, 229), n_obstacles=20, write_bundle=False, write_costmap=False)
 run("1M_modeA", T, steps=10, ref_kind="arc", v0=10.0, grid=(19, 230, 229), write_bundle=False, write_costmap=False)
+run("1M_modeB", T, steps=10, ref_kind="arc", v0=10.0, grid=(19, 230, 229))
+run("200k_modeB", T, steps=20, ref_kind="arc", v0=10.0, grid=(19, 102, 102))

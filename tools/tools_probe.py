@@ -10,6 +10,7 @@ from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hull
 VARIANT = int(os.environ.get('FXV', '2'))
 def t(inp, G, w, steps=40):
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N, max_ref_knots=2048) as eng:
+        eng.set_timing("kernel")
         eng.set_tuning(G, w, VARIANT); eng.upload(inp)
         for _ in range(5): eng.evaluate(); eng.finish()
         ts = []

@@ -13,6 +13,7 @@ b = mode == "modeB"
 inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=grid, n_obstacles=nobs, write_bundle=b, write_costmap=b,
                             hull_builder=build_obstacle_hulls)
 with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
+    eng.set_timing("kernel")
     eng.set_tuning(G, w, var)
     eng.upload(inp)
     for _ in range(steps):

@@ -15,6 +15,7 @@ def run(label, steps=60, **kw):
     inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
     out = {}
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
+        eng.set_timing("kernel")
         for blk in (64, 128, 256):
           for G in (1, 2, 4):
             for w in (2, 3, 4):
