@@ -5,7 +5,8 @@ wrapper (oracle/oracle.py) can share the struct definitions.
 """
 import ctypes as C
 
-FX_ABI_VERSION = 1
+FX_ABI_VERSION = 2
+FX_LON_VELOCITY_KEEPING, FX_LON_STOP_POINT = 0, 1
 
 FX_OK = 0
 FX_ERR_INVALID_ARGUMENT = -1
@@ -54,7 +55,7 @@ class FxVehicle(C.Structure):
 
 class FxProblem(C.Structure):
     _fields_ = [
-        ("N", C.c_int32), ("dt", C.c_double), ("mode", C.c_uint32), ("low_vel_mode", C.c_int32),
+        ("N", C.c_int32), ("dt", C.c_double), ("mode", C.c_uint32), ("low_vel_mode", C.c_int32), ("lon_mode", C.c_int32),
         ("x0_lon", C.c_double * 3), ("x0_lat", C.c_double * 3), ("x0_orientation", C.c_double),
         ("v_des", C.c_double), ("veh", FxVehicle),
         ("tpow", _pd),

@@ -225,6 +225,10 @@ int validate(const FxProblem *p) {
         if (p->nT > 4096 || p->nV > 4096 || p->nD > 4096) return set_err(FX_ERR_CAPACITY, "sampling range longer than 4096");
     }
     if (p->n_cost < 0 || p->n_cost > FX_NUM_COSTS) return set_err(FX_ERR_INVALID_ARGUMENT, "n_cost=%d", p->n_cost);
+    if (p->lon_mode != FX_LON_VELOCITY_KEEPING && p->lon_mode != FX_LON_STOP_POINT)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "lon_mode=%d", p->lon_mode);
+    if (p->lon_mode == FX_LON_STOP_POINT && p->sampling_matrix)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "stop-point sampling takes ranges, not a C x 13 matrix");
     for (int n = 0; n < p->n_cost; n++) {
         if (p->cost_id[n] < 0 || p->cost_id[n] >= FX_NUM_COSTS) return set_err(FX_ERR_INVALID_ARGUMENT, "unknown cost id %d", p->cost_id[n]);
         if (n && p->cost_id[n] <= p->cost_id[n - 1]) return set_err(FX_ERR_INVALID_ARGUMENT, "cost ids must be strictly ascending");
@@ -526,6 +530,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         memcpy(d.x0_lat, p->x0_lat, sizeof(d.x0_lat));
         d.x0_orientation = p->x0_orientation; d.v_des = p->v_des; d.veh = p->veh;
         d.nT = p->nT; d.nV = p->nV; d.nD = p->nD; d.has_matrix = p->sampling_matrix != nullptr;
+        d.lon_mode = p->lon_mode;
         d.C = C; d.g_base = g_base; d.ld = ld; d.M = p->M; d.K = p->K; d.P = p->P; d.n_cost = p->n_cost; d.n_dto = p->n_dto;
         bool extra = false;
         for (int n = 0; n < p->n_cost; n++) {

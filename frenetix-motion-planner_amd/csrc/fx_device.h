@@ -23,6 +23,7 @@ struct DevProblem {
     FxVehicle veh;
     int32_t nT, nV, nD;
     int32_t has_matrix;
+    int32_t lon_mode;  // FX_LON_*: v_samp holds end velocities (quartic) or end positions (quintic to (s, 0, 0))
     int64_t C;       // candidates of this agent evaluated here (the shard)
     int64_t g_base;  // global index of local candidate 0 (multi-GPU candidate sharding)
     int64_t ld;      // leading dimension of every per-candidate output (C rounded up to 64)
@@ -73,6 +74,7 @@ struct ProblemRegs {
     FxVehicle veh;
     int32_t nT, nV, nD;
     int32_t has_matrix;
+    int32_t lon_mode;
     int64_t C, g_base, ld;
     int32_t M, K, P;
     int32_t n_cost, n_dto;
@@ -106,7 +108,7 @@ struct ProblemRegs {
         r.x0_lon[0] = g.x0_lon[0]; r.x0_lon[1] = g.x0_lon[1]; r.x0_lon[2] = g.x0_lon[2];
         r.x0_lat[0] = g.x0_lat[0]; r.x0_lat[1] = g.x0_lat[1]; r.x0_lat[2] = g.x0_lat[2];
         r.x0_orientation = g.x0_orientation; r.v_des = g.v_des; r.veh = g.veh;
-        r.nT = g.nT; r.nV = g.nV; r.nD = g.nD; r.has_matrix = g.has_matrix;
+        r.nT = g.nT; r.nV = g.nV; r.nD = g.nD; r.has_matrix = g.has_matrix; r.lon_mode = g.lon_mode;
         r.C = g.C; r.g_base = g.g_base; r.ld = g.ld; r.M = g.M; r.K = g.K; r.P = g.P;
         r.n_cost = g.n_cost; r.n_dto = g.n_dto;
         r.cost_id = cost_id; r.cost_w = cost_w; r.simpson_corr = g.simpson_corr;

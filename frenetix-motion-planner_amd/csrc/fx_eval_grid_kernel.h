@@ -113,14 +113,12 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
             const int it = (int)(pair / nV), iv = (int)(pair - (int64_t)it * nV);
             T = as_global(P.t_samp)[it]; v1 = as_global(P.v_samp)[iv];
         }
-        // longitudinal quartic (polynomial_trajectory.py:452-488)
-        const double b1 = v1 - ss0 - sss0 * T, b2 = 0.0 - sss0, T2 = T * T;
-        const double cl3 = fdiv(3.0 * b1 - T * b2, 3.0 * T2);
-        const double cl4 = fdiv(T * b2 - 2.0 * b1, 4.0 * T2 * T);
+        double cl3, cl4, cl5;
+        lon_coeffs(P.lon_mode, s0, ss0, sss0, T, v1, 0.0, cl3, cl4, cl5);
         int traj_len = (int)ceil((T + dt) / dt);
         traj_len = traj_len > S ? S : (traj_len < 1 ? 1 : traj_len);
         rows[item] = make_lon_row(
-            i, S, M, dt, a_max, s0, ss0, .5 * sss0, cl3, cl4, traj_len, tp, rp_first, rp_last, guess_scale,
+            i, S, M, dt, a_max, s0, ss0, .5 * sss0, cl3, cl4, cl5, traj_len, tp, rp_first, rp_last, guess_scale,
             [&](int k) {
                 const FX_GLOBAL double *q = kn + (int64_t)k * FX_REF_FIELDS;
                 Knot kt;
@@ -135,17 +133,13 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     // ---- candidate: lateral quintic (reactive_planner.py:158-171) ----
     const double d0 = P.x0_lat[0], dd0 = P.x0_lat[1], ddd0 = P.x0_lat[2];
     const LonRow *__restrict__ my = rows + (int)(pair - pair0) * S;
-    double cl3, cl4;
-    {
-        const double b1 = v1 - ss0 - sss0 * T, b2 = 0.0 - sss0, T2 = T * T;
-        cl3 = fdiv(3.0 * b1 - T * b2, 3.0 * T2);
-        cl4 = fdiv(T * b2 - 2.0 * b1, 4.0 * T2 * T);
-    }
+    double cl3, cl4, cl5;
+    lon_coeffs(P.lon_mode, s0, ss0, sss0, T, v1, 0.0, cl3, cl4, cl5);
     double tau = T;
     if (low_vel) {
         const double cl0 = s0, cl1 = ss0, cl2 = .5 * sss0;
-        double t2 = T * T, t3 = t2 * T, t4 = t2 * t2;
-        double s_lon_goal = (cl0 + cl1 * T + cl2 * t2 + cl3 * t3 + cl4 * t4) - s0;
+        double t2 = T * T, t3 = t2 * T, t4 = t2 * t2, t5 = t3 * t2;  // evaluate_state_at_tau, polynomial_trajectory.py:213-216
+        double s_lon_goal = (cl0 + cl1 * T + cl2 * t2 + cl3 * t3 + cl4 * t4 + cl5 * t5) - s0;
         if (s_lon_goal <= 0) s_lon_goal = T;
         tau = s_lon_goal;
     }
@@ -163,7 +157,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
 
     if (bundle && active && part == 0) {
         FX_GLOBAL double *__restrict__ co = as_global(P.coeffs) + g;
-        co[0 * ld] = s0; co[1 * ld] = ss0; co[2 * ld] = .5 * sss0; co[3 * ld] = cl3; co[4 * ld] = cl4; co[5 * ld] = 0.0;
+        co[0 * ld] = s0; co[1 * ld] = ss0; co[2 * ld] = .5 * sss0; co[3 * ld] = cl3; co[4 * ld] = cl4; co[5 * ld] = cl5;
         co[6 * ld] = L.c0; co[7 * ld] = L.c1; co[8 * ld] = L.c2; co[9 * ld] = L.c3; co[10 * ld] = L.c4; co[11 * ld] = L.c5;
         as_global(P.traj_len)[g] = traj_len;
     }
@@ -227,7 +221,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     W.neg = A.neg; W.acc_viol = A.acc_viol; W.collided = A.collided;
     W.step_reasons = A.step_reasons; W.first_key = A.first_key; W.fail_step = A.fail_step;
     W.sum_abs_d = A.sum_abs_d; W.sum_voff = A.sum_voff; W.pred = A.pred; W.dto = 0.0; W.d_end = A.d_end; W.v_end = A.v_end;
-    W.cl3 = cl3; W.cl4 = cl4; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
+    W.cl3 = cl3; W.cl4 = cl4; W.cl5 = cl5; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
     // wave split: the exchange block sits behind the rows in dynamic LDS
     double *xch = reinterpret_cast<double *>(rows + (size_t)n_pairs_max * S);
     finish_candidate<G, BUNDLE, OBST, false, WSPLIT>(P, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D,

@@ -163,7 +163,7 @@ struct WalkResult {
     uint32_t first_key;     // !dbg: (step << 4 | reason) of the first violated check, 0xffffffff if none
     int fail_step;          // first step of this lane's chunk outside the projection domain, INT_MAX if none
     double sum_abs_d, sum_voff, pred, dto, d_end, v_end;
-    double cl3, cl4, ct3, ct4, ct5;
+    double cl3, cl4, cl5, ct3, ct4, ct5;
     Simpson sim_acc, sim_jerk, sim_orient, sim_path;
 };
 
@@ -191,7 +191,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     uint32_t step_reasons = W.step_reasons, first_key = W.first_key;
     int fail_step = W.fail_step;
     double sum_abs_d = W.sum_abs_d, sum_voff = W.sum_voff, pred = W.pred, dto = W.dto, d_end = W.d_end, v_end = W.v_end;
-    const double cl3 = W.cl3, cl4 = W.cl4, ct3 = W.ct3, ct4 = W.ct4, ct5 = W.ct5;
+    const double cl3 = W.cl3, cl4 = W.cl4, cl5 = W.cl5, ct3 = W.ct3, ct4 = W.ct4, ct5 = W.ct5;
     Simpson &sim_acc = W.sim_acc, &sim_jerk = W.sim_jerk, &sim_orient = W.sim_orient, &sim_path = W.sim_path;
 
     // ---- combine the G parts of a candidate ----
@@ -343,8 +343,8 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
                      720 * ct4 * ct5 * tt4 + 720 * ct5 * ct5 * tt5);
                 break;
             case FX_COST_LONGITUDINAL_JERK:
-                c = (36 * cl3 * cl3 * tt + 144 * cl3 * cl4 * tt2 + 240 * cl3 * 0.0 * tt3 + 192 * cl4 * cl4 * tt3 +
-                     720 * cl4 * 0.0 * tt4 + 720 * 0.0 * 0.0 * tt5);
+                c = (36 * cl3 * cl3 * tt + 144 * cl3 * cl4 * tt2 + 240 * cl3 * cl5 * tt3 + 192 * cl4 * cl4 * tt3 +
+                     720 * cl4 * cl5 * tt4 + 720 * cl5 * cl5 * tt5);
                 break;
             case FX_COST_VELOCITY_OFFSET: {
                 const double e = v_end - P.v_des;
@@ -542,22 +542,13 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     }
 
     // ---- longitudinal quartic (polynomial_trajectory.py:452-488, closed form of the 2x2 solve) ----
-    double cl0, cl1, cl2, cl3, cl4;
-    {
-        double b1 = v1 - ss0 - sss0 * T;
-        double b2 = a1 - sss0;
-        double T2 = T * T;
-        cl0 = s0;
-        cl1 = ss0;
-        cl2 = .5 * sss0;
-        cl3 = fdiv(3.0 * b1 - T * b2, 3.0 * T2);
-        cl4 = fdiv(T * b2 - 2.0 * b1, 4.0 * T2 * T);
-    }
+    double cl0 = s0, cl1 = ss0, cl2 = .5 * sss0, cl3, cl4, cl5;
+    lon_coeffs(P.has_matrix ? FX_LON_VELOCITY_KEEPING : P.lon_mode, s0, ss0, sss0, T, v1, a1, cl3, cl4, cl5);
     // ---- lateral quintic over time (high speed) or arclength (LOW_VEL_MODE), reactive_planner.py:161-171 ----
     double tau = T;
     if (low_vel) {
-        double t2 = T * T, t3 = t2 * T, t4 = t2 * t2;
-        double s_lon_goal = (cl0 + cl1 * T + cl2 * t2 + cl3 * t3 + cl4 * t4) - s0;
+        double t2 = T * T, t3 = t2 * T, t4 = t2 * t2, t5 = t3 * t2;
+        double s_lon_goal = (cl0 + cl1 * T + cl2 * t2 + cl3 * t3 + cl4 * t4 + cl5 * t5) - s0;
         if (s_lon_goal <= 0) s_lon_goal = T;
         tau = s_lon_goal;
     }
@@ -576,7 +567,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
 
     if (bundle && active && part == 0) {
         FX_GLOBAL double *__restrict__ co = as_global(P.coeffs) + g;
-        co[0 * ld] = cl0; co[1 * ld] = cl1; co[2 * ld] = cl2; co[3 * ld] = cl3; co[4 * ld] = cl4; co[5 * ld] = 0.0;
+        co[0 * ld] = cl0; co[1 * ld] = cl1; co[2 * ld] = cl2; co[3 * ld] = cl3; co[4 * ld] = cl4; co[5 * ld] = cl5;
         co[6 * ld] = L.c0; co[7 * ld] = L.c1; co[8 * ld] = L.c2; co[9 * ld] = L.c3; co[10 * ld] = L.c4; co[11 * ld] = L.c5;
         as_global(P.traj_len)[g] = traj_len;
     }
@@ -584,7 +575,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     const double rp_first = knots[0].pos, rp_last = knots[M - 1].pos;
     const double guess_scale = fdiv((double)(M - 1), rp_last - rp_first);
     auto row_at = [&](int i) {
-        return make_lon_row(i, S, M, dt, a_max, cl0, cl1, cl2, cl3, cl4, traj_len, tp, rp_first, rp_last, guess_scale,
+        return make_lon_row(i, S, M, dt, a_max, cl0, cl1, cl2, cl3, cl4, cl5, traj_len, tp, rp_first, rp_last, guess_scale,
                             [&](int k) { return knots[k]; }, [&](int k) { return knots[k].pos; });
     };
     auto lat_eval = [&](int i, double u_lowvel, double &d, double &dv, double &da) {
@@ -674,7 +665,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     W.neg = A.neg; W.acc_viol = A.acc_viol; W.collided = A.collided;
     W.step_reasons = A.step_reasons; W.first_key = A.first_key; W.fail_step = A.fail_step;
     W.sum_abs_d = A.sum_abs_d; W.sum_voff = A.sum_voff; W.pred = A.pred; W.dto = dto; W.d_end = A.d_end; W.v_end = A.v_end;
-    W.cl3 = cl3; W.cl4 = cl4; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
+    W.cl3 = cl3; W.cl4 = cl4; W.cl5 = cl5; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
     if (EXTRA) { W.sim_acc = sim_acc; W.sim_jerk = sim_jerk; W.sim_orient = sim_orient; W.sim_path = sim_path; }
     finish_candidate<G, BUNDLE, OBST, EXTRA>(P, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D, red_cost,
                                              red_idx, red_cnt, fuse);

@@ -65,19 +65,42 @@ __device__ __forceinline__ void sqrt_rsqrt(double x, double &sq, double &rsq) {
     rsq = h + h;
 }
 
+// Longitudinal polynomial c0..c5 with c0 = s0, c1 = ss0, c2 = sss0 / 2 (closed forms of the reference's LAPACK solves):
+//   FX_LON_VELOCITY_KEEPING: quartic to (x1 = end velocity, end acceleration a1)   polynomial_trajectory.py:452-488
+//   FX_LON_STOP_POINT:       quintic to (x1 = end position, 0, 0)                  :293-343, reactive_planner.py:641-643
+__device__ __forceinline__ void lon_coeffs(int lon_mode, double s0, double ss0, double sss0, double T, double x1, double a1,
+                                           double &c3, double &c4, double &c5) {
+    const double T2 = T * T;
+    if (lon_mode == FX_LON_STOP_POINT) {
+        const double T3 = T2 * T, T4 = T3 * T, T5 = T4 * T;
+        const double b0 = x1 - s0 - ss0 * T - .5 * sss0 * T2;
+        const double b1 = 0.0 - ss0 - sss0 * T;
+        const double b2 = 0.0 - sss0;
+        c3 = fdiv(10.0 * b0 - 4.0 * b1 * T + .5 * b2 * T2, T3);
+        c4 = fdiv(-15.0 * b0 + 7.0 * b1 * T - b2 * T2, T4);
+        c5 = fdiv(6.0 * b0 - 3.0 * b1 * T + .5 * b2 * T2, T5);
+    } else {
+        const double b1 = x1 - ss0 - sss0 * T, b2 = a1 - sss0;
+        c3 = fdiv(3.0 * b1 - T * b2, 3.0 * T2);
+        c4 = fdiv(T * b2 - 2.0 * b1, 4.0 * T2 * T);
+        c5 = 0.0;
+    }
+}
+
 // Longitudinal quantities of (T, v1) at step i: quartic sample or horizon extension (reactive_planner.py:313-322),
 // validity / pre-filter predicates (:350-355,375), reference-segment lookup with Python's negative-index wrap
 // (:415-420), interpolate_angle (utils_coordinate_system.py:137-155), reference curvature (:457-460) and the
 // projection foot point + unit normal.  `knot(k)` returns knot k, `kpos(k)` its arclength.
 template <typename KnotFn, typename PosFn>
 __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, double a_max, double cl0, double cl1, double cl2,
-                                               double cl3, double cl4, int traj_len, const double *tp, double rp_first,
+                                               double cl3, double cl4, double cl5, int traj_len, const double *tp, double rp_first,
                                                double rp_last, double guess_scale, KnotFn knot, PosFn kpos) {
     const int ie = i < traj_len ? i : traj_len - 1;  // sample that is evaluated (the last one feeds the extension)
-    const double t1 = tp[ie], t2 = tp[S + ie], t3 = tp[2 * S + ie], t4 = tp[3 * S + ie];
-    double s_i = cl0 + cl1 * t1 + cl2 * t2 + cl3 * t3 + cl4 * t4;
-    double sv_i = cl1 + 2. * cl2 * t1 + 3. * cl3 * t2 + 4. * cl4 * t3;
-    double sa_i = 2 * cl2 + 6 * cl3 * t1 + 12 * cl4 * t2;
+    const double t1 = tp[ie], t2 = tp[S + ie], t3 = tp[2 * S + ie], t4 = tp[3 * S + ie], t5 = tp[4 * S + ie];
+    // calc_position / calc_velocity / calc_acceleration (polynomial_trajectory.py:241-273); c5 = 0 for the quartic
+    double s_i = cl0 + cl1 * t1 + cl2 * t2 + cl3 * t3 + cl4 * t4 + cl5 * t5;
+    double sv_i = cl1 + 2. * cl2 * t1 + 3. * cl3 * t2 + 4. * cl4 * t3 + 5. * cl5 * t4;
+    double sa_i = 2 * cl2 + 6 * cl3 * t1 + 12 * cl4 * t2 + 20 * cl5 * t3;
     if (i >= traj_len) {  // s[i] = s[i-1] + dt * s_dot_end, one rounding per step as in the reference loop
         for (int j = traj_len; j <= i; j++) s_i = s_i + dt * sv_i;
         sa_i = 0.0;

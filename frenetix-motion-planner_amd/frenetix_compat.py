@@ -19,8 +19,9 @@ The reference's C++ back-end adapter (frenetix_motion_planner/reactive_planner_c
 Semantics: SURVEY.md 3.5 -- the *evaluation* follows the reference's Python path (validity, pre-filter, five
 kinematic checks with the hard-coded 0.4 curvature-rate limit, NumPy cost definitions, inverse-Mahalanobis
 `prediction` cost); the functor objects only carry parameters (vehicle limits, weights, v_des, predictions).
-`generate_stopping_trajectories` raises ValueError, which the adapter already handles by falling back to
-regular sampling (:336-341).
+`generate_stopping_trajectories` builds the Python back-end's stop-point set (reactive_planner.py:628-671; the
+upstream C++ sampler is not in the reference tree) and raises ValueError for a stop point behind the ego, which
+the adapter handles by falling back to regular sampling (:336-341).
 """
 import logging
 import sys
@@ -177,6 +178,7 @@ class TrajectoryHandler:
         self._costs: Dict[str, _Cost] = {}
         self._fill: Optional[FillCoordinates] = None
         self._matrix = None
+        self._stop = None
         self._low_vel = False
         self._step: Optional[PlanStepResult] = None
         self.draw_traj_set = True      # get_sorted_trajectories() returns feasible and infeasible ones (:353-358)
@@ -205,16 +207,47 @@ class TrajectoryHandler:
     def reset_Trajectories(self):
         if self._step is not None:
             self._step.invalidate()
-        self._matrix, self._step = None, None
+        self._matrix, self._step, self._stop = None, None, None
 
     def generate_trajectories(self, sampling_matrix, low_vel_mode: bool):
         m = np.ascontiguousarray(sampling_matrix, dtype=np.float64)
         if m.ndim != 2 or m.shape[1] != 13:
             raise ValueError("sampling matrix must be C x 13")
-        self._matrix, self._low_vel = m, bool(low_vel_mode)
+        self._matrix, self._low_vel, self._stop = m, bool(low_vel_mode), None
 
-    def generate_stopping_trajectories(self, *a, **k):
-        raise ValueError("stop-point sampling is not part of this engine; use regular sampling")
+    def generate_stopping_trajectories(self, planner_state, sampling_config, stop_point_s, v_stop=0.0,
+                                       low_vel_mode: bool = False):
+        """Stop-point candidates (reactive_planner_cpp.py:258-290).  The upstream C++ sampler behind this call is not
+        in the reference tree; the set built here is the Python back-end's (reactive_planner.py:628-671): end times
+        TimeSampling(t_min, min(t_max, horizon)), end positions LongitudinalPositionSampling((s0 + s_stop) / 2,
+        s_stop), lateral end states LateralPositionSampling(d0 -+ d_delta) u {d0}, longitudinal quintic to (s, 0, 0).
+        Raises ValueError for a stop point behind the ego, as upstream does (:263-264) -- the adapter then falls back
+        to regular sampling (:336-341)."""
+        from .sampling import LateralPositionSampling, LongitudinalPositionSampling, TimeSampling
+        if planner_state is None or sampling_config is None or getattr(planner_state, "x_cl", None) is None:
+            raise ValueError("generate_stopping_trajectories: planner state / sampling configuration missing")
+        x0_lon = np.asarray(planner_state.x_cl.x0_lon, dtype=np.float64)
+        x0_lat = np.asarray(planner_state.x_cl.x0_lat, dtype=np.float64)
+        if stop_point_s is None or stop_point_s < x0_lon[0]:
+            raise ValueError("stop point behind current longitudinal position")
+        if self._fill is None:
+            raise RuntimeError("FillCoordinates must be registered (add_function) before sampling")
+        cfg = sampling_config
+        horizon = float(self._fill.horizon) if float(self._fill.horizon) < 1000 else float(self._fill.horizon) * self.dt
+        level = max(0, min(int(getattr(cfg, "sampling_level", 2)), int(round(1.0 / self.dt)) - 1))  # TimeSampling step >= dt
+        t_min = max(float(getattr(cfg, "t_min", 1.1)), self.dt)
+        t_max = min(float(getattr(cfg, "t_max", horizon)), horizon)
+        if t_max < t_min:
+            raise ValueError("empty end-time range")
+        d_delta = float(getattr(cfg, "d_delta", 0.4))
+        n = level + 1
+        t = TimeSampling(t_min, t_max, n, self.dt).ordered(level)
+        sv = LongitudinalPositionSampling((x0_lon[0] + stop_point_s) / 2, float(stop_point_s), n).ordered(level)
+        d = LateralPositionSampling(x0_lat[0] - d_delta, x0_lat[0] + d_delta, n).ordered(level, float(x0_lat[0]))
+        if len(t) == 0:
+            raise ValueError("empty end-time range")
+        self._stop = dict(t=t, s=sv, d=d, x0_lon=x0_lon, x0_lat=x0_lat)
+        self._matrix, self._low_vel = None, bool(low_vel_mode)
 
     def _vehicle(self) -> VehicleParams:
         v = VehicleParams()
@@ -244,7 +277,7 @@ class TrajectoryHandler:
         return out
 
     def _evaluate(self):
-        if self._matrix is None:
+        if self._matrix is None and self._stop is None:
             raise RuntimeError("generate_trajectories() must be called before evaluation")
         if self._fill is None:
             raise RuntimeError("FillCoordinates must be registered (add_function) before evaluation")
@@ -254,10 +287,16 @@ class TrajectoryHandler:
         dto = self._costs.get("distance_to_obstacles")
         N = int(round(float(self._fill.horizon) / self.dt)) if float(self._fill.horizon) < 1000 else int(self._fill.horizon)
         preds = self._predictions()
+        if self._stop is not None:
+            st = self._stop
+            sampling = dict(x0_lon=st["x0_lon"], x0_lat=st["x0_lat"], t_samp=st["t"], v_samp=st["s"], d_samp=st["d"],
+                            stop_point=True)
+        else:
+            sampling = dict(x0_lon=self._matrix[0, 2:5], x0_lat=self._matrix[0, 7:10], sampling_matrix=self._matrix)
         inputs = PlanInputs(
-            N=N, dt=self.dt, low_vel_mode=self._low_vel, x0_lon=self._matrix[0, 2:5], x0_lat=self._matrix[0, 7:10],
+            N=N, dt=self.dt, low_vel_mode=self._low_vel,
             x0_orientation=self._fill.initialOrientation, v_des=vo.desired_velocity if vo is not None else 0.0,
-            vehicle=self._vehicle(), coordinate_system=self._fill.coordinateSystem, sampling_matrix=self._matrix,
+            vehicle=self._vehicle(), coordinate_system=self._fill.coordinateSystem, **sampling,
             cost_weights=weights, draw_traj_set=self.draw_traj_set, kinematic_debug=self.kinematic_debug,
             obstacles=pack_predictions(preds, N + 1, build_obstacle_hulls),
             dto_pos=dto.obstacle_positions if dto is not None else None)

@@ -107,6 +107,9 @@ class PlanInputs:
     v_samp: Optional[np.ndarray] = None
     d_samp: Optional[np.ndarray] = None
     sampling_matrix: Optional[np.ndarray] = None
+    # stop-point sampling (reactive_planner.py:628-671): v_samp then holds the sampled END POSITIONS s and the
+    # longitudinal polynomial is the quintic to (s, 0, 0)
+    stop_point: bool = False
     cost_weights: Dict[str, float] = field(default_factory=lambda: dict(DEFAULT_COST_WEIGHTS))
     draw_traj_set: bool = False
     kinematic_debug: bool = False
@@ -132,6 +135,8 @@ class PlanInputs:
             self.sampling_matrix = _f64(self.sampling_matrix)
             if self.sampling_matrix.ndim != 2 or self.sampling_matrix.shape[1] != 13:
                 raise ValueError("sampling_matrix must be C x 13")
+            if self.stop_point:
+                raise ValueError("stop-point sampling takes ranges (the C x 13 matrix has no end-position column)")
         else:
             if self.t_samp is None or self.v_samp is None or self.d_samp is None:
                 raise ValueError("either sampling_matrix or t_samp/v_samp/d_samp are required")
@@ -188,12 +193,15 @@ class PlanInputs:
             return self.sampling_matrix[g].copy()
         nD, nV = len(self.d_samp), len(self.v_samp)
         i_d, i_v, i_t = g % nD, (g // nD) % nV, g // (nD * nV)
+        if self.stop_point:  # end state (s1, 0, 0): end velocity and acceleration are 0; s1 = v_samp[i_v]
+            return np.array([0.0, self.t_samp[i_t], *self.x0_lon, 0.0, 0.0, *self.x0_lat, self.d_samp[i_d], 0.0, 0.0])
         return np.array([0.0, self.t_samp[i_t], *self.x0_lon, self.v_samp[i_v], 0.0, *self.x0_lat,
                          self.d_samp[i_d], 0.0, 0.0])
 
     def as_struct(self) -> _abi.FxProblem:
         p = _abi.FxProblem()
         p.N, p.dt, p.mode, p.low_vel_mode = self.N, self.dt, self.mode, int(bool(self.low_vel_mode))
+        p.lon_mode = _abi.FX_LON_STOP_POINT if self.stop_point else _abi.FX_LON_VELOCITY_KEEPING
         p.x0_lon = (C.c_double * 3)(*self.x0_lon)
         p.x0_lat = (C.c_double * 3)(*self.x0_lat)
         p.x0_orientation, p.v_des = float(self.x0_orientation), float(self.v_des)

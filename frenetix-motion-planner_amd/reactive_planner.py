@@ -216,10 +216,14 @@ class ReactivePlannerHip:
         return [float(s), float(s_velocity), float(s_acceleration)], [float(d), float(d_velocity), float(d_acceleration)]
 
     # ------------------------------------------------------------------ plan (reactive_planner.py:67-130)
-    def _inputs_for_level(self, samp_level: int) -> PlanInputs:
+    def _inputs_for_level(self, samp_level: int, stop_point_s: Optional[float] = None) -> PlanInputs:
         from .engine import build_obstacle_hulls
         x_lon, x_lat = self.x_cl
         t, v, d = self.sampling_handler.ordered_ranges(samp_level, x_lat[0])
+        if stop_point_s is not None:
+            # stop-point sampling: end positions in [(s0 + s_stop) / 2, s_stop] (reactive_planner.py:637-643)
+            self.sampling_handler.set_s_sampling((x_lon[0] + stop_point_s) / 2, stop_point_s)
+            v = self.sampling_handler.s_sampling.ordered(samp_level)
         if self._packed_predictions is None:
             self._packed_predictions = pack_predictions(self.predictions if self.use_prediction else None, self.N + 1,
                                                         build_obstacle_hulls)
@@ -229,20 +233,38 @@ class ReactivePlannerHip:
             pass
         return PlanInputs(N=self.N, dt=self.dT, low_vel_mode=self._LOW_VEL_MODE, x0_lon=x_lon, x0_lat=x_lat,
                           x0_orientation=self.x_0.orientation, v_des=self.desired_velocity, vehicle=self.vehicle_params,
-                          coordinate_system=self.coordinate_system, t_samp=t, v_samp=v, d_samp=d, cost_weights=weights,
+                          coordinate_system=self.coordinate_system, t_samp=t, v_samp=v, d_samp=d,
+                          stop_point=stop_point_s is not None, cost_weights=weights,
                           draw_traj_set=self._draw_traj_set, kinematic_debug=self._kinematic_debug, write_bundle=True,
                           write_costmap=True, collision=self.use_prediction, obstacles=self._packed_predictions)
 
-    def plan(self):
+    def _create_end_point_trajectory_bundle(self, x_0_lon, x_0_lat, stop_point_s, samp_level: int) -> PlanInputs:
+        """Stop-point sampling set of reactive_planner.py:628-671 as engine inputs: T x S x (D u {d0}) with the
+        longitudinal quintic to (s, 0, 0), s in LongitudinalPositionSampling((s0 + s_stop) / 2, s_stop)."""
+        saved = self.x_cl
+        self.x_cl = (list(x_0_lon), list(x_0_lat))
+        try:
+            return self._inputs_for_level(samp_level, stop_point_s=float(stop_point_s))
+        finally:
+            self.x_cl = saved
+
+    def plan(self, stop_point_s: Optional[float] = None):
+        """One plan step.  stop_point_s: arc length of a stop point ahead of the ego -> the candidates are the
+        stop-point set (the reference's C++ back-end switches to it when the behaviour planner supplies a stop point
+        with v < 10 m/s, reactive_planner_cpp.py:332-341; a stop point behind the ego raises ValueError there and
+        falls back to regular sampling, which is what happens here too)."""
         if self.x_cl is None:
             raise RuntimeError("x_cl should have been set prior to plan()")  # reactive_planner_cpp.py:308-309
         if self.desired_velocity is None:
             raise RuntimeError("desired velocity not set (update_externals(desired_velocity=...))")
+        if stop_point_s is not None and stop_point_s < self.x_cl[0][0]:
+            self.msg_logger.info("stop point behind current longitudinal position, falling back to regular planning")
+            stop_point_s = None  # reactive_planner_cpp.py:263-264,336-341
         optimal_trajectory = None
         t0 = time.time()
         samp_level = self._sampling_min
         while optimal_trajectory is None and samp_level < self._sampling_max:
-            optimal_trajectory = self._get_optimal_trajectory(self._inputs_for_level(samp_level), samp_level)
+            optimal_trajectory = self._get_optimal_trajectory(self._inputs_for_level(samp_level, stop_point_s), samp_level)
             samp_level += 1
         self.planning_time = time.time() - t0
 

@@ -76,11 +76,13 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
                 s_knot=40, s_off=0.1, horizon=3.0, dt=0.1, level=None, grid=None, cpp_style=False, v_des=12.0,
                 n_obstacles=0, n_pred=30, cost_weights=None, draw_traj_set=False, kinematic_debug=False,
                 write_bundle=True, write_costmap=True, collision=True, low_vel_threshold=2.0, hull_builder=None,
-                seed=SEED, vehicle=None, x0_orientation=None, as_matrix=False):
+                seed=SEED, vehicle=None, x0_orientation=None, as_matrix=False, stop_point_s=None):
     """One agent's PlanInputs on a synthetic reference.
 
     level: reference sampling level (set-ordered ranges, SamplingHandler) -- or
-    grid=(n_t, n_v, n_d): dense grid (BASELINE configs 2/3/5)."""
+    grid=(n_t, n_v, n_d): dense grid (BASELINE configs 2/3/5).
+    stop_point_s: distance ahead of s0 of a stop point -> stop-point sampling (end positions in
+    [(s0 + s_stop) / 2, s_stop], reactive_planner.py:637) instead of end velocities."""
     veh = vehicle or VehicleParams()
     cs = CoordinateSystem(reference_polyline(ref_kind, n_knots, spacing, kappa))
     N = int(horizon / dt)
@@ -93,6 +95,13 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
                              delta_d_min=-3.0, delta_d_max=3.0, d_ego_pos=False)
         sh.set_v_sampling(*v_sampling_bounds(v0, veh.a_max, horizon, veh.v_max))
         t, v, d = sh.ordered_ranges(level if level is not None else 2, d0, cpp_style=cpp_style, ss0=v0, t_full=N * dt)
+    if stop_point_s is not None:
+        s_stop = s0 + float(stop_point_s)
+        if grid is not None:
+            v = np.linspace((s0 + s_stop) / 2, s_stop, grid[1])
+        else:
+            sh.set_s_sampling((s0 + s_stop) / 2, s_stop)
+            v = sh.s_sampling.ordered(level if level is not None else 2)
     seg = cs.segment_of(s0)
     if x0_orientation is None:
         x0_orientation = float(cs.ref_theta[seg])
@@ -113,6 +122,6 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
                                      dd1_range=0.0, ddd1_range=0.0)
         inp = PlanInputs(sampling_matrix=m, **kw)
     else:
-        inp = PlanInputs(t_samp=t, v_samp=v, d_samp=d, **kw)
+        inp = PlanInputs(t_samp=t, v_samp=v, d_samp=d, stop_point=stop_point_s is not None, **kw)
     inp.predictions = preds
     return inp

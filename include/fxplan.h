@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 1
+#define FX_ABI_VERSION 2
 
 /* ---- status codes (planner.py / reactive_planner_cpp.py raise Python exceptions; the shim maps
  *      <0 -> ValueError, >0 -> RuntimeError, see SURVEY 8b "Error conventions") ---- */
@@ -79,6 +79,15 @@ enum {
 #define FX_MODE_WRITE_COSTMAP   (1u << 3)  /* keep the per-name raw costs (TrajectorySample.costMap) */
 #define FX_MODE_COLLISION       (1u << 4)  /* run the OBB collision stage (planner.use_prediction) */
 
+/* longitudinal sampling mode.
+ * FX_LON_VELOCITY_KEEPING: v_samp = sampled end velocities, quartic to (v, 0) -- _create_trajectory_bundle,
+ *   reactive_planner.py:132-182.
+ * FX_LON_STOP_POINT: v_samp = sampled end POSITIONS s, quintic to (s, 0, 0) -- stop-point sampling,
+ *   _create_end_point_trajectory_bundle, reactive_planner.py:628-671 (cpp: generate_stopping_trajectories,
+ *   reactive_planner_cpp.py:258-290).  Ranges only (the C x 13 matrix has no end-position column). */
+#define FX_LON_VELOCITY_KEEPING 0
+#define FX_LON_STOP_POINT 1
+
 /* vehicle parameters: configuration.py:58-83 (VehicleConfiguration); kappa_max is
  * tan(delta_max)/wheelbase as computed at reactive_planner.py:492 (host computes it once). */
 typedef struct FxVehicle {
@@ -93,6 +102,7 @@ typedef struct FxProblem {
     double dt;
     uint32_t mode;          /* FX_MODE_* */
     int32_t low_vel_mode;   /* planner.py:222-230 */
+    int32_t lon_mode;       /* FX_LON_*: what the longitudinal samples (v_samp) are */
     double x0_lon[3];       /* x_cl[0] = [s, s_dot, s_ddot]   planner.py:567-635 */
     double x0_lat[3];       /* x_cl[1] = [d, d_dot, d_ddot] */
     double x0_orientation;  /* x_0.orientation, used at reactive_planner.py:447 */
@@ -105,7 +115,8 @@ typedef struct FxProblem {
     const double *tpow;
 
     /* sampling: ordered ranges in *iteration order* (sampling_matrix.py:141-195; CPython set
-     * order, reactive_planner.py:149-158).  Candidate g = (it*nV + iv)*nD + id. */
+     * order, reactive_planner.py:149-158).  Candidate g = (it*nV + iv)*nD + id.
+     * v_samp holds end velocities or, with FX_LON_STOP_POINT, end positions (:641-643). */
     int32_t nT, nV, nD;
     const double *t_samp, *v_samp, *d_samp;
     /* ...or an explicit C x 13 matrix (sampling_matrix.py:85-121, reactive_planner_cpp.py:228-253)

@@ -313,8 +313,10 @@ static uint32_t eval_candidate(const FxProblem *p, int64_t g, Cand *cd, double *
     double T, lon0[3], v1, a1, lat0[3], lat1[3];
     candidate_params(p, g, &T, lon0, &v1, &a1, lat0, lat1);
 
-    /* reactive_planner.py:154 */
-    quartic_coeffs(lon0[0], lon0[1], lon0[2], T, v1, a1, cd->cl);
+    if (p->lon_mode == FX_LON_STOP_POINT) /* stop-point sampling: quintic to (s, 0, 0), reactive_planner.py:641-643 */
+        quintic_coeffs(lon0[0], lon0[1], lon0[2], v1, 0.0, 0.0, T, cd->cl);
+    else /* reactive_planner.py:154 */
+        quartic_coeffs(lon0[0], lon0[1], lon0[2], T, v1, a1, cd->cl);
     /* :161-171 */
     double tau = T;
     if (p->low_vel_mode) {
@@ -440,7 +442,9 @@ static uint32_t eval_candidate(const FxProblem *p, int64_t g, Cand *cd, double *
         double yr5 = fabs(np_round5(yaw_rate));
         /* the 5-decimal rounding moves the value by up to 5e-6: near the limit the rint tie matters too */
         if (fabs(yr5 - theta_dot_max) < 2e-5) MARGIN((fabs(fabs(yaw_rate * 1e5) - floor(fabs(yaw_rate * 1e5)) - 0.5)) * 1e-5);
-        if (!(i == 0 && theta_dot_max == 0.0)) MARGIN(yr5 - theta_dot_max); /* 0 > 0 at standstill is exact, not noise */
+        /* 0 > 0 is exact, not noise: wherever the clamped velocity is exactly 0 the limit kappa_max * 0 is exactly 0,
+         * and a yaw rate that rounds to 0.00000 stays there under perturbation (its rint tie is tracked above) */
+        if (!(theta_dot_max == 0.0 && yr5 == 0.0)) MARGIN(yr5 - theta_dot_max);
         if (yr5 > theta_dot_max) { reasons |= 1u << 6; if (!D && !KD) break; }
         double kd = i > 0 ? (kappa_gl[i] - kappa_gl[i - 1]) / dt : 0.;
         MARGIN(fabs(kd) - 0.4);

@@ -39,6 +39,7 @@ def inputs_from_fixture(fx, hull_builder, **override):
                 vehicle=VehicleParams(), coordinate_system=cs, t_samp=fx["t_order"], v_samp=fx["v_order"],
                 d_samp=fx["d_order"], cost_weights=weights, draw_traj_set=bool(kw.get("draw_traj_set", False)),
                 kinematic_debug=bool(kw.get("kinematic_debug", False)),
+                stop_point=kw.get("stop_point_s") is not None,
                 obstacles=pack_predictions(preds, N + 1, hull_builder),
                 dto_pos=fx["dto_pos"] if len(fx["dto_pos"]) else None)
     args.update(override)

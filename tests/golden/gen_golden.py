@@ -59,6 +59,14 @@ SCENARIOS = {
                                      v_des=5.0), 1),
     "arc_slow_brake_l1_prod": (dict(ref_kind="arc", v0=3.0, a0=-6.0, level=1, v_des=5.0), 1),
     "arc_slow_brake_l1_kd": (dict(ref_kind="arc", v0=3.0, a0=-6.0, level=1, kinematic_debug=True, v_des=5.0), 1),
+    # stop-point sampling (_create_end_point_trajectory_bundle, reactive_planner.py:628-671): quintic to (s, 0, 0)
+    "arc_stop_l1_debug": (dict(ref_kind="arc", v0=6.0, level=1, stop_point_s=25.0, v_des=0.0, draw_traj_set=True,
+                               kinematic_debug=True), 1),
+    "arc_stop_l1_prod": (dict(ref_kind="arc", v0=6.0, level=1, stop_point_s=25.0, v_des=0.0), 1),
+    "arc_stop_lv_l1_debug": (dict(ref_kind="arc", v0=1.5, level=1, stop_point_s=6.0, v_des=0.0, draw_traj_set=True,
+                                  kinematic_debug=True), 1),
+    "scurve_stop_l2_kd_obs2": (dict(ref_kind="scurve", kappa=0.02, v0=8.0, level=2, stop_point_s=30.0, v_des=0.0,
+                                    n_obstacles=2, kinematic_debug=True), 7),
 }
 
 
@@ -90,6 +98,8 @@ def to_reference_problem(inp, kw):
     from frenetix_motion_planner_amd.sampling import v_sampling_bounds
     prob["v_min"], prob["v_max"] = v_sampling_bounds(float(inp.x0_lon[1]), veh.a_max, kw.get("horizon", 3.0), veh.v_max)
     prob["horizon"] = kw.get("horizon", 3.0)
+    if kw.get("stop_point_s") is not None:
+        prob["stop_point_s"] = float(inp.x0_lon[0]) + float(kw["stop_point_s"])
     if inp.predictions and "distance_to_obstacles" in inp.cost_weights:
         prob["scenario_obstacles"] = [_Obstacle(p["pos_list"][0]) for p in inp.predictions.values()]
     return prob
@@ -98,7 +108,13 @@ def to_reference_problem(inp, kw):
 def main():
     ref_harness.install()
     index = {}
+    only = set(sys.argv[1:])  # optional: regenerate only the named scenarios
+    index_path = os.path.join(HERE, "INDEX.json")
+    if only and os.path.exists(index_path):
+        index = json.load(open(index_path))
     for name, (kw, stride) in SCENARIOS.items():
+        if only and name not in only:
+            continue
         inp = synthetic.make_inputs(**kw)
         prob = to_reference_problem(inp, kw)
         out = ref_harness.run_reference(prob)

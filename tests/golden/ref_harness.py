@@ -271,10 +271,15 @@ def run_reference(prob):
     level = rp._sampling_min
     S = rp.N + 1
     t_order = np.array(list(rp.sampling_handler.t_sampling.to_range(level)), dtype=np.float64)
-    v_order = np.array(list(rp.sampling_handler.v_sampling.to_range(level)), dtype=np.float64)
     d_order = np.array(list(rp.sampling_handler.d_sampling.to_range(level).union({rp.x_cl[1][0]})), dtype=np.float64)
-
-    bundle = rp._create_trajectory_bundle(rp.x_cl[0], rp.x_cl[1], rp.cost_function, samp_level=level)
+    if prob.get("stop_point_s") is not None:
+        # stop-point sampling (reactive_planner.py:628-671): the longitudinal samples are end positions
+        bundle = rp._create_end_point_trajectory_bundle(rp.x_cl[0], rp.x_cl[1], prob["stop_point_s"], rp.cost_function,
+                                                        level)
+        v_order = np.array(list(rp.sampling_handler.s_sampling.to_range(level)), dtype=np.float64)
+    else:
+        v_order = np.array(list(rp.sampling_handler.v_sampling.to_range(level)), dtype=np.float64)
+        bundle = rp._create_trajectory_bundle(rp.x_cl[0], rp.x_cl[1], rp.cost_function, samp_level=level)
     trajs = list(bundle.trajectories)
     C = len(trajs)
     assert C == len(t_order) * len(v_order) * len(d_order), (C, len(t_order), len(v_order), len(d_order))

@@ -139,6 +139,12 @@ CASES = {
     "ragged_tail": dict(ref_kind="arc", v0=10.0, grid=(3, 7, 13), n_obstacles=2),  # C not a multiple of 64
     "single_candidate": dict(ref_kind="arc", v0=10.0, grid=(1, 1, 1), d0=0.0),
     "no_costs": dict(ref_kind="arc", v0=10.0, grid=(3, 5, 5), cost_weights={}),
+    # stop-point sampling: end positions instead of end velocities, longitudinal quintic (reactive_planner.py:628-671)
+    "stop_dense_obs": dict(ref_kind="arc", v0=7.0, grid=(9, 21, 21), stop_point_s=30.0, v_des=0.0, n_obstacles=4),
+    "stop_lowvel_debug": dict(ref_kind="arc", v0=1.5, grid=(6, 11, 13), stop_point_s=6.0, v_des=0.0, draw_traj_set=True,
+                              kinematic_debug=True),
+    "stop_scurve_kd": dict(ref_kind="scurve", kappa=0.02, v0=9.0, grid=(7, 15, 17), stop_point_s=35.0, v_des=0.0,
+                           kinematic_debug=True, seed=5),
 }
 
 
@@ -160,7 +166,7 @@ def test_synthetic_cases_vs_oracle(eng, name):
 @pytest.mark.parametrize("lanes", [1, 2, 4, 8])
 @pytest.mark.parametrize("wpe", [2, 3, 4])
 @pytest.mark.parametrize("name", ["dense_debug_obs", "dense_prod_obs", "dense_lowvel", "dense_horizon5", "ragged_tail",
-                                  "single_candidate"])
+                                  "single_candidate", "stop_dense_obs", "stop_lowvel_debug"])
 def test_work_decomposition_does_not_change_results(eng, name, lanes, wpe, variant):
     """Every (kernel variant, lanes per candidate, occupancy target) specialisation against the oracle."""
     from oracle import oracle
@@ -246,8 +252,10 @@ def test_split_horizon_on_golden_cases(eng, name, lanes, variant):
         eng.set_tuning(0, 0, 0)
 
 
-def test_generic_and_grid_kernels_agree_bitwise(eng):
-    kw = dict(ref_kind="scurve", kappa=0.02, v0=9.0, grid=(7, 9, 33), n_obstacles=6, draw_traj_set=True, kinematic_debug=True)
+@pytest.mark.parametrize("stop", [None, 28.0])
+def test_generic_and_grid_kernels_agree_bitwise(eng, stop):
+    kw = dict(ref_kind="scurve", kappa=0.02, v0=9.0, grid=(7, 9, 33), n_obstacles=6, draw_traj_set=True, kinematic_debug=True,
+              stop_point_s=stop)
     inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
     outs = []
     try:
@@ -341,6 +349,21 @@ def test_fused_selection_batch(eng):
         for a in range(len(inps)):
             for k in RESULT_KEYS:
                 assert got[a][k] == ref[a][k], (a, k)
+
+
+def test_stop_point_sampling_rejects_a_matrix(eng):
+    inp = synthetic.make_inputs(ref_kind="arc", v0=7.0, grid=(3, 5, 5), as_matrix=True)
+    with pytest.raises(ValueError):
+        inp.stop_point = True
+        inp.__post_init__()
+    st = inp.as_struct()
+    st.lon_mode = _abi.FX_LON_STOP_POINT
+    arr = (_abi.FxProblem * 1)(st)
+    from frenetix_motion_planner_amd._lib import lib
+    assert lib().fx_upload_batch(eng._ctx, 1, arr) < 0  # FX_ERR_INVALID_ARGUMENT
+    st.lon_mode = 7
+    arr = (_abi.FxProblem * 1)(st)
+    assert lib().fx_upload_batch(eng._ctx, 1, arr) < 0
 
 
 def test_topk_is_sorted_prefix(eng):

@@ -179,3 +179,24 @@ def test_shard_arithmetic_and_merge():
     bc, bi, order = merge_survivors(c, i)
     assert (bc, bi) == (2.5, 99) and list(order) == [99, 12, 40, 7, 100]
     assert merge_survivors(np.zeros(2), np.array([-1, -1]))[1] == -1
+
+
+def test_stop_point_inputs():
+    """Stop-point sampling set as the reference builds it (reactive_planner.py:637-643): end positions are
+    LongitudinalPositionSampling((s0 + s_stop) / 2, s_stop) in set order; the matrix form is rejected."""
+    from frenetix_motion_planner_amd.sampling import LongitudinalPositionSampling
+    inp = synthetic.make_inputs(ref_kind="arc", v0=6.0, level=2, stop_point_s=25.0, v_des=0.0)
+    s0 = float(inp.x0_lon[0])
+    assert inp.stop_point and inp.as_struct().lon_mode == _abi.FX_LON_STOP_POINT
+    assert np.array_equal(inp.v_samp, LongitudinalPositionSampling(s0 + 12.5, s0 + 25.0, 3).ordered(2))
+    assert len(inp.v_samp) == 9 and inp.n_candidates == 7 * 9 * 10  # T x S x (D u {d0})
+    row = inp.candidate_params(5)
+    assert row[5] == 0.0 and row[6] == 0.0  # end velocity / acceleration of a stop-point candidate
+    with pytest.raises(ValueError):
+        PlanInputs(sampling_matrix=np.zeros((4, 13)), **_plan_kwargs(inp))
+
+
+def _plan_kwargs(inp):
+    return dict(N=inp.N, dt=inp.dt, low_vel_mode=inp.low_vel_mode, x0_lon=inp.x0_lon, x0_lat=inp.x0_lat,
+                x0_orientation=inp.x0_orientation, v_des=inp.v_des, vehicle=inp.vehicle,
+                coordinate_system=inp.coordinate_system, stop_point=True)
