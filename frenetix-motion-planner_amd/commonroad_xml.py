@@ -1,0 +1,322 @@
+"""CommonRoad (2020a) scenario reader on the standard library's XML parser.
+
+The reference reads scenarios with commonroad-io (`CommonRoadFileReader(path).open()`,
+cr_scenario_handler/utils/general.py) and turns them into planner inputs with commonroad-route-planner and its own
+helpers.  This module covers the part of that the hot path needs, with no third-party dependency:
+
+    read_scenario(path)                      -> Scenario (lanelets, obstacles, planning problems, dt)
+    Scenario.route_reference_path(pp)        -> centre-line polyline from the initial lanelet to the goal lanelet
+                                                (successor-graph BFS; stands in for commonroad-route-planner, which is
+                                                not in the reference tree)
+    Scenario.ground_truth_predictions(...)   -> the predictions dict of prediction_helpers.get_ground_truth_prediction
+                                                (:209-261): pos_list / cov_list / orientation_list / v_list / shape
+    PlanningProblem.initial_planner_state()  -> ReactivePlannerState for ReactivePlannerHip.update_externals
+
+Only what the example scenarios (ZAM_Tjunction-*) use is interpreted: rectangle / circle obstacle shapes, `exact`
+state values (interval values take their midpoint), lanelet bounds and topology, goal position by lanelet reference
+or rectangle.  Traffic signs, lights and intersections are skipped.
+"""
+import xml.etree.ElementTree as ET
+from collections import deque
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+
+@dataclass
+class State:
+    time_step: int
+    position: np.ndarray
+    orientation: float = 0.0
+    velocity: float = 0.0
+    acceleration: float = 0.0
+    yaw_rate: float = 0.0
+    slip_angle: float = 0.0
+
+
+@dataclass
+class Lanelet:
+    lanelet_id: int
+    left_vertices: np.ndarray
+    right_vertices: np.ndarray
+    predecessor: List[int] = field(default_factory=list)
+    successor: List[int] = field(default_factory=list)
+    adj_left: Optional[int] = None
+    adj_left_same_direction: Optional[bool] = None
+    adj_right: Optional[int] = None
+    adj_right_same_direction: Optional[bool] = None
+    lanelet_type: List[str] = field(default_factory=list)
+
+    @property
+    def center_vertices(self) -> np.ndarray:
+        return 0.5 * (self.left_vertices + self.right_vertices)
+
+    def contains(self, p) -> bool:
+        """Point-in-polygon (ray casting) on the lanelet's outline."""
+        poly = np.vstack([self.left_vertices, self.right_vertices[::-1]])
+        x, y = float(p[0]), float(p[1])
+        inside = False
+        j = len(poly) - 1
+        for i in range(len(poly)):
+            xi, yi, xj, yj = poly[i, 0], poly[i, 1], poly[j, 0], poly[j, 1]
+            if (yi > y) != (yj > y) and x < (xj - xi) * (y - yi) / (yj - yi) + xi:
+                inside = not inside
+            j = i
+        return inside
+
+
+@dataclass
+class Obstacle:
+    obstacle_id: int
+    role: str                     # "dynamic" | "static"
+    obstacle_type: str
+    shape: dict                   # {"length", "width"} (rectangle) or {"radius"} (circle)
+    initial_state: State
+    state_list: List[State] = field(default_factory=list)  # trajectory states, first one at initial time + 1
+
+    @property
+    def length(self) -> float:
+        return float(self.shape.get("length", 2 * self.shape.get("radius", 0.0)))
+
+    @property
+    def width(self) -> float:
+        return float(self.shape.get("width", 2 * self.shape.get("radius", 0.0)))
+
+    def state_at_time(self, time_step: int) -> Optional[State]:
+        t0 = self.initial_state.time_step
+        if time_step == t0:
+            return self.initial_state
+        if self.role != "dynamic":
+            return self.initial_state if time_step >= t0 else None
+        k = time_step - t0 - 1
+        return self.state_list[k] if 0 <= k < len(self.state_list) else None
+
+
+@dataclass
+class GoalState:
+    time_interval: Optional[tuple] = None
+    velocity_interval: Optional[tuple] = None
+    orientation_interval: Optional[tuple] = None
+    lanelet_ids: List[int] = field(default_factory=list)
+    rectangles: List[dict] = field(default_factory=list)  # {"length", "width", "orientation", "center"}
+
+
+@dataclass
+class PlanningProblem:
+    planning_problem_id: int
+    initial_state: State
+    goals: List[GoalState]
+
+    def initial_planner_state(self):
+        from .reactive_planner import ReactivePlannerState
+        s = self.initial_state
+        return ReactivePlannerState(time_step=s.time_step, position=np.array(s.position, dtype=np.float64),
+                                    orientation=s.orientation, velocity=s.velocity, acceleration=s.acceleration,
+                                    yaw_rate=s.yaw_rate)
+
+
+@dataclass
+class Scenario:
+    benchmark_id: str
+    dt: float
+    lanelets: Dict[int, Lanelet]
+    obstacles: Dict[int, Obstacle]
+    planning_problems: Dict[int, PlanningProblem]
+
+    # -- lanelet network ------------------------------------------------------------------------------------------
+    def lanelets_at(self, position) -> List[int]:
+        return [i for i, l in self.lanelets.items() if l.contains(position)]
+
+    def route(self, start_ids, goal_ids) -> Optional[List[int]]:
+        """Shortest lanelet sequence (fewest lanelets) along successor edges, lane changes to same-direction
+        neighbours allowed."""
+        goal = set(goal_ids)
+        prev = {s: None for s in start_ids}
+        q = deque(start_ids)
+        while q:
+            cur = q.popleft()
+            if cur in goal:
+                seq = []
+                while cur is not None:
+                    seq.append(cur)
+                    cur = prev[cur]
+                return seq[::-1]
+            ll = self.lanelets[cur]
+            nxt = list(ll.successor)
+            if ll.adj_left is not None and ll.adj_left_same_direction:
+                nxt.append(ll.adj_left)
+            if ll.adj_right is not None and ll.adj_right_same_direction:
+                nxt.append(ll.adj_right)
+            for n in nxt:
+                if n in self.lanelets and n not in prev:
+                    prev[n] = cur
+                    q.append(n)
+        return None
+
+    def route_reference_path(self, planning_problem: PlanningProblem) -> np.ndarray:
+        """Concatenated centre lines of the route from the initial position to the first reachable goal lanelet."""
+        start = self.lanelets_at(planning_problem.initial_state.position)
+        if not start:
+            d = {i: np.min(np.linalg.norm(l.center_vertices - planning_problem.initial_state.position, axis=1))
+                 for i, l in self.lanelets.items()}
+            start = [min(d, key=d.get)]
+        goal_ids = []
+        for g in planning_problem.goals:
+            goal_ids += g.lanelet_ids
+            for r in g.rectangles:
+                goal_ids += self.lanelets_at(r["center"])
+        seq = self.route(start, goal_ids) if goal_ids else None
+        if seq is None:  # no goal lanelet reachable: follow successors as far as they go
+            seq = [start[0]]
+            while self.lanelets[seq[-1]].successor and self.lanelets[seq[-1]].successor[0] not in seq:
+                seq.append(self.lanelets[seq[-1]].successor[0])
+        pts = [self.lanelets[seq[0]].center_vertices]
+        for prev_id, cur_id in zip(seq[:-1], seq[1:]):
+            c = self.lanelets[cur_id].center_vertices
+            if cur_id in self.lanelets[prev_id].successor:
+                if np.allclose(c[0], pts[-1][-1], atol=1e-3):
+                    c = c[1:]  # shared vertex of consecutive lanelets
+            else:
+                pts.pop()      # lane change: continue on the neighbour's centre line instead
+            pts.append(c)
+        return np.vstack(pts)
+
+    # -- predictions ----------------------------------------------------------------------------------------------
+    def ground_truth_predictions(self, time_step: int, pred_horizon: int = 50, obstacle_ids=None) -> dict:
+        """prediction_helpers.get_ground_truth_prediction (:209-261): the obstacles' recorded futures as a prediction.
+        Per obstacle and step ts in [time_step, min(pred_horizon + time_step, len(occupancy_set))): position and
+        orientation of the occupancy at ts, covariance 0.1 I, velocity of trajectory.state_list[ts] (the reference
+        indexes the state list -- which starts one step after the initial state -- with the absolute step)."""
+        out = {}
+        for oid in (obstacle_ids if obstacle_ids is not None else list(self.obstacles)):
+            ob = self.obstacles[oid]
+            len_pred = len(ob.state_list) if ob.role == "dynamic" else pred_horizon
+            pos, cov, yaw, vel = [], [], [], []
+            for ts in range(time_step, min(pred_horizon + time_step, len_pred)):
+                st = ob.state_at_time(ts)
+                if st is None:
+                    continue
+                pos.append(st.position)
+                cov.append([[0.1, 0.0], [0.0, 0.1]])
+                yaw.append(st.orientation)
+                if ob.role == "dynamic":
+                    vel.append(ob.state_list[ts].velocity)  # state_list[ts] is the state of step ts + 1 (:248)
+                else:
+                    vel.append(ob.initial_state.velocity)
+            out[oid] = dict(pos_list=np.array(pos, dtype=np.float64).reshape(-1, 2), cov_list=np.array(cov, dtype=np.float64),
+                            orientation_list=np.array(yaw, dtype=np.float64), v_list=np.array(vel, dtype=np.float64),
+                            shape=dict(length=ob.length, width=ob.width))
+        return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def _num(node, default=0.0) -> float:
+    """<exact>v</exact> or the midpoint of <intervalStart>/<intervalEnd>."""
+    if node is None:
+        return default
+    e = node.find("exact")
+    if e is not None:
+        return float(e.text)
+    a, b = node.find("intervalStart"), node.find("intervalEnd")
+    if a is not None and b is not None:
+        return 0.5 * (float(a.text) + float(b.text))
+    return default
+
+
+def _interval(node):
+    if node is None:
+        return None
+    e = node.find("exact")
+    if e is not None:
+        return (float(e.text), float(e.text))
+    a, b = node.find("intervalStart"), node.find("intervalEnd")
+    return (float(a.text), float(b.text)) if a is not None and b is not None else None
+
+
+def _point(node) -> np.ndarray:
+    return np.array([float(node.find("x").text), float(node.find("y").text)], dtype=np.float64)
+
+
+def _position(node) -> np.ndarray:
+    if node is None:
+        return np.zeros(2)
+    p = node.find("point")
+    if p is not None:
+        return _point(p)
+    for tag in ("rectangle", "circle"):
+        s = node.find(tag)
+        if s is not None and s.find("center") is not None:
+            return _point(s.find("center"))
+    return np.zeros(2)
+
+
+def _state(node) -> State:
+    return State(time_step=int(round(_num(node.find("time")))), position=_position(node.find("position")),
+                 orientation=_num(node.find("orientation")), velocity=_num(node.find("velocity")),
+                 acceleration=_num(node.find("acceleration")), yaw_rate=_num(node.find("yawRate")),
+                 slip_angle=_num(node.find("slipAngle")))
+
+
+def _bound(node) -> np.ndarray:
+    return np.array([_point(p) for p in node.findall("point")], dtype=np.float64)
+
+
+def _shape(node) -> dict:
+    if node is None:
+        return {}
+    r = node.find("rectangle")
+    if r is not None:
+        return dict(length=float(r.find("length").text), width=float(r.find("width").text))
+    c = node.find("circle")
+    if c is not None:
+        return dict(radius=float(c.find("radius").text))
+    return {}
+
+
+def _adjacent(node):
+    if node is None:
+        return None, None
+    return int(node.get("ref")), node.get("drivingDir", "same") == "same"
+
+
+def read_scenario(path: str) -> Scenario:
+    root = ET.parse(path).getroot()
+    if root.tag != "commonRoad":
+        raise ValueError(f"{path}: not a CommonRoad scenario (root element <{root.tag}>)")
+    lanelets = {}
+    for n in root.findall("lanelet"):
+        lid = int(n.get("id"))
+        al, al_same = _adjacent(n.find("adjacentLeft"))
+        ar, ar_same = _adjacent(n.find("adjacentRight"))
+        lanelets[lid] = Lanelet(lid, _bound(n.find("leftBound")), _bound(n.find("rightBound")),
+                                [int(p.get("ref")) for p in n.findall("predecessor")],
+                                [int(p.get("ref")) for p in n.findall("successor")], al, al_same, ar, ar_same,
+                                [t.text for t in n.findall("laneletType")])
+    obstacles = {}
+    for tag, role in (("dynamicObstacle", "dynamic"), ("staticObstacle", "static")):
+        for n in root.findall(tag):
+            oid = int(n.get("id"))
+            traj = n.find("trajectory")
+            states = [_state(s) for s in traj.findall("state")] if traj is not None else []
+            typ = n.find("type")
+            obstacles[oid] = Obstacle(oid, role, typ.text if typ is not None else "unknown", _shape(n.find("shape")),
+                                      _state(n.find("initialState")), states)
+    problems = {}
+    for n in root.findall("planningProblem"):
+        pid = int(n.get("id"))
+        goals = []
+        for g in n.findall("goalState"):
+            gs = GoalState(time_interval=_interval(g.find("time")), velocity_interval=_interval(g.find("velocity")),
+                           orientation_interval=_interval(g.find("orientation")))
+            pos = g.find("position")
+            if pos is not None:
+                gs.lanelet_ids = [int(l.get("ref")) for l in pos.findall("lanelet")]
+                for r in pos.findall("rectangle"):
+                    o = r.find("orientation")
+                    gs.rectangles.append(dict(length=float(r.find("length").text), width=float(r.find("width").text),
+                                              orientation=float(o.text) if o is not None else 0.0,
+                                              center=_point(r.find("center")) if r.find("center") is not None else np.zeros(2)))
+            goals.append(gs)
+        problems[pid] = PlanningProblem(pid, _state(n.find("initialState")), goals)
+    return Scenario(root.get("benchmarkID", ""), float(root.get("timeStepSize", "0.1")), lanelets, obstacles, problems)

@@ -11,7 +11,9 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """plan-step scenarios (INDEX.json of gen_golden.py); other fixtures in the directory have their own tests"""
+    import json
+    return sorted(json.load(open(os.path.join(GOLDEN_DIR, "INDEX.json"))))
 
 
 def load_golden(name):
@@ -46,3 +48,45 @@ def inputs_from_fixture(fx, hull_builder, **override):
     inp = PlanInputs(**args)
     inp.predictions = preds
     return inp
+
+
+import textwrap  # noqa: E402
+
+
+def _pts(pts):
+    return "".join(f"<point><x>{x}</x><y>{y}</y></point>" for x, y in pts)
+
+
+def _state(x, y, th, t, v, extra=""):
+    return (f"<position><point><x>{x}</x><y>{y}</y></point></position><orientation><exact>{th}</exact></orientation>"
+            f"<time><exact>{t}</exact></time><velocity><exact>{v}</exact></velocity>{extra}")
+
+
+def tiny_commonroad_xml(lead_x: float = 30.0) -> str:
+    """A small authored CommonRoad 2020a scenario: two consecutive lanelets + a left neighbour, one dynamic and one
+    static obstacle, one planning problem whose goal is lanelet 2."""
+    xs = np.arange(0, 60.1, 10.0)
+    l1 = _pts([(x, 2.0) for x in xs]), _pts([(x, -2.0) for x in xs])
+    xs2 = np.arange(60, 120.1, 10.0)
+    l2 = _pts([(x, 2.0) for x in xs2]), _pts([(x, -2.0) for x in xs2])
+    l3 = _pts([(x, 6.0) for x in xs]), _pts([(x, 2.0) for x in xs])
+    traj = "".join(f"<state>{_state(lead_x + 0.8 * k, 0.1, 0.0, k, 8.0 + 0.01 * k)}</state>" for k in range(1, 41))
+    xml = textwrap.dedent(f"""\
+        <?xml version='1.0' encoding='UTF-8'?>
+        <commonRoad timeStepSize="0.1" commonRoadVersion="2020a" benchmarkID="ZAM_Tiny-1_1_T-1">
+          <lanelet id="1"><leftBound>{l1[0]}</leftBound><rightBound>{l1[1]}</rightBound><successor ref="2"/>
+            <adjacentLeft ref="3" drivingDir="same"/><laneletType>urban</laneletType></lanelet>
+          <lanelet id="2"><leftBound>{l2[0]}</leftBound><rightBound>{l2[1]}</rightBound><predecessor ref="1"/></lanelet>
+          <lanelet id="3"><leftBound>{l3[0]}</leftBound><rightBound>{l3[1]}</rightBound><adjacentRight ref="1" drivingDir="same"/></lanelet>
+          <dynamicObstacle id="7"><type>car</type><shape><rectangle><length>4.5</length><width>1.9</width></rectangle></shape>
+            <initialState>{_state(lead_x, 0.1, 0.0, 0, 8.0, "<acceleration><exact>0.0</exact></acceleration>")}</initialState>
+            <trajectory>{traj}</trajectory></dynamicObstacle>
+          <staticObstacle id="9"><type>parkedVehicle</type><shape><rectangle><length>4.0</length><width>1.8</width></rectangle></shape>
+            <initialState>{_state(80, -1.0, 0.0, 0, 0.0)}</initialState></staticObstacle>
+          <planningProblem id="100"><initialState>{_state(5, 0.2, 0.01, 0, 9.0, "<yawRate><exact>0.0</exact></yawRate><slipAngle><exact>0.0</exact></slipAngle>")}</initialState>
+            <goalState><position><lanelet ref="2"/></position><time><intervalStart>50</intervalStart><intervalEnd>60</intervalEnd></time>
+              <velocity><intervalStart>0</intervalStart><intervalEnd>12</intervalEnd></velocity></goalState></planningProblem>
+        </commonRoad>""")
+    return xml
+
+

@@ -227,3 +227,31 @@ def test_frenetix_handler_stopping_trajectories():
     assert step.result["n_feasible"] == out["result"]["n_feasible"]
     costs = [tr.cost for tr in trajs]
     assert costs == sorted(costs)
+
+
+def test_scenario_file_to_plan(tmp_path):
+    """CommonRoad XML -> route centre line -> prepared reference path -> ground-truth predictions -> plan step."""
+    from frenetix_motion_planner_amd import commonroad_xml as crx, ref_path
+    from frenetix_motion_planner_amd.reactive_planner import PlannerConfig, ReactivePlannerHip
+    from oracle import oracle
+    from tests.fixtures import tiny_commonroad_xml
+    f = tmp_path / "tiny.xml"
+    f.write_text(tiny_commonroad_xml(lead_x=15.0))
+    sc = crx.read_scenario(str(f))
+    pp = sc.planning_problems[100]
+    reference = ref_path.prepare_reference_path(ref_path.resample_polyline(sc.route_reference_path(pp), 0.125))
+    rp = ReactivePlannerHip(PlannerConfig(dt=sc.dt), VehicleParams())
+    rp.update_externals(reference_path=reference, x_0=pp.initial_planner_state(), desired_velocity=10.0,
+                        predictions=sc.ground_truth_predictions(0, 30))
+    pair = rp.plan()
+    assert pair is not None
+    best = rp.optimal_trajectory
+    inp = rp._inputs_for_level(2)
+    inp.obstacles = synthetic.pack_predictions(rp.predictions, 31, oracle.build_obstacle_hulls)
+    out = oracle.plan_step(inp)
+    assert best.uniqueId == out["result"]["best_index"] and rp.infeasible_count_collision == out["result"]["n_collisions"]
+    # the ego starts 10 m behind a slower car in its lane: the collision stage must have rejected candidates
+    assert out["collision"].sum() > 0 and not out["collision"][best.uniqueId]
+    x = np.array([st.position[0] for st in pair[0]])
+    assert np.all(np.diff(x) > 0) and abs(pair[0][0].position[1] - 0.2) < 1e-9
+    rp.close()
