@@ -35,6 +35,7 @@ FX_FLAG_COLLISION = 1 << 2
 FX_FLAG_RETURNED = 1 << 3
 FX_FLAG_COSTED = 1 << 4
 FX_FLAG_SELECTABLE = 1 << 5
+FX_FLAG_BOUNDARY = 1 << 6
 FX_REASON_SHIFT = 8
 FX_NUM_REASONS = 11
 
@@ -43,6 +44,7 @@ FX_MODE_KINEMATIC_DEBUG = 1 << 1
 FX_MODE_WRITE_BUNDLE = 1 << 2
 FX_MODE_WRITE_COSTMAP = 1 << 3
 FX_MODE_COLLISION = 1 << 4
+FX_MODE_ROAD_BOUNDARY = 1 << 5
 
 _pd = C.POINTER(C.c_double)
 _pi32 = C.POINTER(C.c_int32)
@@ -71,6 +73,8 @@ class FxProblem(C.Structure):
         ("obs_pos", _pd), ("obs_cov_inv", _pd), ("obs_npred", _pi32),
         ("obs_hull", _pd), ("obs_nhull", _pi32),
         ("n_dto", C.c_int32), ("dto_pos", _pd),
+        ("n_bound", C.c_int32), ("bound_piece", _pd), ("bound_bin", C.POINTER(C.c_int32)), ("bound_item", C.POINTER(C.c_int32)),
+        ("bound_d_reach", C.c_double),
     ]
 
 

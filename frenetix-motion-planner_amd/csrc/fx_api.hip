@@ -94,6 +94,9 @@ struct FxContext {
     double *d_costmap = nullptr;
     double *d_coeffs = nullptr;
     int32_t *d_trajlen = nullptr;
+    int32_t *d_bstep = nullptr;       // [total_ld] first road-boundary step per candidate
+    char *h_bound = nullptr, *d_bound = nullptr;  // road-boundary pieces / bins / items (grown on demand)
+    size_t bound_cap = 0;
     double *d_planes = nullptr;
     size_t planes_bytes = 0;
     double *d_part_cost = nullptr;
@@ -239,6 +242,18 @@ int validate(const FxProblem *p) {
     if ((p->mode & FX_MODE_COLLISION) && p->K > 0 && (!p->obs_hull || !p->obs_nhull))
         return set_err(FX_ERR_INVALID_ARGUMENT, "collision stage requested without obstacle hulls");
     if (p->n_dto < 0 || (p->n_dto > 0 && !p->dto_pos)) return set_err(FX_ERR_INVALID_ARGUMENT, "dto_pos missing");
+    if (p->n_bound < 0 || (p->n_bound > 0 && (!p->bound_piece || !p->bound_bin || !p->bound_item)))
+        return set_err(FX_ERR_INVALID_ARGUMENT, "road boundary arrays missing (n_bound=%d)", p->n_bound);
+    if ((p->mode & FX_MODE_ROAD_BOUNDARY) && p->n_bound > 0) {
+        if (p->bound_bin[0] != 0) return set_err(FX_ERR_INVALID_ARGUMENT, "bound_bin[0] must be 0");
+        for (int k = 0; k < p->M; k++)
+            if (p->bound_bin[k + 1] < p->bound_bin[k]) return set_err(FX_ERR_INVALID_ARGUMENT, "bound_bin not ascending at %d", k);
+        const int32_t n_item = p->bound_bin[p->M];
+        for (int32_t j = 0; j < n_item; j++)
+            if (p->bound_item[j] < 0 || p->bound_item[j] >= p->n_bound)
+                return set_err(FX_ERR_INVALID_ARGUMENT, "bound_item[%d]=%d out of range", j, p->bound_item[j]);
+        if (!(p->bound_d_reach > 0.0)) return set_err(FX_ERR_INVALID_ARGUMENT, "bound_d_reach must be positive");
+    }
     return FX_OK;
 }
 
@@ -303,6 +318,7 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     if ((rc = dev_alloc(c, &c->d_costmap, (size_t)FX_NUM_COSTS * c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_coeffs, (size_t)12 * c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_trajlen, c->total_ld))) return rc;
+    if ((rc = dev_alloc(c, &c->d_bstep, c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_part_cost, c->max_blocks_total))) return rc;
     if ((rc = dev_alloc(c, &c->d_part_idx, c->max_blocks_total))) return rc;
     if ((rc = dev_alloc(c, &c->d_counters, (size_t)max_agents * FX_CNT_COUNT))) return rc;
@@ -337,6 +353,9 @@ int32_t fx_destroy(FxContext *c) {
                    c->d_part_cost, c->d_part_idx, c->d_counters, c->d_topk_cost, c->d_topk_idx, c->d_topk_scr_cost,
                    c->d_topk_scr_idx};
     for (void *p : dev) if (p) (void)hipFree(p);
+    if (c->d_bstep) (void)hipFree(c->d_bstep);
+    if (c->d_bound) (void)hipFree(c->d_bound);
+    if (c->h_bound) (void)hipHostFree(c->h_bound);
     void *host[] = {c->h_in, c->h_probs, c->h_counters, c->h_topk_cost, c->h_topk_idx, c->h_pub};
     for (void *p : host) if (p) (void)hipHostFree(p);
     for (auto &t : c->ring) {
@@ -428,6 +447,26 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     }
     c->uploaded = c->evaluated = false;
     Arena ar{c->h_in, c->d_in, 0, c->in_bytes};
+    // road boundary: its own staging block, grown on demand (maps differ by orders of magnitude in size)
+    size_t bound_need = 0;
+    for (int a = 0; a < n_agents; a++) {
+        const FxProblem *p = &probs[a];
+        if ((p->mode & FX_MODE_ROAD_BOUNDARY) && p->n_bound > 0 && p->bound_bin && p->M > 0)
+            bound_need += align_up(sizeof(double) * 4 * (size_t)p->n_bound, 256) + align_up(sizeof(int32_t) * ((size_t)p->M + 1), 256) +
+                          align_up(sizeof(int32_t) * (size_t)std::max(p->bound_bin[p->M], 0), 256);
+    }
+    if (bound_need > c->bound_cap) {
+        if (c->h_bound) (void)hipHostFree(c->h_bound);
+        if (c->d_bound) { (void)hipFree(c->d_bound); c->dev_bytes -= (int64_t)c->bound_cap; }
+        c->h_bound = c->d_bound = nullptr;
+        c->bound_cap = 0;
+        const size_t cap = std::max<size_t>(2 * bound_need, 64 * 1024);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_bound), cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_bound), cap));
+        c->bound_cap = cap;
+        c->dev_bytes += (int64_t)cap;
+    }
+    Arena br{c->h_bound, c->d_bound, 0, c->bound_cap};
     // lanes per candidate: split the horizon over G lanes while the step has too few candidates to give every
     // SIMD of the chip (256 CUs x 4) a few waves; windowed (Simpson) costs need the whole horizon in one lane
     {
@@ -471,7 +510,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                     const size_t S = (size_t)p->N + 1;
                     need = std::max(need, sizeof(double) * (((5 * S + 1) & ~(size_t)1) + (((size_t)p->M + 1) & ~(size_t)1)) +
                                               128 * n_pairs * S +
-                                              (G > 1 ? (size_t)56 * blk : 0));  // + wave-split exchange block
+                                              (G > 1 ? (size_t)64 * blk : 0));  // + wave-split exchange block (5 f64 + 5 u32 per slot)
                 }
                 return need;
             };
@@ -605,12 +644,22 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             d.mode &= ~FX_MODE_COLLISION;
         }
         if (p->n_dto > 0) d.dto_pos = ar.put(p->dto_pos, (size_t)2 * p->n_dto, &ok);
+        if ((p->mode & FX_MODE_ROAD_BOUNDARY) && p->n_bound > 0) {
+            d.n_bound = p->n_bound;
+            d.bound_piece = br.put(p->bound_piece, (size_t)4 * p->n_bound, &ok);
+            d.bound_bin = br.put(p->bound_bin, (size_t)p->M + 1, &ok);
+            d.bound_item = br.put(p->bound_item, (size_t)p->bound_bin[p->M], &ok);
+            d.bound_d_reach = p->bound_d_reach;
+        } else {
+            d.mode &= ~FX_MODE_ROAD_BOUNDARY;
+        }
         if (!ok) return set_err(FX_ERR_CAPACITY, "input arena too small (%zu bytes)", c->in_bytes);
         d.cost = c->d_cost + cand_off;
         d.flags = c->d_flags + cand_off;
         d.costmap = c->d_costmap + (size_t)FX_NUM_COSTS * cand_off;  // [n_cost][ld] inside this agent's slab
         d.coeffs = c->d_coeffs + (size_t)12 * cand_off;
         d.traj_len = c->d_trajlen + cand_off;
+        d.bound_step = c->d_bstep + cand_off;
         d.n_blocks = (int)((C + CPB - 1) / CPB);
         d.part_cost = c->d_part_cost + block_off;
         d.part_idx = c->d_part_idx + block_off;
@@ -620,7 +669,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             planes_need += sizeof(double) * FX_NUM_PLANES * (size_t)S * (size_t)ld;
             c->any_bundle = true;
         }
-        c->any_obst |= p->K > 0;
+        c->any_obst |= p->K > 0 || (d.mode & FX_MODE_ROAD_BOUNDARY);
         if ((d.mode & FX_MODE_COLLISION) || d.n_blocks == 0) c->fusable_step = false;
         c->any_extra |= extra;
         c->max_blocks_step = std::max(c->max_blocks_step, d.n_blocks);
@@ -641,6 +690,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     }
     c->n_agents = n_agents;
     HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, ar.off, hipMemcpyHostToDevice, c->stream));
+    if (br.off) HIP_TRY(hipMemcpyAsync(c->d_bound, c->h_bound, br.off, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_probs, c->h_probs, sizeof(DevProblem) * n_agents, hipMemcpyHostToDevice, c->stream));
     c->uploaded = true;
     c->in_flight = true;
@@ -798,6 +848,18 @@ int32_t fx_read_coeffs_agent(FxContext *c, int32_t agent, int64_t index, double 
     if (traj_len) HIP_TRY(hipMemcpy(traj_len, c->d_trajlen + s.cand_off + index, sizeof(int32_t), hipMemcpyDeviceToHost));
     return FX_OK;
 }
+int32_t fx_read_boundary_steps_agent(FxContext *c, int32_t agent, int32_t *steps) {
+    int rc = check_agent(c, agent);
+    if (rc) return rc;
+    if (!steps) return set_err(FX_ERR_INVALID_ARGUMENT, "steps is NULL");
+    const FxAgentSlot &s = c->slots[agent];
+    if (!(s.mode & FX_MODE_ROAD_BOUNDARY)) return set_err(FX_ERR_NOT_READY, "the step ran without FX_MODE_ROAD_BOUNDARY");
+    HIP_TRY(hipMemcpyAsync(steps, c->d_bstep + s.cand_off, sizeof(int32_t) * s.C, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FX_OK;
+}
+int32_t fx_read_boundary_steps(FxContext *c, int32_t *steps) { return fx_read_boundary_steps_agent(c, 0, steps); }
+
 int32_t fx_read_coeffs(FxContext *c, int64_t index, double *lon6, double *lat6, int32_t *traj_len) {
     return fx_read_coeffs_agent(c, 0, index, lon6, lat6, traj_len);
 }
@@ -914,6 +976,47 @@ int32_t fx_math_selftest(int32_t n, const double *x, double *atan_out, double *s
     HIP_TRY(hipMemcpy(sin_out, d + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(cos_out, d + 3 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d));
+    return FX_OK;
+}
+
+// Road-boundary geometry prep (host only): split segments into pieces, bin them by reference knot.
+int32_t fx_build_boundary_bins(int32_t M, const double *ref_x, const double *ref_y, int32_t n_seg, const double *seg,
+                               double max_len, double reach, int32_t piece_cap, double *piece_out, int32_t *n_piece,
+                               int32_t *bin_out, int32_t item_cap, int32_t *item_out, int32_t *n_item) {
+    if (M < 1 || !ref_x || !ref_y || n_seg < 0 || (n_seg && !seg) || !(max_len > 0.0) || !(reach >= 0.0) || !n_piece || !n_item ||
+        !bin_out)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "fx_build_boundary_bins: bad argument");
+    int64_t np_ = 0;
+    for (int i = 0; i < n_seg; i++) {
+        const double *q = seg + 4 * (size_t)i;
+        const double len = std::sqrt((q[2] - q[0]) * (q[2] - q[0]) + (q[3] - q[1]) * (q[3] - q[1]));
+        const int n = std::max(1, (int)std::ceil(len / max_len));
+        for (int k = 0; k < n; k++, np_++) {
+            if (np_ >= piece_cap || !piece_out) continue;
+            const double t0 = (double)k / n, t1 = (double)(k + 1) / n;
+            const double ax = q[0] + t0 * (q[2] - q[0]), ay = q[1] + t0 * (q[3] - q[1]);
+            const double bx = q[0] + t1 * (q[2] - q[0]), by = q[1] + t1 * (q[3] - q[1]);
+            double *o = piece_out + 4 * (size_t)np_;
+            o[0] = 0.5 * (ax + bx); o[1] = 0.5 * (ay + by); o[2] = 0.5 * (bx - ax); o[3] = 0.5 * (by - ay);
+        }
+    }
+    *n_piece = (int32_t)np_;
+    if (np_ > piece_cap || !piece_out) { *n_item = 0; return set_err(FX_ERR_CAPACITY, "boundary needs %lld pieces", (long long)np_); }
+    int64_t ni = 0;
+    bin_out[0] = 0;
+    for (int k = 0; k < M; k++) {
+        for (int64_t j = 0; j < np_; j++) {
+            const double *o = piece_out + 4 * (size_t)j;
+            const double dx = o[0] - ref_x[k], dy = o[1] - ref_y[k];
+            if (std::sqrt(dx * dx + dy * dy) <= reach + std::sqrt(o[2] * o[2] + o[3] * o[3])) {
+                if (ni < item_cap && item_out) item_out[ni] = (int32_t)j;
+                ni++;
+            }
+        }
+        bin_out[k + 1] = (int32_t)std::min<int64_t>(ni, INT32_MAX);
+    }
+    *n_item = (int32_t)std::min<int64_t>(ni, INT32_MAX);
+    if (ni > item_cap || !item_out) return set_err(FX_ERR_CAPACITY, "boundary bins need %lld items", (long long)ni);
     return FX_OK;
 }
 

@@ -48,7 +48,14 @@ struct DevProblem {
     const double *obs_rec;
     const unsigned long long *obs_pmask, *obs_hmask;
     const double *dto_pos;     // [n_dto][2]
+    // road boundary: pieces (mid x, mid y, half dx, half dy) and per reference knot the pieces in reach (CSR)
+    int32_t n_bound;
+    const double *bound_piece;   // [n_bound][4]
+    const int32_t *bound_bin;    // [M + 1]
+    const int32_t *bound_item;   // [bound_bin[M]]
+    double bound_d_reach;
     // ---- outputs (device) ----
+    int32_t *bound_step;       // [ld] first step that meets the road boundary, -1 if never (FX_MODE_ROAD_BOUNDARY)
     double *cost;              // [ld]
     uint32_t *flags;           // [ld]
     double *costmap;           // [n_cost][ld]      (FX_MODE_WRITE_COSTMAP)
@@ -91,6 +98,12 @@ struct ProblemRegs {
     const double *obs_rec;
     const unsigned long long *obs_pmask, *obs_hmask;
     const double *dto_pos;
+    int32_t n_bound;
+    const double *bound_piece;
+    const int32_t *bound_bin;
+    const int32_t *bound_item;
+    double bound_d_reach;
+    int32_t *bound_step;
     double *cost;
     uint32_t *flags;
     double *costmap;
@@ -115,6 +128,8 @@ struct ProblemRegs {
         r.tpow = g.tpow; r.t_samp = g.t_samp; r.v_samp = g.v_samp; r.d_samp = g.d_samp; r.matrix = g.matrix;
         r.ref = g.ref; r.obs_pos = g.obs_pos; r.obs_cov_inv = g.obs_cov_inv; r.obs_npred = g.obs_npred;
         r.obs_rec = g.obs_rec; r.obs_pmask = g.obs_pmask; r.obs_hmask = g.obs_hmask; r.dto_pos = g.dto_pos;
+        r.n_bound = g.n_bound; r.bound_piece = g.bound_piece; r.bound_bin = g.bound_bin; r.bound_item = g.bound_item;
+        r.bound_d_reach = g.bound_d_reach; r.bound_step = g.bound_step;
         r.cost = g.cost; r.flags = g.flags; r.costmap = g.costmap; r.planes = g.planes; r.coeffs = g.coeffs;
         r.traj_len = g.traj_len; r.part_cost = g.part_cost; r.part_idx = g.part_idx; r.counters = g.counters;
         r.n_blocks = g.n_blocks;

@@ -183,6 +183,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     K.av_switch = a_max * P.veh.v_switch; K.v_des = P.v_des; K.wb = P.veh.wb_rear_axle; K.half_len = P.veh.length / 2;
     K.half_wid = P.veh.width / 2; K.S = S; K.half = S / 2; K.K = P.K; K.low_vel = low_vel; K.dbg = dbg;
     K.do_collision = do_collision;
+    K.n_bound = (OBST && (P.mode & FX_MODE_ROAD_BOUNDARY)) ? P.n_bound : 0; K.bound_d_reach = P.bound_d_reach;
+    const BoundView Bv{as_global(P.bound_piece), as_global(P.bound_bin), as_global(P.bound_item)};
     const FX_GLOBAL double *__restrict__ obs_rec = as_global(P.obs_rec);
     const FX_GLOBAL unsigned long long *__restrict__ obs_pmask = as_global(P.obs_pmask);
     const FX_GLOBAL unsigned long long *__restrict__ obs_hmask = as_global(P.obs_hmask);
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     }
     StepAcc A;
     A.neg = A.acc_viol = A.collided = false;
-    A.step_reasons = 0; A.first_key = 0xffffffffu; A.fail_step = 0x7fffffff;
+    A.step_reasons = 0; A.first_key = 0xffffffffu; A.fail_step = 0x7fffffff; A.bound_step = 0x7fffffff;
     A.sum_abs_d = A.sum_voff = A.pred = A.d_end = A.v_end = 0.0;
     StepOut O;
     FX_GLOBAL double *__restrict__ planes = as_global(P.planes);
@@ -213,13 +215,13 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
         const bool emit = i >= i_begin;
         const LonRow r = my[i];
         walk_step<OBST, (G == 1 || WSPLIT)>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit,
-                                            planes + (int64_t)i * ld + g, ps, Cy, A, O, obs_rec, obs_pmask, obs_hmask);
+                                            planes + (int64_t)i * ld + g, ps, Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv);
     }
 
     FX_STAMP(4);
     WalkResult W;
     W.neg = A.neg; W.acc_viol = A.acc_viol; W.collided = A.collided;
-    W.step_reasons = A.step_reasons; W.first_key = A.first_key; W.fail_step = A.fail_step;
+    W.step_reasons = A.step_reasons; W.first_key = A.first_key; W.fail_step = A.fail_step; W.bound_step = A.bound_step;
     W.sum_abs_d = A.sum_abs_d; W.sum_voff = A.sum_voff; W.pred = A.pred; W.dto = 0.0; W.d_end = A.d_end; W.v_end = A.v_end;
     W.cl3 = cl3; W.cl4 = cl4; W.cl5 = cl5; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
     // wave split: the exchange block sits behind the rows in dynamic LDS

@@ -162,6 +162,7 @@ struct WalkResult {
     uint32_t step_reasons;  // dbg: OR of all violated checks
     uint32_t first_key;     // !dbg: (step << 4 | reason) of the first violated check, 0xffffffff if none
     int fail_step;          // first step of this lane's chunk outside the projection domain, INT_MAX if none
+    int bound_step;         // first step of this lane's chunk whose footprint meets the road boundary, INT_MAX if none
     double sum_abs_d, sum_voff, pred, dto, d_end, v_end;
     double cl3, cl4, cl5, ct3, ct4, ct5;
     Simpson sim_acc, sim_jerk, sim_orient, sim_path;
@@ -190,6 +191,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     bool neg = W.neg, acc_viol = W.acc_viol, collided = W.collided;
     uint32_t step_reasons = W.step_reasons, first_key = W.first_key;
     int fail_step = W.fail_step;
+    uint32_t bound_step = (uint32_t)W.bound_step;
     double sum_abs_d = W.sum_abs_d, sum_voff = W.sum_voff, pred = W.pred, dto = W.dto, d_end = W.d_end, v_end = W.v_end;
     const double cl3 = W.cl3, cl4 = W.cl4, cl5 = W.cl5, ct3 = W.ct3, ct4 = W.ct4, ct5 = W.ct5;
     Simpson &sim_acc = W.sim_acc, &sim_jerk = W.sim_jerk, &sim_orient = W.sim_orient, &sim_path = W.sim_path;
@@ -205,6 +207,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
             step_reasons = group_or<G>(step_reasons);
             first_key = group_min<G>(first_key);
             fail_all = group_min<G>((uint32_t)fail_step);
+            if (OBST) bound_step = group_min<G>(bound_step);
         } else {
             xu[slot] = (uint32_t)fail_step;
             __syncthreads();
@@ -253,6 +256,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
             xu[1 * n_slot + slot] = bits;
             xu[2 * n_slot + slot] = step_reasons;
             xu[3 * n_slot + slot] = first_key;
+            if (OBST) xu[4 * n_slot + slot] = bound_step;
             __syncthreads();
             if (part == 0) {
                 // same association as the xor-shuffle tree: ((p0 + p1) + (p2 + p3)) + ...
@@ -277,11 +281,17 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
                     step_reasons |= xu[2 * n_slot + q * CPB + cand_local];
                     const uint32_t fk = xu[3 * n_slot + q * CPB + cand_local];
                     first_key = fk < first_key ? fk : first_key;
+                    if (OBST) {
+                        const uint32_t bs = xu[4 * n_slot + q * CPB + cand_local];
+                        bound_step = bs < bound_step ? bs : bound_step;
+                    }
                 }
             }
         }
     }
     neg = bits & 1u; acc_viol = bits & 2u; collided = bits & 4u;
+    // a boundary hit after the projection left its domain does not count (the reference's loop has stopped, :537-547)
+    const bool off_road = OBST && bound_step != 0x7fffffffu && (int)bound_step < fail_step;
     if (!dbg) step_reasons = first_key == 0xffffffffu ? 0u : (1u << (first_key & 15u));
     const bool proj_ok = fail_step == 0x7fffffff;
     const bool leader = part == 0;
@@ -319,6 +329,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     if (costed) flags |= FX_FLAG_COSTED;
     if (selectable) flags |= FX_FLAG_SELECTABLE;
     if (selectable && do_collision && collided) flags |= FX_FLAG_COLLISION;
+    if (selectable && off_road) flags |= FX_FLAG_BOUNDARY;
     flags |= reasons << FX_REASON_SHIFT;
 
     FX_STAMP(6);
@@ -367,6 +378,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     if (active && leader) {
         as_global(P.cost)[g] = costed ? total : 0.0;
         as_global(P.flags)[g] = flags;
+        if (OBST && (P.mode & FX_MODE_ROAD_BOUNDARY)) as_global(P.bound_step)[g] = (selectable && off_road) ? (int)bound_step : -1;
     }
 
     FX_STAMP(7);
@@ -387,7 +399,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
         if (lane < 2 + FX_NUM_REASONS && mine) atomicAdd(&red_cnt[lane], mine);
     }
     FX_STAMP(8);
-    const bool eligible = own && selectable && !(flags & FX_FLAG_COLLISION) && total == total;
+    const bool eligible = own && selectable && !(flags & (FX_FLAG_COLLISION | FX_FLAG_BOUNDARY)) && total == total;
     double bc = eligible ? total : INFINITY;
     long long bi = eligible ? (long long)(g + P.g_base) : 0x7fffffffffffffffLL;
     // wave arg-min: candidate indices grow with the lane, so the (cost, index) minimum is the LOWEST lane that
@@ -602,6 +614,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     K.av_switch = a_max * P.veh.v_switch; K.v_des = P.v_des; K.wb = P.veh.wb_rear_axle; K.half_len = P.veh.length / 2;
     K.half_wid = P.veh.width / 2; K.S = S; K.half = S / 2; K.K = P.K; K.low_vel = low_vel; K.dbg = dbg;
     K.do_collision = do_collision;
+    K.n_bound = (OBST && (P.mode & FX_MODE_ROAD_BOUNDARY)) ? P.n_bound : 0; K.bound_d_reach = P.bound_d_reach;
+    const BoundView Bv{as_global(P.bound_piece), as_global(P.bound_bin), as_global(P.bound_item)};
     const FX_GLOBAL double *__restrict__ obs_rec = as_global(P.obs_rec);
     const FX_GLOBAL unsigned long long *__restrict__ obs_pmask = as_global(P.obs_pmask);
     const FX_GLOBAL unsigned long long *__restrict__ obs_hmask = as_global(P.obs_hmask);
@@ -624,7 +638,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     }
     StepAcc A;
     A.neg = A.acc_viol = A.collided = false;
-    A.step_reasons = 0; A.first_key = 0xffffffffu; A.fail_step = 0x7fffffff;
+    A.step_reasons = 0; A.first_key = 0xffffffffu; A.fail_step = 0x7fffffff; A.bound_step = 0x7fffffff;
     A.sum_abs_d = A.sum_voff = A.pred = A.d_end = A.v_end = 0.0;
     StepOut O;
     Simpson sim_acc, sim_jerk, sim_orient, sim_path;
@@ -640,7 +654,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
         const bool emit = i >= i_begin;  // false only for the carry-in step of parts > 0
         const LonRow r = row_at(i);
         walk_step<OBST, G == 1>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit, planes + (int64_t)i * ld + g, ps,
-                                Cy, A, O, obs_rec, obs_pmask, obs_hmask);
+                                Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv);
         if (EXTRA) {
             sim_acc.push(O.a * O.a, S);                                 // partial_cost_functions.py:29-31
             sim_path.push(O.v, S);                                      // :194-195
@@ -663,7 +677,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     // ---- combine parts, flags, cost, outputs, workgroup reductions ----
     WalkResult W;
     W.neg = A.neg; W.acc_viol = A.acc_viol; W.collided = A.collided;
-    W.step_reasons = A.step_reasons; W.first_key = A.first_key; W.fail_step = A.fail_step;
+    W.step_reasons = A.step_reasons; W.first_key = A.first_key; W.fail_step = A.fail_step; W.bound_step = A.bound_step;
     W.sum_abs_d = A.sum_abs_d; W.sum_voff = A.sum_voff; W.pred = A.pred; W.dto = dto; W.d_end = A.d_end; W.v_end = A.v_end;
     W.cl3 = cl3; W.cl4 = cl4; W.cl5 = cl5; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
     if (EXTRA) { W.sim_acc = sim_acc; W.sim_jerk = sim_jerk; W.sim_orient = sim_orient; W.sim_path = sim_path; }

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void fx_topk_slice_kernel(const DevProblem *__
         long long bi = NONE;
         for (int64_t g = lo + tid; g < hi; g += 256) {
             const uint32_t f = flags[g];
-            if ((f & FX_FLAG_SELECTABLE) && !(f & FX_FLAG_COLLISION)) {
+            if ((f & FX_FLAG_SELECTABLE) && !(f & (FX_FLAG_COLLISION | FX_FLAG_BOUNDARY))) {
                 const double c = cost[g];
                 const long long gg = (long long)(g + P.g_base);
                 const bool after = c > lb_c || (c == lb_c && gg > lb_i);

@@ -141,10 +141,12 @@ __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, d
     r.k_r = (k1.curv - k0.curv) * s_lambda + k0.curv;
     r.k_r_d = (k1.curv_d - k0.curv_d) * s_lambda + k0.curv_d;
     r.px = r.py = r.nhx = r.nhy = 0.0;
+    r.pad0 = 0;
     if (s_i >= rp_first && s_i <= rp_last) {
         r.flags |= LON_INDOMAIN;
         int kk = ub - 1;
         kk = kk < 0 ? 0 : (kk > M - 2 ? M - 2 : kk);
+        r.pad0 = (uint32_t)kk;  // reference segment of the foot point: selects the road-boundary bin
         // kk == i0 unless the lookup wrapped (s outside the reference): same segment, same lambda
         const Knot q0 = kk == i0 ? k0 : knot(kk), q1 = kk == i0 ? k1 : knot(kk + 1);
         const double lam = kk == i0 ? s_lambda : fdiv(s_i - q0.pos, q1.pos - q0.pos);
@@ -156,7 +158,7 @@ __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, d
         r.nhx = div_rcp(nx, nn, r_nn);
         r.nhy = div_rcp(ny, nn, r_nn);
     }
-    r.pad0 = 0; r.pad1 = 0.0;
+    r.pad1 = 0.0;
     return r;
 }
 
@@ -190,6 +192,8 @@ struct StepConst {  // wave-uniform constants of the walk
     double dt, r_dt, kappa_max, a_max, v_switch, av_switch, v_des, wb, half_len, half_wid;
     int S, half, K;
     bool low_vel, dbg, do_collision;
+    int n_bound;            // road-boundary pieces (0: stage off)
+    double bound_d_reach;   // |d| beyond this counts as off the road
 };
 
 struct StepCarry {  // per-lane state carried from step to step
@@ -201,6 +205,7 @@ struct StepAcc {  // per-lane accumulators over the emitted steps
     bool neg, acc_viol, collided;
     uint32_t step_reasons, first_key;
     int fail_step;
+    int bound_step;  // first emitted step whose footprint meets the road boundary, INT_MAX if none
     double sum_abs_d, sum_voff, pred, d_end, v_end;
 };
 
@@ -211,10 +216,17 @@ struct StepOut {  // per-step values the windowed (EXTRA) costs of the generic k
 // One step of one candidate.  `planes_i` = address of plane 0 at (step i, this candidate); ps = plane stride.
 // USTEP: the step index is wave-uniform (one lane per candidate, or parts on different waves), so the obstacle
 // records of the step come in through scalar loads; otherwise every lane reads its own step's records.
+// Road boundary of the agent as the walk sees it (address-space-1 pointers; n_bound lives in StepConst).
+struct BoundView {
+    const FX_GLOBAL double *piece;
+    const FX_GLOBAL int32_t *bin, *item;
+};
+
 template <bool OBST, bool USTEP, typename PlanePtr, typename ObsD, typename ObsM>
 __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, const LatPoly &L, const double *tp, int i,
                                           int traj_len, double d_ext, bool emit, bool store, PlanePtr planes_i, int64_t ps,
-                                          StepCarry &C, StepAcc &A, StepOut &O, ObsD obs_rec, ObsM obs_pmask, ObsM obs_hmask) {
+                                          StepCarry &C, StepAcc &A, StepOut &O, ObsD obs_rec, ObsM obs_pmask, ObsM obs_hmask,
+                                          const BoundView &B) {
     const int S = K.S;
     const double s_i = r.s, sv_i = r.sv, sa_i = r.sa;
     // -- lateral polynomial (reactive_planner.py:326-346) --
@@ -360,6 +372,33 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                 C.bx_prev = bx; C.by_prev = by; C.ux_prev = cu; C.uy_prev = su;
             }
         }
+    }
+    // -- road boundary (planner.py:362-381): footprint rectangle vs the pieces binned at this step's
+    //    reference segment; separating axes = the box axes and the piece's normal, touching intersects --
+    if (OBST && K.n_bound > 0) {
+        bool test = emit && (r.flags & LON_INDOMAIN) && A.bound_step == 0x7fffffff;
+        bool hit = test && fabs(d_i) > K.bound_d_reach;
+        test = test && !hit;
+        if (__any(test)) {
+            double su, cu;
+            fxm::sincos(th_gl, &su, &cu);
+            const double cx = fma(K.wb, cu, x_i), cy = fma(K.wb, su, y_i);
+            int j = test ? B.bin[r.pad0] : 0;
+            const int j_end = test ? B.bin[r.pad0 + 1] : 0;
+            while (__any(j < j_end)) {
+                if (j < j_end) {
+                    const FX_GLOBAL double *q = B.piece + 4 * (int64_t)B.item[j];
+                    const double ex0 = q[0] - cx, ey0 = q[1] - cy;
+                    const double ex = ex0 * cu + ey0 * su, ey = ey0 * cu - ex0 * su;
+                    const double hx = q[2] * cu + q[3] * su, hy = q[3] * cu - q[2] * su;
+                    const bool sep = fabs(ex) - (K.half_len + fabs(hx)) > 0 || fabs(ey) - (K.half_wid + fabs(hy)) > 0 ||
+                                     fabs(ex * hy - ey * hx) - (K.half_len * fabs(hy) + K.half_wid * fabs(hx)) > 0;
+                    if (!sep) { hit = true; j = j_end; }  // first hit of this step is enough
+                    else j++;
+                }
+            }
+        }
+        if (hit) A.bound_step = i;
     }
     C.th_prev = th_gl;
     C.kap_prev = kap;

@@ -27,6 +27,31 @@ def build_obstacle_hulls(n_pred, pos, yaw, length, width) -> np.ndarray:
     return out[:n.value]
 
 
+def build_boundary_bins(ref_xy, segments, max_len: float, reach: float):
+    """fx_build_boundary_bins (host geometry of the library): pieces [n][4], bins [M+1], items."""
+    ref = np.ascontiguousarray(ref_xy, dtype=np.float64)
+    rx, ry = np.ascontiguousarray(ref[:, 0]), np.ascontiguousarray(ref[:, 1])
+    seg = np.ascontiguousarray(segments, dtype=np.float64).reshape(-1, 4)
+    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    n_piece, n_item = C.c_int32(0), C.c_int32(0)
+    piece = np.zeros((max(len(seg), 1) * 2, 4))
+    item = np.zeros(max(len(ref) * 16, 1), dtype=np.int32)
+    bins = np.zeros(len(ref) + 1, dtype=np.int32)
+    for _ in range(3):
+        rc = lib().fx_build_boundary_bins(len(ref), rx.ctypes.data_as(pd), ry.ctypes.data_as(pd), len(seg), seg.ctypes.data_as(pd),
+                                          float(max_len), float(reach), len(piece), piece.ctypes.data_as(pd), C.byref(n_piece),
+                                          bins.ctypes.data_as(pi), len(item), item.ctypes.data_as(pi), C.byref(n_item))
+        if rc == 0:
+            return piece[:n_piece.value].copy(), bins, item[:n_item.value].copy()
+        if n_piece.value > len(piece):
+            piece = np.zeros((n_piece.value, 4))
+        elif n_item.value > len(item):
+            item = np.zeros(n_item.value, dtype=np.int32)
+        else:
+            check(rc)
+    check(rc)
+
+
 def math_selftest(x: np.ndarray):
     """(atan, sin, cos) of the device math kernels for the values in x."""
     x = np.ascontiguousarray(x, dtype=np.float64)
@@ -156,6 +181,12 @@ class FrenetEngine:
         check(lib().fx_read_costs_agent(self._ctx, agent, cost.ctypes.data_as(C.POINTER(C.c_double)),
                                         flags.ctypes.data_as(C.POINTER(C.c_uint32))))
         return cost, flags
+
+    def boundary_steps(self, agent: int = 0) -> np.ndarray:
+        """first step at which each candidate's footprint meets the road boundary, -1 if never"""
+        out = np.zeros(self._inputs[agent].n_candidates, dtype=np.int32)
+        check(lib().fx_read_boundary_steps_agent(self._ctx, agent, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
 
     def costmap(self, agent: int = 0) -> np.ndarray:
         """[C, n_cost] raw (unweighted) partial costs, columns in inputs.cost_names order."""

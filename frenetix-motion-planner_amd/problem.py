@@ -90,6 +90,38 @@ def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
     return dict(K=K, P=P, pos=_f64(pos), cov_inv=_f64(cov_inv), npred=npred, hull=_f64(hull), nhull=nhull)
 
 
+def pack_road_boundary(segments, cs: CoordinateSystem, vehicle: "VehicleParams", d_reach: float, max_len: float = 4.0):
+    """Road boundary segments [n][4] = (ax, ay, bx, by) -> what the engine takes (planner.py:362-381, 550-565).
+
+    Pieces no longer than max_len as (mid x, mid y, half dx, half dy), and for every reference knot k the pieces whose
+    midpoint is within reach + half length of it (CSR bins).  reach bounds the distance between knot k and any point of
+    an ego footprint whose foot point lies on reference segment k and whose centre is laterally within d_reach:
+    longest reference segment + d_reach + wb_rear_axle + half diagonal.  (The C-ABI twin is fx_build_boundary_bins.)"""
+    seg = _f64(segments).reshape(-1, 4)
+    a, b = seg[:, :2], seg[:, 2:]
+    length = np.linalg.norm(b - a, axis=1)
+    n_sub = np.maximum(1, np.ceil(length / max_len)).astype(np.int64)
+    idx = np.repeat(np.arange(len(seg)), n_sub)
+    k = np.concatenate([np.arange(n) for n in n_sub]) if len(seg) else np.zeros(0, dtype=np.int64)
+    t0 = (k / n_sub[idx])[:, None]
+    t1 = ((k + 1) / n_sub[idx])[:, None]
+    pa = a[idx] + t0 * (b[idx] - a[idx])
+    pb = a[idx] + t1 * (b[idx] - a[idx])
+    piece = _f64(np.concatenate([0.5 * (pa + pb), 0.5 * (pb - pa)], axis=1)).reshape(-1, 4)
+    ref = cs.reference
+    seg_len = np.linalg.norm(np.diff(ref, axis=0), axis=1)
+    reach = float(seg_len.max() + d_reach + vehicle.wb_rear_axle + 0.5 * np.hypot(vehicle.length, vehicle.width))
+    half = np.linalg.norm(piece[:, 2:], axis=1)
+    bins = np.zeros(len(ref) + 1, dtype=np.int32)
+    items = []
+    for kk in range(len(ref)):
+        near = np.nonzero(np.linalg.norm(piece[:, :2] - ref[kk], axis=1) <= reach + half)[0]
+        items.append(near.astype(np.int32))
+        bins[kk + 1] = bins[kk] + len(near)
+    item = np.concatenate(items).astype(np.int32) if items else np.zeros(0, dtype=np.int32)
+    return dict(n=len(piece), piece=piece, bin=bins, item=np.ascontiguousarray(item), d_reach=float(d_reach), reach=reach)
+
+
 @dataclass
 class PlanInputs:
     # horizon / mode
@@ -119,6 +151,8 @@ class PlanInputs:
     # packed predictions (pack_predictions) and distance_to_obstacles positions
     obstacles: Optional[dict] = None
     dto_pos: Optional[np.ndarray] = None
+    # road boundary: segments [n][4] = (ax, ay, bx, by); the ego footprint must not touch them (planner.py:362-381)
+    road_boundary: Optional[np.ndarray] = None
     # candidate shard of the global grid handled by this engine (multi-GPU); None = everything
     shard: Optional[tuple] = None
 
@@ -151,6 +185,14 @@ class PlanInputs:
         if self.obstacles is None:
             self.obstacles = pack_predictions(None, S, None)
         self._dto = _f64(self.dto_pos).reshape(-1, 2) if self.dto_pos is not None else np.zeros((0, 2))
+        self._bound = None
+        if self.road_boundary is not None and len(self.road_boundary):
+            if isinstance(self.road_boundary, dict):
+                self._bound = self.road_boundary  # already packed (pack_road_boundary), shared between steps
+            else:
+                d_all = np.abs(self.d_samp) if self.sampling_matrix is None else np.abs(self.sampling_matrix[:, 10])
+                d_reach = 1.5 * max(float(d_all.max()) if len(d_all) else 0.0, abs(float(self.x0_lat[0]))) + 2.0
+                self._bound = pack_road_boundary(self.road_boundary, cs, self.vehicle, d_reach)
 
     @property
     def n_samples(self) -> int:
@@ -184,6 +226,8 @@ class PlanInputs:
             m |= _abi.FX_MODE_WRITE_COSTMAP
         if self.collision and self.obstacles["K"] > 0:
             m |= _abi.FX_MODE_COLLISION
+        if self._bound is not None and self._bound["n"] > 0:
+            m |= _abi.FX_MODE_ROAD_BOUNDARY
         return m
 
     def candidate_params(self, g: int):
@@ -227,6 +271,15 @@ class PlanInputs:
         p.obs_pos, p.obs_cov_inv, p.obs_npred = _ptr(o["pos"]), _ptr(o["cov_inv"]), _ptr(o["npred"], C.c_int32)
         p.obs_hull, p.obs_nhull = _ptr(o["hull"]), _ptr(o["nhull"], C.c_int32)
         p.n_dto, p.dto_pos = len(self._dto), _ptr(self._dto)
+        if self._bound is not None and self._bound["n"] > 0:
+            bd = self._bound
+            if len(bd["bin"]) != p.M + 1:
+                raise ValueError("road boundary bins were built for a different reference path")
+            p.n_bound, p.bound_piece = bd["n"], _ptr(bd["piece"])
+            p.bound_bin, p.bound_item = _ptr(bd["bin"], C.c_int32), _ptr(bd["item"], C.c_int32)
+            p.bound_d_reach = bd["d_reach"]
+        else:
+            p.n_bound = 0
         if self.shard is not None:
             b, n = int(self.shard[0]), int(self.shard[1])
             if b < 0 or n < 1 or b + n > self.n_candidates_global:

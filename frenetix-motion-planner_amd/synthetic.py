@@ -72,15 +72,23 @@ def synthetic_predictions(cs: CoordinateSystem, n_obstacles: int, n_pred: int, d
     return preds
 
 
+def offset_road_boundary(cs, half_width: float) -> np.ndarray:
+    """Segments [n][4] of the two polylines reference +- half_width * vertex normal."""
+    left = cs.reference + half_width * cs.normals
+    right = cs.reference - half_width * cs.normals
+    return np.concatenate([np.concatenate([left[:-1], left[1:]], axis=1), np.concatenate([right[:-1], right[1:]], axis=1)])
+
+
 def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0, a0=0.0, d0=0.2, dd0=0.0, ddd0=0.0,
                 s_knot=40, s_off=0.1, horizon=3.0, dt=0.1, level=None, grid=None, cpp_style=False, v_des=12.0,
                 n_obstacles=0, n_pred=30, cost_weights=None, draw_traj_set=False, kinematic_debug=False,
                 write_bundle=True, write_costmap=True, collision=True, low_vel_threshold=2.0, hull_builder=None,
-                seed=SEED, vehicle=None, x0_orientation=None, as_matrix=False, stop_point_s=None):
+                seed=SEED, vehicle=None, x0_orientation=None, as_matrix=False, stop_point_s=None, road_half_width=None):
     """One agent's PlanInputs on a synthetic reference.
 
     level: reference sampling level (set-ordered ranges, SamplingHandler) -- or
     grid=(n_t, n_v, n_d): dense grid (BASELINE configs 2/3/5).
+    road_half_width: road boundary = the reference offset by +-road_half_width (two polylines of segments).
     stop_point_s: distance ahead of s0 of a stop point -> stop-point sampling (end positions in
     [(s0 + s_stop) / 2, s_stop], reactive_planner.py:637) instead of end velocities."""
     veh = vehicle or VehicleParams()
@@ -115,6 +123,8 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
               x0_orientation=x0_orientation, v_des=v_des, vehicle=veh, coordinate_system=cs, cost_weights=weights,
               draw_traj_set=draw_traj_set, kinematic_debug=kinematic_debug, write_bundle=write_bundle,
               write_costmap=write_costmap, collision=collision, obstacles=obstacles)
+    if road_half_width is not None:
+        kw["road_boundary"] = offset_road_boundary(cs, float(road_half_width))
     if as_matrix:
         from .sampling import generate_sampling_matrix
         m = generate_sampling_matrix(t0_range=0.0, t1_range=t, s0_range=s0, ss0_range=v0, sss0_range=a0, ss1_range=v,

@@ -68,6 +68,7 @@ enum {
 #define FX_FLAG_RETURNED   (1u << 3)  /* member of check_feasibility's return list (:353,379,385,567) */
 #define FX_FLAG_COSTED     (1u << 4)  /* cost evaluated (:244-253: all returned in debug, feasible otherwise) */
 #define FX_FLAG_SELECTABLE (1u << 5)  /* walked by trajectory_collision_check (:248,251,258) */
+#define FX_FLAG_BOUNDARY   (1u << 6)  /* planner.py:362-381: the ego footprint leaves the road (boundary_harm != 0) */
 #define FX_REASON_SHIFT 8             /* bits 8..18: reasons 0..10 flagged as in :352,378,384,418,485-531,545 */
 #define FX_REASON_MASK  (0x7FFu << FX_REASON_SHIFT)
 #define FX_NUM_REASONS 11
@@ -78,6 +79,7 @@ enum {
 #define FX_MODE_WRITE_BUNDLE    (1u << 2)  /* materialise the 14-plane SoA TrajectoryBundle in HBM */
 #define FX_MODE_WRITE_COSTMAP   (1u << 3)  /* keep the per-name raw costs (TrajectorySample.costMap) */
 #define FX_MODE_COLLISION       (1u << 4)  /* run the OBB collision stage (planner.use_prediction) */
+#define FX_MODE_ROAD_BOUNDARY   (1u << 5)  /* test the ego footprint against the road boundary (planner.py:362-381) */
 
 /* longitudinal sampling mode.
  * FX_LON_VELOCITY_KEEPING: v_samp = sampled end velocities, quartic to (v, 0) -- _create_trajectory_bundle,
@@ -155,6 +157,15 @@ typedef struct FxProblem {
      * (partial_cost_functions.py:179-184). */
     int32_t n_dto;
     const double *dto_pos;
+    /* road boundary (planner.py:362-381; built once per scenario, :550-565): n_bound straight pieces
+     * bound_piece[n_bound][4] = (mid x, mid y, half dx, half dy), and per reference knot k the pieces that can
+     * touch an ego footprint whose foot point lies on segment k: bound_item[bound_bin[k] .. bound_bin[k+1])
+     * (CSR, M+1 offsets).  Built by fx_build_boundary_bins.  DESIGN.md 4.3 is the normative test. */
+    int32_t n_bound;
+    const double *bound_piece;
+    const int32_t *bound_bin;
+    const int32_t *bound_item;
+    double bound_d_reach;   /* lateral reach the bins were built for; |d| beyond it counts as off the road */
 } FxProblem;
 
 /* Result of one plan step (what _get_optimal_trajectory returns plus the counters it sets,
@@ -254,6 +265,22 @@ int32_t fx_read_coeffs_agent(FxContext *ctx, int32_t agent, int64_t index, doubl
 int32_t fx_read_sample_agent(FxContext *ctx, int32_t agent, int64_t index, double *planes);
 int32_t fx_read_plane_agent(FxContext *ctx, int32_t agent, int32_t plane, double *out);
 int32_t fx_read_topk_batch(FxContext *ctx, int32_t k, double *cost /*[n_agents][k]*/, int64_t *index /*[n_agents][k]*/);
+
+/* ---- road boundary (replaces create_road_boundary_obstacle + trajectories_collision_static_obstacles,
+ *      planner.py:362-381,550-565; commonroad-drivability-checker, not in the reference tree) ----
+ * fx_build_boundary_bins: host-side geometry, no GPU.  Splits the n_seg boundary segments seg[n_seg][4] =
+ * (ax, ay, bx, by) into pieces no longer than max_len, and lists for every reference knot k the pieces whose
+ * midpoint lies within reach + half length of knot k.  piece_out[piece_cap][4], bin_out[M + 1],
+ * item_out[item_cap]; *n_piece / *n_item receive the counts (FX_ERR_CAPACITY when a buffer is too small; the
+ * counts are still set so the caller can re-allocate).  reach must cover the ego footprint around its foot point:
+ * longest reference segment + largest |d| + wb_rear_axle + half diagonal of the vehicle. */
+int32_t fx_build_boundary_bins(int32_t M, const double *ref_x, const double *ref_y, int32_t n_seg, const double *seg,
+                               double max_len, double reach, int32_t piece_cap, double *piece_out, int32_t *n_piece,
+                               int32_t *bin_out, int32_t item_cap, int32_t *item_out, int32_t *n_item);
+/* first step at which each candidate's footprint meets the boundary, -1 if never (FX_MODE_ROAD_BOUNDARY);
+ * boundary_harm = logistic regression of cartesian.v at that step (planner.py:369-375) is left to the caller */
+int32_t fx_read_boundary_steps(FxContext *ctx, int32_t *steps);
+int32_t fx_read_boundary_steps_agent(FxContext *ctx, int32_t agent, int32_t *steps);
 
 /* device pointers of one agent's outputs for callers that keep working on the GPU:
  * cost f64[ld], flags u32[ld], planes f64[14][S][ld] (NULL without FX_MODE_WRITE_BUNDLE) */

@@ -269,6 +269,43 @@ static int ego_collides(const FxProblem *p, const double *x, const double *y, co
     return 0;
 }
 
+/* Road boundary (planner.py:362-381), normative test of DESIGN.md 4.3: ego footprint at step i = rectangle with
+ * centre rear axle + wb_rear_axle along the heading, half extents length/2 x width/2; boundary = straight pieces
+ * (mid, half vector).  Separating axes: the two box axes and the piece's normal; touching intersects.  Returns the
+ * first step that meets any piece, -1 if none.  Steps from the first out-of-domain step on are not tested. */
+static int ego_leaves_road(const FxProblem *p, const double *x, const double *y, const double *th, const double *s,
+                           const double *d, double *margin) {
+    const int S = p->N + 1, M = p->M;
+    const double hl = p->veh.length / 2, hw = p->veh.width / 2, wb = p->veh.wb_rear_axle;
+    for (int i = 0; i < S; i++) {
+        if (!(s[i] >= p->ref_pos[0] && s[i] <= p->ref_pos[M - 1])) break; /* projection failed: loop breaks, :537-547 */
+        /* beyond the lateral reach the boundary structure was built for: off the road by definition */
+        if (margin && fabs(fabs(d[i]) - p->bound_d_reach) < *margin) *margin = fabs(fabs(d[i]) - p->bound_d_reach);
+        if (fabs(d[i]) > p->bound_d_reach) return i;
+        const double ux = cos(th[i]), uy = sin(th[i]);
+        const double cx = x[i] + wb * ux, cy = y[i] + wb * uy;
+        int hit = 0;
+        for (int j = 0; j < p->n_bound; j++) {
+            const double *q = p->bound_piece + 4 * (size_t)j;
+            const double ex0 = q[0] - cx, ey0 = q[1] - cy;
+            const double ex = ex0 * ux + ey0 * uy, ey = ey0 * ux - ex0 * uy;
+            const double hx = q[2] * ux + q[3] * uy, hy = q[3] * ux - q[2] * uy;
+            const double m1 = fabs(ex) - (hl + fabs(hx));
+            const double m2 = fabs(ey) - (hw + fabs(hy));
+            const double m3 = fabs(ex * hy - ey * hx) - (hl * fabs(hy) + hw * fabs(hx));
+            if (margin) {
+                /* the decision is max(m1, m2, m3) > 0 */
+                double mx = m1 > m2 ? m1 : m2;
+                mx = mx > m3 ? mx : m3;
+                if (fabs(mx) < *margin) *margin = fabs(mx);
+            }
+            if (!(m1 > 0 || m2 > 0 || m3 > 0)) hit = 1;
+        }
+        if (hit) return i;
+    }
+    return -1;
+}
+
 /* ---------------------------------------------------------------- one candidate */
 
 typedef struct {
@@ -582,8 +619,17 @@ int64_t fxo_num_candidates(const FxProblem *p) {
  * first_only != 0 skips the plane/collision work that the winner search does not need -- unused
  * here, the oracle always does everything.
  */
+int32_t fxo_plan_step_b(const FxProblem *p, double *coeff_lon, double *coeff_lat, int32_t *traj_len, double *planes,
+                        uint32_t *flags, double *cost, double *costmap, int64_t *order, double *margin, int32_t *bound_step,
+                        FxResult *res);
 int32_t fxo_plan_step(const FxProblem *p, double *coeff_lon, double *coeff_lat, int32_t *traj_len, double *planes,
                       uint32_t *flags, double *cost, double *costmap, int64_t *order, double *margin, FxResult *res) {
+    return fxo_plan_step_b(p, coeff_lon, coeff_lat, traj_len, planes, flags, cost, costmap, order, margin, NULL, res);
+}
+/* same, plus bound_step[C]: first step at which the footprint meets the road boundary, -1 if never */
+int32_t fxo_plan_step_b(const FxProblem *p, double *coeff_lon, double *coeff_lat, int32_t *traj_len, double *planes,
+                        uint32_t *flags, double *cost, double *costmap, int64_t *order, double *margin, int32_t *bound_step,
+                        FxResult *res) {
     const int S = p->N + 1;
     if (S > 255 || p->n_cost > FX_NUM_COSTS) return FX_ERR_INVALID_ARGUMENT;
     const int64_t C = fxo_num_candidates(p);
@@ -606,6 +652,12 @@ int32_t fxo_plan_step(const FxProblem *p, double *coeff_lon, double *coeff_lat, 
         if ((f & FX_FLAG_SELECTABLE) && (p->mode & FX_MODE_COLLISION) && p->K > 0) {
             if (ego_collides(p, pl + FX_PL_X * S, pl + FX_PL_Y * S, pl + FX_PL_THETA * S, &mg)) f |= FX_FLAG_COLLISION;
         }
+        int bstep = -1;
+        if ((f & FX_FLAG_SELECTABLE) && (p->mode & FX_MODE_ROAD_BOUNDARY) && p->n_bound > 0) {
+            bstep = ego_leaves_road(p, pl + FX_PL_X * S, pl + FX_PL_Y * S, pl + FX_PL_THETA * S, pl + FX_PL_S * S, pl + FX_PL_D * S, &mg);
+            if (bstep >= 0) f |= FX_FLAG_BOUNDARY;
+        }
+        if (bound_step) bound_step[g] = bstep;
         if (margin) margin[g] = mg;
         flags[g] = f;
         cost[g] = (f & FX_FLAG_COSTED) ? total : 0.0;
@@ -631,7 +683,8 @@ int32_t fxo_plan_step(const FxProblem *p, double *coeff_lon, double *coeff_lat, 
     for (int64_t j = 0; j < n_ci; j++) {
         uint32_t f = flags[ci[j].i];
         if (!(f & FX_FLAG_SELECTABLE)) continue;
-        if (f & FX_FLAG_COLLISION) { res->n_collisions++; continue; }
+        if (f & FX_FLAG_COLLISION) res->n_collisions++; /* planner.py:356-357 */
+        if (f & (FX_FLAG_COLLISION | FX_FLAG_BOUNDARY)) continue; /* :384 */
         res->best_index = g0 + ci[j].i; /* global id */
         res->best_cost = ci[j].c;
         break;
@@ -657,9 +710,12 @@ int32_t fxo_plan_range(const FxProblem *p, int64_t g0, int64_t g1, uint32_t *fla
         uint32_t f = eval_candidate(p, g, &cd, pl, raw, &total, NULL);
         if ((f & FX_FLAG_SELECTABLE) && (p->mode & FX_MODE_COLLISION) && p->K > 0)
             if (ego_collides(p, pl + FX_PL_X * S, pl + FX_PL_Y * S, pl + FX_PL_THETA * S, NULL)) f |= FX_FLAG_COLLISION;
+        if ((f & FX_FLAG_SELECTABLE) && (p->mode & FX_MODE_ROAD_BOUNDARY) && p->n_bound > 0)
+            if (ego_leaves_road(p, pl + FX_PL_X * S, pl + FX_PL_Y * S, pl + FX_PL_THETA * S, pl + FX_PL_S * S, pl + FX_PL_D * S, NULL) >= 0)
+                f |= FX_FLAG_BOUNDARY;
         flags[g - g0] = f;
         cost[g - g0] = (f & FX_FLAG_COSTED) ? total : 0.0;
-        if ((f & FX_FLAG_SELECTABLE) && !(f & FX_FLAG_COLLISION) && (*best < 0 || total < *best_cost)) {
+        if ((f & FX_FLAG_SELECTABLE) && !(f & (FX_FLAG_COLLISION | FX_FLAG_BOUNDARY)) && (*best < 0 || total < *best_cost)) {
             *best = g;
             *best_cost = total;
         }

@@ -32,6 +32,9 @@ def lib():
         L.fxo_plan_step.argtypes = [C.POINTER(_abi.FxProblem), pd, pd, pi32, pd, pu32, pd, pd, pi64, pd,
                                     C.POINTER(_abi.FxResult)]
         L.fxo_plan_step.restype = C.c_int32
+        L.fxo_plan_step_b.argtypes = [C.POINTER(_abi.FxProblem), pd, pd, pi32, pd, pu32, pd, pd, pi64, pd, pi32,
+                                      C.POINTER(_abi.FxResult)]
+        L.fxo_plan_step_b.restype = C.c_int32
         L.fxo_plan_range.argtypes = [C.POINTER(_abi.FxProblem), C.c_int64, C.c_int64, pu32, pd, pi64, pd]
         L.fxo_plan_range.restype = C.c_int32
         L.fxo_num_candidates.argtypes = [C.POINTER(_abi.FxProblem)]
@@ -76,12 +79,12 @@ def plan_step(inputs, want_planes=True):
         coeff_lon=np.zeros((Cn, 6)), coeff_lat=np.zeros((Cn, 6)), traj_len=np.zeros(Cn, np.int32),
         planes=np.zeros((Cn, _abi.FX_NUM_PLANES, S)) if want_planes else None,
         flags=np.zeros(Cn, np.uint32), cost=np.zeros(Cn), costmap=np.zeros((Cn, max(nc, 1))),
-        order=np.zeros(Cn, np.int64), margin=np.zeros(Cn))
+        order=np.zeros(Cn, np.int64), margin=np.zeros(Cn), boundary_step=np.full(Cn, -1, np.int32))
     res = _abi.FxResult()
-    rc = lib().fxo_plan_step(C.byref(prob), _p(out["coeff_lon"]), _p(out["coeff_lat"]), _p(out["traj_len"], C.c_int32),
-                             _p(out["planes"]) if want_planes else None, _p(out["flags"], C.c_uint32),
-                             _p(out["cost"]), _p(out["costmap"]), _p(out["order"], C.c_int64), _p(out["margin"]),
-                             C.byref(res))
+    rc = lib().fxo_plan_step_b(C.byref(prob), _p(out["coeff_lon"]), _p(out["coeff_lat"]), _p(out["traj_len"], C.c_int32),
+                               _p(out["planes"]) if want_planes else None, _p(out["flags"], C.c_uint32),
+                               _p(out["cost"]), _p(out["costmap"]), _p(out["order"], C.c_int64), _p(out["margin"]),
+                               _p(out["boundary_step"], C.c_int32), C.byref(res))
     if rc != 0:
         raise ValueError(f"fxo_plan_step failed: {rc}")
     out["costmap"] = out["costmap"][:, :nc]
@@ -89,7 +92,8 @@ def plan_step(inputs, want_planes=True):
     f = out["flags"]
     for name, bit in (("valid", _abi.FX_FLAG_VALID), ("feasible", _abi.FX_FLAG_FEASIBLE),
                       ("collision", _abi.FX_FLAG_COLLISION), ("returned", _abi.FX_FLAG_RETURNED),
-                      ("costed", _abi.FX_FLAG_COSTED), ("selectable", _abi.FX_FLAG_SELECTABLE)):
+                      ("costed", _abi.FX_FLAG_COSTED), ("selectable", _abi.FX_FLAG_SELECTABLE),
+                      ("boundary", _abi.FX_FLAG_BOUNDARY)):
         out[name] = (f & bit) != 0
     out["reasons"] = (f >> _abi.FX_REASON_SHIFT) & 0x7FF
     return out
