@@ -182,6 +182,32 @@ class Scenario:
             pts.append(c)
         return np.vstack(pts)
 
+    def road_boundary_segments(self, tol: float = 0.05) -> np.ndarray:
+        """Outer border of the drivable area as segments [n][4] = (ax, ay, bx, by): every lanelet-bound segment that
+        is neither shared with a neighbouring lanelet nor inside another lanelet (turning lanelets of an intersection
+        overlap each other).  Stands in for commonroad_dc's `create_road_boundary_obstacle(scenario,
+        method="aligned_triangulation")` (planner.py:550-565), whose triangles fill the outside of the same border."""
+        segs = []
+        ll = list(self.lanelets.values())
+        for l in ll:
+            for side, bound in (("left", l.left_vertices), ("right", l.right_vertices)):
+                nb = l.adj_left if side == "left" else l.adj_right
+                if nb is not None and nb in self.lanelets:
+                    continue  # shared with the neighbouring lane
+                inward = (l.right_vertices - l.left_vertices) if side == "left" else (l.left_vertices - l.right_vertices)
+                for i in range(len(bound) - 1):
+                    a, b = bound[i], bound[i + 1]
+                    if np.allclose(a, b):
+                        continue
+                    mid = 0.5 * (a + b)
+                    n = 0.5 * (inward[i] + inward[i + 1])
+                    n = n / max(np.linalg.norm(n), 1e-12)
+                    probe = mid - tol * n  # just outside this lanelet
+                    if any(o is not l and o.contains(probe) for o in ll):
+                        continue           # drivable on the other side: not a border
+                    segs.append([a[0], a[1], b[0], b[1]])
+        return np.array(segs, dtype=np.float64).reshape(-1, 4)
+
     # -- predictions ----------------------------------------------------------------------------------------------
     def ground_truth_predictions(self, time_step: int, pred_horizon: int = 50, obstacle_ids=None) -> dict:
         """prediction_helpers.get_ground_truth_prediction (:209-261): the obstacles' recorded futures as a prediction.

@@ -83,6 +83,9 @@ class ReactivePlannerHip:
         self._device = device
         self._engine = engine
         self.road_boundary_check = road_boundary_check
+        self.road_boundary = None          # segments [n][4]; checked on the GPU (set_road_boundary)
+        self._packed_boundary = None
+        self.params_harm = {"log_reg": {"ignore_angle": {"const": -4.591, "speed": 0.185}}}  # configurations/harm_parameters.json
 
         self.x_0: Optional[ReactivePlannerState] = None
         self.x_cl: Optional[Tuple[List, List]] = None
@@ -167,6 +170,13 @@ class ReactivePlannerHip:
     def set_cost_function(self, cost_weights):
         self.cost_weights = dict(cost_weights)
 
+    def set_road_boundary(self, segments):
+        """Road boundary as straight segments [n][4] = (ax, ay, bx, by) (planner.py:550-565 builds it once per
+        scenario).  The footprint test of planner.py:362-381 then runs inside the evaluation kernel for every
+        candidate; trajectories that leave the road carry `boundary_harm` != 0 and are never selected."""
+        self.road_boundary = None if segments is None else np.ascontiguousarray(segments, dtype=np.float64).reshape(-1, 4)
+        self._packed_boundary = None
+
     def set_predictions(self, predictions: dict):
         self.use_prediction = True
         self.predictions = predictions
@@ -227,6 +237,15 @@ class ReactivePlannerHip:
         if self._packed_predictions is None:
             self._packed_predictions = pack_predictions(self.predictions if self.use_prediction else None, self.N + 1,
                                                         build_obstacle_hulls)
+        boundary = None
+        if self.road_boundary is not None and len(self.road_boundary):
+            from .problem import pack_road_boundary
+            d_reach = 1.5 * max(float(np.max(np.abs(d))), abs(float(x_lat[0]))) + 2.0
+            pb = self._packed_boundary
+            if pb is None or pb["d_reach"] < d_reach or len(pb["bin"]) != len(self.coordinate_system.reference) + 1:
+                pb = self._packed_boundary = pack_road_boundary(self.road_boundary, self.coordinate_system,
+                                                                self.vehicle_params, d_reach)
+            boundary = pb
         weights = {k: w for k, w in self.cost_weights.items() if w != 0}
         if not self._packed_predictions["K"]:
             # prediction_costs over an empty predictions dict is 0 for every candidate
@@ -236,7 +255,8 @@ class ReactivePlannerHip:
                           coordinate_system=self.coordinate_system, t_samp=t, v_samp=v, d_samp=d,
                           stop_point=stop_point_s is not None, cost_weights=weights,
                           draw_traj_set=self._draw_traj_set, kinematic_debug=self._kinematic_debug, write_bundle=True,
-                          write_costmap=True, collision=self.use_prediction, obstacles=self._packed_predictions)
+                          write_costmap=True, collision=self.use_prediction, obstacles=self._packed_predictions,
+                          road_boundary=boundary)
 
     def _create_end_point_trajectory_bundle(self, x_0_lon, x_0_lat, stop_point_s, samp_level: int) -> PlanInputs:
         """Stop-point sampling set of reactive_planner.py:628-671 as engine inputs: T x S x (D u {d0}) with the
@@ -285,6 +305,8 @@ class ReactivePlannerHip:
             self.last_step.invalidate()
         res = self.engine.plan_step(inputs)
         step = PlanStepResult(self.engine, inputs, res)
+        lr = self.params_harm["log_reg"]["ignore_angle"]
+        step.harm_coeff = (lr["const"], lr["speed"])
         self.last_step = step
         self._total_count = res["n_candidates"]
         hist = list(res["reason_hist"]) if self._kinematic_debug else [0] * 11

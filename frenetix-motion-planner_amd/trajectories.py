@@ -84,7 +84,7 @@ class TrajectorySample:
         # writable from Python (planner.py:325-326,381-382)
         self._ego_risk = None
         self._obst_risk = None
-        self.boundary_harm = None
+        self._boundary_harm = None
         self._coll_detected = bool(flags & _abi.FX_FLAG_COLLISION) if (flags & _abi.FX_FLAG_SELECTABLE) else None
         self.harm_occ_module = None
         self._planes = None
@@ -95,6 +95,29 @@ class TrajectorySample:
     @property
     def cost(self) -> float:
         return self._cost
+
+    @property
+    def leaves_road(self) -> Optional[bool]:
+        """True/False for walked candidates when the step ran the road-boundary stage, else None"""
+        if not (self._step.inputs.mode & _abi.FX_MODE_ROAD_BOUNDARY) or not (self._flags & _abi.FX_FLAG_SELECTABLE):
+            return None
+        return bool(self._flags & _abi.FX_FLAG_BOUNDARY)
+
+    @property
+    def boundary_harm(self):
+        """planner.py:369-381: logistic regression of the velocity at the first step outside the road, 0 inside."""
+        if self._boundary_harm is not None or self.leaves_road is None:
+            return self._boundary_harm
+        if not self.leaves_road:
+            return 0
+        i = int(self._step.boundary_steps[self.uniqueId])
+        v = float(self.cartesian.v[i])
+        c = self._step.harm_coeff
+        return float(1.0 / (1.0 + np.exp(-c[0] - c[1] * v)))
+
+    @boundary_harm.setter
+    def boundary_harm(self, value):
+        self._boundary_harm = value
 
     @property
     def reasons(self) -> int:
@@ -121,6 +144,8 @@ class TrajectorySample:
         self._need_planes()
         _ = self.costMap
         _ = self.trajectory_long
+        if self.leaves_road:
+            self._boundary_harm = self.boundary_harm
         return self
 
     @property
@@ -196,6 +221,15 @@ class PlanStepResult:
         self.cost, self.flags = engine.costs(agent)
         self._stale = False
         self._samples = {}
+        self.harm_coeff = (-4.591, 0.185)  # log_reg.ignore_angle const / speed (configurations/harm_parameters.json)
+        self._bsteps = None
+
+    @property
+    def boundary_steps(self) -> np.ndarray:
+        if self._bsteps is None:
+            self._check()
+            self._bsteps = self.engine.boundary_steps(self.agent)
+        return self._bsteps
 
     def invalidate(self):
         """The engine is about to run another step: device buffers will be overwritten."""

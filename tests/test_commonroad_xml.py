@@ -50,6 +50,16 @@ def test_route_and_reference_path(tiny):
     assert abs(np.median(seg) - 1.0) < 0.02 and prepared[0, 0] < -25 and prepared[-1, 0] > 145  # extended both ends
 
 
+def test_road_boundary_segments(tiny):
+    b = tiny.road_boundary_segments()
+    assert b.shape == (24, 4)
+    ys = sorted(set(np.round(b[:, 1], 6)))
+    assert ys == [-2.0, 2.0, 6.0]                                   # outer borders only; the shared lane line is not one
+    on_mid = b[np.isclose(b[:, 1], 2.0)]
+    assert on_mid[:, [0, 2]].min() >= 60.0                          # y = 2 is a border only where lanelet 3 has ended
+    assert np.isclose(np.linalg.norm(b[:, 2:] - b[:, :2], axis=1).sum(), 120 + 60 + 60)
+
+
 def test_ground_truth_predictions(tiny):
     """prediction_helpers.py:209-261 including its state_list[ts] velocity indexing."""
     pr = tiny.ground_truth_predictions(time_step=3, pred_horizon=30)
@@ -82,3 +92,10 @@ def test_example_scenario_of_the_reference():
     assert abs(d) < 2.0 and 25 < s < cs.ref_pos[-1] - 30
     preds = sc.ground_truth_predictions(0, 30)
     assert set(preds) == set(sc.obstacles) and all(len(p["pos_list"]) == 30 for p in preds.values())
+    border = sc.road_boundary_segments()
+    total = sum(len(l.left_vertices) + len(l.right_vertices) - 2 for l in sc.lanelets.values())
+    assert 0 < len(border) < total                                  # shared and overlapped bounds are dropped
+    # the initial footprint centre is inside the road: no border segment within half a vehicle width of it
+    p0 = pp.initial_state.position
+    mid = 0.5 * (border[:, :2] + border[:, 2:])
+    assert np.min(np.linalg.norm(mid - p0, axis=1)) > 0.9

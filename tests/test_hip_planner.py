@@ -243,13 +243,21 @@ def test_scenario_file_to_plan(tmp_path):
     rp = ReactivePlannerHip(PlannerConfig(dt=sc.dt), VehicleParams())
     rp.update_externals(reference_path=reference, x_0=pp.initial_planner_state(), desired_velocity=10.0,
                         predictions=sc.ground_truth_predictions(0, 30))
+    rp.set_road_boundary(sc.road_boundary_segments())
     pair = rp.plan()
     assert pair is not None
     best = rp.optimal_trajectory
     inp = rp._inputs_for_level(2)
+    assert inp.mode & _abi.FX_MODE_ROAD_BOUNDARY
     inp.obstacles = synthetic.pack_predictions(rp.predictions, 31, oracle.build_obstacle_hulls)
     out = oracle.plan_step(inp)
     assert best.uniqueId == out["result"]["best_index"] and rp.infeasible_count_collision == out["result"]["n_collisions"]
+    # the lane is 4 m wide and the left neighbour ends at x = 60: wide lateral end states leave the road
+    assert out["boundary"].sum() > 0 and best.leaves_road is False and best.boundary_harm == 0
+    g_off = int(np.nonzero(out["boundary"])[0][0])
+    off = rp.last_step.sample(g_off)
+    i_off = int(out["boundary_step"][g_off])
+    assert off.leaves_road and off.boundary_harm == pytest.approx(1.0 / (1.0 + np.exp(4.591 - 0.185 * off.cartesian.v[i_off])))
     # the ego starts 10 m behind a slower car in its lane: the collision stage must have rejected candidates
     assert out["collision"].sum() > 0 and not out["collision"][best.uniqueId]
     x = np.array([st.position[0] for st in pair[0]])
