@@ -346,3 +346,64 @@ def read_scenario(path: str) -> Scenario:
             goals.append(gs)
         problems[pid] = PlanningProblem(pid, _state(n.find("initialState")), goals)
     return Scenario(root.get("benchmarkID", ""), float(root.get("timeStepSize", "0.1")), lanelets, obstacles, problems)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Compact JSON form of a Scenario (what this reader interprets, nothing else) -- the fixture format of
+# tests/golden/*.scenario.json: the XML is not on the GPU box, the numbers are.
+def _state_row(s: State) -> list:
+    return [s.time_step, float(s.position[0]), float(s.position[1]), s.orientation, s.velocity, s.acceleration, s.yaw_rate,
+            s.slip_angle]
+
+
+def _row_state(r) -> State:
+    return State(int(r[0]), np.array([r[1], r[2]], dtype=np.float64), float(r[3]), float(r[4]), float(r[5]), float(r[6]),
+                 float(r[7]))
+
+
+def scenario_to_dict(sc: Scenario) -> dict:
+    return dict(
+        benchmark_id=sc.benchmark_id, dt=sc.dt,
+        lanelets=[dict(id=l.lanelet_id, left=l.left_vertices.tolist(), right=l.right_vertices.tolist(),
+                       predecessor=l.predecessor, successor=l.successor, adj_left=l.adj_left,
+                       adj_left_same=l.adj_left_same_direction, adj_right=l.adj_right,
+                       adj_right_same=l.adj_right_same_direction, type=l.lanelet_type) for l in sc.lanelets.values()],
+        obstacles=[dict(id=o.obstacle_id, role=o.role, type=o.obstacle_type, shape=o.shape,
+                        initial=_state_row(o.initial_state), states=[_state_row(s) for s in o.state_list])
+                   for o in sc.obstacles.values()],
+        planning_problems=[dict(id=p.planning_problem_id, initial=_state_row(p.initial_state),
+                                goals=[dict(time=g.time_interval, velocity=g.velocity_interval,
+                                            orientation=g.orientation_interval, lanelets=g.lanelet_ids,
+                                            rectangles=[dict(r, center=[float(r["center"][0]), float(r["center"][1])])
+                                                        for r in g.rectangles]) for g in p.goals])
+                           for p in sc.planning_problems.values()])
+
+
+def scenario_from_dict(d: dict) -> Scenario:
+    lanelets = {l["id"]: Lanelet(l["id"], np.array(l["left"], dtype=np.float64), np.array(l["right"], dtype=np.float64),
+                                 list(l["predecessor"]), list(l["successor"]), l["adj_left"], l["adj_left_same"],
+                                 l["adj_right"], l["adj_right_same"], list(l["type"])) for l in d["lanelets"]}
+    obstacles = {o["id"]: Obstacle(o["id"], o["role"], o["type"], dict(o["shape"]), _row_state(o["initial"]),
+                                   [_row_state(r) for r in o["states"]]) for o in d["obstacles"]}
+    problems = {}
+    for p in d["planning_problems"]:
+        goals = [GoalState(time_interval=tuple(g["time"]) if g["time"] else None,
+                           velocity_interval=tuple(g["velocity"]) if g["velocity"] else None,
+                           orientation_interval=tuple(g["orientation"]) if g["orientation"] else None,
+                           lanelet_ids=list(g["lanelets"]),
+                           rectangles=[dict(r, center=np.array(r["center"], dtype=np.float64)) for r in g["rectangles"]])
+                 for g in p["goals"]]
+        problems[p["id"]] = PlanningProblem(p["id"], _row_state(p["initial"]), goals)
+    return Scenario(d["benchmark_id"], float(d["dt"]), lanelets, obstacles, problems)
+
+
+def write_scenario_json(sc: Scenario, path: str):
+    import json
+    with open(path, "w") as fh:
+        json.dump(scenario_to_dict(sc), fh, separators=(",", ":"))
+
+
+def read_scenario_json(path: str) -> Scenario:
+    import json
+    with open(path) as fh:
+        return scenario_from_dict(json.load(fh))

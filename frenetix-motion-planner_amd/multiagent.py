@@ -1,0 +1,264 @@
+"""Batched multi-agent stepping: every agent's plan step of a simulation step in ONE launch per GPU (SURVEY.md 8 f4,
+BASELINE configs 4 and 5).
+
+The reference runs agents in separate processes -- `AgentBatch.run / step_simulation / _step_agents`
+(cr_scenario_handler/simulation/agent_batch.py:86-189) under `Simulation._step_parallel_simulation`
+(simulation.py:621-663): each process loops over its agents and calls `agent.step_agent`, results come back pickled
+through Queues, and the main process merges the new trajectories into the next step's scenario / predictions.  Agents
+are independent given the predictions frozen at the start of a step, so here
+
+    * `AgentBatchHip`        -- all agents of this rank share one FrenetEngine context with `max_agents` slots; their
+                                first sampling level is evaluated in one batched launch (`fx_evaluate` over a grid of
+                                (workgroups, agents)); an agent whose level finds nothing escalates on its own,
+    * `MultiAgentSimulation` -- closed loop over a scenario: agent selection as simulation.py:168-211, predictions =
+                                recorded futures of non-agent obstacles + the planned trajectories of the other agents
+                                (what the reference obtains by writing the plans back into the scenario), agents
+                                round-robin over ranks (`distributed.agents_of_rank`), and ONE all-gather per
+                                simulation step of the planned trajectories [agents_per_rank][S][5] so every rank
+                                builds the same predictions for the next step.
+
+Out of scope: goal/collision status bookkeeping of `Agent`, visualisation, evaluation, the prediction
+network -- only the stepping that feeds the hot path.
+"""
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .commonroad_xml import GoalState, PlanningProblem, Scenario, State
+from .distributed import agents_of_rank
+from .frenet_interface import FrenetPlannerInterfaceHip
+from .problem import VehicleParams
+from .reactive_planner import PlannerConfig
+
+
+def select_agent_obstacles(scenario: Scenario, number_of_agents: int = -1) -> List[int]:
+    """simulation.py:168-211: dynamic cars that move more than 10 m, start on exactly one lanelet and end on one."""
+    ids = []
+    for oid, ob in scenario.obstacles.items():
+        if ob.role != "dynamic" or ob.obstacle_type != "car" or not ob.state_list:
+            continue
+        if np.linalg.norm(ob.initial_state.position - ob.state_list[-1].position) <= 10:
+            continue
+        if len(scenario.lanelets_at(ob.initial_state.position)) != 1:
+            continue
+        if len(scenario.lanelets_at(ob.state_list[-1].position)) == 0:
+            continue
+        ids.append(oid)
+    if -1 < number_of_agents < len(ids):
+        ids = ids[:number_of_agents]
+    return ids
+
+
+def planning_problem_for_obstacle(scenario: Scenario, obstacle_id: int) -> PlanningProblem:
+    """simulation.py:213-330 in short: initial state = the obstacle's, goal = the lanelet of its final state (the one
+    whose direction fits the final orientation best), time +-20 steps, velocity +-2 m/s around the final state."""
+    ob = scenario.obstacles[obstacle_id]
+    fin = ob.state_list[-1]
+    cands = scenario.lanelets_at(fin.position)
+
+    def heading_error(lid):
+        c = scenario.lanelets[lid].center_vertices
+        k = int(np.argmin(np.linalg.norm(c - fin.position, axis=1)))
+        k = min(max(k, 0), len(c) - 2)
+        th = np.arctan2(c[k + 1, 1] - c[k, 1], c[k + 1, 0] - c[k, 0])
+        return abs((th - fin.orientation + np.pi) % (2 * np.pi) - np.pi)
+
+    lid = min(cands, key=heading_error)
+    goal = GoalState(time_interval=(max(fin.time_step - 20, 0), fin.time_step + 20),
+                     velocity_interval=(fin.velocity - 2, fin.velocity + 2), lanelet_ids=[lid])
+    init = State(time_step=ob.initial_state.time_step, position=np.array(ob.initial_state.position, dtype=np.float64),
+                 orientation=ob.initial_state.orientation, velocity=ob.initial_state.velocity,
+                 acceleration=ob.initial_state.acceleration, yaw_rate=ob.initial_state.yaw_rate)
+    return PlanningProblem(obstacle_id, init, [goal])
+
+
+def trajectory_as_prediction(states: Sequence, shape: dict, wb_rear_axle: float, first: int = 0) -> dict:
+    """A planned trajectory (rear-axle states) as a prediction of the other agents: centre positions
+    (state.py:30-39), orientation, covariance 0.1 I (prediction_helpers.py:245)."""
+    st = states[first:]
+    th = np.array([s.orientation for s in st])
+    pos = np.array([s.position for s in st]).reshape(-1, 2) + wb_rear_axle * np.stack([np.cos(th), np.sin(th)], axis=1)
+    n = len(st)
+    return dict(pos_list=pos, cov_list=np.tile(np.eye(2) * 0.1, (n, 1, 1)), orientation_list=th,
+                v_list=np.array([s.velocity for s in st]), shape=dict(shape))
+
+
+class AgentBatchHip:
+    """The agents of one rank stepped together: one batched launch for every agent that plans in this step."""
+
+    def __init__(self, agents: List[FrenetPlannerInterfaceHip], max_candidates: int, device: int = 0, max_ref_knots: int = 4096,
+                 max_obstacles: int = 64, engine=None):
+        self.agents = list(agents)
+        N = max(a.planner.N for a in self.agents) if self.agents else 30
+        if engine is None:
+            from .engine import FrenetEngine
+            engine = FrenetEngine(max_candidates=max_candidates, max_steps=N, max_ref_knots=max_ref_knots,
+                                  max_obstacles=max_obstacles, max_pred_steps=max(64, N + 2), device=device,
+                                  max_agents=max(len(self.agents), 1))
+        self.engine = engine
+        self.launches = 0
+        self.escalations = 0
+        self.last_batch_ms = 0.0
+
+    def step(self, global_timestep: int, predictions: Dict[int, dict]) -> Dict[int, Optional[list]]:
+        """agent_batch.py:140-189: update every agent with its predictions, plan (batched), finish the step.
+        predictions: {agent id: predictions dict of that agent}.  Returns {agent id: selected Cartesian state list
+        (None: no trajectory found)}."""
+        planning, passive = [], []
+        for a in self.agents:
+            a.update_planner(None, predictions.get(a.id, {}))
+            inp = a.begin_step()
+            (planning if inp is not None else passive).append((a, inp))
+        out: Dict[int, Optional[list]] = {}
+        if planning:
+            t0 = time.time()
+            results = self.engine.plan_batch([inp for _, inp in planning])
+            self.launches += 1
+            self.last_batch_ms = (time.time() - t0) * 1e3
+            for j, (a, inp) in enumerate(planning):
+                p = a.planner
+                best = p.plan_consume(inp, results[j], self.engine, j)
+                if best is None and p._sampling_min + 1 < p._sampling_max:
+                    self.escalations += 1
+                    pair = p.plan_escalate(t0)
+                else:
+                    pair = p.plan_finish(best, t0)
+                sel, _ = a.finish_step(pair, global_timestep)
+                out[a.id] = sel
+        for a, _ in passive:
+            sel, _ = a.finish_step(None, global_timestep)
+            out[a.id] = sel[0] if sel is not None else None
+        return out
+
+    def close(self):
+        self.engine.close()
+        for a in self.agents:
+            a.close()
+
+
+class MultiAgentSimulation:
+    """Closed-loop multi-agent run of a scenario on the batched engine (BASELINE config 4)."""
+
+    FIELDS = 5  # x, y (rear axle), orientation, velocity, valid
+
+    def __init__(self, scenario: Scenario, config: Optional[PlannerConfig] = None, vehicle: Optional[VehicleParams] = None,
+                 number_of_agents: int = -1, sampling_level: Optional[int] = None, device: int = 0, group=None,
+                 use_road_boundary: bool = False, max_candidates: Optional[int] = None, engine_factory=None):
+        """engine_factory: callable returning an engine object (tests inject a stand-in); default = FrenetEngine."""
+        import torch.distributed as dist
+        self.scenario = scenario
+        self.config = config or PlannerConfig()
+        if sampling_level is not None:
+            self.config.sampling_min, self.config.sampling_max = sampling_level, sampling_level + 1
+        self.vehicle = vehicle or VehicleParams()
+        self.dist = dist if dist.is_available() and dist.is_initialized() else None
+        self.group = group
+        self.rank = self.dist.get_rank(group) if self.dist else 0
+        self.world = self.dist.get_world_size(group) if self.dist else 1
+        # agents: the scenario's planning problems first, then the selected obstacles (simulation.py:131-166)
+        self.problems: Dict[int, PlanningProblem] = dict(scenario.planning_problems)
+        self.agent_obstacles = select_agent_obstacles(scenario, number_of_agents)
+        for oid in self.agent_obstacles:
+            self.problems[oid] = planning_problem_for_obstacle(scenario, oid)
+        self.agent_ids = list(self.problems)
+        self.shapes = {i: (dict(length=scenario.obstacles[i].length, width=scenario.obstacles[i].width)
+                           if i in scenario.obstacles else dict(length=self.vehicle.length, width=self.vehicle.width))
+                       for i in self.agent_ids}
+        self.my_slots = agents_of_rank(len(self.agent_ids), self.rank, self.world)
+        n = 2 ** (self.config.sampling_max) + 1
+        cap = max_candidates or max(16 * (n + 1) * (n + 1), 4096)
+        mine = [FrenetPlannerInterfaceHip(self.agent_ids[k], scenario, self.problems[self.agent_ids[k]], config=self._cfg(),
+                                          vehicle=self.vehicle, device=device, use_road_boundary=use_road_boundary,
+                                          engine=engine_factory() if engine_factory else None)
+                for k in self.my_slots]
+        self.batch = AgentBatchHip(mine, max_candidates=cap, device=device,
+                                   engine=engine_factory() if engine_factory else None)
+        self.S = self.batch.agents[0].planner.N + 1 if mine else int(self.config.planning_horizon / self.config.dt) + 1
+        self.time_step = 0
+        # planned trajectories of ALL agents, identical on every rank after the exchange: [agents][S][FIELDS]
+        self.plans = np.zeros((len(self.agent_ids), self.S, self.FIELDS))
+        self.history: Dict[int, list] = {i: [] for i in self.agent_ids}
+
+    def _cfg(self) -> PlannerConfig:
+        import copy
+        return copy.deepcopy(self.config)
+
+    # -- predictions of one agent: everything but itself ---------------------------------------------------------
+    def predictions_for(self, agent_id: int) -> dict:
+        t = self.time_step
+        horizon = self.S - 1
+        others = [o for o in self.scenario.obstacles if o not in self.problems]
+        preds = self.scenario.ground_truth_predictions(t, horizon, obstacle_ids=others)
+        preds = {k: v for k, v in preds.items() if len(v["pos_list"])}
+        for k, aid in enumerate(self.agent_ids):
+            if aid == agent_id:
+                continue
+            rows = self.plans[k]
+            valid = rows[:, 4] > 0
+            if valid.any():
+                r = rows[valid]
+                th = r[:, 2]
+                pos = r[:, :2] + self.vehicle.wb_rear_axle * np.stack([np.cos(th), np.sin(th)], axis=1)
+                m = len(r)
+                preds[aid] = dict(pos_list=pos, cov_list=np.tile(np.eye(2) * 0.1, (m, 1, 1)), orientation_list=th.copy(),
+                                  v_list=r[:, 3].copy(), shape=dict(self.shapes[aid]))
+            elif aid in self.scenario.obstacles:  # no plan yet: the recorded future (first step)
+                gt = self.scenario.ground_truth_predictions(t, horizon, obstacle_ids=[aid])[aid]
+                if len(gt["pos_list"]):
+                    preds[aid] = gt
+        return preds
+
+    def _exchange(self, local_rows: np.ndarray) -> np.ndarray:
+        """ONE all-gather per simulation step: [per_rank][S][FIELDS] from every rank -> plans of all agents."""
+        per = (len(self.agent_ids) + self.world - 1) // self.world
+        buf = np.zeros((per, self.S, self.FIELDS))
+        buf[:len(local_rows)] = local_rows
+        if self.world == 1:
+            gathered = buf[None]
+        else:
+            import torch
+            t = torch.from_numpy(buf)
+            cuda = self.dist.get_backend(self.group) == "nccl"
+            if cuda:
+                t = t.cuda()
+                g = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+                self.dist.all_gather_into_tensor(g, t, group=self.group)
+                gathered = g.cpu().numpy()
+            else:
+                gl = [torch.empty_like(t) for _ in range(self.world)]
+                self.dist.all_gather(gl, t, group=self.group)
+                gathered = torch.stack(gl).numpy()
+        plans = np.zeros_like(self.plans)
+        for r in range(self.world):
+            for j, k in enumerate(agents_of_rank(len(self.agent_ids), r, self.world)):
+                plans[k] = gathered[r, j]
+        return plans
+
+    def step(self) -> Dict[int, Optional[list]]:
+        """One simulation step of every agent (simulation.py:621-663 + agent_batch.py:140-189)."""
+        preds = {a.id: self.predictions_for(a.id) for a in self.batch.agents}
+        selected = self.batch.step(self.time_step, preds)
+        local = np.zeros((len(self.batch.agents), self.S, self.FIELDS))
+        for j, a in enumerate(self.batch.agents):
+            sel = selected.get(a.id)
+            if sel is None:
+                continue
+            # the part of the stored trajectory that lies ahead of the agent's new state (index 1 + counter - 1)
+            ahead = sel[a.replanning_counter:]
+            for i, st in enumerate(ahead[:self.S]):
+                local[j, i] = (st.position[0], st.position[1], st.orientation, st.velocity, 1.0)
+        self.plans = self._exchange(local)
+        for k, aid in enumerate(self.agent_ids):
+            if self.plans[k, 0, 4] > 0:
+                self.history[aid].append(self.plans[k, 0, :4].copy())
+        self.time_step += 1
+        return selected
+
+    def run(self, n_steps: int):
+        for _ in range(n_steps):
+            self.step()
+        return self.history
+
+    def close(self):
+        self.batch.close()

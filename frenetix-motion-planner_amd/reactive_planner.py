@@ -117,6 +117,9 @@ class ReactivePlannerHip:
         self.last_step: Optional[PlanStepResult] = None
         self.planning_time = None
         self._packed_predictions = None
+        self.logger = None               # logging_formats.DataLoggingCosts (planner.py:150-158)
+        self.record_state_list = []
+        self.record_input_list = []
 
     # ------------------------------------------------------------------ engine
     @property
@@ -286,6 +289,40 @@ class ReactivePlannerHip:
         while optimal_trajectory is None and samp_level < self._sampling_max:
             optimal_trajectory = self._get_optimal_trajectory(self._inputs_for_level(samp_level, stop_point_s), samp_level)
             samp_level += 1
+        return self.plan_finish(optimal_trajectory, t0)
+
+    # -- the same step in phases, so that a batch of planners can share ONE launch (multiagent.AgentBatchHip) --
+    def plan_begin(self, stop_point_s: Optional[float] = None) -> PlanInputs:
+        """Inputs of the first sampling level of this plan step (checks as in plan())."""
+        if self.x_cl is None:
+            raise RuntimeError("x_cl should have been set prior to plan()")
+        if self.desired_velocity is None:
+            raise RuntimeError("desired velocity not set (update_externals(desired_velocity=...))")
+        if stop_point_s is not None and stop_point_s < self.x_cl[0][0]:
+            stop_point_s = None
+        self._stop_point_s = stop_point_s
+        return self._inputs_for_level(self._sampling_min, stop_point_s)
+
+    def plan_consume(self, inputs: PlanInputs, res: dict, engine, agent: int = 0):
+        """Take this planner's share of a batched launch (first sampling level); returns the chosen trajectory
+        (materialised -- the batch engine's buffers are reused) or None when the level has to escalate."""
+        best = self._consume_result(inputs, res, engine, agent)
+        if best is not None:
+            best.materialise()
+        return best
+
+    def plan_escalate(self, t0: float):
+        """Remaining sampling levels on the planner's own engine after the batched first level found nothing."""
+        optimal_trajectory = None
+        samp_level = self._sampling_min + 1
+        while optimal_trajectory is None and samp_level < self._sampling_max:
+            optimal_trajectory = self._get_optimal_trajectory(
+                self._inputs_for_level(samp_level, getattr(self, "_stop_point_s", None)), samp_level)
+            samp_level += 1
+        return self.plan_finish(optimal_trajectory, t0)
+
+    def plan_finish(self, optimal_trajectory, t0: float):
+        """reactive_planner.py:99-130: packaging, standstill fallback, logging hook."""
         self.planning_time = time.time() - t0
 
         self.trajectory_pair = self._compute_trajectory_pair(optimal_trajectory) if optimal_trajectory is not None else None
@@ -297,14 +334,34 @@ class ReactivePlannerHip:
         if optimal_trajectory is not None and hasattr(optimal_trajectory, "materialise"):
             optimal_trajectory.materialise()  # survives the next step's overwrite of the device bundle
         self.optimal_trajectory = optimal_trajectory
+        self.plan_postprocessing(optimal_trajectory, self.planning_time)
         return self.trajectory_pair
+
+    def plan_postprocessing(self, optimal_trajectory, planning_time, replanning_counter=0):
+        """planner.py:637-649: the logging hook (logging_formats.DataLoggingCosts as `self.logger`)."""
+        if self.logger is None:
+            return
+        if optimal_trajectory is not None:
+            ego = self.ego_vehicle_history[-1] if self.ego_vehicle_history else None
+            self.logger.log(optimal_trajectory, time_step=self.x_0.time_step,
+                            infeasible_kinematics=self._infeasible_count_kinematics,
+                            percentage_kinematics=self.infeasible_kinematics_percentage, planning_time=planning_time,
+                            ego_vehicle=ego, desired_velocity=self.desired_velocity, replanning_counter=replanning_counter)
+            self.logger.log_predicition(self.predictions)
+        if self.save_all_traj and self.all_traj is not None and replanning_counter == 0:
+            self.logger.log_all_trajectories(self.all_traj, self.x_0.time_step)
 
     def _get_optimal_trajectory(self, inputs: PlanInputs, samp_lvl: int):
         """reactive_planner.py:184-272: feasibility, costs, stable sort, collision walk -- one fused launch."""
         if self.last_step is not None:
             self.last_step.invalidate()
         res = self.engine.plan_step(inputs)
-        step = PlanStepResult(self.engine, inputs, res)
+        return self._consume_result(inputs, res, self.engine, 0)
+
+    def _consume_result(self, inputs: PlanInputs, res: dict, engine, agent: int):
+        if self.last_step is not None:
+            self.last_step.invalidate()
+        step = PlanStepResult(engine, inputs, res, agent)
         lr = self.params_harm["log_reg"]["ignore_angle"]
         step.harm_coeff = (lr["const"], lr["speed"])
         self.last_step = step
@@ -320,8 +377,8 @@ class ReactivePlannerHip:
         if best is None or self.road_boundary_check is None:
             return best
         # host-side walk over the GPU's survivors for checks that stay on the host (planner.py:362-390)
-        _, idx = self.engine.topk(self.config.survivors)
-        for g in idx[0]:
+        _, idx = engine.topk(self.config.survivors)
+        for g in idx[agent]:
             if g < 0:
                 break
             cand = step.sample(int(g) - inputs.shard_begin)
@@ -381,6 +438,14 @@ class ReactivePlannerHip:
             while state.orientation > interval_end:
                 state.orientation -= 2 * np.pi
         return state_list
+
+    def record_state_and_input(self, state: ReactivePlannerState):
+        """planner.py:245-262: recorded states and the control inputs (acceleration, steering-angle speed) between them."""
+        self.record_state_list.append(state)
+        rate = ((state.steering_angle - self.record_state_list[-2].steering_angle) / self.dT
+                if len(self.record_state_list) > 1 else 0.0)
+        self.record_input_list.append(dict(time_step=state.time_step, acceleration=state.acceleration,
+                                           steering_angle_speed=rate))
 
     def close(self):
         if self._engine is not None:

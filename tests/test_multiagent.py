@@ -1,0 +1,202 @@
+"""Per-agent glue (FrenetPlannerInterfaceHip, VelocityPlanner) and batched multi-agent stepping (AgentBatchHip,
+MultiAgentSimulation) -- BASELINE config 4 (multi-agent ZAM_Tjunction) on the data fixture
+tests/golden/ZAM_Tjunction-1_42_T-1.scenario.json.
+
+CPU tests drive the host logic with the oracle-backed stand-in engine (tests/oracle_engine.py); GPU tests run the same
+closed loop on the HIP engine and compare it with the stand-in, and check batched == individually stepped.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURE = os.path.join(ROOT, "tests", "golden", "ZAM_Tjunction-1_42_T-1.scenario.json")
+XML = "/root/reference/example_scenarios/ZAM_Tjunction-1_42_T-1.xml"
+
+from frenetix_motion_planner_amd import commonroad_xml as crx  # noqa: E402
+from frenetix_motion_planner_amd import multiagent  # noqa: E402
+from frenetix_motion_planner_amd.frenet_interface import (FrenetPlannerInterfaceHip, VelocityPlanner,  # noqa: E402
+                                                          create_from_initial_state)
+from frenetix_motion_planner_amd.reactive_planner import PlannerConfig  # noqa: E402
+from tests.oracle_engine import OracleEngine  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def scenario():
+    return crx.read_scenario_json(FIXTURE)
+
+
+@pytest.mark.skipif(not os.path.exists(XML), reason="reference example scenarios not present (GPU box)")
+def test_fixture_is_what_the_reader_extracts_from_the_xml():
+    assert crx.scenario_to_dict(crx.read_scenario(XML)) == crx.scenario_to_dict(crx.read_scenario_json(FIXTURE))
+
+
+def test_agent_selection_and_goal_creation(scenario):
+    ids = multiagent.select_agent_obstacles(scenario)
+    assert ids == [1, 4, 5, 7]                       # obstacle 2 moves only 7.3 m (simulation.py:191-192)
+    assert multiagent.select_agent_obstacles(scenario, 2) == [1, 4]
+    for oid in ids:
+        pp = multiagent.planning_problem_for_obstacle(scenario, oid)
+        fin = scenario.obstacles[oid].state_list[-1]
+        g = pp.goals[0]
+        assert scenario.lanelets[g.lanelet_ids[0]].contains(fin.position)
+        assert g.time_interval == (fin.time_step - 20, fin.time_step + 20)
+        assert g.velocity_interval == (fin.velocity - 2, fin.velocity + 2)
+        assert len(scenario.route_reference_path(pp)) >= 2
+
+
+def test_initial_state_shift_and_velocity_planner(scenario):
+    pp = scenario.planning_problems[60000]
+    x0 = create_from_initial_state(pp.initial_state, 2.5789, 1.4227)
+    o = pp.initial_state.orientation
+    assert np.allclose(x0.position + 1.4227 * np.array([np.cos(o), np.sin(o)]), pp.initial_state.position)
+    assert x0.steering_angle == 0.0 and x0.velocity == pp.initial_state.velocity
+    itf = FrenetPlannerInterfaceHip(60000, scenario, pp, engine=OracleEngine())
+    vp = itf.velocity_planner
+    assert vp.used_goal_metric == "lanelets_of_goal_position" and vp.goal_s_position is not None
+    s0 = itf.x_cl[0][0]
+    steps = vp.calc_remaining_time_steps(0, 0.0)
+    lo, hi = pp.goals[0].time_interval
+    assert steps == int((lo + hi) / 2)
+    want = (vp.goal_s_position - s0) / round(steps * scenario.dt, 3)
+    v = vp.calculate_desired_velocity(itf.x_0, s0)
+    assert v == pytest.approx(min(max(want, x0.velocity - 5), x0.velocity + 5))
+    assert VelocityPlanner.clip_velocity(100.0, 10.0) == 15.0 and VelocityPlanner.clip_velocity(-3.0, 2.0) == 0
+
+
+def test_replanning_counter_and_state_handover(scenario):
+    """frenet_interface.py:231-287: a plan step every `replanning_frequency` steps, the steps between advance along the
+    stored trajectory; x_cl is always (lon_list[k], lat_list[k]) of the stored pair."""
+    pp = scenario.planning_problems[60000]
+    eng = OracleEngine()
+    calls = []
+    plan_step = eng.plan_step
+    eng.plan_step = lambda inp: (calls.append(1), plan_step(inp))[1]
+    itf = FrenetPlannerInterfaceHip(60000, scenario, pp, engine=eng)
+    preds = scenario.ground_truth_predictions(0, 30)
+    pair = None
+    for t in range(7):
+        itf.update_planner(None, preds)
+        planned = itf.needs_plan()
+        sel, cnt = itf.step_interface(t)
+        assert planned == (t % 3 == 0) and cnt == t % 3 and len(calls) == t // 3 + 1
+        if planned:
+            pair = itf.trajectory_pair
+            assert sel is pair[0]
+        k = 1 + cnt
+        assert itf.x_cl == (pair[2][k], pair[3][k])
+        assert itf.x_0.time_step == pair[0][k].time_step == t + 1
+        assert np.array_equal(itf.x_0.position, pair[0][k].position)
+    assert len(itf.record_state_list) == 8 and len(itf.record_input_list) == 8
+    assert itf.record_input_list[2]["steering_angle_speed"] == pytest.approx(
+        (itf.record_state_list[2].steering_angle - itf.record_state_list[1].steering_angle) / 0.1)
+
+
+def _run_sim(sc, steps, **kw):
+    sim = multiagent.MultiAgentSimulation(sc, **kw)
+    winners = []
+    for _ in range(steps):
+        sim.step()
+        winners.append([a.optimal_trajectory.uniqueId if a.optimal_trajectory is not None else -1 for a in sim.batch.agents])
+    return sim, winners
+
+
+def test_batched_step_equals_individual_steps_cpu(scenario):
+    """AgentBatchHip (one plan_batch per step) against each agent stepped on its own (agent_batch.py:186-189)."""
+    sim, winners = _run_sim(scenario, 4, engine_factory=OracleEngine)
+    assert sim.batch.launches == 2 and sim.agent_ids == [60000, 1, 4, 5, 7]
+    solo = multiagent.MultiAgentSimulation(scenario, engine_factory=OracleEngine)
+    for t in range(4):
+        local = np.zeros((len(solo.batch.agents), solo.S, solo.FIELDS))
+        for j, a in enumerate(solo.batch.agents):
+            a.update_planner(None, solo.predictions_for(a.id))
+            sel, _ = a.step_interface(t)
+            cart = sel if isinstance(sel, list) else sel[0]
+            for i, st in enumerate(cart[a.replanning_counter:][:solo.S]):
+                local[j, i] = (st.position[0], st.position[1], st.orientation, st.velocity, 1.0)
+        solo.plans = solo._exchange(local)
+        solo.time_step += 1
+    assert np.array_equal(solo.plans, sim.plans)
+    # every agent sees the four others (and obstacle 2, which is no agent) as predictions
+    p = sim.predictions_for(60000)
+    assert set(p) == {1, 2, 4, 5, 7} and all(len(v["pos_list"]) >= 28 for v in p.values())
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = crx.read_scenario_json(FIXTURE)
+        sim, winners = _run_sim(sc, 4, engine_factory=OracleEngine)
+        q.put((rank, [a.id for a in sim.batch.agents], sim.plans.copy(), winners))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_agent_sharding_world2_gloo(scenario):
+    """Agents round-robin over two ranks, one all-gather of the planned trajectories per step: every rank ends with
+    the plans a single process computes."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in range(2)], key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single, _ = _run_sim(scenario, 4, engine_factory=OracleEngine)
+    assert got[0][1] == [60000, 4, 7] and got[1][1] == [1, 5]
+    assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][2], single.plans)
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_closed_loop_on_the_engine_matches_the_oracle_engine(scenario):
+    """Config 4 closed loop, 9 simulation steps (3 plan steps per agent): same winners, states within 1e-6."""
+    hip, w_hip = _run_sim(scenario, 9)
+    ora, w_ora = _run_sim(scenario, 9, engine_factory=OracleEngine)
+    try:
+        assert w_hip == w_ora
+        assert np.abs(hip.plans - ora.plans).max() < 1e-6
+        assert hip.batch.launches == 3                      # one batched launch per plan step for all five agents
+    finally:
+        hip.close()
+
+
+@pytest.mark.gpu
+def test_config4_sized_batch(scenario):
+    """Sampling level 4 (10 x 33 x 34 = 11 220 candidates per agent), five agents in one launch vs one agent at a time."""
+    cfg = PlannerConfig(sampling_min=4, sampling_max=5)
+    sim = multiagent.MultiAgentSimulation(scenario, config=cfg)
+    try:
+        preds = {a.id: sim.predictions_for(a.id) for a in sim.batch.agents}
+        for a in sim.batch.agents:
+            a.update_planner(None, preds[a.id])
+        inputs = [a.begin_step() for a in sim.batch.agents]
+        assert all(i.n_candidates == 11220 for i in inputs)
+        batch = sim.batch.engine.plan_batch(inputs)
+        costs = [sim.batch.engine.costs(j) for j in range(len(inputs))]
+        for j, inp in enumerate(inputs):
+            one = sim.batch.engine.plan_step(inp)
+            c, f = sim.batch.engine.costs(0)
+            assert one["best_index"] == batch[j]["best_index"] and one["best_cost"] == batch[j]["best_cost"]
+            assert one["n_feasible"] == batch[j]["n_feasible"] and one["n_collisions"] == batch[j]["n_collisions"]
+            assert np.array_equal(f, costs[j][1]) and np.array_equal(c, costs[j][0])
+    finally:
+        sim.close()
