@@ -93,7 +93,8 @@ class AgentBatchHip:
         N = max(a.planner.N for a in self.agents) if self.agents else 30
         if engine is None:
             from .engine import FrenetEngine
-            engine = FrenetEngine(max_candidates=max_candidates, max_steps=N, max_ref_knots=max_ref_knots,
+            # the context's capacity is the TOTAL over its agent slots (fx_create_batch)
+            engine = FrenetEngine(max_candidates=max_candidates * max(len(self.agents), 1), max_steps=N, max_ref_knots=max_ref_knots,
                                   max_obstacles=max_obstacles, max_pred_steps=max(64, N + 2), device=device,
                                   max_agents=max(len(self.agents), 1))
         self.engine = engine
