@@ -14,6 +14,15 @@ kernel + (N > 1) top-k kernel and ONE RCCL all-gather of the per-GPU survivors, 
 winner is in host memory when the step ends).  For N > 1 the global grid is N x 50 388 candidates (the
 velocity range is sampled N times denser) and each rank evaluates a contiguous shard: weak scaling.
 
+Other workloads (parity-test configurations of BASELINE.json, measured on request -- the default line stays config 2):
+  --workload config5   "synthetic stress": `--agents-per-gpu` (default 32 = 256 agents / 8 GPUs) agents per GPU x
+                       39 x 51 x 52 = 103 428 candidates x 51 samples (5 s horizon), 20 predicted obstacles per agent,
+                       select-only, one batched launch per step, per-agent top-32 survivors all-gathered (agent sharding:
+                       N GPUs carry N x 32 agents -- weak scaling);
+  --workload config4   multi-agent ZAM_Tjunction closed loop (5 agents, sampling level 4 = 11 220 candidates per agent,
+                       materialised bundle, collision stage against the other agents' plans): a step = one simulation
+                       step of every agent (host glue + one batched launch when the agents replan).
+
 Prints ONE JSON line (rank 0).  `value` = candidates evaluated by all ranks / wall time of the K timed steps.
 """
 import argparse
@@ -30,6 +39,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 BYTES_PER_CAND_MODE_A = 40     # 3 x 8 B read + 8 B cost + 4 B flags + 4 B index
 GRID = (19, 51, 51)            # n_t, n_v, n_d (+ d0) -> 50 388
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: FP64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
+STRESS_GRID = (39, 51, 51)     # config 5: T = 1.1 .. 4.9 (39) x 51 x 51 (+ d0), 5 s horizon
+
+
+def algorithmic_flops_per_candidate(n_samples, n_obstacles):
+    """~5.5 kflop per candidate at 31 samples without obstacles (~177 flop per step) plus ~100 flop per
+    (obstacle, step) for the prediction cost and the OBB test (65 kflop at K = 20, N = 30)."""
+    return 177.0 * n_samples + 100.0 * n_obstacles * (n_samples - 1)
 
 
 def bundle_bytes_per_candidate(n_samples):
@@ -101,7 +118,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["config2", "config3"], default="config2")
+    ap.add_argument("--workload", choices=["config2", "config3", "config4", "config5"], default="config2")
+    ap.add_argument("--agents-per-gpu", type=int, default=32, help="config5: agents evaluated per GPU in one batched launch")
+    ap.add_argument("--sampling-level", type=int, default=4, help="config4: sampling level of every agent (4 -> 11 220 candidates)")
     ap.add_argument("--select-only", action="store_true", help="Mode A: no SoA bundle write")
     ap.add_argument("--topk", type=int, default=1, help="survivors per GPU in the exchange (1: the winner, no top-k kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -131,6 +150,11 @@ def main():
 
     from frenetix_motion_planner_amd.distributed import ShardedEvaluator
     from frenetix_motion_planner_amd.engine import FrenetEngine
+
+    if args.workload == "config5":
+        return bench_stress(args, world, rank, local_rank, torch, dist)
+    if args.workload == "config4":
+        return bench_multiagent(args, world, rank, local_rank, torch, dist)
 
     inp = make_workload(args, world)
     C_global = inp.n_candidates_global
@@ -220,6 +244,146 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _timed(args, world, dist, torch, step):
+    """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.  Returns (elapsed s, per-step
+    host latencies)."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    lat = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        step()
+        lat.append(time.perf_counter() - ts)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, lat
+
+
+def bench_stress(args, world, rank, local_rank, torch, dist):
+    """BASELINE config 5: agents sharded over the GPUs, one batched launch per step, per-agent top-k gather."""
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator
+    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+    n_local = args.agents_per_gpu
+    k = 32 if args.topk == 1 else args.topk
+    agents = synthetic.stress_agents(n_local, grid=STRESS_GRID, first_agent=rank * n_local, hull_builder=build_obstacle_hulls)
+    C_local = sum(a.n_candidates for a in agents)
+    S, K = agents[0].n_samples, int(agents[0].obstacles["K"])
+    eng = FrenetEngine(max_candidates=C_local + 64 * n_local, max_steps=agents[0].N, max_ref_knots=1024, max_obstacles=32,
+                       max_pred_steps=64, device=local_rank, max_agents=n_local)
+    ev = ShardedEvaluator(eng, k=k)
+    ev.setup_agents(n_local)
+    eng.set_timing(args.timing, every=args.timing_every)
+    eng.upload(agents)
+    last = {}
+
+    def step():
+        last["res"], last["surv"] = ev.step_agents_enqueued()
+
+    elapsed, lat = _timed(args, world, dist, torch, step)
+    n_timed = min(256, (args.steps + args.timing_every - 1) // args.timing_every)
+    evalk, kern = eng.kernel_times(n_timed)
+    if rank == 0:
+        C_global = C_local * world  # every rank carries the same number of candidates (same grid per agent)
+        eval_ms = float(np.mean(evalk))
+        alg_bytes = BYTES_PER_CAND_MODE_A * C_local
+        achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
+        flops = algorithmic_flops_per_candidate(S, K) * C_local
+        tf = flops / (eval_ms * 1e-3) / 1e12
+        res = last["res"]
+        out = {
+            "metric": "candidate trajectories/sec (50-step horizon, 20 obstacles per agent)",
+            "value": C_global * args.steps / elapsed, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config5 (synthetic stress): {n_local} agents/GPU x {agents[0].n_candidates} candidates x "
+                                   f"{S} samples, {K} predicted obstacles per agent (prediction cost + OBB collision), select-only "
+                                   f"(Mode A), one batched launch per step, top-{k} survivors per agent",
+                       "agents_global": n_local * world, "agents_per_gpu": n_local, "candidates_global": C_global,
+                       "candidates_per_gpu": C_local, "samples": S, "obstacles": K,
+                       "parallelism": f"agent-shard x{world}, all-gather of per-agent top-{k}" if world > 1 else "single GPU"},
+            "plan_step_p50_ms": float(np.percentile(lat, 50) * 1e3), "plan_step_p95_ms": float(np.percentile(lat, 95) * 1e3),
+            "device_ms_per_step": float(np.mean(kern)), "eval_kernel_ms": eval_ms,
+            "agents_with_winner": int(sum(r["best_index"] >= 0 for r in res)),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "fx_eval_grid_kernel (batched over agents)",
+                         "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_candidate": BYTES_PER_CAND_MODE_A,
+                         "avg_launch_ms": eval_ms, "launches_timed": int(len(evalk)),
+                         "note": "select-only writes 12 B per candidate: this workload is FP64-issue-bound, see `compute`"},
+            "compute": {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_candidate": algorithmic_flops_per_candidate(S, K)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle
+            one = synthetic.stress_agents(1, grid=STRESS_GRID, hull_builder=oracle.build_obstacle_hulls)[0]
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < 12.0:
+                oracle.plan_range(one, 0, one.n_candidates)
+                reps += 1
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": reps * one.n_candidates / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
+                                   "sample": f"{reps} plan steps of agent 0 ({one.n_candidates} candidates x {S} samples, {K} obstacles) "
+                                             f"in {dt:.1f} s, oracle/fx_oracle.c single thread", "cpu": _cpu_model(),
+                                   "host_cores": os.cpu_count()}
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_multiagent(args, world, rank, local_rank, torch, dist):
+    """BASELINE config 4: closed-loop multi-agent ZAM_Tjunction, agents round-robin over the GPUs."""
+    from frenetix_motion_planner_amd import commonroad_xml as crx
+    from frenetix_motion_planner_amd.multiagent import MultiAgentSimulation
+    from frenetix_motion_planner_amd.reactive_planner import PlannerConfig
+    sc = crx.read_scenario_json(os.path.join(ROOT, "tests", "golden", "ZAM_Tjunction-1_42_T-1.scenario.json"))
+    lvl = args.sampling_level
+    cfg = PlannerConfig(sampling_min=lvl, sampling_max=lvl + 1)
+    sim = MultiAgentSimulation(sc, config=cfg, device=local_rank)
+    counts = {"cands": 0, "batch_ms": []}
+
+    def step():
+        before = sim.batch.launches
+        sim.step()
+        if sim.batch.launches > before:
+            counts["batch_ms"].append(sim.batch.last_batch_ms)
+
+    elapsed, lat = _timed(args, world, dist, torch, step)
+    if rank == 0:
+        n_agents = len(sim.agent_ids)
+        per_agent = sim.batch.agents[0].planner.last_step.n_candidates if sim.batch.agents[0].planner.last_step else 0
+        plan_steps = len(counts["batch_ms"])
+        out = {
+            "metric": "candidate trajectories/sec (30-step horizon), closed-loop multi-agent simulation",
+            "value": per_agent * n_agents * plan_steps / elapsed, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "ZAM_Tjunction-1_42_T-1 (scenario fixture), agents' own plans as predictions",
+            "config": {"workload": f"BASELINE config4: multi-agent ZAM_Tjunction, {n_agents} agents x {per_agent} candidates x 31 samples "
+                                   f"(sampling level {lvl}), bundle materialised, collision stage; a step = one simulation step "
+                                   "(replanning every 3rd step)",
+                       "agents": n_agents, "candidates_per_agent": per_agent, "plan_steps_timed": plan_steps,
+                       "parallelism": f"agent round-robin x{world}, one all-gather of the plans per step" if world > 1 else "single GPU"},
+            "sim_step_p50_ms": float(np.percentile(lat, 50) * 1e3), "sim_step_p95_ms": float(np.percentile(lat, 95) * 1e3),
+            "batched_plan_launch_ms": float(np.mean(counts["batch_ms"])) if plan_steps else None,
+            "escalations": sim.batch.escalations,
+        }
+        print(json.dumps(out))
+    sim.close()
     if world > 1:
         dist.destroy_process_group()
 

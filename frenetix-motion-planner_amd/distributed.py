@@ -130,6 +130,43 @@ class ShardedEvaluator:
         res["global_best_cost"], res["global_best_index"], res["survivors"] = best_c, best_i, order
         return res
 
+    # ---- agent sharding with a top-k survivor gather (BASELINE config 5) ----
+    def setup_agents(self, n_local_agents: int):
+        """Exchange buffers for `n_local_agents` agents per rank: [cost k | index k] per agent, one all-gather of
+        n_local * 16 * k bytes per rank and step."""
+        self.n_local = int(n_local_agents)
+        if self.on_device:
+            dev = self.torch.device("cuda", self.torch.cuda.current_device())
+            n = self.n_local * self.k
+            self._asurv = self.torch.empty(2 * n, dtype=self.torch.float64, device=dev)
+            self._agath = self.torch.empty(self.world * 2 * n, dtype=self.torch.float64, device=dev)
+            self.engine.set_winner_buffer(0)
+
+    def step_agents_enqueued(self, exchange: bool = True):
+        """One batched launch over this rank's (already uploaded) agents, per-agent top-k on the device, ONE all-gather
+        of every rank's survivors, published to the host.  Returns (results of the local agents, survivors
+        (cost [W, n_local, k], index [W, n_local, k]) or None)."""
+        self.engine.evaluate()
+        surv = None
+        if exchange:
+            n = self.n_local * self.k
+            if self.on_device:
+                base = self._asurv.data_ptr()
+                self.engine.topk_to_device(self.k, base, base + 8 * n)
+                if self.world > 1 or self.force_exchange:
+                    self.dist.all_gather_into_tensor(self._agath, self._asurv, group=self.group)
+                    src, w = self._agath, self.world
+                else:
+                    src, w = self._asurv, 1
+                self.engine.publish(src.data_ptr(), w * 2 * n)
+                g = self.engine.wait_published().reshape(w, 2, self.n_local, self.k)
+                surv = (g[:, 0].copy(), g[:, 1].copy().view(np.int64))
+            else:
+                c, i = self.engine.topk(self.k)
+                surv = (c[None], i[None])
+        res = self.engine.finish()
+        return res, surv
+
     def plan_agents(self, agent_inputs: Sequence) -> List[Optional[dict]]:
         """Agent sharding: rank r evaluates agents r, r+W, ... in one batched launch; winners are
         all-gathered so every rank knows every agent's (cost, index).  Returns a list over ALL agents of

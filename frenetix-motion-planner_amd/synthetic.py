@@ -49,12 +49,17 @@ def dense_ranges(n_t: int, n_v: int, n_d: int, v0: float, veh: VehicleParams, ho
 
 
 def synthetic_predictions(cs: CoordinateSystem, n_obstacles: int, n_pred: int, dt: float, s_center: float,
-                          rng: np.random.Generator, corridor=(120.0, 12.0)):
-    """K obstacles, constant velocity along/against the reference tangent."""
+                          rng: np.random.Generator, corridor=(120.0, 12.0), min_gap: float = 0.0):
+    """K obstacles, constant velocity along/against the reference tangent.
+    min_gap > 0: an obstacle that would start within min_gap metres (arc length) of s_center is drawn again, so the
+    ego does not start inside an obstacle."""
     preds = {}
     for k in range(n_obstacles):
-        s0 = s_center + rng.uniform(-0.15, 0.85) * corridor[0]
-        d0 = rng.uniform(-0.5, 0.5) * corridor[1]
+        while True:
+            s0 = s_center + rng.uniform(-0.15, 0.85) * corridor[0]
+            d0 = rng.uniform(-0.5, 0.5) * corridor[1]
+            if abs(s0 - s_center) >= min_gap:
+                break
         s0 = float(np.clip(s0, cs.ref_pos[2], cs.ref_pos[-3]))
         seg = cs.segment_of(s0)
         yaw_ref = float(cs.ref_theta[seg])
@@ -83,7 +88,8 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
                 s_knot=40, s_off=0.1, horizon=3.0, dt=0.1, level=None, grid=None, cpp_style=False, v_des=12.0,
                 n_obstacles=0, n_pred=30, cost_weights=None, draw_traj_set=False, kinematic_debug=False,
                 write_bundle=True, write_costmap=True, collision=True, low_vel_threshold=2.0, hull_builder=None,
-                seed=SEED, vehicle=None, x0_orientation=None, as_matrix=False, stop_point_s=None, road_half_width=None):
+                seed=SEED, vehicle=None, x0_orientation=None, as_matrix=False, stop_point_s=None, road_half_width=None,
+                obstacle_min_gap=0.0):
     """One agent's PlanInputs on a synthetic reference.
 
     level: reference sampling level (set-ordered ranges, SamplingHandler) -- or
@@ -114,7 +120,7 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
     if x0_orientation is None:
         x0_orientation = float(cs.ref_theta[seg])
     rng = np.random.default_rng(seed)
-    preds = synthetic_predictions(cs, n_obstacles, n_pred, dt, s0, rng) if n_obstacles else None
+    preds = synthetic_predictions(cs, n_obstacles, n_pred, dt, s0, rng, min_gap=obstacle_min_gap) if n_obstacles else None
     weights = dict(cost_weights if cost_weights is not None else DEFAULT_COST_WEIGHTS)
     if not preds:
         weights.pop("prediction", None) if cost_weights is None else None
@@ -135,3 +141,27 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
         inp = PlanInputs(t_samp=t, v_samp=v, d_samp=d, stop_point=stop_point_s is not None, **kw)
     inp.predictions = preds
     return inp
+
+
+def stress_agents(n_agents: int, grid=(39, 51, 51), horizon: float = 5.0, n_obstacles: int = 20, first_agent: int = 0,
+                  hull_builder=None, write_bundle: bool = False, seed: int = SEED, **kw):
+    """BASELINE config 5 ("synthetic stress"): agents that differ by seeded v0 in [2, 20] m/s, d0 in [-1, 1] m and a
+    reference curvature in [-0.02, 0.02] 1/m, each with its own 20 predicted obstacles; horizon 5 s (N = 50),
+    T = 1.1 .. 4.9 step 0.1 (39) x 51 end velocities x 51 (+ d0) lateral offsets = 103 428 candidates with d0 added
+    (101 439 when d0 is one of the 51 samples).  Agent a's draw depends only on (seed, a), so any rank can build any
+    agent: `first_agent` selects the slice [first_agent, first_agent + n_agents) of the global agent list."""
+    agents = []
+    for a in range(first_agent, first_agent + n_agents):
+        rng = np.random.default_rng([seed, a])
+        v0 = float(rng.uniform(2.0, 20.0))
+        d0 = float(np.round(rng.uniform(-1.0, 1.0), 3))
+        kappa = float(rng.uniform(-0.02, 0.02))
+        if abs(kappa) < 1e-4:
+            kappa = 1e-4
+        args = dict(ref_kind="arc", n_knots=500, spacing=0.5, kappa=kappa, v0=v0, d0=d0, horizon=horizon, grid=grid,
+                    v_des=float(np.clip(v0 + rng.uniform(-2.0, 4.0), 1.0, 25.0)), n_obstacles=n_obstacles,
+                    n_pred=int(round(horizon / 0.1)), write_bundle=write_bundle, write_costmap=write_bundle,
+                    seed=int(rng.integers(1 << 30)), hull_builder=hull_builder if n_obstacles else None, obstacle_min_gap=12.0)
+        args.update(kw)
+        agents.append(make_inputs(**args))
+    return agents
