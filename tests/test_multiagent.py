@@ -195,8 +195,10 @@ def test_config4_sized_batch(scenario):
         for j, inp in enumerate(inputs):
             one = sim.batch.engine.plan_step(inp)
             c, f = sim.batch.engine.costs(0)
-            assert one["best_index"] == batch[j]["best_index"] and one["best_cost"] == batch[j]["best_cost"]
+            assert one["best_index"] == batch[j]["best_index"] and one["best_cost"] == pytest.approx(batch[j]["best_cost"], rel=1e-12)
             assert one["n_feasible"] == batch[j]["n_feasible"] and one["n_collisions"] == batch[j]["n_collisions"]
-            assert np.array_equal(f, costs[j][1]) and np.array_equal(c, costs[j][0])
+            # the batched launch may split a candidate's horizon over a different number of lanes than the single
+            # launch (auto-tuning by total wave count): cost sums agree to rounding, decisions exactly
+            assert np.array_equal(f, costs[j][1]) and np.allclose(c, costs[j][0], rtol=1e-12, atol=0)
     finally:
         sim.close()
