@@ -122,7 +122,7 @@ struct FxContext {
     int n_agents = 0;
     std::vector<FxAgentSlot> slots;
     bool uploaded = false, evaluated = false;
-    int max_blocks_step = 0, M_max_step = 0, S_max_step = 0;
+    int max_blocks_step = 0, M_max_step = 0, S_max_step = 0, K_max_step = 0;
     int G_step = 1, wpe_step = 2;          // lanes per candidate / occupancy target of the current step
     int G_force = 0, wpe_force = 0;        // fx_set_tuning overrides (0 = automatic)
     int variant_force = 0;                 // 0 auto, 1 generic kernel, 2 grid kernel
@@ -158,6 +158,7 @@ size_t input_bytes_for(int64_t cand, int S, int M, int K, int Pn, bool matrix) {
     b += align_up(sizeof(double) * 4 * (size_t)K * Pn, 256);
     b += align_up(sizeof(double) * 6 * (size_t)K * (Pn > 0 ? Pn : 1), 256);
     b += align_up(sizeof(double) * 12 * (size_t)K * S, 256) + 2 * align_up(sizeof(unsigned long long) * S, 256);
+    b += align_up(sizeof(double) * FX_HOT_STRIDE * (size_t)K * S, 256);  // hot obstacle table
     b += 2 * align_up(sizeof(int32_t) * (size_t)K, 256);
     b += align_up(sizeof(double) * 2 * (size_t)K, 256);           // dto positions (<= K)
     return b + 4096;
@@ -492,7 +493,11 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         c->G_step = G;
         // large grids: 4 waves per SIMD (128 VGPRs, a few spills) beats 2 at full VGPR budget; small grids are
         // latency-bound with 1-2 waves per SIMD anyway and run faster unspilled
-        c->wpe_step = c->wpe_force ? c->wpe_force : (waves1 >= 3072 ? 4 : 2);
+        // with the obstacle stage the walk needs ~220 VGPRs: three waves per SIMD (168 VGPRs, few spills) is the best
+        // trade at scale, four spill inside the obstacle loop (tools/obst_sweep.py)
+        bool obst_any = false;
+        for (int a = 0; a < n_agents; a++) obst_any |= probs[a].K > 0;
+        c->wpe_step = c->wpe_force ? c->wpe_force : (waves1 >= 3072 ? (obst_any ? 3 : 4) : 2);
         // grid kernel: sampling ranges, no windowed costs, and the longitudinal rows of a workgroup fit in LDS.
         // Workgroup size: the smallest of 64/128/256 lanes whose LDS footprint still lets a CU hold the target
         // number of waves (small workgroups balance small grids at wave granularity).
@@ -502,6 +507,9 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         size_t lds_need = 0;
         int block = FX_BLOCK;
         if (grid_ok) {
+            size_t hot_block = 0;
+            for (int a = 0; a < n_agents; a++)
+                hot_block = std::max(hot_block, align_up(sizeof(double) * FX_HOT_STRIDE * (size_t)std::max(probs[a].K, 0), 16));
             auto lds_for = [&](int blk) {
                 size_t need = 0;
                 for (int a = 0; a < n_agents; a++) {
@@ -512,7 +520,8 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                                               128 * n_pairs * S +
                                               (G > 1 ? (size_t)64 * blk : 0));  // + wave-split exchange block (5 f64 + 5 u32 per slot)
                 }
-                return need;
+                // + one staging block of the step's hot obstacle table per wave
+                return need + (size_t)(blk / 64) * hot_block;
             };
             const int want_waves = 4 * c->wpe_step;
             block = 0;
@@ -542,6 +551,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     c->fusable_step = true;
     c->max_blocks_step = 0;
     c->M_max_step = 0;
+    c->K_max_step = 0;
     c->S_max_step = 0;
     for (int a = 0; a < n_agents; a++) {
         const FxProblem *p = &probs[a];
@@ -618,7 +628,9 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                 const unsigned long long *dpm = nullptr, *dhm = nullptr;
                 unsigned long long *pm = ar.host_slot<unsigned long long>(S, &dpm, &ok);
                 unsigned long long *hm = ar.host_slot<unsigned long long>(S, &dhm, &ok);
-                if (rec && pm && hm) {
+                const double *dhot = nullptr;
+                double *hot = ar.host_slot<double>((size_t)S * p->K * FX_HOT_STRIDE, &dhot, &ok);
+                if (rec && pm && hm && hot) {
                     for (int i = 0; i < S; i++) {
                         pm[i] = hm[i] = 0ULL;
                         for (int k = 0; k < p->K; k++) {
@@ -635,10 +647,14 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                                 for (int e = 0; e < 6; e++) q[6 + e] = oh[e];
                                 hm[i] |= 1ULL << k;
                             }
+                            double *h = hot + ((size_t)i * p->K + k) * FX_HOT_STRIDE;
+                            for (int e = 0; e < 8; e++) h[e] = q[e];
+                            h[8] = (q[10] + q[11]) * 1.000001;  // radius of a circle that holds the hull, with slack
+                            h[9] = 0.0;
                         }
                     }
                 }
-                d.obs_rec = dev; d.obs_pmask = dpm; d.obs_hmask = dhm;
+                d.obs_rec = dev; d.obs_pmask = dpm; d.obs_hmask = dhm; d.obs_hot = dhot;
             }
         } else {
             d.mode &= ~FX_MODE_COLLISION;
@@ -674,6 +690,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         c->any_extra |= extra;
         c->max_blocks_step = std::max(c->max_blocks_step, d.n_blocks);
         c->M_max_step = std::max(c->M_max_step, p->M);
+        c->K_max_step = std::max(c->K_max_step, std::max(p->K, 0));
         c->S_max_step = std::max(c->S_max_step, S);
         FxAgentSlot &sl = c->slots[a];
         sl.C = C; sl.ld = ld; sl.cand_off = cand_off; sl.S = S; sl.n_cost = p->n_cost; sl.n_blocks = d.n_blocks; sl.mode = d.mode;
@@ -723,7 +740,7 @@ int32_t fx_evaluate(FxContext *c) {
     // last workgroup reduces and publishes (fx_eval_kernel.h, "fused selection")
     c->seq++;
     c->fused_step = c->fuse_enabled && c->fusable_step && c->eval_launched;
-    FuseArgs fuse{c->fused_step ? c->h_counters_dev : nullptr, c->seq, c->dev_winner};
+    FuseArgs fuse{c->fused_step ? c->h_counters_dev : nullptr, c->seq, c->dev_winner, c->K_max_step};
     if (c->eval_launched)
     {
         if (c->use_grid)

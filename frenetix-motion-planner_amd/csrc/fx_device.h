@@ -9,6 +9,8 @@
 #include "../../include/fxplan.h"
 
 #define FX_BLOCK 256            // candidates per workgroup (4 wave64)
+#define FX_HOT_STRIDE 10        // doubles per (step, obstacle) entry of the hot obstacle table (80 B)
+#define FX_HOT_PRE 4            // table elements per lane prefetched one step ahead (covers K <= 25 obstacles)
 #define FX_REF_FIELDS 8         // per knot: pos, theta, curv, curv_d, x, y, nx, ny  (64 B, AoS in LDS)
 #define FX_MAX_SAMPLES 128      // N+1 <= 128
 
@@ -47,6 +49,9 @@ struct DevProblem {
     // prediction / a hull that ego step i meets.  One contiguous 96-byte record per (step, obstacle).
     const double *obs_rec;
     const unsigned long long *obs_pmask, *obs_hmask;
+    // the part of a record every (step, obstacle) visit needs, 80 B: hot[S][K][10] = {mu_x, mu_y, iv00, iv01, iv10,
+    // iv11, hull cx, hull cy, (h1 + h2) * (1 + 1e-6), 0}; a wave copies its step's block to LDS with one coalesced load
+    const double *obs_hot;
     const double *dto_pos;     // [n_dto][2]
     // road boundary: pieces (mid x, mid y, half dx, half dy) and per reference knot the pieces in reach (CSR)
     int32_t n_bound;
@@ -97,6 +102,7 @@ struct ProblemRegs {
     const int32_t *obs_npred;
     const double *obs_rec;
     const unsigned long long *obs_pmask, *obs_hmask;
+    const double *obs_hot;
     const double *dto_pos;
     int32_t n_bound;
     const double *bound_piece;
@@ -127,7 +133,7 @@ struct ProblemRegs {
         r.cost_id = cost_id; r.cost_w = cost_w; r.simpson_corr = g.simpson_corr;
         r.tpow = g.tpow; r.t_samp = g.t_samp; r.v_samp = g.v_samp; r.d_samp = g.d_samp; r.matrix = g.matrix;
         r.ref = g.ref; r.obs_pos = g.obs_pos; r.obs_cov_inv = g.obs_cov_inv; r.obs_npred = g.obs_npred;
-        r.obs_rec = g.obs_rec; r.obs_pmask = g.obs_pmask; r.obs_hmask = g.obs_hmask; r.dto_pos = g.dto_pos;
+        r.obs_rec = g.obs_rec; r.obs_pmask = g.obs_pmask; r.obs_hmask = g.obs_hmask; r.obs_hot = g.obs_hot; r.dto_pos = g.dto_pos;
         r.n_bound = g.n_bound; r.bound_piece = g.bound_piece; r.bound_bin = g.bound_bin; r.bound_item = g.bound_item;
         r.bound_d_reach = g.bound_d_reach; r.bound_step = g.bound_step;
         r.cost = g.cost; r.flags = g.flags; r.costmap = g.costmap; r.planes = g.planes; r.coeffs = g.coeffs;
@@ -170,6 +176,7 @@ struct FuseArgs {
     unsigned long long *host_result;  // pinned + mapped [n_agents][FX_CNT_COUNT + 1]
     unsigned long long seq;           // sequence word the host polls for
     double *dev_winner;               // optional device copy of (cost, index) per agent
+    int32_t k_max;                    // largest obstacle count of the launch's agents (sizes the per-wave hot blocks)
 };
 
 // Pointers stored inside DevProblem are loaded from memory, so the compiler only knows them as generic ("flat")

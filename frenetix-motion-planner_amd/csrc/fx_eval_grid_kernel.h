@@ -209,13 +209,26 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     FX_GLOBAL double *__restrict__ planes = as_global(P.planes);
     const int64_t ps = (int64_t)S * ld;
 
+    // hot obstacle table: staged per wave when the step index is wave-uniform (one lane per candidate or wave split);
+    // the blocks sit behind the exchange block in dynamic LDS
+    constexpr bool HOT = OBST && (G == 1 || WSPLIT);
+    ObsHot Hs;
+    Hs.lds = nullptr; Hs.tab = as_global(P.obs_hot); Hs.n_el = P.K * FX_HOT_STRIDE; Hs.lane = tid & 63;
+    if (HOT && P.K > 0) {
+        char *hot_base = reinterpret_cast<char *>(rows + (size_t)n_pairs_max * S) + (G > 1 ? (size_t)64 * BLK : 0);
+        const size_t hot_block = (sizeof(double) * FX_HOT_STRIDE * (size_t)fuse.k_max + 15) & ~(size_t)15;
+        Hs.lds = reinterpret_cast<double *>(hot_base + (size_t)(tid >> 6) * hot_block);
+        if (i_first < i_end) Hs.prefetch(i_first);
+    }
+
     FX_STAMP(3);
 #pragma unroll 1
     for (int i = i_first; i < i_end; i++) {
         const bool emit = i >= i_begin;
         const LonRow r = my[i];
-        walk_step<OBST, (G == 1 || WSPLIT)>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit,
-                                            planes + (int64_t)i * ld + g, ps, Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv);
+        walk_step<OBST, (G == 1 || WSPLIT), HOT>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit,
+                                                 planes + (int64_t)i * ld + g, ps, Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv,
+                                                 &Hs, i + 1 < i_end ? i + 1 : -1);
     }
 
     FX_STAMP(4);

@@ -188,6 +188,12 @@ struct LatPoly {
     }
 };
 
+// a 64-bit value known to be wave-uniform, moved to scalar registers
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffu)) |
+           ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32);
+}
+
 struct StepConst {  // wave-uniform constants of the walk
     double dt, r_dt, kappa_max, a_max, v_switch, av_switch, v_des, wb, half_len, half_wid;
     int S, half, K;
@@ -222,12 +228,49 @@ struct BoundView {
     const FX_GLOBAL int32_t *bin, *item;
 };
 
-template <bool OBST, bool USTEP, typename PlanePtr, typename ObsD, typename ObsM>
+// Per-wave staging of the hot obstacle table (grid kernel, wave-uniform step index).  The walk visits every
+// (step, obstacle) pair; fetching each 96-byte record with scalar loads inside the obstacle loop costs one
+// scalar-cache / L2 round trip per visit, which is what bounded the obstacle stage.  Instead the wave copies the
+// K x 80 B block of the step with ONE coalesced vector load, issued a whole step ahead (`pre`), parks it in its own
+// LDS block and the obstacle loop reads entries back with broadcast ds_read_b128, two entries in flight.
+struct ObsHot {
+    double *lds;                    // this wave's block [K][FX_HOT_STRIDE] (nullptr: staging off)
+    const FX_GLOBAL double *tab;    // hot[S][K][FX_HOT_STRIDE]
+    int n_el;                       // K * FX_HOT_STRIDE
+    int lane;
+    double pre[FX_HOT_PRE];         // elements lane, lane + 64, ... of the NEXT staged step
+
+    __device__ __forceinline__ void prefetch(int step) {
+        const FX_GLOBAL double *src = tab + (int64_t)step * n_el;
+#pragma unroll
+        for (int j = 0; j < FX_HOT_PRE; j++) {
+            const int e = lane + 64 * j;
+            pre[j] = e < n_el ? src[e] : 0.0;
+        }
+    }
+    // park the prefetched block of `step` in LDS (elements beyond the prefetch window come straight from memory),
+    // then start the load of `next` (< 0: none)
+    __device__ __forceinline__ void stage(int step, int next) {
+#pragma unroll
+        for (int j = 0; j < FX_HOT_PRE; j++) {
+            const int e = lane + 64 * j;
+            if (e < n_el) lds[e] = pre[j];
+        }
+        if (n_el > 64 * FX_HOT_PRE) {
+            const FX_GLOBAL double *src = tab + (int64_t)step * n_el;
+            for (int e = lane + 64 * FX_HOT_PRE; e < n_el; e += 64) lds[e] = src[e];
+        }
+        if (next >= 0) prefetch(next);
+    }
+};
+
+template <bool OBST, bool USTEP, bool HOT = false, typename PlanePtr, typename ObsD, typename ObsM>
 __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, const LatPoly &L, const double *tp, int i,
                                           int traj_len, double d_ext, bool emit, bool store, PlanePtr planes_i, int64_t ps,
                                           StepCarry &C, StepAcc &A, StepOut &O, ObsD obs_rec, ObsM obs_pmask, ObsM obs_hmask,
-                                          const BoundView &B) {
+                                          const BoundView &B, ObsHot *H = nullptr, int i_next = -1) {
     const int S = K.S;
+    if (OBST && HOT && USTEP && K.K > 0) H->stage(__builtin_amdgcn_readfirstlane(i), i_next);
     const double s_i = r.s, sv_i = r.sv, sa_i = r.sa;
     // -- lateral polynomial (reactive_planner.py:326-346) --
     double d_i, dv_i, da_i;
@@ -329,7 +372,73 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
         if (i >= K.half && i < S - 1) A.sum_voff += fabs(v_i - K.v_des);        // :125-127
         if (i == S - 1) { A.d_end = d_i; A.v_end = v_i; }
     }
-    if (OBST && K.K > 0) {  // a batched launch may mix agents with and without obstacles
+    if (OBST && HOT && USTEP && K.K > 0) {
+        // ---- obstacle stage on the staged table: one pass over the obstacles that have a prediction or a hull at
+        //      this step, entries read from the wave's LDS block two at a time (ping-pong), all branches wave-uniform
+        const int iu = __builtin_amdgcn_readfirstlane(i);
+        unsigned long long pm = obs_pmask[iu], hm_now = obs_hmask[iu];
+        const unsigned long long hm_next = iu + 1 < S ? obs_hmask[iu + 1] : 0ULL;
+        pm = uniform_u64(pm); hm_now = uniform_u64(hm_now);
+        if (!emit) pm = 0ULL;
+        unsigned long long hm = 0ULL;
+        Obb hull;
+        hull.cx = hull.cy = hull.ex = hull.ey = hull.h1 = hull.h2 = 0.0;
+        double re = 0.0;
+        if (K.do_collision && (hm_now | hm_next) != 0ULL && i >= 1) {
+            double su, cu;
+            fxm::sincos(th_gl, &su, &cu);
+            const double bx = fma(K.wb, cu, x_i), by = fma(K.wb, su, y_i);
+            hm = emit ? hm_now : 0ULL;
+            if (hm) {
+                hull = obb_hull(C.bx_prev, C.by_prev, C.ux_prev, C.uy_prev, bx, by, cu, su, K.half_len, K.half_wid);
+                re = (hull.h1 + hull.h2) * 1.000001;
+            }
+            C.bx_prev = bx; C.by_prev = by; C.ux_prev = cu; C.uy_prev = su;
+        }
+        unsigned long long um = pm | hm;
+        if (um) {
+            const auto rec_i = obs_rec + (int64_t)iu * K.K * 12;
+            struct Ent { double mx, my, a, b, c, d, hx, hy, hr; };
+            auto fetch = [&](int k) {
+                const double2 *q = reinterpret_cast<const double2 *>(H->lds + k * FX_HOT_STRIDE);
+                const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                Ent e;
+                e.mx = q0.x; e.my = q0.y; e.a = q1.x; e.b = q1.y; e.c = q2.x; e.d = q2.y; e.hx = q3.x; e.hy = q3.y;
+                e.hr = H->lds[k * FX_HOT_STRIDE + 8];
+                return e;
+            };
+            auto visit = [&](const Ent &e, int k) {
+                if ((pm >> k) & 1ULL) {  // prediction cost (collision_probability.py:283-292)
+                    const double e0 = x_i - e.mx, e1 = y_i - e.my;
+                    const double r0 = fma(e1, e.c, e0 * e.a), r1 = fma(e1, e.d, e0 * e.b);
+                    const double m = fma(r1, e1, r0 * e0);
+                    const double mm = m * m;
+                    double t = rcp_nr(mm);
+                    if (__any(!(mm > 0.0))) t = mm > 0.0 ? t : 1.0 / mm;
+                    A.pred += t;
+                }
+                if ((hm >> k) & 1ULL) {  // broad phase on the hull circles, exact axis test for whatever is near
+                    const double tx = e.hx - hull.cx, ty = e.hy - hull.cy;
+                    const double rr = e.hr + re;
+                    const bool near = !(fma(tx, tx, ty * ty) > rr * rr);
+                    if (__any(near)) A.collided |= obb_overlap(hull, rec_i + k * 12 + 6);
+                }
+            };
+            int k0 = __builtin_ctzll(um);
+            um &= um - 1;
+            Ent ea = fetch(k0), eb = ea;
+            while (true) {
+                int k1 = -1;
+                if (um) { k1 = __builtin_ctzll(um); um &= um - 1; eb = fetch(k1); }
+                visit(ea, k0);
+                if (k1 < 0) break;
+                k0 = -1;
+                if (um) { k0 = __builtin_ctzll(um); um &= um - 1; ea = fetch(k0); }
+                visit(eb, k1);
+                if (k0 < 0) break;
+            }
+        }
+    } else if (OBST && K.K > 0) {  // a batched launch may mix agents with and without obstacles
         const int nK = K.K;
         const int iu = USTEP ? __builtin_amdgcn_readfirstlane(i) : i;
         const auto rec_i = obs_rec + (int64_t)iu * nK * 12;
@@ -363,10 +472,19 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                 if (hm) {
                     // OBB-sum hull of ego boxes (i-1, i) lives at time index i-1 and meets obstacle hull i-2
                     const Obb hull = obb_hull(C.bx_prev, C.by_prev, C.ux_prev, C.uy_prev, bx, by, cu, su, K.half_len, K.half_wid);
+                    // broad phase: a box lies inside the circle around its centre with radius h1 + h2 (>= its half
+                    // diagonal), so two boxes whose centres are farther apart than the sum of those radii are
+                    // separated and the axis test below would say so.  The 1e-6 slack keeps every pair that is
+                    // anywhere near touching (and every NaN) on the exact path, so decisions are unchanged.
+                    const double re = (hull.h1 + hull.h2) * 1.000001;
                     while (hm) {
                         const int k = __builtin_ctzll(hm);
                         hm &= hm - 1;
-                        A.collided |= obb_overlap(hull, rec_i + k * 12 + 6);
+                        const auto q = rec_i + k * 12 + 6;
+                        const double tx = q[0] - hull.cx, ty = q[1] - hull.cy;
+                        const double rr = fma(q[4] + q[5], 1.000001, re);
+                        const bool near = !(fma(tx, tx, ty * ty) > rr * rr);
+                        if (USTEP ? __any(near) : near) A.collided |= obb_overlap(hull, q);
                     }
                 }
                 C.bx_prev = bx; C.by_prev = by; C.ux_prev = cu; C.uy_prev = su;

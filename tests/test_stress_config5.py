@@ -80,7 +80,9 @@ def test_full_size_stress_properties():
             assert np.array_equal(c2, per[a][0]) and np.array_equal(f2, per[a][1]) and res2[a]["best_index"] == res[a]["best_index"]
         one = eng.plan_step(agents[2])
         c1, f1 = eng.costs(0)
-        assert np.array_equal(c1, per[2][0]) and np.array_equal(f1, per[2][1]) and one["best_index"] == res[2]["best_index"]
+        # a single-agent launch may split the horizon differently (auto-tuning by wave count): sums agree to rounding
+        assert np.allclose(c1, per[2][0], rtol=1e-12, atol=0) and np.array_equal(f1, per[2][1])
+        assert one["best_index"] == res[2]["best_index"]
     # the oracle over every candidate of two agents
     ora = synthetic.stress_agents(2, hull_builder=oracle.build_obstacle_hulls)
     for a in range(2):
