@@ -61,6 +61,7 @@ class PlannerConfig:
     sampling_min: int = 2
     sampling_max: int = 3
     emergency_mode: str = "stopping"
+    emergency_selection: bool = False  # C++ back-end only (reactive_planner_cpp.py:404-413); the Python back-end returns None
     cost_weights: Dict[str, float] = field(default_factory=lambda: dict(DEFAULT_COST_WEIGHTS))
     draw_traj_set: bool = True       # debug.yaml:8
     kinematic_debug: bool = True     # debug.yaml:20
@@ -331,11 +332,42 @@ class ReactivePlannerHip:
         if optimal_trajectory is None and self.x_0.velocity <= 0.1:
             self.msg_logger.warning('Planning standstill for the current scenario')
             optimal_trajectory = self._compute_standstill_trajectory()
+        # no collision-free trajectory but kinematically feasible ones: the C++ back-end's emergency selection
+        # (reactive_planner_cpp.py:404-413; the "risk" mode needs the harm model and stays outside)
+        if optimal_trajectory is None and self.config.emergency_mode == "stopping" and self.config.emergency_selection \
+                and self.last_step is not None:
+            optimal_trajectory = self._select_stopping_trajectory(self.last_step, self.x_cl[1][0])
+            if optimal_trajectory is not None:
+                self.msg_logger.warning("No optimal trajectory available. Select stopping trajectory!")
+                self.trajectory_pair = self._compute_trajectory_pair(optimal_trajectory)
+                self.ego_vehicle_history.append(self.trajectory_pair[0])
         if optimal_trajectory is not None and hasattr(optimal_trajectory, "materialise"):
             optimal_trajectory.materialise()  # survives the next step's overwrite of the device bundle
         self.optimal_trajectory = optimal_trajectory
         self.plan_postprocessing(optimal_trajectory, self.planning_time)
         return self.trajectory_pair
+
+    @staticmethod
+    def _select_stopping_trajectory(step: PlanStepResult, d_pos: float):
+        """reactive_planner_cpp.py:443-466: of the kinematically feasible candidates the one with the lowest end
+        velocity, then the shortest horizon, then the lateral end position closest to the current one -- the first
+        existing combination of product(unique v, unique t, d sorted by |d - d_pos|)."""
+        inp = step.inputs
+        if inp.sampling_matrix is not None:
+            return None
+        feas = np.nonzero(step.mask(_abi.FX_FLAG_VALID) & step.mask(_abi.FX_FLAG_FEASIBLE) & step.mask(_abi.FX_FLAG_RETURNED))[0]
+        if len(feas) == 0:
+            return None
+        t, v, d = np.asarray(inp.t_samp), np.asarray(inp.v_samp), np.asarray(inp.d_samp)
+        g = feas + inp.shard_begin
+        i_d = g % len(d)
+        pair = g // len(d)
+        i_v, i_t = pair % len(v), pair // len(v)
+        d_sorted = np.unique(d)
+        d_rank_of = {float(x): r for r, x in enumerate(d_sorted[np.argsort(np.abs(d_sorted - d_pos), kind="stable")])}
+        d_rank = np.array([d_rank_of[float(x)] for x in d[i_d]])
+        order = np.lexsort((d_rank, t[i_t], v[i_v]))
+        return step.sample(int(feas[order[0]]))
 
     def plan_postprocessing(self, optimal_trajectory, planning_time, replanning_counter=0):
         """planner.py:637-649: the logging hook (logging_formats.DataLoggingCosts as `self.logger`)."""

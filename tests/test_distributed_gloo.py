@@ -225,3 +225,35 @@ def test_rccl_exchange_k1_uses_selection_result():
             eng.set_winner_buffer(0)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_agent_sharded_topk_gather_single_rank():
+    """BASELINE config 5's exchange: per-agent top-k written into one torch buffer, ONE all-gather, published to the
+    host -- with a one-rank nccl group, compared with the engine's own top-k read-back."""
+    import torch
+    import torch.distributed as dist
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator
+    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        agents = synthetic.stress_agents(5, grid=(7, 9, 9), n_obstacles=6, hull_builder=build_obstacle_hulls)
+        with FrenetEngine(max_candidates=sum(a.n_candidates for a in agents) + 5 * 64, max_steps=50, max_agents=5, device=0) as eng:
+            ref = eng.plan_batch(agents)
+            tc, ti = eng.topk(32)
+            ev = ShardedEvaluator(eng, k=32, force_exchange=True)
+            assert ev.on_device
+            ev.setup_agents(5)
+            eng.upload(agents)
+            for _ in range(2):
+                res, (sc, si) = ev.step_agents_enqueued()
+            assert sc.shape == (1, 5, 32) and si.shape == (1, 5, 32)
+            assert np.array_equal(si[0], ti) and np.array_equal(sc[0][ti >= 0], tc[ti >= 0])
+            for a in range(5):
+                assert res[a]["best_index"] == ref[a]["best_index"] == (ti[a, 0] if ti[a, 0] >= 0 else -1)
+    finally:
+        dist.destroy_process_group()
