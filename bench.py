@@ -40,6 +40,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 BYTES_PER_CAND_MODE_A = 40     # 3 x 8 B read + 8 B cost + 4 B flags + 4 B index
 GRID = (19, 51, 51)            # n_t, n_v, n_d (+ d0) -> 50 388
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: FP64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
+LEAD_GAP = 25.0                # config 3: obstacle 0 is a slow lead vehicle 25 m ahead (the cheapest candidates collide)
 STRESS_GRID = (39, 51, 51)     # config 5: T = 1.1 .. 4.9 (39) x 51 x 51 (+ d0), 5 s horizon
 
 
@@ -58,34 +59,56 @@ def make_workload(args, world):
     from frenetix_motion_planner_amd.engine import build_obstacle_hulls
     n_obst = 20 if args.workload == "config3" else 0
     grid = (GRID[0], GRID[1] * world, GRID[2])
-    return synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=grid, n_obstacles=n_obst, n_pred=30,
+    return synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=grid, n_obstacles=n_obst, n_pred=30, lead_gap=LEAD_GAP,
                                  write_bundle=not args.select_only, write_costmap=not args.select_only,
                                  draw_traj_set=False, kinematic_debug=False,
                                  hull_builder=build_obstacle_hulls if n_obst else None)
 
 
-def cpu_baseline(args, seconds=12.0):
-    """The CPU oracle (scalar C port of the reference's algorithm, 1 thread) on the same workload, on this
-    box's host cores.  Reported, not optimised; a bounded sample of whole plan steps."""
-    from frenetix_motion_planner_amd import synthetic
+def _host_threads():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
+def _time_oracle(inp, seconds, n_threads):
     from oracle import oracle
-    n_obst = 20 if args.workload == "config3" else 0
-    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=GRID, n_obstacles=n_obst, n_pred=30,
-                                hull_builder=oracle.build_obstacle_hulls if n_obst else None)
     C = inp.n_candidates
     oracle.plan_range(inp, 0, min(C, 2000))  # warm-up
     t0 = time.perf_counter()
-    done = 0
     reps = 0
     while time.perf_counter() - t0 < seconds:
-        oracle.plan_range(inp, 0, C)
-        done += C
+        oracle.plan_range(inp, 0, C, n_threads=n_threads)
         reps += 1
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} whole plan steps of the same workload ({C} candidates x {inp.n_samples} samples) in {dt:.1f} s, "
-                      "oracle/fx_oracle.c single thread",
-            "cpu": _cpu_model(), "host_cores": os.cpu_count()}
+    return reps * C / dt, reps, dt
+
+
+def cpu_baseline_of(inp, what):
+    """The CPU oracle (scalar C restatement of the reference's algorithm) on the same workload, on this box's host
+    cores: whole plan steps for ~8 s on every available core (pthreads over candidate chunks -- the stand-in for the
+    upstream OpenMP handler, which is not installable offline) and ~5 s on one thread.  Reported, not optimised."""
+    threads = _host_threads()
+    one, reps1, dt1 = _time_oracle(inp, 5.0, 1)
+    out = {"value": one, "unit": "trajectories/s", "cores": 1, "kind": "port",
+           "sample": f"{reps1} whole plan steps of {what} in {dt1:.1f} s, oracle/fx_oracle.c single thread",
+           "cpu": _cpu_model(), "host_cores": os.cpu_count()}
+    if threads > 1:
+        many, repsN, dtN = _time_oracle(inp, 8.0, threads)
+        out.update({"value": many, "cores": threads, "single_thread_value": one,
+                    "sample": f"{repsN} whole plan steps of {what} in {dtN:.1f} s on {threads} threads "
+                              f"(oracle/fx_oracle.c, candidate chunks over pthreads); single thread: {reps1} steps in {dt1:.1f} s"})
+    return out
+
+
+def cpu_baseline(args):
+    from frenetix_motion_planner_amd import synthetic
+    from oracle import oracle
+    n_obst = 20 if args.workload == "config3" else 0
+    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=GRID, n_obstacles=n_obst, n_pred=30, lead_gap=LEAD_GAP,
+                                hull_builder=oracle.build_obstacle_hulls if n_obst else None)
+    return cpu_baseline_of(inp, f"the same workload ({inp.n_candidates} candidates x {inp.n_samples} samples)")
 
 
 def pmc_traffic(args, world):
@@ -330,16 +353,7 @@ def bench_stress(args, world, rank, local_rank, torch, dist):
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle
             one = synthetic.stress_agents(1, grid=STRESS_GRID, hull_builder=oracle.build_obstacle_hulls)[0]
-            t0 = time.perf_counter()
-            reps = 0
-            while time.perf_counter() - t0 < 12.0:
-                oracle.plan_range(one, 0, one.n_candidates)
-                reps += 1
-            dt = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": reps * one.n_candidates / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
-                                   "sample": f"{reps} plan steps of agent 0 ({one.n_candidates} candidates x {S} samples, {K} obstacles) "
-                                             f"in {dt:.1f} s, oracle/fx_oracle.c single thread", "cpu": _cpu_model(),
-                                   "host_cores": os.cpu_count()}
+            out["cpu_baseline"] = cpu_baseline_of(one, f"agent 0 ({one.n_candidates} candidates x {S} samples, {K} obstacles)")
         print(json.dumps(out))
     eng.close()
     if world > 1:

@@ -49,10 +49,12 @@ def dense_ranges(n_t: int, n_v: int, n_d: int, v0: float, veh: VehicleParams, ho
 
 
 def synthetic_predictions(cs: CoordinateSystem, n_obstacles: int, n_pred: int, dt: float, s_center: float,
-                          rng: np.random.Generator, corridor=(120.0, 12.0), min_gap: float = 0.0):
+                          rng: np.random.Generator, corridor=(120.0, 12.0), min_gap: float = 0.0, lead_gap: float = 0.0):
     """K obstacles, constant velocity along/against the reference tangent.
     min_gap > 0: an obstacle that would start within min_gap metres (arc length) of s_center is drawn again, so the
-    ego does not start inside an obstacle."""
+    ego does not start inside an obstacle.  lead_gap > 0: obstacle 0 is a slow lead vehicle (3 m/s) on the reference
+    line lead_gap metres ahead, so that the cheapest candidates -- the ones that keep the lane at the desired speed --
+    run into it (SURVEY 8d asks that a good share of the otherwise-best candidates collide)."""
     preds = {}
     for k in range(n_obstacles):
         while True:
@@ -60,11 +62,13 @@ def synthetic_predictions(cs: CoordinateSystem, n_obstacles: int, n_pred: int, d
             d0 = rng.uniform(-0.5, 0.5) * corridor[1]
             if abs(s0 - s_center) >= min_gap:
                 break
+        direction = 1.0 if rng.uniform() < 0.7 else -1.0
+        speed = rng.uniform(3.0, 12.0)
+        if k == 0 and lead_gap > 0:
+            s0, d0, direction, speed = s_center + lead_gap, 0.0, 1.0, 3.0
         s0 = float(np.clip(s0, cs.ref_pos[2], cs.ref_pos[-3]))
         seg = cs.segment_of(s0)
         yaw_ref = float(cs.ref_theta[seg])
-        direction = 1.0 if rng.uniform() < 0.7 else -1.0
-        speed = rng.uniform(3.0, 12.0)
         yaw = yaw_ref if direction > 0 else yaw_ref + np.pi
         p0 = cs.convert_to_cartesian_coords(s0, d0)
         steps = np.arange(1, n_pred + 1) * dt
@@ -89,7 +93,7 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
                 n_obstacles=0, n_pred=30, cost_weights=None, draw_traj_set=False, kinematic_debug=False,
                 write_bundle=True, write_costmap=True, collision=True, low_vel_threshold=2.0, hull_builder=None,
                 seed=SEED, vehicle=None, x0_orientation=None, as_matrix=False, stop_point_s=None, road_half_width=None,
-                obstacle_min_gap=0.0):
+                obstacle_min_gap=0.0, lead_gap=0.0):
     """One agent's PlanInputs on a synthetic reference.
 
     level: reference sampling level (set-ordered ranges, SamplingHandler) -- or
@@ -120,7 +124,8 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
     if x0_orientation is None:
         x0_orientation = float(cs.ref_theta[seg])
     rng = np.random.default_rng(seed)
-    preds = synthetic_predictions(cs, n_obstacles, n_pred, dt, s0, rng, min_gap=obstacle_min_gap) if n_obstacles else None
+    preds = synthetic_predictions(cs, n_obstacles, n_pred, dt, s0, rng, min_gap=obstacle_min_gap,
+                                  lead_gap=lead_gap) if n_obstacles else None
     weights = dict(cost_weights if cost_weights is not None else DEFAULT_COST_WEIGHTS)
     if not preds:
         weights.pop("prediction", None) if cost_weights is None else None

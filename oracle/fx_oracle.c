@@ -27,6 +27,7 @@
  * Arithmetic order mirrors the NumPy expressions term by term (compile with -ffp-contract=off);
  * np.sum is reproduced as NumPy's 8-accumulator pairwise summation.
  */
+#include <pthread.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -721,6 +722,69 @@ int32_t fxo_plan_range(const FxProblem *p, int64_t g0, int64_t g1, uint32_t *fla
         }
     }
     return FX_OK;
+}
+
+/* The same leg on n_threads host threads (contiguous chunks of [g0,g1), merged with the (cost, index) order of the
+ * single-thread loop).  The upstream C++ handler evaluates its trajectory list with OpenMP
+ * (evaluate_all_current_functions_concurrent, reactive_planner_cpp.py:347-349); that library is not in the reference
+ * tree, so the reported many-core CPU figure is this restatement on plain pthreads. */
+#define FXO_MT_CHUNK 256
+typedef struct {
+    const FxProblem *p;
+    int64_t g0, g1;
+    uint32_t *flags;
+    double *cost;
+    int64_t *next;       /* shared chunk counter */
+    int64_t best;
+    double best_cost;
+    int32_t rc;
+} RangeJob;
+
+static void *range_worker(void *arg) {
+    RangeJob *j = (RangeJob *)arg;
+    for (;;) {  /* chunks of FXO_MT_CHUNK candidates handed out through a shared counter (candidates differ in cost) */
+        const int64_t c = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
+        const int64_t a = j->g0 + c * FXO_MT_CHUNK;
+        if (a >= j->g1) break;
+        const int64_t b = a + FXO_MT_CHUNK < j->g1 ? a + FXO_MT_CHUNK : j->g1;
+        int64_t best;
+        double bc;
+        const int32_t rc = fxo_plan_range(j->p, a, b, j->flags + (a - j->g0), j->cost + (a - j->g0), &best, &bc);
+        if (rc != FX_OK) j->rc = rc;
+        /* lexicographic (cost, index): what the sequential loop's strict '<' yields */
+        if (best >= 0 && (j->best < 0 || bc < j->best_cost || (bc == j->best_cost && best < j->best))) { j->best = best; j->best_cost = bc; }
+    }
+    return NULL;
+}
+
+int32_t fxo_plan_range_mt(const FxProblem *p, int64_t g0, int64_t g1, int32_t n_threads, uint32_t *flags, double *cost,
+                          int64_t *best, double *best_cost) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    RangeJob *jobs = (RangeJob *)calloc((size_t)n_threads, sizeof(RangeJob));
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    int64_t next = 0;
+    if (!jobs || !th) { free(jobs); free(th); return FX_ERR_INVALID_ARGUMENT; }
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t].p = p; jobs[t].g0 = g0; jobs[t].g1 = g1; jobs[t].flags = flags; jobs[t].cost = cost; jobs[t].next = &next;
+        jobs[t].best = -1; jobs[t].best_cost = 0.0; jobs[t].rc = FX_OK;
+        if (pthread_create(&th[t], NULL, range_worker, &jobs[t]) != 0) { range_worker(&jobs[t]); th[t] = 0; }
+    }
+    int32_t rc = FX_OK;
+    *best = -1;
+    *best_cost = 0.0;
+    for (int t = 0; t < n_threads; t++) {
+        if (th[t]) pthread_join(th[t], NULL);
+        if (jobs[t].rc != FX_OK) rc = jobs[t].rc;
+        if (jobs[t].best >= 0 && (*best < 0 || jobs[t].best_cost < *best_cost ||
+                                  (jobs[t].best_cost == *best_cost && jobs[t].best < *best))) {
+            *best = jobs[t].best;
+            *best_cost = jobs[t].best_cost;
+        }
+    }
+    free(jobs);
+    free(th);
+    return rc;
 }
 
 /* exported for tests of the normative pieces */

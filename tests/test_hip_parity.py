@@ -452,3 +452,26 @@ def test_config2_full_size_properties():
         c = out["costed"] & robust
         assert (np.abs(cost[c] - out["cost"][c]) / np.maximum(np.abs(out["cost"][c]), 1e-12)).max() < COST_RTOL
         assert res["best_index"] == out["result"]["best_index"]
+
+
+def test_config3_full_size_vs_oracle():
+    """BASELINE config 3 at full size (50 388 x 31, 20 predicted obstacles, collision stage): every candidate against
+    the oracle; the generator's promise that a good share of the otherwise-best candidates collide."""
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    from oracle import oracle
+    kw = dict(ref_kind="arc", v0=10.0, grid=(19, 51, 51), n_obstacles=20, n_pred=30, lead_gap=25.0)  # = bench.py config3
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw), want_planes=False)
+    with FrenetEngine(max_candidates=inp.n_candidates) as e:
+        for select_only in (False, True):
+            inp.write_bundle = inp.write_costmap = not select_only
+            res = e.plan_step(inp)
+            cost, flags = e.costs()
+            robust = out["margin"] >= FRAGILE
+            assert np.array_equal(flags[robust], out["flags"][robust])
+            c = out["costed"] & robust
+            assert (np.abs(cost[c] - out["cost"][c]) / np.maximum(np.abs(out["cost"][c]), 1e-12)).max() < COST_RTOL
+            assert res["best_index"] == out["result"]["best_index"] and res["n_collisions"] == out["result"]["n_collisions"]
+    sel = np.nonzero(out["selectable"])[0]
+    best500 = sel[np.argsort(out["cost"][sel], kind="stable")][:500]
+    assert out["collision"][best500].mean() >= 0.25 and out["result"]["n_collisions"] > 500 and out["result"]["best_index"] >= 0

@@ -115,3 +115,16 @@ def test_costs_and_order(case):
     elif not len(fx["walk_ids"]):
         assert out["result"]["best_index"] == -1 or not robust[out["result"]["best_index"]]
     del ref_walk
+
+
+def test_threaded_range_leg_equals_the_sequential_one():
+    """bench.py's many-core cpu_baseline leg: chunks over pthreads give the flags, costs and winner of the loop."""
+    from frenetix_motion_planner_amd import synthetic
+    from oracle import oracle
+    inp = synthetic.make_inputs(ref_kind="scurve", v0=9.0, grid=(5, 11, 13), n_obstacles=4, hull_builder=oracle.build_obstacle_hulls)
+    f1, c1, b1, bc1 = oracle.plan_range(inp, 0, inp.n_candidates)
+    for nt in (2, 5):
+        f, c, b, bc = oracle.plan_range(inp, 0, inp.n_candidates, n_threads=nt)
+        assert np.array_equal(f, f1) and np.array_equal(c, c1) and (b, bc) == (b1, bc1)
+    out = oracle.plan_step(inp, want_planes=False)
+    assert b1 == out["result"]["best_index"] and np.array_equal(f1, out["flags"])
