@@ -218,7 +218,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
         char *hot_base = reinterpret_cast<char *>(rows + (size_t)n_pairs_max * S) + (G > 1 ? (size_t)64 * BLK : 0);
         const size_t hot_block = (sizeof(double) * FX_HOT_STRIDE * (size_t)fuse.k_max + 15) & ~(size_t)15;
         Hs.lds = reinterpret_cast<double *>(hot_base + (size_t)(tid >> 6) * hot_block);
-        if (i_first < i_end) Hs.prefetch(i_first);
+        if (FX_HOT_LDS && i_first < i_end) Hs.prefetch(i_first);
     }
 
     FX_STAMP(3);

@@ -270,7 +270,9 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                                           StepCarry &C, StepAcc &A, StepOut &O, ObsD obs_rec, ObsM obs_pmask, ObsM obs_hmask,
                                           const BoundView &B, ObsHot *H = nullptr, int i_next = -1) {
     const int S = K.S;
+#if FX_HOT_LDS
     if (OBST && HOT && USTEP && K.K > 0) H->stage(__builtin_amdgcn_readfirstlane(i), i_next);
+#endif
     const double s_i = r.s, sv_i = r.sv, sa_i = r.sa;
     // -- lateral polynomial (reactive_planner.py:326-346) --
     double d_i, dv_i, da_i;
@@ -399,6 +401,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
         if (um) {
             const auto rec_i = obs_rec + (int64_t)iu * K.K * 12;
             struct Ent { double mx, my, a, b, c, d, hx, hy, hr; };
+#if FX_HOT_LDS
             auto fetch = [&](int k) {
                 const double2 *q = reinterpret_cast<const double2 *>(H->lds + k * FX_HOT_STRIDE);
                 const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
@@ -407,6 +410,17 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                 e.hr = H->lds[k * FX_HOT_STRIDE + 8];
                 return e;
             };
+#else
+            // scalar path: the entry is wave-uniform, so it travels once per wave (scalar cache -> SGPRs) instead of
+            // once per lane; the next entry is requested before the current one is consumed
+            const auto hot_i = H->tab + (int64_t)iu * H->n_el;
+            auto fetch = [&](int k) {
+                const auto q = hot_i + k * FX_HOT_STRIDE;
+                Ent e;
+                e.mx = q[0]; e.my = q[1]; e.a = q[2]; e.b = q[3]; e.c = q[4]; e.d = q[5]; e.hx = q[6]; e.hy = q[7]; e.hr = q[8];
+                return e;
+            };
+#endif
             auto visit = [&](const Ent &e, int k) {
                 if ((pm >> k) & 1ULL) {  // prediction cost (collision_probability.py:283-292)
                     const double e0 = x_i - e.mx, e1 = y_i - e.my;
