@@ -73,14 +73,25 @@ def _host_threads():
 
 
 def _time_oracle(inp, seconds, n_threads):
+    """(trajectories/s, passes, seconds): whole passes over the candidate set; with threads the team lives for a batch of
+    passes (sized from a probe so that the leg takes about `seconds`)."""
     from oracle import oracle
     C = inp.n_candidates
     oracle.plan_range(inp, 0, min(C, 2000))  # warm-up
+    if n_threads <= 1:
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < seconds:
+            oracle.plan_range(inp, 0, C)
+            reps += 1
+        dt = time.perf_counter() - t0
+        return reps * C / dt, reps, dt
     t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < seconds:
-        oracle.plan_range(inp, 0, C, n_threads=n_threads)
-        reps += 1
+    oracle.plan_range(inp, 0, C, n_threads=n_threads, reps=2)
+    probe = (time.perf_counter() - t0) / 2
+    reps = int(max(4, min(2000, seconds / max(probe, 1e-4))))
+    t0 = time.perf_counter()
+    oracle.plan_range(inp, 0, C, n_threads=n_threads, reps=reps)
     dt = time.perf_counter() - t0
     return reps * C / dt, reps, dt
 

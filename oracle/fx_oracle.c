@@ -27,6 +27,7 @@
  * Arithmetic order mirrors the NumPy expressions term by term (compile with -ffp-contract=off);
  * np.sum is reproduced as NumPy's 8-accumulator pairwise summation.
  */
+#define _POSIX_C_SOURCE 200809L /* pthread barriers under -std=c11 */
 #include <pthread.h>
 #include <math.h>
 #include <stdint.h>
@@ -728,13 +729,15 @@ int32_t fxo_plan_range(const FxProblem *p, int64_t g0, int64_t g1, uint32_t *fla
  * single-thread loop).  The upstream C++ handler evaluates its trajectory list with OpenMP
  * (evaluate_all_current_functions_concurrent, reactive_planner_cpp.py:347-349); that library is not in the reference
  * tree, so the reported many-core CPU figure is this restatement on plain pthreads. */
-#define FXO_MT_CHUNK 256
+#define FXO_MT_CHUNK 64
 typedef struct {
     const FxProblem *p;
     int64_t g0, g1;
     uint32_t *flags;
     double *cost;
-    int64_t *next;       /* shared chunk counter */
+    int64_t *next;            /* shared chunk counter */
+    pthread_barrier_t *bar;   /* NULL for a single pass */
+    int32_t reps, tid;
     int64_t best;
     double best_cost;
     int32_t rc;
@@ -742,46 +745,75 @@ typedef struct {
 
 static void *range_worker(void *arg) {
     RangeJob *j = (RangeJob *)arg;
-    for (;;) {  /* chunks of FXO_MT_CHUNK candidates handed out through a shared counter (candidates differ in cost) */
-        const int64_t c = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
-        const int64_t a = j->g0 + c * FXO_MT_CHUNK;
-        if (a >= j->g1) break;
-        const int64_t b = a + FXO_MT_CHUNK < j->g1 ? a + FXO_MT_CHUNK : j->g1;
-        int64_t best;
-        double bc;
-        const int32_t rc = fxo_plan_range(j->p, a, b, j->flags + (a - j->g0), j->cost + (a - j->g0), &best, &bc);
-        if (rc != FX_OK) j->rc = rc;
-        /* lexicographic (cost, index): what the sequential loop's strict '<' yields */
-        if (best >= 0 && (j->best < 0 || bc < j->best_cost || (bc == j->best_cost && best < j->best))) { j->best = best; j->best_cost = bc; }
+    for (int32_t r = 0; r < j->reps; r++) {
+        j->best = -1;
+        j->best_cost = 0.0;
+        for (;;) {  /* chunks of FXO_MT_CHUNK candidates handed out through a shared counter (candidates differ in cost) */
+            const int64_t c = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
+            const int64_t a = j->g0 + c * FXO_MT_CHUNK;
+            if (a >= j->g1) break;
+            const int64_t b = a + FXO_MT_CHUNK < j->g1 ? a + FXO_MT_CHUNK : j->g1;
+            int64_t best;
+            double bc;
+            const int32_t rc = fxo_plan_range(j->p, a, b, j->flags + (a - j->g0), j->cost + (a - j->g0), &best, &bc);
+            if (rc != FX_OK) j->rc = rc;
+            /* lexicographic (cost, index): what the sequential loop's strict '<' yields */
+            if (best >= 0 && (j->best < 0 || bc < j->best_cost || (bc == j->best_cost && best < j->best))) { j->best = best; j->best_cost = bc; }
+        }
+        if (j->bar) {  /* one plan step done by everybody; thread 0 re-arms the counter for the next one */
+            pthread_barrier_wait(j->bar);
+            if (j->tid == 0 && r + 1 < j->reps) __atomic_store_n(j->next, 0, __ATOMIC_RELAXED);
+            pthread_barrier_wait(j->bar);
+        }
     }
     return NULL;
 }
 
-int32_t fxo_plan_range_mt(const FxProblem *p, int64_t g0, int64_t g1, int32_t n_threads, uint32_t *flags, double *cost,
-                          int64_t *best, double *best_cost) {
+/* reps whole passes over [g0,g1) on n_threads threads that live for the whole call (bench.py times the call, so thread
+ * start-up is amortised over the passes like a handler that keeps its OpenMP team); outputs are those of the last pass */
+int32_t fxo_plan_range_mt(const FxProblem *p, int64_t g0, int64_t g1, int32_t n_threads, int32_t reps, uint32_t *flags,
+                          double *cost, int64_t *best, double *best_cost) {
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 1024) n_threads = 1024;
+    if (reps < 1) reps = 1;
     RangeJob *jobs = (RangeJob *)calloc((size_t)n_threads, sizeof(RangeJob));
     pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
     int64_t next = 0;
+    pthread_barrier_t bar;
     if (!jobs || !th) { free(jobs); free(th); return FX_ERR_INVALID_ARGUMENT; }
+    int started = 0;
+    /* the barrier needs the exact number of participants: create the threads first, then count */
+    pthread_barrier_t *barp = reps > 1 ? &bar : NULL;
+    if (barp && pthread_barrier_init(&bar, NULL, (unsigned)n_threads) != 0) { free(jobs); free(th); return FX_ERR_INVALID_ARGUMENT; }
     for (int t = 0; t < n_threads; t++) {
         jobs[t].p = p; jobs[t].g0 = g0; jobs[t].g1 = g1; jobs[t].flags = flags; jobs[t].cost = cost; jobs[t].next = &next;
+        jobs[t].bar = barp; jobs[t].reps = reps; jobs[t].tid = t;
         jobs[t].best = -1; jobs[t].best_cost = 0.0; jobs[t].rc = FX_OK;
-        if (pthread_create(&th[t], NULL, range_worker, &jobs[t]) != 0) { range_worker(&jobs[t]); th[t] = 0; }
+        if (pthread_create(&th[t], NULL, range_worker, &jobs[t]) != 0) break;
+        started++;
     }
     int32_t rc = FX_OK;
+    if (started < n_threads) {
+        /* could not start the whole team: a barrier would never release -- finish what started as single passes is not
+         * possible either, so report the failure (the caller retries with fewer threads) */
+        rc = FX_ERR_INVALID_ARGUMENT;
+        if (!barp) for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+        else for (int t = 0; t < started; t++) pthread_cancel(th[t]), pthread_join(th[t], NULL);
+    }
     *best = -1;
     *best_cost = 0.0;
-    for (int t = 0; t < n_threads; t++) {
-        if (th[t]) pthread_join(th[t], NULL);
+    for (int t = 0; t < started && rc == FX_OK; t++) {
+        pthread_join(th[t], NULL);
         if (jobs[t].rc != FX_OK) rc = jobs[t].rc;
+    }
+    for (int t = 0; t < started && rc == FX_OK; t++) {
         if (jobs[t].best >= 0 && (*best < 0 || jobs[t].best_cost < *best_cost ||
                                   (jobs[t].best_cost == *best_cost && jobs[t].best < *best))) {
             *best = jobs[t].best;
             *best_cost = jobs[t].best_cost;
         }
     }
+    if (barp) pthread_barrier_destroy(&bar);
     free(jobs);
     free(th);
     return rc;

@@ -37,7 +37,7 @@ def lib():
         L.fxo_plan_step_b.restype = C.c_int32
         L.fxo_plan_range.argtypes = [C.POINTER(_abi.FxProblem), C.c_int64, C.c_int64, pu32, pd, pi64, pd]
         L.fxo_plan_range.restype = C.c_int32
-        L.fxo_plan_range_mt.argtypes = [C.POINTER(_abi.FxProblem), C.c_int64, C.c_int64, C.c_int32, pu32, pd, pi64, pd]
+        L.fxo_plan_range_mt.argtypes = [C.POINTER(_abi.FxProblem), C.c_int64, C.c_int64, C.c_int32, C.c_int32, pu32, pd, pi64, pd]
         L.fxo_plan_range_mt.restype = C.c_int32
         L.fxo_num_candidates.argtypes = [C.POINTER(_abi.FxProblem)]
         L.fxo_num_candidates.restype = C.c_int64
@@ -101,9 +101,9 @@ def plan_step(inputs, want_planes=True):
     return out
 
 
-def plan_range(inputs, g0, g1, n_threads=1):
+def plan_range(inputs, g0, g1, n_threads=1, reps=1):
     """Timed leg of bench.py's cpu_baseline: evaluate candidates [g0, g1) without keeping planes (n_threads > 1:
-    contiguous chunks on that many host threads)."""
+    chunks handed to that many host threads, `reps` whole passes by the same team of threads)."""
     prob = inputs.as_struct()
     n = g1 - g0
     flags = np.zeros(n, np.uint32)
@@ -111,8 +111,8 @@ def plan_range(inputs, g0, g1, n_threads=1):
     best = C.c_int64(-1)
     bc = C.c_double(0)
     if n_threads > 1:
-        rc = lib().fxo_plan_range_mt(C.byref(prob), g0, g1, int(n_threads), _p(flags, C.c_uint32), _p(cost), C.byref(best),
-                                     C.byref(bc))
+        rc = lib().fxo_plan_range_mt(C.byref(prob), g0, g1, int(n_threads), int(reps), _p(flags, C.c_uint32), _p(cost),
+                                     C.byref(best), C.byref(bc))
     else:
         rc = lib().fxo_plan_range(C.byref(prob), g0, g1, _p(flags, C.c_uint32), _p(cost), C.byref(best), C.byref(bc))
     if rc != 0:
