@@ -438,18 +438,77 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                     if (__any(near)) A.collided |= obb_overlap(hull, rec_i + k * 12 + 6);
                 }
             };
-            int k0 = __builtin_ctzll(um);
-            um &= um - 1;
-            Ent ea = fetch(k0), eb = ea;
-            while (true) {
-                int k1 = -1;
-                if (um) { k1 = __builtin_ctzll(um); um &= um - 1; eb = fetch(k1); }
-                visit(ea, k0);
-                if (k1 < 0) break;
-                k0 = -1;
-                if (um) { k0 = __builtin_ctzll(um); um &= um - 1; ea = fetch(k0); }
-                visit(eb, k1);
-                if (k0 < 0) break;
+            // Dense fast path (the usual case: every obstacle has a prediction at this step, and either all or none
+            // have a hull): straight-line code for two obstacles at a time -- two independent dependency chains, no
+            // branch on a vector compare inside the loop.  The rare events are only recorded (a lane whose Mahalanobis
+            // term is not positive; an obstacle some lane is near) and settled after the loop.
+            const int nK = K.K;
+            const unsigned long long full = nK >= 64 ? ~0ULL : ((1ULL << nK) - 1ULL);
+            if (pm == full && (hm == 0ULL || hm == full)) {
+                const bool coll = hm != 0ULL;
+                const double pred0 = A.pred;
+                bool bad = false;
+                unsigned long long nm = 0ULL;  // obstacles that need the exact axis test
+                auto pred_term = [&](const Ent &e) {
+                    const double e0 = x_i - e.mx, e1 = y_i - e.my;
+                    const double r0 = fma(e1, e.c, e0 * e.a), r1 = fma(e1, e.d, e0 * e.b);
+                    const double m = fma(r1, e1, r0 * e0);
+                    const double mm = m * m;
+                    bad |= !(mm > 0.0);
+                    return rcp_nr(mm);
+                };
+                auto is_near = [&](const Ent &e) {
+                    const double tx = e.hx - hull.cx, ty = e.hy - hull.cy;
+                    const double rr = e.hr + re;
+                    return !(fma(tx, tx, ty * ty) > rr * rr);
+                };
+                int k = 0;
+                for (; k + 1 < nK; k += 2) {
+                    const Ent ea = fetch(k), eb = fetch(k + 1);
+                    const double ta = pred_term(ea), tb = pred_term(eb);
+                    A.pred += ta;
+                    A.pred += tb;
+                    if (coll) {
+                        const bool na = is_near(ea), nb = is_near(eb);
+                        nm |= (__any(na) ? 1ULL : 0ULL) << k;
+                        nm |= (__any(nb) ? 2ULL : 0ULL) << k;
+                    }
+                }
+                if (k < nK) {
+                    const Ent ea = fetch(k);
+                    A.pred += pred_term(ea);
+                    if (coll) nm |= (__any(is_near(ea)) ? 1ULL : 0ULL) << k;
+                }
+                if (__any(bad)) {  // exact division where the fast reciprocal does not apply: redo the step's sum in order
+                    A.pred = pred0;
+                    for (int j = 0; j < nK; j++) {
+                        const Ent e = fetch(j);
+                        const double e0 = x_i - e.mx, e1 = y_i - e.my;
+                        const double r0 = fma(e1, e.c, e0 * e.a), r1 = fma(e1, e.d, e0 * e.b);
+                        const double m = fma(r1, e1, r0 * e0);
+                        const double mm = m * m;
+                        A.pred += mm > 0.0 ? rcp_nr(mm) : 1.0 / mm;
+                    }
+                }
+                while (nm) {
+                    const int j = __builtin_ctzll(nm);
+                    nm &= nm - 1;
+                    A.collided |= obb_overlap(hull, rec_i + j * 12 + 6);
+                }
+            } else {
+                int k0 = __builtin_ctzll(um);
+                um &= um - 1;
+                Ent ea = fetch(k0), eb = ea;
+                while (true) {
+                    int k1 = -1;
+                    if (um) { k1 = __builtin_ctzll(um); um &= um - 1; eb = fetch(k1); }
+                    visit(ea, k0);
+                    if (k1 < 0) break;
+                    k0 = -1;
+                    if (um) { k0 = __builtin_ctzll(um); um &= um - 1; ea = fetch(k0); }
+                    visit(eb, k1);
+                    if (k0 < 0) break;
+                }
             }
         }
     } else if (OBST && K.K > 0) {  // a batched launch may mix agents with and without obstacles
