@@ -475,3 +475,38 @@ def test_config3_full_size_vs_oracle():
     sel = np.nonzero(out["selectable"])[0]
     best500 = sel[np.argsort(out["cost"][sel], kind="stable")][:500]
     assert out["collision"][best500].mean() >= 0.25 and out["result"]["n_collisions"] > 500 and out["result"]["best_index"] >= 0
+
+
+@pytest.mark.parametrize("lanes,mapping", [(1, 0), (2, 2), (4, 2), (2, 1)])
+def test_many_ragged_obstacles(eng, lanes, mapping):
+    """40 obstacles (more than the hot table's one-step prefetch window of 25) whose predictions end at different steps:
+    the masked obstacle loop, the dense fast path on the early steps and the lane-split fallback all against the oracle."""
+    from oracle import oracle
+    from frenetix_motion_planner_amd.problem import pack_predictions
+    kw = dict(ref_kind="scurve", kappa=0.015, v0=9.0, grid=(6, 9, 11), n_obstacles=40, n_pred=30, lead_gap=40.0, seed=3,
+              obstacle_min_gap=10.0)
+
+    def build(hulls):
+        inp = synthetic.make_inputs(hull_builder=hulls, **kw)
+        preds = {}
+        for j, (key, pr) in enumerate(inp.predictions.items()):
+            n = 30 if j % 4 == 0 else (3 + (7 * j) % 27)           # some full length, the rest 3 .. 29 steps, one of 2
+            if j == 5:
+                n = 2                                                # <= 2 predicted steps: no hull at all
+            preds[key] = dict(pos_list=pr["pos_list"][:n], cov_list=pr["cov_list"][:n], orientation_list=pr["orientation_list"][:n],
+                              shape=pr["shape"])
+        inp.obstacles = pack_predictions(preds, inp.n_samples, hulls)
+        inp.predictions = preds
+        return inp
+
+    out = oracle.plan_step(build(oracle.build_obstacle_hulls))
+    inp = build(hip_hulls())
+    assert inp.obstacles["K"] == 40
+    eng.set_tuning(lanes, 0, 2, 0, mapping)
+    try:
+        res = eng.plan_step(inp)
+        compare(eng, inp, out, res)
+        assert res["best_index"] == out["result"]["best_index"] and res["n_collisions"] == out["result"]["n_collisions"]
+        assert out["collision"].sum() > 100 and out["result"]["n_collisions"] > 50 and res["best_index"] >= 0
+    finally:
+        eng.set_tuning(0, 0, 0, 0, 0)
