@@ -524,18 +524,24 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                 return need + (size_t)(blk / 64) * hot_block;
             };
             const int want_waves = 4 * c->wpe_step;
+            const size_t lds_cap = (160 * 1024) / 2 - 512;  // two workgroups per CU (static LDS of the kernels: 256 B)
             block = 0;
+            int best_waves = 0;
             for (int blk : {256, 128, 64}) {
                 const size_t need = lds_for(blk);
                 const int by_lds = (int)((160 * 1024) / (need + 256));
-                if (by_lds * (blk / 64) >= want_waves) { block = blk; lds_need = need; break; }
+                const int waves = by_lds * (blk / 64);
+                if (waves >= want_waves && need <= lds_cap) { block = blk; lds_need = need; break; }
+                // nothing reaches the target (few lateral samples per pair -> many rows): keep the workgroup size that
+                // holds the most waves per CU among those whose rows fit at all
+                if (need <= lds_cap && waves > best_waves) { best_waves = waves; block = blk; lds_need = need; }
             }
             if (c->block_force) { block = c->block_force; lds_need = lds_for(block); }
             if (!block) { block = FX_BLOCK; lds_need = lds_for(block); }
-            if (lds_need > 78 * 1024) grid_ok = false;   // at least two workgroups per CU
+            if (lds_need > lds_cap) grid_ok = false;   // at least two workgroups per CU
         }
         if (c->variant_force == 1) grid_ok = false;
-        if (c->variant_force == 2 && !grid_ok) return set_err(FX_ERR_INVALID_ARGUMENT, "grid kernel forced but not applicable");
+        if (c->variant_force == 2 && !grid_ok) return set_err(FX_ERR_INVALID_ARGUMENT, "grid kernel forced but not applicable (G=%d block=%d rows+tables need %zu B of LDS per workgroup)", G, block, lds_need);
         c->use_grid = grid_ok;
         c->lds_step = lds_need;
         c->block_step = grid_ok ? block : FX_BLOCK;

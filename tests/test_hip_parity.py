@@ -478,7 +478,7 @@ def test_config3_full_size_vs_oracle():
 
 
 @pytest.mark.parametrize("lanes,mapping", [(1, 0), (2, 2), (4, 2), (2, 1)])
-def test_many_ragged_obstacles(eng, lanes, mapping):
+def test_many_ragged_obstacles(lanes, mapping):
     """40 obstacles (more than the hot table's one-step prefetch window of 25) whose predictions end at different steps:
     the masked obstacle loop, the dense fast path on the early steps and the lane-split fallback all against the oracle."""
     from oracle import oracle
@@ -502,11 +502,10 @@ def test_many_ragged_obstacles(eng, lanes, mapping):
     out = oracle.plan_step(build(oracle.build_obstacle_hulls))
     inp = build(hip_hulls())
     assert inp.obstacles["K"] == 40
-    eng.set_tuning(lanes, 0, 2, 0, mapping)
-    try:
-        res = eng.plan_step(inp)
-        compare(eng, inp, out, res)
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    with FrenetEngine(max_candidates=4096, max_obstacles=64, max_pred_steps=64) as e:
+        e.set_tuning(lanes, 0, 2, 0, mapping)
+        res = e.plan_step(inp)
+        compare(e, inp, out, res)
         assert res["best_index"] == out["result"]["best_index"] and res["n_collisions"] == out["result"]["n_collisions"]
         assert out["collision"].sum() > 100 and out["result"]["n_collisions"] > 50 and res["best_index"] >= 0
-    finally:
-        eng.set_tuning(0, 0, 0, 0, 0)
