@@ -115,6 +115,8 @@ struct FxContext {
     double *d_topk_scr_cost = nullptr;     // [max_agents][64 slices][64]
     long long *d_topk_scr_idx = nullptr;
     double *h_topk_cost = nullptr;
+    double *h_cand = nullptr;  // pinned staging of fx_read_candidate_agent: planes | coeffs | raw costs | cost | traj_len | flags
+    size_t h_cand_doubles = 0;
     long long *h_topk_idx = nullptr;
     int64_t total_ld = 0;  // capacity of per-candidate arrays (elements)
     int64_t max_blocks_total = 0;
@@ -336,6 +338,8 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     if ((rc = dev_alloc(c, &c->d_topk_scr_cost, (size_t)max_agents * 64 * 64))) return rc;
     if ((rc = dev_alloc(c, &c->d_topk_scr_idx, (size_t)max_agents * 64 * 64))) return rc;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_topk_cost), sizeof(double) * max_agents * 64, hipHostMallocDefault));
+    c->h_cand_doubles = (size_t)FX_NUM_PLANES * (max_steps + 1) + 12 + FX_NUM_COSTS + 4;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_cand), sizeof(double) * c->h_cand_doubles, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_topk_idx), sizeof(long long) * max_agents * 64, hipHostMallocDefault));
     c->slots.resize(max_agents);
     return FX_OK;
@@ -357,7 +361,7 @@ int32_t fx_destroy(FxContext *c) {
     if (c->d_bstep) (void)hipFree(c->d_bstep);
     if (c->d_bound) (void)hipFree(c->d_bound);
     if (c->h_bound) (void)hipHostFree(c->h_bound);
-    void *host[] = {c->h_in, c->h_probs, c->h_counters, c->h_topk_cost, c->h_topk_idx, c->h_pub};
+    void *host[] = {c->h_in, c->h_probs, c->h_counters, c->h_topk_cost, c->h_topk_idx, c->h_pub, c->h_cand};
     for (void *p : host) if (p) (void)hipHostFree(p);
     for (auto &t : c->ring) {
         if (t.e0) (void)hipEventDestroy(t.e0);
@@ -900,6 +904,44 @@ int32_t fx_read_sample_agent(FxContext *c, int32_t agent, int64_t index, double 
     return FX_OK;
 }
 int32_t fx_read_sample(FxContext *c, int64_t index, double *planes) { return fx_read_sample_agent(c, 0, index, planes); }
+
+int32_t fx_read_candidate_agent(FxContext *c, int32_t agent, int64_t index, double *planes, double *coeffs12, int32_t *traj_len,
+                                double *raw_costs, double *cost, uint32_t *flags) {
+    int rc = check_agent(c, agent);
+    if (rc) return rc;
+    const FxAgentSlot &s = c->slots[agent];
+    if (index < 0 || index >= s.C) return set_err(FX_ERR_INVALID_ARGUMENT, "candidate %lld out of range", (long long)index);
+    const bool bundle = (s.mode & FX_MODE_WRITE_BUNDLE) != 0, cmap = (s.mode & FX_MODE_WRITE_COSTMAP) != 0;
+    if ((planes || coeffs12 || traj_len) && !bundle) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_BUNDLE");
+    if (raw_costs && !cmap) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_COSTMAP");
+    // all pieces go to one pinned block with asynchronous copies; ONE synchronisation
+    double *hp = c->h_cand;
+    const size_t n_pl = (size_t)FX_NUM_PLANES * s.S;
+    double *h_co = hp + n_pl, *h_rc = h_co + 12, *h_c = h_rc + FX_NUM_COSTS;
+    int32_t *h_tl = reinterpret_cast<int32_t *>(h_c + 1);
+    uint32_t *h_fl = reinterpret_cast<uint32_t *>(h_c + 2);
+    if (n_pl + 12 + FX_NUM_COSTS + 4 > c->h_cand_doubles) return set_err(FX_ERR_CAPACITY, "candidate staging block too small");
+    if (planes)
+        HIP_TRY(hipMemcpy2DAsync(hp, sizeof(double), c->h_probs[agent].planes + index, sizeof(double) * s.ld, sizeof(double), n_pl,
+                                 hipMemcpyDeviceToHost, c->stream));
+    if (coeffs12)
+        HIP_TRY(hipMemcpy2DAsync(h_co, sizeof(double), c->d_coeffs + (size_t)12 * s.cand_off + index, sizeof(double) * s.ld,
+                                 sizeof(double), 12, hipMemcpyDeviceToHost, c->stream));
+    if (traj_len) HIP_TRY(hipMemcpyAsync(h_tl, c->d_trajlen + s.cand_off + index, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (raw_costs && s.n_cost > 0)
+        HIP_TRY(hipMemcpy2DAsync(h_rc, sizeof(double), c->d_costmap + (size_t)FX_NUM_COSTS * s.cand_off + index, sizeof(double) * s.ld,
+                                 sizeof(double), s.n_cost, hipMemcpyDeviceToHost, c->stream));
+    if (cost) HIP_TRY(hipMemcpyAsync(h_c, c->d_cost + s.cand_off + index, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (flags) HIP_TRY(hipMemcpyAsync(h_fl, c->d_flags + s.cand_off + index, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (planes) memcpy(planes, hp, sizeof(double) * n_pl);
+    if (coeffs12) memcpy(coeffs12, h_co, sizeof(double) * 12);
+    if (traj_len) *traj_len = *h_tl;
+    if (raw_costs) memcpy(raw_costs, h_rc, sizeof(double) * s.n_cost);
+    if (cost) *cost = *h_c;
+    if (flags) *flags = *h_fl;
+    return FX_OK;
+}
 
 int32_t fx_read_plane_agent(FxContext *c, int32_t agent, int32_t plane, double *out) {
     int rc = check_agent(c, agent);

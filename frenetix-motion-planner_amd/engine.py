@@ -209,6 +209,22 @@ class FrenetEngine:
         check(lib().fx_read_sample_agent(self._ctx, agent, int(index), out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    def candidate(self, index: int, agent: int = 0) -> dict:
+        """Everything one trajectory object exposes, with one synchronisation: planes [14, S], lon / lat coefficients,
+        traj_len, raw partial costs (inputs.cost_names order), total cost, flag word."""
+        inp = self._inputs[agent]
+        planes = np.zeros((_abi.FX_NUM_PLANES, inp.n_samples))
+        co = np.zeros(12)
+        raw = np.zeros(max(len(inp.cost_names), 1))
+        tl, cost, flags = C.c_int32(0), C.c_double(0.0), C.c_uint32(0)
+        pd = C.POINTER(C.c_double)
+        have_b, have_c = bool(inp.write_bundle), bool(inp.write_costmap) and len(inp.cost_names) > 0
+        check(lib().fx_read_candidate_agent(self._ctx, agent, int(index), planes.ctypes.data_as(pd) if have_b else None,
+                                            co.ctypes.data_as(pd) if have_b else None, C.byref(tl) if have_b else None,
+                                            raw.ctypes.data_as(pd) if have_c else None, C.byref(cost), C.byref(flags)))
+        return dict(planes=planes if have_b else None, lon=co[:6].copy(), lat=co[6:].copy(), traj_len=tl.value,
+                    raw_costs=raw[:len(inp.cost_names)] if have_c else None, cost=cost.value, flags=flags.value)
+
     def plane(self, name_or_index, agent: int = 0) -> np.ndarray:
         """[S, C] one plane of every candidate."""
         inp = self._inputs[agent]

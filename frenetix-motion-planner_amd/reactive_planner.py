@@ -447,19 +447,29 @@ class ReactivePlannerHip:
 
     # ------------------------------------------------------------------ output packaging (planner.py:394-447)
     def _compute_trajectory_pair(self, trajectory) -> tuple:
-        cart_list, cl_list, lon_list, lat_list = [], [], [], []
         c, k = trajectory.cartesian, trajectory.curvilinear
-        for i in range(len(c.x)):
-            yaw_rate = (c.theta[i] - c.theta[i - 1]) / self.dT if i > 0 else self.x_0.yaw_rate
-            cart_list.append(ReactivePlannerState(
-                time_step=self.x_0.time_step + i, position=np.array([c.x[i], c.y[i]]), orientation=float(c.theta[i]),
-                velocity=float(c.v[i]), acceleration=float(c.a[i]), yaw_rate=float(yaw_rate),
-                steering_angle=float(np.arctan2(self.vehicle_params.wheelbase * c.kappa[i], 1.0))))
-            cl_list.append(dict(time_step=self.x_0.time_step + i, position=np.array([k.s[i], k.d[i]]), velocity=float(c.v[i]),
-                                acceleration=float(c.a[i]), orientation=float(c.theta[i]), yaw_rate=float(c.kappa[i])))
-            lon_list.append([float(k.s[i]), float(k.s_dot[i]), float(k.s_ddot[i])])
-            lat_list.append([float(k.d[i]), float(k.d_dot[i]), float(k.d_ddot[i])])
-        self.shift_orientation(cart_list, interval_start=self.x_0.orientation - np.pi, interval_end=self.x_0.orientation + np.pi)
+        n = len(c.x)
+        theta = np.asarray(c.theta, dtype=np.float64)
+        yaw_rate = np.empty(n)
+        yaw_rate[0] = self.x_0.yaw_rate
+        yaw_rate[1:] = (theta[1:] - theta[:-1]) / self.dT
+        steer = np.arctan2(self.vehicle_params.wheelbase * np.asarray(c.kappa, dtype=np.float64), 1.0)
+        # shift_orientation (planner.py:536-542): into [x_0.orientation - pi, x_0.orientation + pi]
+        lo, hi = self.x_0.orientation - np.pi, self.x_0.orientation + np.pi
+        orient = theta.copy()
+        for _ in range(4):
+            orient = np.where(orient < lo, orient + 2 * np.pi, orient)
+            orient = np.where(orient > hi, orient - 2 * np.pi, orient)
+        pos = np.stack([np.asarray(c.x, dtype=np.float64), np.asarray(c.y, dtype=np.float64)], axis=1)
+        sd = np.stack([np.asarray(k.s, dtype=np.float64), np.asarray(k.d, dtype=np.float64)], axis=1)
+        t0 = self.x_0.time_step
+        v, a, kap = np.asarray(c.v).tolist(), np.asarray(c.a).tolist(), np.asarray(c.kappa).tolist()
+        th, yr, st, orl = theta.tolist(), yaw_rate.tolist(), steer.tolist(), orient.tolist()
+        cart_list = [ReactivePlannerState(t0 + i, pos[i], orl[i], v[i], a[i], yr[i], st[i]) for i in range(n)]
+        cl_list = [dict(time_step=t0 + i, position=sd[i], velocity=v[i], acceleration=a[i], orientation=th[i], yaw_rate=kap[i])
+                   for i in range(n)]
+        lon_list = np.stack([k.s, k.s_dot, k.s_ddot], axis=1).tolist()
+        lat_list = np.stack([k.d, k.d_dot, k.d_ddot], axis=1).tolist()
         return cart_list, cl_list, lon_list, lat_list
 
     @staticmethod

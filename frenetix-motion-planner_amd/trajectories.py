@@ -74,11 +74,26 @@ class TrajectorySample:
     def __init__(self, step: "PlanStepResult", index: int):
         self._step = step
         self.uniqueId = int(index)
-        flags = int(step.flags[index])
+        self._planes = None
+        self._costmap = None
+        self._coeffs = None
+        if step.have_arrays:
+            flags = int(step.flags[index])
+            self._cost = float(step.cost[index])
+        else:
+            # the step's cost / flag arrays have not been read back: fetch this candidate whole (one synchronisation)
+            rec = step.fetch_candidate(index)
+            flags = int(rec["flags"])
+            self._cost = float(rec["cost"])
+            if rec["planes"] is not None:
+                self._planes = rec["planes"]
+                self._coeffs = (rec["lon"], rec["lat"], rec["traj_len"])
+            if rec["raw_costs"] is not None:
+                names, w = step.inputs.cost_names, step.inputs.cost_weights
+                self._costmap = {n: (float(rec["raw_costs"][k]), float(w[n] * rec["raw_costs"][k])) for k, n in enumerate(names)}
         self._flags = flags
         self.feasible = bool(flags & _abi.FX_FLAG_FEASIBLE)
         self.valid = bool(flags & _abi.FX_FLAG_VALID)
-        self._cost = float(step.cost[index])
         self.dt = step.inputs.dt
         self.horizon = step.inputs.N * step.inputs.dt
         # writable from Python (planner.py:325-326,381-382)
@@ -87,9 +102,6 @@ class TrajectorySample:
         self._boundary_harm = None
         self._coll_detected = bool(flags & _abi.FX_FLAG_COLLISION) if (flags & _abi.FX_FLAG_SELECTABLE) else None
         self.harm_occ_module = None
-        self._planes = None
-        self._costmap = None
-        self._coeffs = None
 
     # ---- cheap attributes ----
     @property
@@ -218,11 +230,34 @@ class PlanStepResult:
 
     def __init__(self, engine, inputs, result: dict, agent: int = 0):
         self.engine, self.inputs, self.result, self.agent = engine, inputs, result, agent
-        self.cost, self.flags = engine.costs(agent)
+        self._cost = self._flags = None   # [C] arrays, read back on first use (all_traj, masks, sorted lists)
         self._stale = False
         self._samples = {}
         self.harm_coeff = (-4.591, 0.185)  # log_reg.ignore_angle const / speed (configurations/harm_parameters.json)
         self._bsteps = None
+
+    @property
+    def have_arrays(self) -> bool:
+        return self._cost is not None or not hasattr(self.engine, "candidate")
+
+    def _load_arrays(self):
+        if self._cost is None:
+            self._check()
+            self._cost, self._flags = self.engine.costs(self.agent)
+
+    @property
+    def cost(self) -> np.ndarray:
+        self._load_arrays()
+        return self._cost
+
+    @property
+    def flags(self) -> np.ndarray:
+        self._load_arrays()
+        return self._flags
+
+    def fetch_candidate(self, index) -> dict:
+        self._check()
+        return self.engine.candidate(int(index), self.agent)
 
     @property
     def boundary_steps(self) -> np.ndarray:
@@ -261,7 +296,7 @@ class PlanStepResult:
     # ---- views the planner needs ----
     @property
     def n_candidates(self) -> int:
-        return len(self.cost)
+        return int(self.result["n_candidates"])
 
     def mask(self, bit) -> np.ndarray:
         return (self.flags & bit) != 0

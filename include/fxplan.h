@@ -264,6 +264,12 @@ int32_t fx_read_costmap_agent(FxContext *ctx, int32_t agent, double *raw);
 int32_t fx_read_coeffs_agent(FxContext *ctx, int32_t agent, int64_t index, double *lon6, double *lat6, int32_t *traj_len);
 int32_t fx_read_sample_agent(FxContext *ctx, int32_t agent, int64_t index, double *planes);
 int32_t fx_read_plane_agent(FxContext *ctx, int32_t agent, int32_t plane, double *out);
+/* Everything a trajectory object of ONE candidate exposes (frenetix TrajectorySample: cartesian / curvilinear arrays,
+ * coefficients, costMap, cost, feasibility -- reactive_planner_cpp.py:355-357,456,470-482) in one call with one stream
+ * synchronisation: planes [FX_NUM_PLANES][S], coeffs12 = lon[6] | lat[6], traj_len, raw partial costs [n_cost], total
+ * cost and flag word.  Any output pointer may be NULL.  What the planner reads back for the chosen trajectory. */
+int32_t fx_read_candidate_agent(FxContext *ctx, int32_t agent, int64_t index, double *planes, double *coeffs12,
+                                int32_t *traj_len, double *raw_costs, double *cost, uint32_t *flags);
 int32_t fx_read_topk_batch(FxContext *ctx, int32_t k, double *cost /*[n_agents][k]*/, int64_t *index /*[n_agents][k]*/);
 
 /* ---- road boundary (replaces create_road_boundary_obstacle + trajectories_collision_static_obstacles,

@@ -9,6 +9,10 @@ export TMPDIR=/tmp
 python3 bench.py --steps 300 --warmup 30 > $O/bench_config2_modeB.json 2> $O/bench_config2_modeB.err
 python3 bench.py --steps 300 --warmup 30 --select-only --no-cpu-baseline > $O/bench_config2_modeA.json 2>/dev/null
 python3 bench.py --steps 200 --warmup 20 --workload config3 > $O/bench_config3.json 2>/dev/null
+python3 bench.py --steps 30 --warmup 3 --workload config5 > $O/bench_config5.json 2>/dev/null
+python3 bench.py --steps 60 --warmup 6 --workload config4 > $O/bench_config4.json 2>/dev/null
+python3 tools/e2e_step.py > $O/e2e_step.json 2>/dev/null
+python3 tools/obst_split.py > $O/obst_split.txt 2>/dev/null
 BENCH="python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH > $O/stats.log 2>&1)
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" \

@@ -82,6 +82,66 @@ __global__ void k_planes_split(double* __restrict__ out, long ld, int S, long C)
         v += 1.0;
     }
 }
+// tile layout: out[tile][step][plane][64]: every wave streams one contiguous 14*S*512 B region
+__global__ void k_tile(double* __restrict__ out, int S, long C) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= C) return;
+    const long tile = g >> 6; const int lane = (int)(g & 63);
+    double v = (double)g;
+    double* base = out + tile * (long)S * 14 * 64 + lane;
+    for (int i = 0; i < S; i++) {
+        double* row = base + (long)i * 14 * 64;
+#pragma unroll
+        for (int p = 0; p < 14; p++) row[p * 64] = v + p;
+        v += 1.0;
+    }
+}
+// tile layout, plane-major inside the tile: out[tile][plane][step][64]
+__global__ void k_tile_pm(double* __restrict__ out, int S, long C) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= C) return;
+    const long tile = g >> 6; const int lane = (int)(g & 63);
+    double v = (double)g;
+    double* base = out + tile * (long)S * 14 * 64 + lane;
+    for (int i = 0; i < S; i++) {
+        double* row = base + (long)i * 64;
+#pragma unroll
+        for (int p = 0; p < 14; p++) row[(long)p * S * 64] = v + p;
+        v += 1.0;
+    }
+}
+// tile layout with the horizon split over 2 waves of a workgroup (wave w of a pair walks steps [w*CH, (w+1)*CH))
+__global__ void k_tile_ws2(double* __restrict__ out, int S, long C) {
+    const int CPB = blockDim.x / 2;
+    const int part = threadIdx.x / CPB, cl = threadIdx.x - part * CPB;
+    long g = (long)blockIdx.x * CPB + cl;
+    if (g >= C) return;
+    const long tile = g >> 6; const int lane = (int)(g & 63);
+    const int CH = (S + 1) / 2, i0 = part * CH, i1 = min(S, i0 + CH);
+    double v = (double)g;
+    double* base = out + tile * (long)S * 14 * 64 + lane;
+    for (int i = i0; i < i1; i++) {
+        double* row = base + (long)i * 14 * 64;
+#pragma unroll
+        for (int p = 0; p < 14; p++) row[p * 64] = v + p;
+        v += 1.0;
+    }
+}
+__global__ void k_planes_ws2(double* __restrict__ out, long ld, int S, long C) {
+    const int CPB = blockDim.x / 2;
+    const int part = threadIdx.x / CPB, cl = threadIdx.x - part * CPB;
+    long g = (long)blockIdx.x * CPB + cl;
+    if (g >= C) return;
+    const int CH = (S + 1) / 2, i0 = part * CH, i1 = min(S, i0 + CH);
+    double v = (double)g;
+    for (int i = i0; i < i1; i++) {
+        double* row = out + (long)i * ld + g;
+        long ps = (long)S * ld;
+#pragma unroll
+        for (int p = 0; p < 14; p++) row[p * ps] = v + p;
+        v += 1.0;
+    }
+}
 // streaming: each lane writes 16 B, consecutive, grid-stride
 __global__ void k_stream16(double2* __restrict__ out, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,6 +165,11 @@ int main() {
         printf("%-28s best %.1f us  avg %.1f us  -> %.2f TB/s (best)\n", name, best * 1e3, sum / 20 * 1e3, n * 8 / (best * 1e-3) / 1e12);
     };
     timeit("plane pattern (256 thr)", [&] { hipLaunchKernelGGL(k_planes, dim3((C + 255) / 256), dim3(256), 0, 0, d, ld, S, C); });
+    timeit("tile [t][i][p][64] (256 thr)", [&] { hipLaunchKernelGGL(k_tile, dim3((C + 255) / 256), dim3(256), 0, 0, d, S, C); });
+    timeit("tile [t][i][p][64] (64 thr)", [&] { hipLaunchKernelGGL(k_tile, dim3((C + 63) / 64), dim3(64), 0, 0, d, S, C); });
+    timeit("tile [t][p][i][64] (256 thr)", [&] { hipLaunchKernelGGL(k_tile_pm, dim3((C + 255) / 256), dim3(256), 0, 0, d, S, C); });
+    timeit("tile wave-split 2 (256 thr)", [&] { hipLaunchKernelGGL(k_tile_ws2, dim3((C + 127) / 128), dim3(256), 0, 0, d, S, C); });
+    timeit("planes wave-split 2 (256 thr)", [&] { hipLaunchKernelGGL(k_planes_ws2, dim3((C + 127) / 128), dim3(256), 0, 0, d, ld, S, C); });
     timeit("plane pattern (64 thr)", [&] { hipLaunchKernelGGL(k_planes, dim3((C + 63) / 64), dim3(64), 0, 0, d, ld, S, C); });
     timeit("plane pattern NT (256 thr)", [&] { hipLaunchKernelGGL(k_planes_nt, dim3((C + 255) / 256), dim3(256), 0, 0, d, ld, S, C); });
     timeit("work=20 c+s plain", [&] { hipLaunchKernelGGL(k_planes_work2<false>, dim3((C + 255) / 256), dim3(256), 0, 0, d, ld, S, C, 20, 1.0); });
