@@ -108,7 +108,8 @@ class AgentBatchHip:
         (None: no trajectory found)}."""
         planning, passive = [], []
         for a in self.agents:
-            a.update_planner(None, predictions.get(a.id, {}))
+            if a.id in predictions or a.needs_plan():
+                a.update_planner(None, predictions.get(a.id, {}))
             inp = a.begin_step()
             (planning if inp is not None else passive).append((a, inp))
         out: Dict[int, Optional[list]] = {}
@@ -238,7 +239,8 @@ class MultiAgentSimulation:
 
     def step(self) -> Dict[int, Optional[list]]:
         """One simulation step of every agent (simulation.py:621-663 + agent_batch.py:140-189)."""
-        preds = {a.id: self.predictions_for(a.id) for a in self.batch.agents}
+        # predictions are only read by agents that replan in this step (two of three steps just advance, :261-277)
+        preds = {a.id: self.predictions_for(a.id) for a in self.batch.agents if a.needs_plan()}
         selected = self.batch.step(self.time_step, preds)
         local = np.zeros((len(self.batch.agents), self.S, self.FIELDS))
         for j, a in enumerate(self.batch.agents):
