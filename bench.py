@@ -66,10 +66,28 @@ def make_workload(args, world):
 
 
 def _host_threads():
+    """Host threads this process can really run at once: the affinity mask capped by the cgroup CPU quota (the GPU box
+    shows 256 CPUs but grants 16 cores' worth of time)."""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        return max(1, os.cpu_count() or 1)
+        n = max(1, os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
 
 
 def _time_oracle(inp, seconds, n_threads):
@@ -108,7 +126,9 @@ def cpu_baseline_of(inp, what):
     if threads > 1:
         many, repsN, dtN = _time_oracle(inp, 8.0, threads)
         out.update({"value": many, "cores": threads, "single_thread_value": one,
-                    "sample": f"{repsN} whole plan steps of {what} in {dtN:.1f} s on {threads} threads "
+                    "cpu_quota_cores": threads,
+                    "sample": f"{repsN} whole plan steps of {what} in {dtN:.1f} s on {threads} threads (= the cores this "
+                              f"process is granted) "
                               f"(oracle/fx_oracle.c, candidate chunks over pthreads); single thread: {reps1} steps in {dt1:.1f} s"})
     return out
 
