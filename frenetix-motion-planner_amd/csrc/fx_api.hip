@@ -54,6 +54,9 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
+// bundles up to this size use write-through plane stores.  tools/store_sweep.py on MI355X: write-through is faster up to
+// ~0.5 GB (41 vs 45 us at 175 MB) and equal beyond (740 vs 746 us at 3.5 GB), so there is no upper limit by default.
+#define FX_STORE_WT_MAX_BYTES (~(size_t)0)
 #define FX_PUB_MAX 16384  // doubles: 8 ranks x 64 survivors x 2 x 16 agents
 
 struct FxAgentSlot {
@@ -130,6 +133,7 @@ struct FxContext {
     int variant_force = 0;                 // 0 auto, 1 generic kernel, 2 grid kernel
     int block_force = 0;                   // grid-kernel workgroup size override (0 auto)
     int wsplit_force = 0;                  // 0 auto, 1 lane split, 2 wave split
+    int store_force = 0;                   // 0 auto, 1 write-back, 2 write-through plane stores
     bool wsplit_step = false;
     int block_step = FX_BLOCK;
     bool use_grid = false;                 // current step runs fx_eval_grid_kernel
@@ -404,6 +408,13 @@ int32_t fx_set_winner_buffer(FxContext *c, void *d_winner) {
     return FX_OK;
 }
 
+int32_t fx_set_store_mode(FxContext *c, int32_t store_mode) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (store_mode < 0 || store_mode > 2) return set_err(FX_ERR_INVALID_ARGUMENT, "store mode must be 0 (auto), 1 (write-back) or 2 (write-through)");
+    c->store_force = store_mode;
+    return FX_OK;
+}
+
 int32_t fx_set_part_mapping(FxContext *c, int32_t mapping) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     if (mapping < 0 || mapping > 2) return set_err(FX_ERR_INVALID_ARGUMENT, "mapping must be 0 (auto), 1 (lane split) or 2 (wave split)");
@@ -501,7 +512,11 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         // trade at scale, four spill inside the obstacle loop (tools/obst_sweep.py)
         bool obst_any = false;
         for (int a = 0; a < n_agents; a++) obst_any |= probs[a].K > 0;
-        c->wpe_step = c->wpe_force ? c->wpe_force : (waves1 >= 3072 ? (obst_any ? 3 : 4) : 2);
+        // a materialised bundle makes the walk store-bound: more resident waves only add spills (1 M candidates, Mode B:
+        // 651 us at 2 waves per SIMD, 697 us at 4 -- tools/sweep_1m_modeB.py)
+        bool bundle_any = false;
+        for (int a = 0; a < n_agents; a++) bundle_any |= (probs[a].mode & FX_MODE_WRITE_BUNDLE) != 0;
+        c->wpe_step = c->wpe_force ? c->wpe_force : (waves1 >= 3072 ? (bundle_any ? 2 : (obst_any ? 3 : 4)) : 2);
         // grid kernel: sampling ranges, no windowed costs, and the longitudinal rows of a workgroup fit in LDS.
         // Workgroup size: the smallest of 64/128/256 lanes whose LDS footprint still lets a CU hold the target
         // number of waves (small workgroups balance small grids at wave granularity).
@@ -710,6 +725,12 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     if (planes_need) {
         int rc = ensure_planes(c, planes_need);
         if (rc) return rc;
+        // plane stores: write-through while the step's whole bundle is small (FX_STORE_WT_MAX_BYTES, measured), else write-back
+        const bool wt = c->store_force == 2 || (c->store_force == 0 && planes_need <= FX_STORE_WT_MAX_BYTES);
+        for (int a = 0; a < n_agents; a++) {
+            c->h_probs[a].mode &= ~FX_MODE_INT_STORE_WT;
+            if (wt) c->h_probs[a].mode |= FX_MODE_INT_STORE_WT;
+        }
         for (int a = 0; a < n_agents; a++)
             if (c->h_probs[a].mode & FX_MODE_WRITE_BUNDLE)
                 c->h_probs[a].planes = reinterpret_cast<double *>(reinterpret_cast<char *>(c->d_planes) +

@@ -9,6 +9,7 @@
 #include "../../include/fxplan.h"
 
 #define FX_BLOCK 256            // candidates per workgroup (4 wave64)
+#define FX_MODE_INT_STORE_WT (1u << 30)  // internal DevProblem.mode bit: write-through plane stores (fx_set_store_mode)
 #define FX_HOT_STRIDE 10        // doubles per (step, obstacle) entry of the hot obstacle table (80 B)
 #ifndef FX_HOT_LDS
 #define FX_HOT_LDS 1            // 1: stage the hot table per wave in LDS (broadcast reads); 0: scalar loads, one entry ahead

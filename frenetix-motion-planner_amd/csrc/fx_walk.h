@@ -17,6 +17,14 @@
 #include "fx_device.h"
 #include "fx_math.h"
 
+// Plane stores of the bundle: plain write-back stores, or agent-scope (write-through) stores that leave nothing dirty in
+// the XCD's L2 for the end-of-kernel write-back (StepConst::store_wt, chosen by the host from the bundle size)
+#define FX_PLANE_STORE(ptr, val)                                                                        \
+    do {                                                                                                \
+        if (K.store_wt) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   \
+        else *(ptr) = (val);                                                                            \
+    } while (0)
+
 namespace fxk {
 
 struct alignas(16) LonRow {  // longitudinal quantities of one (pair, step); 128 B
@@ -198,6 +206,7 @@ struct StepConst {  // wave-uniform constants of the walk
     double dt, r_dt, kappa_max, a_max, v_switch, av_switch, v_des, wb, half_len, half_wid;
     int S, half, K;
     bool low_vel, dbg, do_collision;
+    bool store_wt;          // write-through plane stores
     int n_bound;            // road-boundary pieces (0: stage off)
     double bound_d_reach;   // |d| beyond this counts as off the road
 };
@@ -352,20 +361,20 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
 
     // -- SoA bundle (trajectories.py:56-334) --
     if (store) {
-        planes_i[FX_PL_X * ps] = x_i;
-        planes_i[FX_PL_Y * ps] = y_i;
-        planes_i[FX_PL_THETA * ps] = th_gl;
-        planes_i[FX_PL_V * ps] = v_i;
-        planes_i[FX_PL_A * ps] = a_i;
-        planes_i[FX_PL_KAPPA * ps] = kap;
-        planes_i[FX_PL_KAPPA_DOT * ps] = kap_dot;
-        planes_i[FX_PL_S * ps] = s_i;
-        planes_i[FX_PL_D * ps] = d_i;
-        planes_i[FX_PL_THETA_CL * ps] = th_cl;
-        planes_i[FX_PL_S_DOT * ps] = sv_i;
-        planes_i[FX_PL_S_DDOT * ps] = sa_i;
-        planes_i[FX_PL_D_DOT * ps] = dv_i;
-        planes_i[FX_PL_D_DDOT * ps] = da_i;
+        FX_PLANE_STORE(planes_i + FX_PL_X * ps, x_i);
+        FX_PLANE_STORE(planes_i + FX_PL_Y * ps, y_i);
+        FX_PLANE_STORE(planes_i + FX_PL_THETA * ps, th_gl);
+        FX_PLANE_STORE(planes_i + FX_PL_V * ps, v_i);
+        FX_PLANE_STORE(planes_i + FX_PL_A * ps, a_i);
+        FX_PLANE_STORE(planes_i + FX_PL_KAPPA * ps, kap);
+        FX_PLANE_STORE(planes_i + FX_PL_KAPPA_DOT * ps, kap_dot);
+        FX_PLANE_STORE(planes_i + FX_PL_S * ps, s_i);
+        FX_PLANE_STORE(planes_i + FX_PL_D * ps, d_i);
+        FX_PLANE_STORE(planes_i + FX_PL_THETA_CL * ps, th_cl);
+        FX_PLANE_STORE(planes_i + FX_PL_S_DOT * ps, sv_i);
+        FX_PLANE_STORE(planes_i + FX_PL_S_DDOT * ps, sa_i);
+        FX_PLANE_STORE(planes_i + FX_PL_D_DOT * ps, dv_i);
+        FX_PLANE_STORE(planes_i + FX_PL_D_DDOT * ps, da_i);
     }
 
     // -- partial costs, streamed --

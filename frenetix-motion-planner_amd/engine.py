@@ -107,6 +107,10 @@ class FrenetEngine:
         check(lib().fx_set_block_size(self._ctx, int(block_size)))
         check(lib().fx_set_part_mapping(self._ctx, int(mapping)))
 
+    def set_store_mode(self, mode: int = 0):
+        """Plane stores of the bundle: 0 auto, 1 write-back, 2 write-through (agent scope); results are unaffected."""
+        check(lib().fx_set_store_mode(self._ctx, int(mode)))
+
     def set_winner_buffer(self, d_ptr: int):
         """Device buffer [n_agents][2] (cost f64, global index i64) every step's winner is also written to."""
         check(lib().fx_set_winner_buffer(self._ctx, C.c_void_p(d_ptr)))

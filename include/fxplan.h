@@ -214,6 +214,10 @@ int32_t fx_wait_published(FxContext *ctx, double *out);
 int32_t fx_set_part_mapping(FxContext *ctx, int32_t mapping);
 /* workgroup size of the grid kernel: 0 (auto), 64, 128 or 256 lanes */
 int32_t fx_set_block_size(FxContext *ctx, int32_t block_size);
+/* how the bundle's plane stores leave the CU: 0 auto (by bundle size), 1 plain write-back stores, 2 write-through
+ * (agent-scope) stores -- nothing dirty is left in the L2s for the end-of-kernel write-back, which pays off while the
+ * whole bundle is small (measured on MI355X: 42 vs 45 us at 175 MB, 780 vs 650 us at 3.5 GB).  Results are unaffected. */
+int32_t fx_set_store_mode(FxContext *ctx, int32_t store_mode);
 
 /* ---- staging: copy the shared inputs of a plan step to the device (borrowed for the call).
  *      Replaces handler.generate_trajectories(matrix, low_vel_mode) + the functor registration

@@ -142,6 +142,20 @@ __global__ void k_planes_ws2(double* __restrict__ out, long ld, int S, long C) {
         v += 1.0;
     }
 }
+// plane pattern with write-through stores (agent / system scope): nothing dirty left in L2 at kernel end
+template <int SCOPE>
+__global__ void k_planes_wt(double* __restrict__ out, long ld, int S, long C) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= C) return;
+    double v = (double)g;
+    for (int i = 0; i < S; i++) {
+        double* row = out + (long)i * ld + g;
+        long ps = (long)S * ld;
+#pragma unroll
+        for (int p = 0; p < 14; p++) __hip_atomic_store(row + p * ps, v + p, __ATOMIC_RELAXED, SCOPE);
+        v += 1.0;
+    }
+}
 // streaming: each lane writes 16 B, consecutive, grid-stride
 __global__ void k_stream16(double2* __restrict__ out, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,6 +184,8 @@ int main() {
     timeit("tile [t][p][i][64] (256 thr)", [&] { hipLaunchKernelGGL(k_tile_pm, dim3((C + 255) / 256), dim3(256), 0, 0, d, S, C); });
     timeit("tile wave-split 2 (256 thr)", [&] { hipLaunchKernelGGL(k_tile_ws2, dim3((C + 127) / 128), dim3(256), 0, 0, d, S, C); });
     timeit("planes wave-split 2 (256 thr)", [&] { hipLaunchKernelGGL(k_planes_ws2, dim3((C + 127) / 128), dim3(256), 0, 0, d, ld, S, C); });
+    timeit("planes, agent-scope stores", [&] { hipLaunchKernelGGL(k_planes_wt<__HIP_MEMORY_SCOPE_AGENT>, dim3((C + 255) / 256), dim3(256), 0, 0, d, ld, S, C); });
+    timeit("planes, system-scope stores", [&] { hipLaunchKernelGGL(k_planes_wt<__HIP_MEMORY_SCOPE_SYSTEM>, dim3((C + 255) / 256), dim3(256), 0, 0, d, ld, S, C); });
     timeit("plane pattern (64 thr)", [&] { hipLaunchKernelGGL(k_planes, dim3((C + 63) / 64), dim3(64), 0, 0, d, ld, S, C); });
     timeit("plane pattern NT (256 thr)", [&] { hipLaunchKernelGGL(k_planes_nt, dim3((C + 255) / 256), dim3(256), 0, 0, d, ld, S, C); });
     timeit("work=20 c+s plain", [&] { hipLaunchKernelGGL(k_planes_work2<false>, dim3((C + 255) / 256), dim3(256), 0, 0, d, ld, S, C, 20, 1.0); });
