@@ -442,6 +442,11 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     FX_STAMP(12);
     FX_STAMP(15);
     if (ticket != (unsigned long long)(P.n_blocks - 1)) return;
+    unsigned long long *out = fuse.host_result + (size_t)blockIdx.y * (FX_CNT_COUNT + 1);
+    // counters: read and zero in one agent-scope exchange (the next step starts from a clean block); issued first so
+    // that its round trip overlaps the loads of the partials
+    unsigned long long cnt = 0ULL;
+    if (lane < FX_CNT_BEST_IDX) cnt = atomicExch(&P.counters[lane], 0ULL);
     bc = INFINITY;
     bi = 0x7fffffffffffffffLL;
     for (int b = lane; b < P.n_blocks; b += 64) {
@@ -455,9 +460,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
         const long long oi = __shfl_xor(bi, off);
         if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
     }
-    unsigned long long *out = fuse.host_result + (size_t)blockIdx.y * (FX_CNT_COUNT + 1);
-    // counters: read and zero in one agent-scope exchange (the next step starts from a clean block)
-    if (lane < FX_CNT_BEST_IDX) out[lane] = atomicExch(&P.counters[lane], 0ULL);
+    if (lane < FX_CNT_BEST_IDX) out[lane] = cnt;
     if (lane == 0) {
         const bool none = bi == 0x7fffffffffffffffLL;
         if (fuse.dev_winner) {
@@ -469,8 +472,9 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
         out[FX_CNT_COLLISIONS] = 0ULL;
         __hip_atomic_store(&P.counters[FX_DCNT_TICKET], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // every lane's result words are out (vmcnt 0 is per wave) before lane 0 releases the sequence word
-    __threadfence_system();
+    // every lane's result words have been acknowledged (the counter is per wave) before lane 0 releases the sequence
+    // word; the release store itself orders lane 0's own stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(&out[FX_CNT_COUNT], fuse.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
