@@ -144,12 +144,12 @@ def cpu_baseline(args):
 
 def pmc_traffic(args, world):
     """HBM bytes per launch of the evaluation kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r1/final_config2_modeB_rocprof_summary.json; tools/collect_profiles.sh): WRITE_SIZE [KiB] x 1024 +
+    (profiles/r1/s2_config2_modeB_rocprof_summary.json; tools/collect_profiles.sh): WRITE_SIZE [KiB] x 1024 +
     FETCH_SIZE [KiB] x 1024 x 2 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half of the bytes read).  PMC
     counters cannot be collected from inside the timed run, so other workloads report null."""
     if args.workload != "config2" or args.select_only or world != 1:
         return None, None
-    path = os.path.join(ROOT, "profiles", "r1", "final_config2_modeB_rocprof_summary.json")
+    path = os.path.join(ROOT, "profiles", "r1", "s2_config2_modeB_rocprof_summary.json")
     try:
         pmc = json.load(open(path))["pmc_per_launch_mean"]
         return pmc["WRITE_SIZE"] * 1024.0 + 2.0 * pmc["FETCH_SIZE"] * 1024.0, os.path.relpath(path, ROOT)
