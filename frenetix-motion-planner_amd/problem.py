@@ -53,6 +53,38 @@ def _ptr(a, typ=C.c_double):
     return a.ctypes.data_as(C.POINTER(typ)) if a is not None and a.size else C.POINTER(typ)()
 
 
+_TPOW_CACHE: Dict[tuple, tuple] = {}
+
+
+def _tpow_cached(dt: float, S: int):
+    """(table, pointer, Simpson correction) of a (dt, S) pair -- the same for every plan step of a planner"""
+    key = (float(dt), int(S))
+    c = _TPOW_CACHE.get(key)
+    if c is None:
+        t = _f64(time_power_table(dt, S))
+        c = _TPOW_CACHE[key] = (t, _ptr(t), (C.c_double * 3)(*simpson_even_correction(dt)))
+    return c
+
+
+def _ref_cached(cs: CoordinateSystem):
+    """kernel-side arrays of a coordinate system and their pointers, built once per reference path"""
+    c = getattr(cs, "_fx_kernel_arrays", None)
+    if c is None:
+        arr = {k: _f64(v) for k, v in dict(
+            x=cs.reference[:, 0], y=cs.reference[:, 1], nx=cs.normals[:, 0], ny=cs.normals[:, 1], pos=cs.ref_pos,
+            theta=cs.ref_theta, curv=cs.ref_curv, curv_d=cs.ref_curv_d).items()}
+        c = cs._fx_kernel_arrays = (arr, {k: _ptr(v) for k, v in arr.items()})
+    return c
+
+
+def _dict_ptrs(d: dict, spec):
+    """pointers into the arrays of a packed dict (predictions, road boundary), cached inside the dict"""
+    c = d.get("_ptrs")
+    if c is None:
+        c = d["_ptrs"] = {k: _ptr(d[k], t) for k, t in spec}
+    return c
+
+
 def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
     """predictions dict {id: {'pos_list' [P,2], 'cov_list' [P,2,2], 'orientation_list' [P],
     'shape': {'length','width'}}} (prediction_helpers.py:209-261) -> packed arrays.
@@ -160,11 +192,9 @@ class PlanInputs:
         self.x0_lon = _f64(self.x0_lon)
         self.x0_lat = _f64(self.x0_lat)
         S = self.N + 1
-        self._tpow = _f64(time_power_table(self.dt, S))
+        self._tpow = _tpow_cached(self.dt, S)[0]
         cs = self.coordinate_system
-        self._ref = {k: _f64(v) for k, v in dict(
-            x=cs.reference[:, 0], y=cs.reference[:, 1], nx=cs.normals[:, 0], ny=cs.normals[:, 1], pos=cs.ref_pos,
-            theta=cs.ref_theta, curv=cs.ref_curv, curv_d=cs.ref_curv_d).items()}
+        self._ref = _ref_cached(cs)[0]
         if self.sampling_matrix is not None:
             self.sampling_matrix = _f64(self.sampling_matrix)
             if self.sampling_matrix.ndim != 2 or self.sampling_matrix.shape[1] != 13:
@@ -250,7 +280,8 @@ class PlanInputs:
         p.x0_lat = (C.c_double * 3)(*self.x0_lat)
         p.x0_orientation, p.v_des = float(self.x0_orientation), float(self.v_des)
         p.veh = self.vehicle.as_struct()
-        p.tpow = _ptr(self._tpow)
+        tp = _tpow_cached(self.dt, self.N + 1)
+        p.tpow = tp[1]
         if self.sampling_matrix is not None:
             p.sampling_matrix, p.n_rows = _ptr(self.sampling_matrix), self.sampling_matrix.shape[0]
             p.nT = p.nV = p.nD = 0
@@ -258,25 +289,25 @@ class PlanInputs:
             p.nT, p.nV, p.nD = len(self.t_samp), len(self.v_samp), len(self.d_samp)
             p.t_samp, p.v_samp, p.d_samp = _ptr(self.t_samp), _ptr(self.v_samp), _ptr(self.d_samp)
             p.n_rows = 0
-        r = self._ref
+        r, rp = _ref_cached(self.coordinate_system)
         p.M = len(r["pos"])
-        p.ref_x, p.ref_y, p.ref_nx, p.ref_ny = _ptr(r["x"]), _ptr(r["y"]), _ptr(r["nx"]), _ptr(r["ny"])
-        p.ref_pos, p.ref_theta, p.ref_curv, p.ref_curv_d = (_ptr(r["pos"]), _ptr(r["theta"]), _ptr(r["curv"]),
-                                                             _ptr(r["curv_d"]))
+        p.ref_x, p.ref_y, p.ref_nx, p.ref_ny = rp["x"], rp["y"], rp["nx"], rp["ny"]
+        p.ref_pos, p.ref_theta, p.ref_curv, p.ref_curv_d = rp["pos"], rp["theta"], rp["curv"], rp["curv_d"]
         p.n_cost = len(self._cost_id)
         p.cost_id, p.cost_w = _ptr(self._cost_id, C.c_int32), _ptr(self._cost_w)
-        p.simpson_corr = (C.c_double * 3)(*simpson_even_correction(self.dt))
+        p.simpson_corr = tp[2]
         o = self.obstacles
         p.K, p.P = int(o["K"]), int(o["P"])
-        p.obs_pos, p.obs_cov_inv, p.obs_npred = _ptr(o["pos"]), _ptr(o["cov_inv"]), _ptr(o["npred"], C.c_int32)
-        p.obs_hull, p.obs_nhull = _ptr(o["hull"]), _ptr(o["nhull"], C.c_int32)
+        op = _dict_ptrs(o, (("pos", C.c_double), ("cov_inv", C.c_double), ("npred", C.c_int32), ("hull", C.c_double),
+                            ("nhull", C.c_int32)))
+        p.obs_pos, p.obs_cov_inv, p.obs_npred, p.obs_hull, p.obs_nhull = op["pos"], op["cov_inv"], op["npred"], op["hull"], op["nhull"]
         p.n_dto, p.dto_pos = len(self._dto), _ptr(self._dto)
         if self._bound is not None and self._bound["n"] > 0:
             bd = self._bound
             if len(bd["bin"]) != p.M + 1:
                 raise ValueError("road boundary bins were built for a different reference path")
-            p.n_bound, p.bound_piece = bd["n"], _ptr(bd["piece"])
-            p.bound_bin, p.bound_item = _ptr(bd["bin"], C.c_int32), _ptr(bd["item"], C.c_int32)
+            bp = _dict_ptrs(bd, (("piece", C.c_double), ("bin", C.c_int32), ("item", C.c_int32)))
+            p.n_bound, p.bound_piece, p.bound_bin, p.bound_item = bd["n"], bp["piece"], bp["bin"], bp["item"]
             p.bound_d_reach = bd["d_reach"]
         else:
             p.n_bound = 0
