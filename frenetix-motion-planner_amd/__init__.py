@@ -15,7 +15,10 @@ from .problem import PlanInputs, VehicleParams, DEFAULT_COST_WEIGHTS, pack_predi
 def __getattr__(name):
     import importlib
     lazy = {"FrenetEngine": ".engine", "ReactivePlannerHip": ".reactive_planner",
-            "TrajectorySample": ".trajectories", "frenetix": ".frenetix_compat"}
+            "TrajectorySample": ".trajectories", "frenetix": ".frenetix_compat",
+            "FrenetPlannerInterfaceHip": ".frenet_interface", "AgentBatchHip": ".multiagent",
+            "MultiAgentSimulation": ".multiagent", "DataLoggingCosts": ".logging_formats", "SqlLogger": ".logging_formats",
+            "ShardedEvaluator": ".distributed"}
     if name in lazy:
         mod = importlib.import_module(lazy[name], __name__)
         return mod if name == "frenetix" else getattr(mod, name)
