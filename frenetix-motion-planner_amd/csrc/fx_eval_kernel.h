@@ -236,7 +236,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
                             const double r0 = fma(e1, iv[2], e0 * iv[0]), r1 = fma(e1, iv[3], e0 * iv[1]);
                             const double m = fma(r1, e1, r0 * e0);
                             const double mm = m * m;
-                            pred += mm > 0.0 ? rcp_nr(mm) : 1.0 / mm;
+                            pred += mm > 0.0 ? rcp_pred(mm) : 1.0 / mm;
                         }
             }
         }

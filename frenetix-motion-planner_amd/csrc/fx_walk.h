@@ -50,6 +50,14 @@ __device__ __forceinline__ double rcp_nr(double d) {
     return fma(r, e, r);
 }
 
+// 1/d of a prediction-cost term: hardware estimate (~28 bits) + ONE Newton step, <= 11 ulp (tools/micro/rcpacc.hip).
+// The term is one of K*S summands of a cost that is compared at 1e-9; every kernel variant uses this same function.
+__device__ __forceinline__ double rcp_pred(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+}
+
 // n / d with one residual correction on the quotient (correctly rounded for the operands of this kernel)
 __device__ __forceinline__ double fdiv(double n, double d) {
     const double r = rcp_nr(d);
@@ -436,7 +444,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                     const double r0 = fma(e1, e.c, e0 * e.a), r1 = fma(e1, e.d, e0 * e.b);
                     const double m = fma(r1, e1, r0 * e0);
                     const double mm = m * m;
-                    double t = rcp_nr(mm);
+                    double t = rcp_pred(mm);
                     if (__any(!(mm > 0.0))) t = mm > 0.0 ? t : 1.0 / mm;
                     A.pred += t;
                 }
@@ -464,7 +472,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                     const double m = fma(r1, e1, r0 * e0);
                     const double mm = m * m;
                     bad |= !(mm > 0.0);
-                    return rcp_nr(mm);
+                    return rcp_pred(mm);
                 };
                 auto is_near = [&](const Ent &e) {
                     const double tx = e.hx - hull.cx, ty = e.hy - hull.cy;
@@ -496,7 +504,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                         const double r0 = fma(e1, e.c, e0 * e.a), r1 = fma(e1, e.d, e0 * e.b);
                         const double m = fma(r1, e1, r0 * e0);
                         const double mm = m * m;
-                        A.pred += mm > 0.0 ? rcp_nr(mm) : 1.0 / mm;
+                        A.pred += mm > 0.0 ? rcp_pred(mm) : 1.0 / mm;
                     }
                 }
                 while (nm) {
@@ -537,7 +545,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
             const double r0 = fma(e1, q[4], e0 * q[2]), r1 = fma(e1, q[5], e0 * q[3]);
             const double m = fma(r1, e1, r0 * e0);
             const double mm = m * m;
-            A.pred += mm > 0.0 ? rcp_nr(mm) : 1.0 / mm;
+            A.pred += mm > 0.0 ? rcp_pred(mm) : 1.0 / mm;
         }
         if (K.do_collision) {
             // ego box: centre = rear axle + wb_rear_axle along heading (state.py:30-39), heading theta_gl; it is needed
