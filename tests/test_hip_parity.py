@@ -540,3 +540,47 @@ def test_north_star_target_one_million_candidates():
     assert (np.abs(cost[c] - c_ref[c]) / np.maximum(np.abs(c_ref[c]), 1e-12)).max() < COST_RTOL
     assert res["best_index"] == best and res["best_cost"] == pytest.approx(best_cost, rel=1e-9)
     assert ((f_ref & _abi.FX_FLAG_COLLISION) != 0)[sel].mean() > 0.25
+
+
+def _random_case(rng):
+    kind = ["straight", "arc", "scurve"][int(rng.integers(3))]
+    horizon = [2.0, 3.0, 5.0][int(rng.integers(3))]
+    kw = dict(ref_kind=kind, kappa=float(rng.uniform(0.002, 0.03)) * (1 if rng.uniform() < 0.5 else -1) if kind != "scurve"
+              else float(rng.uniform(0.005, 0.02)),
+              n_knots=int(rng.integers(250, 600)), spacing=float(rng.uniform(0.4, 1.0)),
+              v0=float([0.0, 0.5, 1.5, 4.0, 10.0, 22.0][int(rng.integers(6))]), a0=float(rng.uniform(-2, 2)),
+              d0=float(np.round(rng.uniform(-1.5, 1.5), 2)), dd0=float(rng.uniform(-0.3, 0.3)), ddd0=float(rng.uniform(-0.3, 0.3)),
+              horizon=horizon, v_des=float(rng.uniform(0, 20)), n_obstacles=int(rng.integers(0, 9)), n_pred=int(horizon / 0.1),
+              draw_traj_set=bool(rng.integers(2)), kinematic_debug=bool(rng.integers(2)), seed=int(rng.integers(1 << 30)),
+              lead_gap=float(rng.uniform(10, 40)) if rng.uniform() < 0.3 else 0.0)
+    if rng.uniform() < 0.5:
+        kw["level"] = int(rng.integers(0, 3))
+    else:
+        kw["grid"] = (int(rng.integers(1, 8)), int(rng.integers(1, 12)), int(rng.integers(1, 12)))
+    if rng.uniform() < 0.15 and kw["v0"] > 1.0:
+        kw["stop_point_s"] = float(rng.uniform(5, 40))
+    if rng.uniform() < 0.2:
+        kw["road_half_width"] = float(rng.uniform(2.5, 5.0))
+    return kw
+
+
+@pytest.mark.parametrize("case", range(32))
+def test_random_scenarios_vs_oracle(case):
+    """Seeded random scenarios (reference shape and curvature sign, standstill ... 22 m/s, horizons 2 / 3 / 5 s, sampling levels
+    and dense grids down to a single candidate, 0-8 obstacles, debug flag sets, stop-point sampling, road boundary): every
+    candidate of each against the oracle, under the automatic work decomposition."""
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    from oracle import oracle
+    rng = np.random.default_rng([20241008, case])
+    kw = _random_case(rng)
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
+    with FrenetEngine(max_candidates=max(inp.n_candidates, 64), max_steps=inp.N, max_pred_steps=max(64, inp.N + 2)) as e:
+        res = e.plan_step(inp)
+        compare(e, inp, out, res)
+        if np.all(out["margin"] >= FRAGILE):
+            assert res["best_index"] == out["result"]["best_index"] and res["n_collisions"] == out["result"]["n_collisions"]
+        if "road_half_width" in kw:
+            bs = e.boundary_steps()
+            walked = out["selectable"] & (out["margin"] >= FRAGILE)
+            assert np.array_equal(bs[walked], out["boundary_step"][walked])
