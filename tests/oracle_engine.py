@@ -57,3 +57,8 @@ class OracleEngine:
 
     def sample(self, index, agent=0):
         return self.last[agent][1]["planes"][index].copy()
+
+    def plane(self, name_or_index, agent=0):
+        from frenetix_motion_planner_amd import _abi
+        p = _abi.PLANE_INDEX[name_or_index] if isinstance(name_or_index, str) else int(name_or_index)
+        return np.ascontiguousarray(self.last[agent][1]["planes"][:, p, :].T)

@@ -73,3 +73,36 @@ def test_plan_phases_equal_plan():
         outs.append((rp.optimal_trajectory.uniqueId, np.array(pair[2]), rp.infeasible_count_collision,
                      list(rp._infeasible_count_kinematics)))
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2:] == outs[1][2:]
+
+
+def test_planner_logging_hook(tmp_path):
+    """planner.py:637-649: plan() feeds the logger -- logs.csv gets one line per plan step, predictions.csv likewise,
+    trajectories.csv / trajectories.db every returned trajectory when save_all_traj is on."""
+    import sqlite3
+    from frenetix_motion_planner_amd.logging_formats import DataLoggingCosts
+    ref = synthetic.reference_polyline("arc", 400, 0.5, 0.01)
+    cs = synthetic.CoordinateSystem(ref)
+    s0 = float(cs.ref_pos[40]) + 0.1
+    x0 = ReactivePlannerState(time_step=7, position=cs.convert_to_cartesian_coords(s0, 0.2), orientation=float(cs.ref_theta[40]),
+                              velocity=9.0)
+    preds = synthetic.synthetic_predictions(cs, 3, 30, 0.1, s0, np.random.default_rng(5))
+    rp = ReactivePlannerHip(PlannerConfig(save_all_traj=True, sampling_min=1, sampling_max=2), VehicleParams(), engine=OracleEngine())
+    rp.logger = DataLoggingCosts(str(tmp_path), save_all_traj=True, cost_params=dict(rp.cost_weights))
+    rp.update_externals(reference_path=ref, x_0=x0, desired_velocity=11.0, predictions=preds)
+    assert rp.plan() is not None
+    n_all = len(rp.all_traj)
+    rp.logger.close()
+    logs = open(tmp_path / "logs.csv").read().splitlines()
+    assert len(logs) == 2 and logs[1].startswith("7;") and logs[1].split(";")[4] == "True"
+    assert len(logs[0].split(";")) == len(logs[1].split(";"))
+    traj = open(tmp_path / "trajectories.csv").read().splitlines()
+    assert len(traj) == 1 + n_all and traj[1].split(";")[0] == "7"
+    assert open(tmp_path / "predictions.csv").read().count("\n") == 1
+    con = sqlite3.connect(tmp_path / "trajectories.db")
+    assert con.execute("SELECT COUNT(*) FROM trajectories").fetchone()[0] == n_all
+    best = con.execute("SELECT id FROM costs ORDER BY costs_cumulative_weighted LIMIT 1").fetchone()[0]
+    feas_best = con.execute("SELECT c.id FROM costs c JOIN infeasability i ON i.id = c.id AND i.time_step = c.time_step "
+                            "WHERE i.feasible = 1 ORDER BY c.costs_cumulative_weighted LIMIT 1").fetchone()[0]
+    assert feas_best == rp.optimal_trajectory.uniqueId or rp.infeasible_count_collision > 0
+    assert best is not None
+    con.close()
