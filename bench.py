@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timing", choices=["stream", "kernel"], default="kernel",
                     help="HIP events around the evaluation kernel: attached to the kernel (hipExtLaunchKernel) or stream events")
-    ap.add_argument("--timing-every", type=int, default=8,
+    ap.add_argument("--timing-every", type=int, default=16,
                     help="attach the events to every n-th launch of the timed region (they are read after it)")
     args = ap.parse_args()
 
