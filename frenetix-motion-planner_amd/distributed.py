@@ -91,22 +91,31 @@ class ShardedEvaluator:
             res["global_best_index"], res["global_best_cost"] = res["best_index"], res["best_cost"]
             return res
         self.engine.evaluate()
-        gc, gi = self._exchange_on_device()
+        self._enqueue_exchange()
+        # the local result block is published by the evaluation kernel itself: unpack it while the all-gather runs
         res = self.engine.finish()[0]
+        gc, gi = self._collect_exchange()
         best_c, best_i, order = merge_survivors(gc, gi)
         res["global_best_cost"], res["global_best_index"], res["survivors"] = best_c, best_i, order
         return res
 
-    def _exchange_on_device(self):
-        """top-k straight into the torch buffer (torch's stream), ONE RCCL all-gather, one D2H of W*16*k bytes."""
+    def _enqueue_exchange(self):
+        """top-k straight into the torch buffer (torch's stream), ONE RCCL all-gather, publication of W*16*k bytes to
+        pinned host memory -- all enqueued behind the evaluation kernel, nothing waited for."""
         k = self.k
         if k > 1:
             self.engine.topk_to_device(k, self._surv.data_ptr(), self._surv.data_ptr() + 8 * k)
         self.dist.all_gather_into_tensor(self._gath, self._surv, group=self.group)
         # the engine copies the gathered block into pinned host memory on the same stream and the host polls for it
         self.engine.publish(self._gath.data_ptr(), self.world * 2 * k)
-        g = self.engine.wait_published().reshape(self.world, 2, k)
+
+    def _collect_exchange(self):
+        g = self.engine.wait_published().reshape(self.world, 2, self.k)
         return g[:, 0, :].copy(), g[:, 1, :].copy().view(np.int64)
+
+    def _exchange_on_device(self):
+        self._enqueue_exchange()
+        return self._collect_exchange()
 
     def plan_step(self, inputs) -> dict:
         """Evaluate this rank's shard, exchange survivors, return the global winner (same on all ranks)."""
