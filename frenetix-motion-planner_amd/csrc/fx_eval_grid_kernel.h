@@ -226,7 +226,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     for (int i = i_first; i < i_end; i++) {
         const bool emit = i >= i_begin;
         const LonRow r = my[i];
-        walk_step<OBST, (G == 1 || WSPLIT), HOT>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit,
+        walk_step<OBST, (G == 1 || WSPLIT), HOT, (WPE <= 2)>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit,
                                                  planes + (int64_t)i * ld + g, ps, Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv,
                                                  &Hs, i + 1 < i_end ? i + 1 : -1);
     }

@@ -281,7 +281,7 @@ struct ObsHot {
     }
 };
 
-template <bool OBST, bool USTEP, bool HOT = false, typename PlanePtr, typename ObsD, typename ObsM>
+template <bool OBST, bool USTEP, bool HOT = false, bool FX_OBS_UNROLL4 = false, typename PlanePtr, typename ObsD, typename ObsM>
 __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, const LatPoly &L, const double *tp, int i,
                                           int traj_len, double d_ext, bool emit, bool store, PlanePtr planes_i, int64_t ps,
                                           StepCarry &C, StepAcc &A, StepOut &O, ObsD obs_rec, ObsM obs_pmask, ObsM obs_hmask,
@@ -480,6 +480,25 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                     return !(fma(tx, tx, ty * ty) > rr * rr);
                 };
                 int k = 0;
+                if (FX_OBS_UNROLL4) {
+                    // four obstacles per iteration: all twenty LDS reads are issued before the first use and four
+                    // independent chains run interleaved -- what a wave needs when it is (almost) alone on its SIMD
+                    for (; k + 3 < nK; k += 4) {
+                        const Ent ea = fetch(k), eb = fetch(k + 1), ec = fetch(k + 2), ed = fetch(k + 3);
+                        const double ta = pred_term(ea), tb = pred_term(eb), tc = pred_term(ec), td = pred_term(ed);
+                        A.pred += ta;
+                        A.pred += tb;
+                        A.pred += tc;
+                        A.pred += td;
+                        if (coll) {
+                            const bool na = is_near(ea), nb = is_near(eb), nc = is_near(ec), nd = is_near(ed);
+                            nm |= (__any(na) ? 1ULL : 0ULL) << k;
+                            nm |= (__any(nb) ? 2ULL : 0ULL) << k;
+                            nm |= (__any(nc) ? 4ULL : 0ULL) << k;
+                            nm |= (__any(nd) ? 8ULL : 0ULL) << k;
+                        }
+                    }
+                }
                 for (; k + 1 < nK; k += 2) {
                     const Ent ea = fetch(k), eb = fetch(k + 1);
                     const double ta = pred_term(ea), tb = pred_term(eb);
