@@ -586,21 +586,24 @@ def test_random_scenarios_vs_oracle(case):
             assert np.array_equal(bs[walked], out["boundary_step"][walked])
 
 
+@pytest.mark.parametrize("horizon", [3.0, 10.0])
 @pytest.mark.parametrize("lanes,mapping", [(0, 0), (1, 0), (2, 0)])
-def test_maximum_obstacle_count_and_long_horizon(lanes, mapping):
+def test_maximum_obstacle_count_and_long_horizon(lanes, mapping, horizon):
     """The capacity edges of the obstacle stage: K = 64 obstacles (every bit of the per-step masks, bit 63 included) and a
     10 s horizon (N = 100 steps) -- against the oracle."""
     from frenetix_motion_planner_amd.engine import FrenetEngine
     from oracle import oracle
-    kw = dict(ref_kind="arc", kappa=0.008, n_knots=900, spacing=0.5, v0=3.0, horizon=10.0, grid=(9, 7, 9), n_obstacles=64,
-              n_pred=100, seed=11, obstacle_min_gap=45.0, v_des=4.0)
+    # 10 s: the rows of a workgroup do not fit LDS -> generic kernel; 3 s: grid kernel with the staged hot table (64 x 80 B per wave)
+    kw = dict(ref_kind="arc", kappa=0.008, n_knots=900, spacing=0.5, v0=3.0 if horizon > 5 else 9.0, horizon=horizon,
+              grid=(9, 7, 9) if horizon > 5 else (7, 9, 21), n_obstacles=64, n_pred=int(horizon * 10), seed=11,
+              obstacle_min_gap=45.0 if horizon > 5 else 14.0, v_des=4.0 if horizon > 5 else 10.0)
     inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
     out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
-    assert inp.obstacles["K"] == 64 and inp.N == 100
+    assert inp.obstacles["K"] == 64 and inp.N == int(horizon * 10)
     with FrenetEngine(max_candidates=4096, max_steps=100, max_ref_knots=1024, max_obstacles=64, max_pred_steps=128) as e:
         e.set_tuning(lanes, 0, 0, 0, mapping)
         res = e.plan_step(inp)
         compare(e, inp, out, res)
         if np.all(out["margin"] >= FRAGILE):
             assert res["best_index"] == out["result"]["best_index"] and res["n_collisions"] == out["result"]["n_collisions"]
-    assert out["collision"].sum() > 20 and out["result"]["n_collisions"] > 10 and out["result"]["best_index"] >= 0
+    assert out["collision"].sum() > 20 and out["result"]["n_feasible"] > 20
