@@ -40,18 +40,24 @@ extern "C" int fx_probe_read(unsigned long long *out, size_t n_words) {
 // counts the colliding candidates that the reference's cost-ordered walk would have visited before it
 // (planner.py:336-357 `_collision_counter`).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void fx_select_kernel(const DevProblem *__restrict__ probs, unsigned long long *host_result,
-                                                         unsigned long long seq, double *dev_winner) {
-    __shared__ double sc[16];
-    __shared__ long long si[16];
+// grid = (FX_SELECT_SLICES, n_agents): every workgroup reduces the (few hundred) partials to the winner on its own, counts
+// the colliding candidates ordered before the winner in its slice of the candidates (loads of four iterations in
+// flight), adds its count to the agent's device counter and takes a ticket; the workgroup that draws the last ticket
+// publishes the result block.  One workgroup scanning 50 000 candidates took ~30 us; the slices take ~5.
+#define FX_SELECT_SLICES 32
+__global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__restrict__ probs, unsigned long long *host_result,
+                                                        unsigned long long seq, double *dev_winner) {
+    __shared__ double sc[4];
+    __shared__ long long si[4];
     __shared__ unsigned int scnt;
-    const DevProblem &P = probs[blockIdx.x];
+    __shared__ unsigned long long s_ticket;
+    const DevProblem &P = probs[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double bc = INFINITY;
     long long bi = 0x7fffffffffffffffLL;
-    for (int b = tid; b < P.n_blocks; b += 1024) {
-        const double c = as_global(P.part_cost)[b];
-        const long long ix = as_global(P.part_idx)[b];
+    for (int b = tid; b < P.n_blocks; b += 256) {
+        const double c = __hip_atomic_load(as_global(P.part_cost) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long ix = __hip_atomic_load(as_global(P.part_idx) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c < bc || (c == bc && ix < bi)) { bc = c; bi = ix; }
     }
 #pragma unroll
@@ -64,38 +70,56 @@ __global__ __launch_bounds__(1024) void fx_select_kernel(const DevProblem *__res
     if (tid == 0) scnt = 0;
     __syncthreads();
     bc = sc[0]; bi = si[0];
-    for (int w = 1; w < 16; w++)
+    for (int w = 1; w < 4; w++)
         if (sc[w] < bc || (sc[w] == bc && si[w] < bi)) { bc = sc[w]; bi = si[w]; }
     const bool none = bi == 0x7fffffffffffffffLL;
     // colliding selectable candidates ordered before the winner (all of them when nothing is collision-free)
-    unsigned int cnt = 0;
     if (P.mode & FX_MODE_COLLISION) {
-        for (int64_t g = tid; g < P.C; g += 1024) {
-            const uint32_t f = as_global(P.flags)[g];
-            if ((f & FX_FLAG_SELECTABLE) && (f & FX_FLAG_COLLISION)) {
-                const double c = as_global(P.cost)[g];
-                if (none || c < bc || (c == bc && g + P.g_base < bi)) cnt++;
+        const int64_t per = (P.C + FX_SELECT_SLICES - 1) / FX_SELECT_SLICES;
+        const int64_t g0 = (int64_t)blockIdx.x * per, g1 = min(P.C, g0 + per);
+        const FX_GLOBAL uint32_t *__restrict__ fl = as_global(P.flags);
+        const FX_GLOBAL double *__restrict__ co = as_global(P.cost);
+        unsigned int cnt = 0;
+        for (int64_t g = g0 + tid; g < g1; g += 4 * 256) {
+            uint32_t f[4];
+            double c[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t gu = g + u * 256;
+                f[u] = gu < g1 ? fl[gu] : 0u;
+                c[u] = gu < g1 ? co[gu] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t gu = g + u * 256;
+                if ((f[u] & FX_FLAG_SELECTABLE) && (f[u] & FX_FLAG_COLLISION) && (none || c[u] < bc || (c[u] == bc && gu + P.g_base < bi))) cnt++;
             }
         }
         for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
         if (lane == 0 && cnt) atomicAdd(&scnt, cnt);
+        __syncthreads();
+        if (tid == 0 && scnt) atomicAdd(&P.counters[FX_CNT_COLLISIONS], (unsigned long long)scnt);
+    }
+    // the workgroup that draws the last ticket of this agent publishes
+    if (tid == 0) {
+        __threadfence();
+        s_ticket = atomicAdd(&P.counters[FX_DCNT_TICKET], 1ULL);
     }
     __syncthreads();
+    if (s_ticket != (unsigned long long)(FX_SELECT_SLICES - 1)) return;
     // Publish the step's result straight into pinned host memory (the host polls the sequence word instead of
     // paying for a D2H copy and a stream synchronisation) and leave the device counters zeroed for the next step.
-    unsigned long long *out = host_result + (size_t)blockIdx.x * (FX_CNT_COUNT + 1);
-    if (tid < FX_CNT_BEST_IDX) {
-        out[tid] = P.counters[tid];
-        P.counters[tid] = 0ULL;
-    }
+    unsigned long long *out = host_result + (size_t)blockIdx.y * (FX_CNT_COUNT + 1);
+    if (tid < FX_CNT_BEST_IDX) out[tid] = atomicExch(&P.counters[tid], 0ULL);
     if (tid == 0 && dev_winner) {  // (cost, index bits) of the winner, device-resident for the multi-GPU exchange
-        dev_winner[2 * blockIdx.x] = none ? INFINITY : bc;
-        reinterpret_cast<long long *>(dev_winner)[2 * blockIdx.x + 1] = none ? -1 : bi;
+        dev_winner[2 * blockIdx.y] = none ? INFINITY : bc;
+        reinterpret_cast<long long *>(dev_winner)[2 * blockIdx.y + 1] = none ? -1 : bi;
     }
     if (tid == 0) {
         out[FX_CNT_BEST_IDX] = none ? ~0ULL : (unsigned long long)bi;
         out[FX_CNT_BEST_COST] = none ? 0ULL : (unsigned long long)__double_as_longlong(bc);
-        out[FX_CNT_COLLISIONS] = scnt;
+        out[FX_CNT_COLLISIONS] = atomicExch(&P.counters[FX_CNT_COLLISIONS], 0ULL);
+        __hip_atomic_store(&P.counters[FX_DCNT_TICKET], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (tid == 0) {
@@ -315,7 +339,7 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
 
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
                                        unsigned long long seq, double *dev_winner, hipStream_t stream) {
-    hipLaunchKernelGGL(fx_select_kernel, dim3(n_agents), dim3(1024), 0, stream, d_probs, host_result, seq, dev_winner);
+    hipLaunchKernelGGL(fx_select_kernel, dim3(FX_SELECT_SLICES, n_agents), dim3(256), 0, stream, d_probs, host_result, seq, dev_winner);
     return hipGetLastError();
 }
 
