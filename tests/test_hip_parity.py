@@ -52,8 +52,17 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0):
     assert abs(res["n_feasible"] - ref["n_feasible"]) <= n_frag
     assert np.abs(np.array(res["reason_hist"]) - np.array(ref["reason_hist"])).max() <= n_frag
     assert res["n_candidates"] == ref["n_candidates"]
+    # A candidate whose theta_cl comes within 1e-3 of pi/2 (d' = d_dot / s_dot with s_dot ~ 1e-3, or a lateral polynomial over a
+    # few centimetres of arc length in LOW_VEL_MODE: 1 / cos > 1e3, "velocities" of 1e7 m/s, costs of 1e22) carries no digits in
+    # the reference either -- cos(atan(d')) and tan(atan(d')) lose them.  Such candidates are infeasible by orders of magnitude
+    # and only exist under the debug flag sets; their decisions (flags, reasons, counters) are compared, their numbers are not.
+    degenerate = np.zeros(len(flags), dtype=bool)
+    if out.get("planes") is not None:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sec = np.abs(1.0 / np.cos(out["planes"][:, 9, :]))
+        degenerate = ~(np.nan_to_num(sec, nan=np.inf).max(axis=1) <= 1e3)
     # costs
-    c = out["costed"] & robust & ((flags & _abi.FX_FLAG_COSTED) != 0)
+    c = out["costed"] & robust & ((flags & _abi.FX_FLAG_COSTED) != 0) & ~degenerate
     if c.any():
         rel = np.abs(cost[c] - out["cost"][c]) / np.maximum(np.abs(out["cost"][c]), 1e-12)
         assert rel.max() < COST_RTOL, f"cost rel err {rel.max()}"
@@ -78,6 +87,7 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0):
         refp = out["planes"]
         err = np.abs(got - refp) / (1.0 + np.abs(refp).max(axis=2, keepdims=True))
         err[~stored] = 0
+        err[degenerate] = 0
         assert err.max() < STATE_TOL, f"plane err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
         # coefficients / traj_len of a few candidates
         for g in np.linspace(0, inp.n_candidates - 1, 5).astype(int):

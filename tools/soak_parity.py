@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Parity soak on the GPU box: N seeded random scenarios (tests/test_hip_parity.py::_random_case) against the oracle.
+usage: python tools/soak_parity.py [first_case] [n_cases]"""
+import os, sys, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from frenetix_motion_planner_amd import synthetic
+from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+from oracle import oracle
+from tests.test_hip_parity import _random_case, compare, FRAGILE
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+bad = 0
+stats = dict(cands=0, winners=0, collided=0, fragile=0)
+for case in range(first, first + n):
+    rng = np.random.default_rng([20241008, case])
+    kw = _random_case(rng)
+    try:
+        inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
+        out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
+        with FrenetEngine(max_candidates=max(inp.n_candidates, 64), max_steps=inp.N, max_pred_steps=max(64, inp.N + 2)) as e:
+            res = e.plan_step(inp)
+            compare(e, inp, out, res)
+            robust = bool(np.all(out["margin"] >= FRAGILE))
+            if robust:
+                assert res["best_index"] == out["result"]["best_index"], (res["best_index"], out["result"]["best_index"])
+                assert res["n_collisions"] == out["result"]["n_collisions"]
+        stats["cands"] += inp.n_candidates
+        stats["winners"] += out["result"]["best_index"] >= 0
+        stats["collided"] += int(out["collision"].sum())
+        stats["fragile"] += int((out["margin"] < FRAGILE).sum())
+    except Exception as ex:
+        bad += 1
+        print("CASE", case, "FAILED:", repr(ex)[:300], kw, flush=True)
+print(f"soak: {n} cases from {first}: {bad} failures; {stats}", flush=True)
