@@ -20,7 +20,18 @@ for case in range(first, first + n):
         inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
         out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
         with FrenetEngine(max_candidates=max(inp.n_candidates, 64), max_steps=inp.N, max_pred_steps=max(64, inp.N + 2)) as e:
-            res = e.plan_step(inp)
+            if os.environ.get("FX_SOAK_TUNING"):  # also walk through the work decompositions / kernel variants
+                tn = (int(rng.choice([0, 1, 2, 4, 8])), int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 1, 2])),
+                      int(rng.choice([0, 64, 128, 256])), int(rng.choice([0, 1, 2])))
+                e.set_tuning(*tn)
+                e.set_store_mode(int(rng.integers(0, 3)))
+                try:
+                    res = e.plan_step(inp)
+                except ValueError:  # a forced variant that does not apply to this case
+                    e.set_tuning(0, 0, 0, 0, 0)
+                    res = e.plan_step(inp)
+            else:
+                res = e.plan_step(inp)
             compare(e, inp, out, res)
             robust = bool(np.all(out["margin"] >= FRAGILE))
             if robust:
