@@ -15,6 +15,7 @@ winner is in host memory when the step ends).  For N > 1 the global grid is N x 
 velocity range is sampled N times denser) and each rank evaluates a contiguous shard: weak scaling.
 
 Other workloads (parity-test configurations of BASELINE.json, measured on request -- the default line stays config 2):
+  --workload config1   the ego of ZAM_Tjunction-1_42_T-1, default sampling (630 candidates), 5 predicted obstacles;
   --workload config5   "synthetic stress": `--agents-per-gpu` (default 32 = 256 agents / 8 GPUs) agents per GPU x
                        39 x 51 x 52 = 103 428 candidates x 51 samples (5 s horizon), 20 predicted obstacles per agent,
                        select-only, one batched launch per step, per-agent top-32 survivors all-gathered (agent sharding:
@@ -172,7 +173,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["config2", "config3", "config4", "config5"], default="config2")
+    ap.add_argument("--workload", choices=["config1", "config2", "config3", "config4", "config5"], default="config2")
     ap.add_argument("--agents-per-gpu", type=int, default=32, help="config5: agents evaluated per GPU in one batched launch")
     ap.add_argument("--sampling-level", type=int, default=4, help="config4: sampling level of every agent (4 -> 11 220 candidates)")
     ap.add_argument("--select-only", action="store_true", help="Mode A: no SoA bundle write")
@@ -205,6 +206,8 @@ def main():
     from frenetix_motion_planner_amd.distributed import ShardedEvaluator
     from frenetix_motion_planner_amd.engine import FrenetEngine
 
+    if args.workload == "config1":
+        return bench_scenario_step(args, world, rank, local_rank, torch, dist)
     if args.workload == "config5":
         return bench_stress(args, world, rank, local_rank, torch, dist)
     if args.workload == "config4":
@@ -387,6 +390,64 @@ def bench_stress(args, world, rank, local_rank, torch, dist):
             out["cpu_baseline"] = cpu_baseline_of(one, f"agent 0 ({one.n_candidates} candidates x {S} samples, {K} obstacles)")
         print(json.dumps(out))
     eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_scenario_step(args, world, rank, local_rank, torch, dist):
+    """BASELINE config 1 on the engine: the ego of ZAM_Tjunction-1_42_T-1, default sampling (level 2: 630 candidates x 31
+    samples), the scenario's five cars as predicted obstacles, debug flag set of the reference's default configuration
+    (bundle materialised, every candidate evaluated), collision stage.  A step = one plan step with resident inputs."""
+    from frenetix_motion_planner_amd import commonroad_xml as crx
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    from frenetix_motion_planner_amd.frenet_interface import FrenetPlannerInterfaceHip
+    sc = crx.read_scenario_json(os.path.join(ROOT, "tests", "golden", "ZAM_Tjunction-1_42_T-1.scenario.json"))
+    itf = FrenetPlannerInterfaceHip(60000, sc, sc.planning_problems[60000], device=local_rank)
+    itf.update_planner(None, sc.ground_truth_predictions(0, 30))
+    inp = itf.begin_step()
+    eng = FrenetEngine(max_candidates=4096, max_steps=inp.N, max_ref_knots=4096, max_obstacles=32, max_pred_steps=64, device=local_rank)
+    eng.set_timing(args.timing, every=args.timing_every)
+    eng.upload(inp)
+    last = {}
+
+    def step():
+        eng.evaluate()
+        last["res"] = eng.finish()[0]
+
+    elapsed, lat = _timed(args, world, dist, torch, step)
+    n_timed = min(256, (args.steps + args.timing_every - 1) // args.timing_every)
+    evalk, kern = eng.kernel_times(n_timed)
+    if rank == 0:
+        C, S = inp.n_candidates, inp.n_samples
+        eval_ms = float(np.mean(evalk))
+        alg = bundle_bytes_per_candidate(S) * C
+        out = {
+            "metric": "candidate trajectories/sec (30-step horizon)", "value": C * args.steps / elapsed, "unit": "trajectories/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "ZAM_Tjunction-1_42_T-1 (scenario fixture): ego planning problem, ground-truth predictions of the five cars",
+            "config": {"workload": f"BASELINE config1: ZAM_Tjunction-1_42_T-1 single agent, default sampling level 2 ({C} candidates x {S} "
+                                   "samples), 5 predicted obstacles, draw_traj_set / kinematic_debug as in debug.yaml, bundle materialised",
+                       "candidates": C, "samples": S, "obstacles": int(inp.obstacles["K"]), "parallelism": "single GPU"},
+            "plan_step_p50_ms": float(np.percentile(lat, 50) * 1e3), "plan_step_p95_ms": float(np.percentile(lat, 95) * 1e3),
+            "device_ms_per_step": float(np.mean(kern)), "eval_kernel_ms": eval_ms,
+            "winner": {"index": int(last["res"]["best_index"]), "cost": float(last["res"]["best_cost"]),
+                       "n_feasible": int(last["res"]["n_feasible"]), "n_collisions": int(last["res"]["n_collisions"])},
+            "roofline": {"bound": "hbm", "achieved": alg / (eval_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+                         "avg_launch_ms": eval_ms, "launches_timed": int(len(evalk)),
+                         "note": "630 candidates = 10 waves: the step is launch-latency-bound, not bandwidth-bound"},
+            "reference_python_path": "about 1.2e3 trajectories/s on one core (measured in the build container, BASELINE.md section 3)",
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle
+            from frenetix_motion_planner_amd.problem import pack_predictions
+            inp.obstacles = pack_predictions(inp.predictions if hasattr(inp, "predictions") and inp.predictions else
+                                             sc.ground_truth_predictions(0, 30), S, oracle.build_obstacle_hulls)
+            out["cpu_baseline"] = cpu_baseline_of(inp, f"the same plan step ({C} candidates x {S} samples, 5 obstacles)")
+        print(json.dumps(out))
+    eng.close()
+    itf.close()
     if world > 1:
         dist.destroy_process_group()
 
