@@ -503,6 +503,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         int G = 1;
         if (waves1 < 3072) G = 2;
         if (waves1 < 200) G = 4;
+        if (waves1 < 64) G = 8;   // planner-sized grids (<= ~4 000 candidates): 8 lanes x 4 steps, 128-lane workgroups (32 vs 41 us)
         if (c->G_force) G = c->G_force;
         if (extra_any) G = 1;
         c->G_step = G;
@@ -546,7 +547,9 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             const size_t lds_cap = (160 * 1024) / 2 - 512;  // two workgroups per CU (static LDS of the kernels: 256 B)
             block = 0;
             int best_waves = 0;
-            for (int blk : {256, 128, 64}) {
+            const int order_big[3] = {256, 128, 64}, order_small[3] = {128, 256, 64};
+            for (int bi = 0; bi < 3; bi++) {
+                const int blk = (G == 8 ? order_small : order_big)[bi];
                 const size_t need = lds_for(blk);
                 const int by_lds = (int)((160 * 1024) / (need + 256));
                 const int waves = by_lds * (blk / 64);
