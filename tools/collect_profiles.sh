@@ -11,6 +11,7 @@ python3 bench.py --steps 300 --warmup 30 --select-only --no-cpu-baseline > $O/be
 python3 bench.py --steps 200 --warmup 20 --workload config3 > $O/bench_config3.json 2>/dev/null
 python3 bench.py --steps 30 --warmup 3 --workload config5 > $O/bench_config5.json 2>/dev/null
 python3 bench.py --steps 60 --warmup 6 --workload config4 > $O/bench_config4.json 2>/dev/null
+python3 bench.py --steps 300 --warmup 30 --workload config1 > $O/bench_config1.json 2>/dev/null
 python3 tools/e2e_step.py > $O/e2e_step.json 2>/dev/null
 python3 tools/obst_split.py > $O/obst_split.txt 2>/dev/null
 BENCH="python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline"
