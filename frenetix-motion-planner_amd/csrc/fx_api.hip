@@ -846,6 +846,11 @@ int32_t fx_finish_batch(FxContext *c, FxResult *res) {
 
 int32_t fx_finish(FxContext *c, FxResult *res) { return fx_finish_batch(c, res); }
 
+int32_t fx_step(FxContext *c, FxResult *res) {
+    const int rc = fx_evaluate(c);
+    return rc ? rc : fx_finish_batch(c, res);
+}
+
 int32_t fx_plan_step(FxContext *c, const FxProblem *prob, FxResult *res) {
     int rc = fx_upload(c, prob);
     if (rc) return rc;

@@ -52,6 +52,32 @@ def merge_survivors(cost: np.ndarray, index: np.ndarray):
     return float(c[order[0]]), int(i[order[0]]), i[order]
 
 
+class _RawStepResult:
+    """Dict-like view of one FxResult (winner and counters are already in host memory; nothing is converted until read)."""
+
+    def __init__(self, raw):
+        self._raw = raw
+
+    def __getitem__(self, key):
+        if key == "global_best_index":
+            key = "best_index"
+        elif key == "global_best_cost":
+            key = "best_cost"
+        v = getattr(self._raw, key)
+        return list(v) if key == "reason_hist" else v
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except AttributeError:
+            return default
+
+    def as_dict(self) -> dict:
+        d = self._raw.as_dict()
+        d["global_best_index"], d["global_best_cost"] = d["best_index"], d["best_cost"]
+        return d
+
+
 class ShardedEvaluator:
     """Candidate-sharded plan step.  `engine` is a FrenetEngine (or anything with plan_step / topk /
     topk_to_device / set_stream); `group` a torch.distributed process group (None = default group, or
@@ -86,6 +112,8 @@ class ShardedEvaluator:
     def step_enqueued(self) -> dict:
         """Evaluate + exchange for inputs that are already uploaded (bench.py's timed step)."""
         if self.world == 1 and not self.force_exchange:
+            if hasattr(self.engine, "step_raw"):   # one call across the boundary; the result stays a C struct
+                return _RawStepResult(self.engine.step_raw()[0])
             self.engine.evaluate()
             res = self.engine.finish()[0]
             res["global_best_index"], res["global_best_cost"] = res["best_index"], res["best_cost"]

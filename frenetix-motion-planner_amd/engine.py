@@ -167,6 +167,16 @@ class FrenetEngine:
         out = [r.as_dict() for r in res]
         return out
 
+    def step_raw(self):
+        """evaluate() + finish() for the resident inputs in ONE call across the boundary; returns the FxResult array
+        (fields as attributes: best_index, best_cost, n_feasible, ...) without building Python dicts."""
+        n = len(self._inputs)
+        res = getattr(self, "_res_buf", None)
+        if res is None or len(res) != n:
+            res = self._res_buf = (_abi.FxResult * n)()
+        check(lib().fx_step(self._ctx, res))
+        return res
+
     def plan_step(self, inputs: PlanInputs) -> dict:
         self.upload(inputs)
         self.evaluate()

@@ -233,6 +233,9 @@ int32_t fx_evaluate(FxContext *ctx);
 int32_t fx_finish(FxContext *ctx, FxResult *res);
 /* convenience: upload + evaluate + finish */
 int32_t fx_plan_step(FxContext *ctx, const FxProblem *prob, FxResult *res);
+/* evaluate + finish for inputs that are already resident (the handler re-evaluating its current trajectory set,
+ * reactive_planner_cpp.py:345-349): one call across the boundary per plan step; res[n_agents] */
+int32_t fx_step(FxContext *ctx, FxResult *res);
 
 /* ---- read-back (TrajectorySample views are materialised lazily from the SoA bundle;
  *      reactive_planner_cpp.py:353 get_sorted_trajectories, trajectories.py:337-477) ---- */
