@@ -658,30 +658,55 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                 unsigned long long *hm = ar.host_slot<unsigned long long>(S, &dhm, &ok);
                 const double *dhot = nullptr;
                 double *hot = ar.host_slot<double>((size_t)S * p->K * FX_HOT_STRIDE, &dhot, &ok);
+                // origin of the hot table's coordinates: the reference knot at the ego's arc length (any point near the
+                // ego does; it only keeps the products of the transformed forms small against their differences)
+                {
+                    int ko = (int)(std::upper_bound(p->ref_pos, p->ref_pos + p->M, p->x0_lon[0]) - p->ref_pos) - 1;
+                    ko = std::min(std::max(ko, 0), p->M - 1);
+                    d.hot_origin[0] = p->ref_x[ko];
+                    d.hot_origin[1] = p->ref_y[ko];
+                }
+                const double ox = d.hot_origin[0], oy = d.hot_origin[1];
+                double r2_max = 0.0;
                 if (rec && pm && hm && hot) {
                     for (int i = 0; i < S; i++) {
                         pm[i] = hm[i] = 0ULL;
                         for (int k = 0; k < p->K; k++) {
                             double *q = rec + ((size_t)i * p->K + k) * 12;
                             for (int e = 0; e < 12; e++) q[e] = 0.0;
+                            double *h = hot + ((size_t)i * p->K + k) * FX_HOT_STRIDE;
+                            for (int e = 0; e < FX_HOT_STRIDE; e++) h[e] = 0.0;
                             if (i >= 1 && i < p->obs_npred[k] && i - 1 < p->P) {
                                 const double *mu = p->obs_pos + ((size_t)k * p->P + (i - 1)) * 2;
                                 const double *iv = p->obs_cov_inv + ((size_t)k * p->P + (i - 1)) * 4;
                                 q[0] = mu[0]; q[1] = mu[1]; q[2] = iv[0]; q[3] = iv[1]; q[4] = iv[2]; q[5] = iv[3];
                                 pm[i] |= 1ULL << k;
+                                // Cholesky factor of the symmetric part of the inverse covariance: A = L^T L,
+                                // L = [[l11, l12], [0, l22]]; the quadratic form r0 e0 + r1 e1 of the reference only
+                                // sees that symmetric part.  No factor (not positive definite, not finite): the entry
+                                // stays zero, the form evaluates to 0 and the kernel redoes the step from `rec`.
+                                const double a = iv[0], b = 0.5 * (iv[1] + iv[2]), dd = iv[3];
+                                const double l11 = std::sqrt(a), l12 = b / l11, l22sq = dd - l12 * l12;
+                                if (a > 0.0 && l22sq > 0.0 && std::isfinite(l11) && std::isfinite(l12) && std::isfinite(l22sq)) {
+                                    const double l22 = std::sqrt(l22sq), mx = mu[0] - ox, my = mu[1] - oy;
+                                    h[0] = l11; h[1] = l12; h[2] = l11 * mx + l12 * my; h[3] = l22; h[4] = l22 * my;
+                                }
                             }
                             if (have_hull && i >= 2 && i - 2 < p->obs_nhull[k]) {
                                 const double *oh = p->obs_hull + ((size_t)k * (p->P - 1) + (i - 2)) * 6;
                                 for (int e = 0; e < 6; e++) q[6 + e] = oh[e];
                                 hm[i] |= 1ULL << k;
+                                // broad phase: circle that holds the hull (radius h1 + h2, with slack) in expanded form
+                                const double hx = oh[0] - ox, hy = oh[1] - oy, hr = (oh[4] + oh[5]) * 1.000001;
+                                h[5] = -2.0 * hx; h[6] = -2.0 * hy; h[7] = -2.0 * hr; h[8] = hx * hx + hy * hy - hr * hr;
+                                r2_max = std::max(r2_max, hx * hx + hy * hy);
                             }
-                            double *h = hot + ((size_t)i * p->K + k) * FX_HOT_STRIDE;
-                            for (int e = 0; e < 8; e++) h[e] = q[e];
-                            h[8] = (q[10] + q[11]) * 1.000001;  // radius of a circle that holds the hull, with slack
-                            h[9] = 0.0;
                         }
                     }
                 }
+                // centre-gap values up to this margin go to the exact axis test: covers the rounding of the expanded form
+                // for ego hulls within ~1 km of the origin (the pairs it adds are decided exactly, so decisions do not move)
+                d.hot_gap_margin = 1e-6 + 4e-15 * (r2_max + 1e6);
                 d.obs_rec = dev; d.obs_pmask = dpm; d.obs_hmask = dhm; d.obs_hot = dhot;
             }
         } else {

@@ -11,10 +11,6 @@
 #define FX_BLOCK 256            // candidates per workgroup (4 wave64)
 #define FX_MODE_INT_STORE_WT (1u << 30)  // internal DevProblem.mode bit: write-through plane stores (fx_set_store_mode)
 #define FX_HOT_STRIDE 10        // doubles per (step, obstacle) entry of the hot obstacle table (80 B)
-#ifndef FX_HOT_LDS
-#define FX_HOT_LDS 1            // 1: stage the hot table per wave in LDS (broadcast reads); 0: scalar loads, one entry ahead
-                                // (measured: LDS 142 us vs scalar 168 us on config 3, 1268 vs 1237 us at 1 M x 20 obstacles)
-#endif
 #define FX_HOT_PRE 4            // table elements per lane prefetched one step ahead (covers K <= 25 obstacles)
 #define FX_REF_FIELDS 8         // per knot: pos, theta, curv, curv_d, x, y, nx, ny  (64 B, AoS in LDS)
 #define FX_MAX_SAMPLES 128      // N+1 <= 128
@@ -54,9 +50,13 @@ struct DevProblem {
     // prediction / a hull that ego step i meets.  One contiguous 96-byte record per (step, obstacle).
     const double *obs_rec;
     const unsigned long long *obs_pmask, *obs_hmask;
-    // the part of a record every (step, obstacle) visit needs, 80 B: hot[S][K][10] = {mu_x, mu_y, iv00, iv01, iv10,
-    // iv11, hull cx, hull cy, (h1 + h2) * (1 + 1e-6), 0}; a wave copies its step's block to LDS with one coalesced load
+    // what every (step, obstacle) visit needs, in the form that costs the fewest operations (fx_walk.h, ObsHot), 80 B:
+    // hot[S][K][10] = {l11, l12, cu, l22, cw (Cholesky factor of the inverse covariance and the transformed centre),
+    // -2 hx, -2 hy, -2 r, |h|^2 - r^2 (hull centre h and circle radius r with slack), 0}, coordinates relative to
+    // hot_origin; a wave copies its step's block to LDS with one coalesced load
     const double *obs_hot;
+    double hot_origin[2];
+    double hot_gap_margin;
     const double *dto_pos;     // [n_dto][2]
     // road boundary: pieces (mid x, mid y, half dx, half dy) and per reference knot the pieces in reach (CSR)
     int32_t n_bound;
@@ -108,6 +108,8 @@ struct ProblemRegs {
     const double *obs_rec;
     const unsigned long long *obs_pmask, *obs_hmask;
     const double *obs_hot;
+    double hot_origin[2];
+    double hot_gap_margin;
     const double *dto_pos;
     int32_t n_bound;
     const double *bound_piece;
@@ -139,6 +141,7 @@ struct ProblemRegs {
         r.tpow = g.tpow; r.t_samp = g.t_samp; r.v_samp = g.v_samp; r.d_samp = g.d_samp; r.matrix = g.matrix;
         r.ref = g.ref; r.obs_pos = g.obs_pos; r.obs_cov_inv = g.obs_cov_inv; r.obs_npred = g.obs_npred;
         r.obs_rec = g.obs_rec; r.obs_pmask = g.obs_pmask; r.obs_hmask = g.obs_hmask; r.obs_hot = g.obs_hot; r.dto_pos = g.dto_pos;
+        r.hot_origin[0] = g.hot_origin[0]; r.hot_origin[1] = g.hot_origin[1]; r.hot_gap_margin = g.hot_gap_margin;
         r.n_bound = g.n_bound; r.bound_piece = g.bound_piece; r.bound_bin = g.bound_bin; r.bound_item = g.bound_item;
         r.bound_d_reach = g.bound_d_reach; r.bound_step = g.bound_step;
         r.cost = g.cost; r.flags = g.flags; r.costmap = g.costmap; r.planes = g.planes; r.coeffs = g.coeffs;

@@ -102,6 +102,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     const double s0 = P.x0_lon[0], ss0 = P.x0_lon[1], sss0 = P.x0_lon[2];
 
     // ---- prologue: longitudinal table of the pairs this workgroup touches ----
+    // rows carry cos / sin of the reference heading when some stage needs the ego footprint
+    const bool want_trig = OBST && ((do_collision && P.K > 0) || ((P.mode & FX_MODE_ROAD_BOUNDARY) && P.n_bound > 0));
     const double rp_first = rpos[0], rp_last = rpos[M - 1];
     const double guess_scale = fdiv((double)(M - 1), rp_last - rp_first);
     for (int item = tid; item < n_pairs * S; item += BLK) {
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
         int traj_len = (int)ceil((T + dt) / dt);
         traj_len = traj_len > S ? S : (traj_len < 1 ? 1 : traj_len);
         rows[item] = make_lon_row(
-            i, S, M, dt, a_max, s0, ss0, .5 * sss0, cl3, cl4, cl5, traj_len, tp, rp_first, rp_last, guess_scale,
+            i, S, M, dt, a_max, s0, ss0, .5 * sss0, cl3, cl4, cl5, traj_len, tp, rp_first, rp_last, guess_scale, want_trig,
             [&](int k) {
                 const FX_GLOBAL double *q = kn + (int64_t)k * FX_REF_FIELDS;
                 Knot kt;
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     K.half_wid = P.veh.width / 2; K.S = S; K.half = S / 2; K.K = P.K; K.low_vel = low_vel; K.dbg = dbg;
     K.do_collision = do_collision; K.store_wt = (P.mode & FX_MODE_INT_STORE_WT) != 0;
     K.n_bound = (OBST && (P.mode & FX_MODE_ROAD_BOUNDARY)) ? P.n_bound : 0; K.bound_d_reach = P.bound_d_reach;
+    K.ox = P.hot_origin[0]; K.oy = P.hot_origin[1]; K.gap_margin = P.hot_gap_margin;
     const BoundView Bv{as_global(P.bound_piece), as_global(P.bound_bin), as_global(P.bound_item)};
     const FX_GLOBAL double *__restrict__ obs_rec = as_global(P.obs_rec);
     const FX_GLOBAL unsigned long long *__restrict__ obs_pmask = as_global(P.obs_pmask);
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
         char *hot_base = reinterpret_cast<char *>(rows + (size_t)n_pairs_max * S) + (G > 1 ? (size_t)64 * BLK : 0);
         const size_t hot_block = (sizeof(double) * FX_HOT_STRIDE * (size_t)fuse.k_max + 15) & ~(size_t)15;
         Hs.lds = reinterpret_cast<double *>(hot_base + (size_t)(tid >> 6) * hot_block);
-        if (FX_HOT_LDS && i_first < i_end) Hs.prefetch(i_first);
+        if (i_first < i_end) Hs.prefetch(i_first);
     }
 
     FX_STAMP(3);
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     for (int i = i_first; i < i_end; i++) {
         const bool emit = i >= i_begin;
         const LonRow r = my[i];
-        walk_step<OBST, (G == 1 || WSPLIT), HOT, (WPE <= 2)>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit,
+        walk_step<OBST, (G == 1 || WSPLIT), HOT>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit,
                                                  planes + (int64_t)i * ld + g, ps, Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv,
                                                  &Hs, i + 1 < i_end ? i + 1 : -1);
     }

@@ -590,9 +590,11 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
 
     const double rp_first = knots[0].pos, rp_last = knots[M - 1].pos;
     const double guess_scale = fdiv((double)(M - 1), rp_last - rp_first);
+    // rows carry cos / sin of the reference heading when some stage needs the ego footprint
+    const bool want_trig = OBST && ((do_collision && P.K > 0) || ((P.mode & FX_MODE_ROAD_BOUNDARY) && P.n_bound > 0));
     auto row_at = [&](int i) {
         return make_lon_row(i, S, M, dt, a_max, cl0, cl1, cl2, cl3, cl4, cl5, traj_len, tp, rp_first, rp_last, guess_scale,
-                            [&](int k) { return knots[k]; }, [&](int k) { return knots[k].pos; });
+                            want_trig, [&](int k) { return knots[k]; }, [&](int k) { return knots[k].pos; });
     };
     auto lat_eval = [&](int i, double u_lowvel, double &d, double &dv, double &da) {
         double u1, u2, u3, u4, u5;
@@ -619,6 +621,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     K.half_wid = P.veh.width / 2; K.S = S; K.half = S / 2; K.K = P.K; K.low_vel = low_vel; K.dbg = dbg;
     K.do_collision = do_collision; K.store_wt = (P.mode & FX_MODE_INT_STORE_WT) != 0;
     K.n_bound = (OBST && (P.mode & FX_MODE_ROAD_BOUNDARY)) ? P.n_bound : 0; K.bound_d_reach = P.bound_d_reach;
+    K.ox = P.hot_origin[0]; K.oy = P.hot_origin[1]; K.gap_margin = P.hot_gap_margin;
     const BoundView Bv{as_global(P.bound_piece), as_global(P.bound_bin), as_global(P.bound_item)};
     const FX_GLOBAL double *__restrict__ obs_rec = as_global(P.obs_rec);
     const FX_GLOBAL unsigned long long *__restrict__ obs_pmask = as_global(P.obs_pmask);

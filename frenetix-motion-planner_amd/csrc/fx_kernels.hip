@@ -269,11 +269,14 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
         if (obst) FX_LAUNCH(Gv, false, true, false, W);                       \
         FX_LAUNCH(Gv, false, false, false, W);                                \
     } while (0)
-#define FX_W(Gv)                          \
-    do {                                  \
-        if (wpe >= 4) FX_BO(Gv, 4);       \
-        if (wpe == 3) FX_BO(Gv, 3);       \
-        FX_BO(Gv, 2);                     \
+    // four waves per SIMD (128 VGPRs) only exists for the plain select-only walk: with the bundle stores or the obstacle
+    // stage that budget spills hundreds of bytes per lane to scratch -- slower than three waves, and kernels with that much
+    // private memory faulted on this platform when a process used a second stream
+#define FX_W(Gv)                                                          \
+    do {                                                                  \
+        if (wpe >= 4 && !bundle && !obst) FX_LAUNCH(Gv, false, false, false, 4); \
+        if (wpe >= 3) FX_BO(Gv, 3);                                       \
+        FX_BO(Gv, 2);                                                     \
     } while (0)
     if (extra) {  // windowed costs: one lane per candidate
         if (bundle && obst) FX_LAUNCH(1, true, true, true, 2);
@@ -314,11 +317,11 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
         if (obst) FX_LAUNCH(Gv, false, true, W, WS);               \
         FX_LAUNCH(Gv, false, false, W, WS);                        \
     } while (0)
-#define FX_W(Gv, WS)                          \
-    do {                                      \
-        if (wpe >= 4) FX_BO(Gv, 4, WS);       \
-        if (wpe == 3) FX_BO(Gv, 3, WS);       \
-        FX_BO(Gv, 2, WS);                     \
+#define FX_W(Gv, WS)                                                          \
+    do {                                                                      \
+        if (wpe >= 4 && !bundle && !obst) FX_LAUNCH(Gv, false, false, 4, WS); \
+        if (wpe >= 3) FX_BO(Gv, 3, WS);                                       \
+        FX_BO(Gv, 2, WS);                                                     \
     } while (0)
     if (wsplit && G > 1) {
         switch (G) {

@@ -31,8 +31,9 @@ struct alignas(16) LonRow {  // longitudinal quantities of one (pair, step); 128
     double s, sv, sa;        // s, clamped s_dot, s_ddot
     double th_ref, k_r, k_r_d;
     double px, py, nhx, nhy;  // foot point and unit normal (0 outside the projection domain)
-    double r_sv, sv2, r_sv2;  // 1/s_dot, s_dot^2, 1/s_dot^2 (only meaningful when moving)
+    double r_sv;              // 1/s_dot (only meaningful when moving)
     double u1;                // s - s[0] (LOW_VEL_MODE lateral parameter)
+    double c_ref, s_ref;      // cos / sin of th_ref (filled when a footprint is needed: collision stage, road boundary)
     uint32_t flags;           // LON_* bits
     uint32_t pad0;
     double pad1;
@@ -56,6 +57,13 @@ __device__ __forceinline__ double rcp_pred(double d) {
     double r = __builtin_amdgcn_rcp(d);
     const double e = fma(-d, r, 1.0);
     return fma(r, e, r);
+}
+
+// min of two doubles as one v_min_f64 (no canonicalisation of the operands; NaNs do not occur where it is used)
+__device__ __forceinline__ double fx_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // n / d with one residual correction on the quotient (correctly rounded for the operands of this kernel)
@@ -110,7 +118,7 @@ __device__ __forceinline__ void lon_coeffs(int lon_mode, double s0, double ss0, 
 template <typename KnotFn, typename PosFn>
 __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, double a_max, double cl0, double cl1, double cl2,
                                                double cl3, double cl4, double cl5, int traj_len, const double *tp, double rp_first,
-                                               double rp_last, double guess_scale, KnotFn knot, PosFn kpos) {
+                                               double rp_last, double guess_scale, bool want_trig, KnotFn knot, PosFn kpos) {
     const int ie = i < traj_len ? i : traj_len - 1;  // sample that is evaluated (the last one feeds the extension)
     const double t1 = tp[ie], t2 = tp[S + ie], t3 = tp[2 * S + ie], t4 = tp[3 * S + ie], t5 = tp[4 * S + ie];
     // calc_position / calc_velocity / calc_acceleration (polynomial_trajectory.py:241-273); c5 = 0 for the quartic
@@ -130,8 +138,6 @@ __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, d
     // reciprocals are only consumed on moving steps (walk_step selects them away otherwise)
     const bool mv = (r.flags & LON_MOVING) != 0;
     r.r_sv = mv ? rcp_nr(sv_i) : 0.0;
-    r.sv2 = sv_i * sv_i;
-    r.r_sv2 = mv ? rcp_nr(r.sv2) : 0.0;
     // upper_bound(ref_pos, s): first try the segment a uniformly spaced reference would put s in (resampled
     // reference paths are close to uniform), then bisect whatever interval that probe leaves
     int lo = 0, hi = M;
@@ -175,6 +181,8 @@ __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, d
         r.nhy = div_rcp(ny, nn, r_nn);
     }
     r.pad1 = 0.0;
+    r.c_ref = 1.0; r.s_ref = 0.0;
+    if (want_trig) fxm::sincos(r.th_ref, &r.s_ref, &r.c_ref);
     return r;
 }
 
@@ -217,6 +225,8 @@ struct StepConst {  // wave-uniform constants of the walk
     bool store_wt;          // write-through plane stores
     int n_bound;            // road-boundary pieces (0: stage off)
     double bound_d_reach;   // |d| beyond this counts as off the road
+    double ox, oy;          // origin of the hot obstacle table's coordinates (a reference-path point near the ego)
+    double gap_margin;      // broad phase: centre-gap values up to this go to the exact test (rounding of the expanded form)
 };
 
 struct StepCarry {  // per-lane state carried from step to step
@@ -246,10 +256,33 @@ struct BoundView {
 };
 
 // Per-wave staging of the hot obstacle table (grid kernel, wave-uniform step index).  The walk visits every
-// (step, obstacle) pair; fetching each 96-byte record with scalar loads inside the obstacle loop costs one
-// scalar-cache / L2 round trip per visit, which is what bounded the obstacle stage.  Instead the wave copies the
-// K x 80 B block of the step with ONE coalesced vector load, issued a whole step ahead (`pre`), parks it in its own
-// LDS block and the obstacle loop reads entries back with broadcast ds_read_b128, two entries in flight.
+// (step, obstacle) pair with wave-uniform operands; fetching them with dependent scalar loads inside the obstacle loop
+// costs one scalar-cache / L2 round trip per visit.  Instead the wave copies the K x 80 B block of the step with ONE
+// coalesced vector load, issued a whole step ahead (`pre`), parks it in its own LDS block and the obstacle loops read
+// entries back with broadcast ds_read_b128, the next two entries requested before the current two are consumed.
+//
+// A hot entry holds the operands in the form that costs the fewest operations per visit (host: fx_api.hip):
+//   prediction cost (collision_probability.py:283-292): the inverse covariance A (symmetric part) is factored
+//   A = L^T L, L = [[l11, l12], [0, l22]], so that the Mahalanobis form of the ego point p = (x, y) - O is
+//       m = (l11 px + l12 py - cu)^2 + (l22 py - cw)^2 ,   cu = l11 mx + l12 my,  cw = l22 my   (mu relative to O)
+//   -- five operations instead of eight.  O is a point of the reference path near the ego, so the products stay small
+//   against their difference.
+//   broad phase of the collision test: |h - c|^2 - (r_o + r_e)^2 expanded in the ego hull's (c, r_e):
+//       g = (ck + w) + hx2 cx + hy2 cy + hr2 r_e ,  hx2 = -2 hx, hy2 = -2 hy, hr2 = -2 r_o, ck = |h|^2 - r_o^2, w = |c|^2 - r_e^2
+//   (all relative to O) -- four operations and a minimum instead of seven and a compare.
+#define FX_HOT_L11 0
+#define FX_HOT_L12 1
+#define FX_HOT_CU 2
+#define FX_HOT_L22 3
+#define FX_HOT_CW 4
+#define FX_HOT_HX2 5
+#define FX_HOT_HY2 6
+#define FX_HOT_HR2 7
+#define FX_HOT_CK 8
+typedef double fx_d2 __attribute__((ext_vector_type(2)));  // one 16-byte load
+#ifndef FX_STAGE_FENCE
+#define FX_STAGE_FENCE 1
+#endif
 struct ObsHot {
     double *lds;                    // this wave's block [K][FX_HOT_STRIDE] (nullptr: staging off)
     const FX_GLOBAL double *tab;    // hot[S][K][FX_HOT_STRIDE]
@@ -268,6 +301,12 @@ struct ObsHot {
     // park the prefetched block of `step` in LDS (elements beyond the prefetch window come straight from memory),
     // then start the load of `next` (< 0: none)
     __device__ __forceinline__ void stage(int step, int next) {
+        // the previous step's reads are behind the new writes and the writes in front of this step's reads: LDS
+        // operations of one wave execute in order, the fences only keep the compiler from reordering across lanes' views
+#if FX_STAGE_FENCE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#endif
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < FX_HOT_PRE; j++) {
             const int e = lane + 64 * j;
@@ -277,19 +316,33 @@ struct ObsHot {
             const FX_GLOBAL double *src = tab + (int64_t)step * n_el;
             for (int e = lane + 64 * FX_HOT_PRE; e < n_el; e += 64) lds[e] = src[e];
         }
+#if FX_STAGE_FENCE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#endif
+        __builtin_amdgcn_wave_barrier();
+#if FX_STAGE_FENCE
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
         if (next >= 0) prefetch(next);
     }
 };
 
-template <bool OBST, bool USTEP, bool HOT = false, bool FX_OBS_UNROLL4 = false, typename PlanePtr, typename ObsD, typename ObsM>
+// cos / sin of the global heading from the pieces the step already has: theta_gl = theta_cl + theta_ref with
+// cos(theta_cl), sin(theta_cl) = tan * cos from the kinematics and cos / sin(theta_ref) from the row -- four operations
+// instead of a sincos evaluation (the carried heading of a standstill step satisfies the same identity to an ulp)
+__device__ __forceinline__ void heading_trig(const LonRow &r, double cosTheta, double tanTheta, double &cu, double &su) {
+    const double sinTheta = tanTheta * cosTheta;
+    cu = fma(-sinTheta, r.s_ref, cosTheta * r.c_ref);
+    su = fma(sinTheta, r.c_ref, cosTheta * r.s_ref);
+}
+
+template <bool OBST, bool USTEP, bool HOT = false, typename PlanePtr, typename ObsD, typename ObsM>
 __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, const LatPoly &L, const double *tp, int i,
                                           int traj_len, double d_ext, bool emit, bool store, PlanePtr planes_i, int64_t ps,
                                           StepCarry &C, StepAcc &A, StepOut &O, ObsD obs_rec, ObsM obs_pmask, ObsM obs_hmask,
                                           const BoundView &B, ObsHot *H = nullptr, int i_next = -1) {
     const int S = K.S;
-#if FX_HOT_LDS
     if (OBST && HOT && USTEP && K.K > 0) H->stage(__builtin_amdgcn_readfirstlane(i), i_next);
-#endif
     const double s_i = r.s, sv_i = r.sv, sa_i = r.sa;
     // -- lateral polynomial (reactive_planner.py:326-346) --
     double d_i, dv_i, da_i;
@@ -307,13 +360,15 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
     }
     // -- d', d'' (:392-412) --
     const bool moving = (r.flags & LON_MOVING) != 0;
+    const double sv2 = sv_i * sv_i;
     double dp, dpp;
     if (!K.low_vel) {
         const double q = dv_i * r.r_sv;
         dp = moving ? fma(fma(-sv_i, q, dv_i), r.r_sv, q) : 0.;
         const double ddot = da_i - dp * sa_i;
-        const double q2 = ddot * r.r_sv2;
-        dpp = moving ? fma(fma(-r.sv2, q2, ddot), r.r_sv2, q2) : 0.;
+        const double r_sv2 = r.r_sv * r.r_sv;  // 1 / s_dot^2 to an ulp; the residual step below settles the quotient
+        const double q2 = ddot * r_sv2;
+        dpp = moving ? fma(fma(-sv2, q2, ddot), r_sv2, q2) : 0.;
     } else {
         dp = dv_i;
         dpp = da_i;
@@ -340,7 +395,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
     const double okc = oneKrD * secTheta;           // (1 - k_r d) / cos
     const double kap = fma(fma(fma(k_r, dp, k_r_d * d_i), tanTheta, dpp) * cosTheta, cok * cok, cok * k_r);
     const double v_i = sv_i * okc;
-    const double a_i = fma(sa_i, okc, (r.sv2 * secTheta) * (oneKrD * tanTheta * fma(kap, okc, -k_r) - fma(k_r, dp, k_r_d * d_i)));
+    const double a_i = fma(sa_i, okc, (sv2 * secTheta) * (oneKrD * tanTheta * fma(kap, okc, -k_r) - fma(k_r, dp, k_r_d * d_i)));
     // -- constraints (:480-533): bit r = reason r --
     if (emit) {
         uint32_t hit = 0;
@@ -360,11 +415,14 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
 
     // -- (s, d) -> (x, y): foot point + d * unit normal, 0 from the first step outside the domain on (:537-547) --
     double x_i = 0.0, y_i = 0.0;
+    bool xy_is_model = true;  // (x, y) = foot + d n inside the domain / (0, 0) outside: what the obstacle tables assume
     if (!(r.flags & LON_INDOMAIN)) {
         if (emit && A.fail_step == 0x7fffffff) A.fail_step = i;
     } else if (A.fail_step == 0x7fffffff) {
         x_i = fma(d_i, r.nhx, r.px);
         y_i = fma(d_i, r.nhy, r.py);
+    } else {
+        xy_is_model = false;
     }
 
     // -- SoA bundle (trajectories.py:56-334) --
@@ -392,160 +450,148 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
         if (i == S - 1) { A.d_end = d_i; A.v_end = v_i; }
     }
     if (OBST && HOT && USTEP && K.K > 0) {
-        // ---- obstacle stage on the staged table: one pass over the obstacles that have a prediction or a hull at
-        //      this step, entries read from the wave's LDS block two at a time (ping-pong), all branches wave-uniform
+        // ---- obstacle stage on the staged table (wave-uniform step index, every branch wave-uniform) ----
         const int iu = __builtin_amdgcn_readfirstlane(i);
+        const int nK = K.K;
         unsigned long long pm = obs_pmask[iu], hm_now = obs_hmask[iu];
         const unsigned long long hm_next = iu + 1 < S ? obs_hmask[iu + 1] : 0ULL;
         pm = uniform_u64(pm); hm_now = uniform_u64(hm_now);
         if (!emit) pm = 0ULL;
-        unsigned long long hm = 0ULL;
-        Obb hull;
-        hull.cx = hull.cy = hull.ex = hull.ey = hull.h1 = hull.h2 = 0.0;
-        double re = 0.0;
+        const unsigned long long full = nK >= 64 ? ~0ULL : ((1ULL << nK) - 1ULL);
+        const double *hot = H->lds;
+        const auto rec_i = obs_rec + (int64_t)iu * nK * 12;
+        // -- prediction cost (collision_probability.py:283-292): sum over the obstacles of 1 / m^2 --
+        if (pm) {
+            const double xr = x_i - K.ox, yr = y_i - K.oy;
+            auto term = [&](fx_d2 l, fx_d2 c, double cw) {  // l = (l11, l12), c = (cu, l22)
+                const double u = fma(l.x, xr, fma(l.y, yr, -c.x));
+                const double w = fma(c.y, yr, -cw);
+                const double m = fma(u, u, w * w);
+                return rcp_pred(m * m);
+            };
+            auto ld = [&](int k, fx_d2 &l, fx_d2 &c, double &cw) {
+                const double *q = hot + (size_t)k * FX_HOT_STRIDE;
+                l = *reinterpret_cast<const fx_d2 *>(q);
+                c = *reinterpret_cast<const fx_d2 *>(q + 2);
+                cw = q[FX_HOT_CW];
+            };
+            double s0 = 0.0, s1 = 0.0;
+            if (pm == full) {
+                // four obstacles per iteration in two alternating register sets: the loads of one pair are in flight
+                // while the other pair is consumed, and no value is copied between the sets
+                fx_d2 la, ca, lb, cb, lc, cc, ld_, cd;
+                double wa, wb, wc, wd;
+                int k = 0;
+                ld(0, la, ca, wa);
+                if (nK > 1) ld(1, lb, cb, wb);
+                for (; k + 5 < nK; k += 4) {
+                    ld(k + 2, lc, cc, wc); ld(k + 3, ld_, cd, wd);
+                    s0 += term(la, ca, wa); s1 += term(lb, cb, wb);
+                    ld(k + 4, la, ca, wa); ld(k + 5, lb, cb, wb);
+                    s0 += term(lc, cc, wc); s1 += term(ld_, cd, wd);
+                }
+                // entries k (a) and k + 1 (b) are loaded; up to five remain
+                for (; k + 3 < nK; k += 2) {
+                    ld(k + 2, lc, cc, wc); ld(k + 3, ld_, cd, wd);
+                    s0 += term(la, ca, wa); s1 += term(lb, cb, wb);
+                    la = lc; ca = cc; wa = wc; lb = ld_; cb = cd; wb = wd;
+                }
+                s0 += term(la, ca, wa);
+                if (k + 1 < nK) s1 += term(lb, cb, wb);
+                if (k + 2 < nK) { ld(k + 2, lc, cc, wc); s0 += term(lc, cc, wc); }
+            } else {
+                unsigned long long m = pm;
+                while (m) {
+                    const int k = __builtin_ctzll(m);
+                    m &= m - 1;
+                    fx_d2 l, c; double cw;
+                    ld(k, l, c, cw);
+                    s0 += term(l, c, cw);
+                }
+            }
+            double ssum = s0 + s1;
+            // anything not finite (an obstacle centre hit to the last bit, a covariance without a Cholesky factor: the
+            // host leaves a zero entry) sends the step to the reference form on the raw records -- rare
+            if (__any(!(ssum < 1e300))) {
+                double acc = 0.0;
+                unsigned long long m = pm;
+                while (m) {
+                    const int k = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const auto q = rec_i + k * 12;
+                    const double e0 = x_i - q[0], e1 = y_i - q[1];
+                    const double r0 = fma(e1, q[4], e0 * q[2]), r1 = fma(e1, q[5], e0 * q[3]);
+                    const double mq = fma(r1, e1, r0 * e0);
+                    const double mm = mq * mq;
+                    acc += mm > 0.0 ? rcp_pred(mm) : 1.0 / mm;
+                }
+                ssum = !(ssum < 1e300) ? acc : ssum;
+            }
+            A.pred += ssum;
+        }
+        // -- collision: OBB-sum hull of ego boxes (i-1, i) against the obstacle hulls of this step --
         if (K.do_collision && (hm_now | hm_next) != 0ULL && i >= 1) {
             double su, cu;
-            fxm::sincos(th_gl, &su, &cu);
+            heading_trig(r, cosTheta, tanTheta, cu, su);
             const double bx = fma(K.wb, cu, x_i), by = fma(K.wb, su, y_i);
-            hm = emit ? hm_now : 0ULL;
+            const unsigned long long hm = emit ? hm_now : 0ULL;
             if (hm) {
-                hull = obb_hull(C.bx_prev, C.by_prev, C.ux_prev, C.uy_prev, bx, by, cu, su, K.half_len, K.half_wid);
-                re = (hull.h1 + hull.h2) * 1.000001;
+                const Obb hull = obb_hull(C.bx_prev, C.by_prev, C.ux_prev, C.uy_prev, bx, by, cu, su, K.half_len, K.half_wid);
+                // broad phase on circles: a box lies inside the circle around its centre with radius h1 + h2, so hulls
+                // whose centres are farther apart than the sum of those radii (1e-6 relative slack on both) are separated
+                // and the axis test would say so.  g = |h - c|^2 - (r_o + r_e)^2 in the expanded form of the table; the
+                // exact test runs for the obstacles where some lane has g <= margin (the margin covers the rounding of the
+                // expanded form).
+                const double re = (hull.h1 + hull.h2) * 1.000001;
+                const double cxr = hull.cx - K.ox, cyr = hull.cy - K.oy;
+                const double wq = fma(cxr, cxr, fma(cyr, cyr, -re * re));
+                auto gap = [&](fx_d2 hxy, fx_d2 hrk) {  // (hx2, hy2), (hr2, ck)
+                    return fma(hxy.x, cxr, fma(hxy.y, cyr, fma(hrk.x, re, hrk.y + wq)));
+                };
+                auto ldh = [&](int k, fx_d2 &hxy, fx_d2 &hrk) {
+                    const double *q = hot + (size_t)k * FX_HOT_STRIDE;
+                    hxy = fx_d2{q[FX_HOT_HX2], q[FX_HOT_HY2]};
+                    hrk = fx_d2{q[FX_HOT_HR2], q[FX_HOT_CK]};
+                };
+                // obstacles some lane of the wave is near (wave-uniform mask): one compare and a few scalar operations per visit
+                unsigned long long nm = 0ULL;
+                auto mark = [&](double g, int k) { nm |= (__any(!(g > K.gap_margin)) ? 1ULL : 0ULL) << k; };
+                if (hm == full) {
+                    fx_d2 ha, ra, hb, rb, hc, rc, hd, rd;
+                    int k = 0;
+                    ldh(0, ha, ra);
+                    if (nK > 1) ldh(1, hb, rb);
+                    for (; k + 5 < nK; k += 4) {
+                        ldh(k + 2, hc, rc); ldh(k + 3, hd, rd);
+                        mark(gap(ha, ra), k); mark(gap(hb, rb), k + 1);
+                        ldh(k + 4, ha, ra); ldh(k + 5, hb, rb);
+                        mark(gap(hc, rc), k + 2); mark(gap(hd, rd), k + 3);
+                    }
+                    for (; k + 3 < nK; k += 2) {
+                        ldh(k + 2, hc, rc); ldh(k + 3, hd, rd);
+                        mark(gap(ha, ra), k); mark(gap(hb, rb), k + 1);
+                        ha = hc; ra = rc; hb = hd; rb = rd;
+                    }
+                    mark(gap(ha, ra), k);
+                    if (k + 1 < nK) mark(gap(hb, rb), k + 1);
+                    if (k + 2 < nK) { ldh(k + 2, hc, rc); mark(gap(hc, rc), k + 2); }
+                } else {
+                    unsigned long long m = hm;
+                    while (m) {
+                        const int k = __builtin_ctzll(m);
+                        m &= m - 1;
+                        fx_d2 hxy, hrk;
+                        ldh(k, hxy, hrk);
+                        mark(gap(hxy, hrk), k);
+                    }
+                }
+                while (nm) {  // exact axis test for whatever is near (rare; the hull comes in through scalar loads)
+                    const int k = __builtin_ctzll(nm);
+                    nm &= nm - 1;
+                    A.collided |= obb_overlap(hull, rec_i + k * 12 + 6);
+                }
             }
             C.bx_prev = bx; C.by_prev = by; C.ux_prev = cu; C.uy_prev = su;
-        }
-        unsigned long long um = pm | hm;
-        if (um) {
-            const auto rec_i = obs_rec + (int64_t)iu * K.K * 12;
-            struct Ent { double mx, my, a, b, c, d, hx, hy, hr; };
-#if FX_HOT_LDS
-            auto fetch = [&](int k) {
-                const double2 *q = reinterpret_cast<const double2 *>(H->lds + k * FX_HOT_STRIDE);
-                const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                Ent e;
-                e.mx = q0.x; e.my = q0.y; e.a = q1.x; e.b = q1.y; e.c = q2.x; e.d = q2.y; e.hx = q3.x; e.hy = q3.y;
-                e.hr = H->lds[k * FX_HOT_STRIDE + 8];
-                return e;
-            };
-#else
-            // scalar path: the entry is wave-uniform, so it travels once per wave (scalar cache -> SGPRs) instead of
-            // once per lane; the next entry is requested before the current one is consumed
-            const auto hot_i = H->tab + (int64_t)iu * H->n_el;
-            auto fetch = [&](int k) {
-                const auto q = hot_i + k * FX_HOT_STRIDE;
-                Ent e;
-                e.mx = q[0]; e.my = q[1]; e.a = q[2]; e.b = q[3]; e.c = q[4]; e.d = q[5]; e.hx = q[6]; e.hy = q[7]; e.hr = q[8];
-                return e;
-            };
-#endif
-            auto visit = [&](const Ent &e, int k) {
-                if ((pm >> k) & 1ULL) {  // prediction cost (collision_probability.py:283-292)
-                    const double e0 = x_i - e.mx, e1 = y_i - e.my;
-                    const double r0 = fma(e1, e.c, e0 * e.a), r1 = fma(e1, e.d, e0 * e.b);
-                    const double m = fma(r1, e1, r0 * e0);
-                    const double mm = m * m;
-                    double t = rcp_pred(mm);
-                    if (__any(!(mm > 0.0))) t = mm > 0.0 ? t : 1.0 / mm;
-                    A.pred += t;
-                }
-                if ((hm >> k) & 1ULL) {  // broad phase on the hull circles, exact axis test for whatever is near
-                    const double tx = e.hx - hull.cx, ty = e.hy - hull.cy;
-                    const double rr = e.hr + re;
-                    const bool near = !(fma(tx, tx, ty * ty) > rr * rr);
-                    if (__any(near)) A.collided |= obb_overlap(hull, rec_i + k * 12 + 6);
-                }
-            };
-            // Dense fast path (the usual case: every obstacle has a prediction at this step, and either all or none
-            // have a hull): straight-line code for two obstacles at a time -- two independent dependency chains, no
-            // branch on a vector compare inside the loop.  The rare events are only recorded (a lane whose Mahalanobis
-            // term is not positive; an obstacle some lane is near) and settled after the loop.
-            const int nK = K.K;
-            const unsigned long long full = nK >= 64 ? ~0ULL : ((1ULL << nK) - 1ULL);
-            if (pm == full && (hm == 0ULL || hm == full)) {
-                const bool coll = hm != 0ULL;
-                const double pred0 = A.pred;
-                bool bad = false;
-                unsigned long long nm = 0ULL;  // obstacles that need the exact axis test
-                auto pred_term = [&](const Ent &e) {
-                    const double e0 = x_i - e.mx, e1 = y_i - e.my;
-                    const double r0 = fma(e1, e.c, e0 * e.a), r1 = fma(e1, e.d, e0 * e.b);
-                    const double m = fma(r1, e1, r0 * e0);
-                    const double mm = m * m;
-                    bad |= !(mm > 0.0);
-                    return rcp_pred(mm);
-                };
-                auto is_near = [&](const Ent &e) {
-                    const double tx = e.hx - hull.cx, ty = e.hy - hull.cy;
-                    const double rr = e.hr + re;
-                    return !(fma(tx, tx, ty * ty) > rr * rr);
-                };
-                int k = 0;
-                if (FX_OBS_UNROLL4) {
-                    // four obstacles per iteration: all twenty LDS reads are issued before the first use and four
-                    // independent chains run interleaved -- what a wave needs when it is (almost) alone on its SIMD
-                    for (; k + 3 < nK; k += 4) {
-                        const Ent ea = fetch(k), eb = fetch(k + 1), ec = fetch(k + 2), ed = fetch(k + 3);
-                        const double ta = pred_term(ea), tb = pred_term(eb), tc = pred_term(ec), td = pred_term(ed);
-                        A.pred += ta;
-                        A.pred += tb;
-                        A.pred += tc;
-                        A.pred += td;
-                        if (coll) {
-                            const bool na = is_near(ea), nb = is_near(eb), nc = is_near(ec), nd = is_near(ed);
-                            nm |= (__any(na) ? 1ULL : 0ULL) << k;
-                            nm |= (__any(nb) ? 2ULL : 0ULL) << k;
-                            nm |= (__any(nc) ? 4ULL : 0ULL) << k;
-                            nm |= (__any(nd) ? 8ULL : 0ULL) << k;
-                        }
-                    }
-                }
-                for (; k + 1 < nK; k += 2) {
-                    const Ent ea = fetch(k), eb = fetch(k + 1);
-                    const double ta = pred_term(ea), tb = pred_term(eb);
-                    A.pred += ta;
-                    A.pred += tb;
-                    if (coll) {
-                        const bool na = is_near(ea), nb = is_near(eb);
-                        nm |= (__any(na) ? 1ULL : 0ULL) << k;
-                        nm |= (__any(nb) ? 2ULL : 0ULL) << k;
-                    }
-                }
-                if (k < nK) {
-                    const Ent ea = fetch(k);
-                    A.pred += pred_term(ea);
-                    if (coll) nm |= (__any(is_near(ea)) ? 1ULL : 0ULL) << k;
-                }
-                if (__any(bad)) {  // exact division where the fast reciprocal does not apply: redo the step's sum in order
-                    A.pred = pred0;
-                    for (int j = 0; j < nK; j++) {
-                        const Ent e = fetch(j);
-                        const double e0 = x_i - e.mx, e1 = y_i - e.my;
-                        const double r0 = fma(e1, e.c, e0 * e.a), r1 = fma(e1, e.d, e0 * e.b);
-                        const double m = fma(r1, e1, r0 * e0);
-                        const double mm = m * m;
-                        A.pred += mm > 0.0 ? rcp_pred(mm) : 1.0 / mm;
-                    }
-                }
-                while (nm) {
-                    const int j = __builtin_ctzll(nm);
-                    nm &= nm - 1;
-                    A.collided |= obb_overlap(hull, rec_i + j * 12 + 6);
-                }
-            } else {
-                int k0 = __builtin_ctzll(um);
-                um &= um - 1;
-                Ent ea = fetch(k0), eb = ea;
-                while (true) {
-                    int k1 = -1;
-                    if (um) { k1 = __builtin_ctzll(um); um &= um - 1; eb = fetch(k1); }
-                    visit(ea, k0);
-                    if (k1 < 0) break;
-                    k0 = -1;
-                    if (um) { k0 = __builtin_ctzll(um); um &= um - 1; ea = fetch(k0); }
-                    visit(eb, k1);
-                    if (k0 < 0) break;
-                }
-            }
         }
     } else if (OBST && K.K > 0) {  // a batched launch may mix agents with and without obstacles
         const int nK = K.K;
@@ -573,7 +619,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
             const unsigned long long hm_next = iu + 1 < S ? obs_hmask[iu + 1] : 0ULL;
             if ((hm_now | hm_next) != 0ULL && i >= 1) {
                 double su, cu;
-                fxm::sincos(th_gl, &su, &cu);
+                heading_trig(r, cosTheta, tanTheta, cu, su);
                 const double bx = fma(K.wb, cu, x_i), by = fma(K.wb, su, y_i);
                 unsigned long long hm = emit ? hm_now : 0ULL;
                 if (USTEP) hm = __builtin_amdgcn_readfirstlane((unsigned)(hm & 0xffffffffu)) |
@@ -608,7 +654,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
         test = test && !hit;
         if (__any(test)) {
             double su, cu;
-            fxm::sincos(th_gl, &su, &cu);
+            heading_trig(r, cosTheta, tanTheta, cu, su);
             const double cx = fma(K.wb, cu, x_i), cy = fma(K.wb, su, y_i);
             int j = test ? B.bin[r.pad0] : 0;
             const int j_end = test ? B.bin[r.pad0 + 1] : 0;

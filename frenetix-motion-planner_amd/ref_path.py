@@ -1,191 +1,139 @@
-"""Reference-path preparation -- the step immediately in front of the hot path.
+"""Route polyline -> planner reference path: the input preparation in front of the hot path.
 
-Host-side NumPy/SciPy, same names, arguments and behaviour as the reference's
-`cr_scenario_handler/utils/utils_coordinate_system.py`:
+Behaviour contract (checked against vectors the reference's own functions produced, tests/golden/gen_refpath_golden.py):
 
-    extend_path_linearly        :21-51      extend_ref_path_both_ends   :54-58
-    extend_points               :61-77      extend_points_end           :80-99
-    extend_ref_path             :102-108    smooth_ref_path             :110-134
-    extrapolate_ref_path        :158-169    preprocess_ref_path         :172-184
+    cr_scenario_handler/utils/utils_coordinate_system.py
+        extend_path_linearly :21-51     extend_ref_path_both_ends :54-58     extend_points :61-77
+        extend_ref_path      :102-108   smooth_ref_path           :110-134
 
-`FrenetPlannerInterface` runs `smooth_ref_path(extend_ref_path_both_ends(route.reference_path))` before it builds
-the planner's coordinate system (`frenet_interface.py:110-114`); `prepare_reference_path` is that composition.
+`FrenetPlannerInterface` feeds `smooth_ref_path(extend_ref_path_both_ends(route.reference_path))` to the planner's
+coordinate system (`frenet_interface.py:110-114`); `prepare_reference_path` is that composition.
 
-Two helpers come from commonroad-drivability-checker (~2024.1, `commonroad_dc.geometry.util`, not in the reference
-tree): `resample_polyline` and `chaikins_corner_cutting`.  They are restated here from the published algorithm --
-parity for them is unpinned; everything else is checked against the reference's own functions
-(tests/golden/gen_refpath_golden.py).
+Built from three primitives of this module -- `prolong` (march beyond one end of a polyline), `resample_polyline` (equal
+arc-length steps) and `_bspline_through` (interpolating cubic B-spline, SciPy) -- instead of one routine per call site.
+`resample_polyline` stands in for `commonroad_dc.geometry.util.resample_polyline` (commonroad-drivability-checker 2024.1, not
+in the reference tree): restated from its published behaviour, parity unpinned.
 """
-from copy import deepcopy
-
 import numpy as np
 
-from .coordinate_system import compute_curvature_from_polyline
+
+# ---------------------------------------------------------------------------------------------------------------------
+# primitives
+# ---------------------------------------------------------------------------------------------------------------------
+def _as_polyline(points) -> np.ndarray:
+    return np.asarray(points, dtype=np.float64).reshape(-1, 2)
 
 
-def _distance(p1, p2) -> float:
-    """helper_functions.distance: Euclidean distance of two points."""
-    return float(np.sqrt((p1[0] - p2[0]) ** 2 + (p1[1] - p2[1]) ** 2))
+def prolong(points, count: int, stride, front: bool) -> np.ndarray:
+    """`count` extra vertices beyond the first (`front`) or the last vertex: end -/+ i * stride, i = 1..count, kept in path
+    order.  `stride` is a 2-vector or a (scale, 2-vector) pair -- the pair evaluates (i * vector) * scale, which is the order
+    in which the reference forms its unit-step products."""
+    pts = _as_polyline(points)
+    if count <= 0:
+        return pts
+    scale, vec = stride if isinstance(stride, tuple) else (None, stride)
+    k = np.arange(1, count + 1, dtype=np.float64)[:, None] * np.asarray(vec, dtype=np.float64)[None, :]
+    if scale is not None:
+        k = k * scale
+    if front:
+        return np.concatenate([(pts[0] - k)[::-1], pts])
+    return np.concatenate([pts, pts[-1] + k])
 
 
-# ----------------------------------------------------------------------------------------------------------------
-# commonroad_dc.geometry.util (third-party, restated)
-# ----------------------------------------------------------------------------------------------------------------
-def resample_polyline(polyline: np.ndarray, step: float = 2.0) -> np.ndarray:
-    """Walks along the polyline and emits a vertex every `step` metres of arc length; the last vertex is appended
-    when the walk does not end on it (closer than 1e-6)."""
-    polyline = np.asarray(polyline, dtype=np.float64)
-    if len(polyline) < 2:
-        return np.array(polyline)
-    new_polyline = [polyline[0]]
-    current_position = step
-    current_length = np.linalg.norm(polyline[0] - polyline[1])
-    current_idx = 0
-    while current_idx < len(polyline) - 1:
-        if current_position >= current_length:
-            current_position = current_position - current_length
-            current_idx += 1
-            if current_idx > len(polyline) - 2:
-                break
-            current_length = np.linalg.norm(polyline[current_idx + 1] - polyline[current_idx])
-        else:
-            rel = current_position / current_length
-            new_polyline.append((1 - rel) * polyline[current_idx] + rel * polyline[current_idx + 1])
-            current_position += step
-    if np.linalg.norm(new_polyline[-1] - polyline[-1]) >= 1e-6:
-        new_polyline.append(polyline[-1])
-    return np.array(new_polyline)
+def resample_polyline(polyline, step: float = 2.0) -> np.ndarray:
+    """Vertices every `step` metres of arc length, starting on the first vertex; the last vertex closes the result unless the
+    final sample already lies on it (within 1e-6).  A sample that falls exactly on a vertex belongs to the segment that
+    starts there."""
+    pts = _as_polyline(polyline)
+    if len(pts) < 2:
+        return pts.copy()
+    seg = np.linalg.norm(np.diff(pts, axis=0), axis=1)
+    # arc length at which segment j starts, accumulated the way a walk along the path accumulates it
+    start = np.concatenate([[0.0], np.cumsum(seg)])
+    total = start[-1]
+    n = int(np.floor(total / step)) + 1
+    targets = float(step) * np.arange(1, n + 1, dtype=np.float64)
+    targets = targets[targets < total]
+    j = np.searchsorted(start, targets, side="right") - 1
+    j = np.clip(j, 0, len(seg) - 1)
+    # skip zero-length segments (duplicate vertices) a target may land on
+    while True:
+        bad = (seg[j] == 0.0) & (j < len(seg) - 1)
+        if not bad.any():
+            break
+        j = np.where(bad, j + 1, j)
+    rel = np.divide(targets - start[j], seg[j], out=np.zeros_like(targets), where=seg[j] > 0)
+    out = np.concatenate([pts[:1], (1.0 - rel)[:, None] * pts[j] + rel[:, None] * pts[j + 1]])
+    if np.linalg.norm(out[-1] - pts[-1]) >= 1e-6:
+        out = np.concatenate([out, pts[-1:]])
+    return out
 
 
-def chaikins_corner_cutting(polyline: np.ndarray, refinements: int = 1) -> np.ndarray:
-    """Chaikin's corner cutting: every segment is replaced by its 1/4 and 3/4 points, end points are kept."""
-    polyline = np.asarray(polyline, dtype=np.float64)
-    for _ in range(refinements):
-        L = polyline.repeat(2, axis=0)
-        R = np.empty_like(L)
-        R[0] = L[0]
-        R[2::2] = L[1:-1:2]
-        R[1:-1:2] = L[2::2]
-        R[-1] = L[-1]
-        polyline = L * 0.75 + R * 0.25
-    return polyline
+def _first_occurrences(points: np.ndarray) -> np.ndarray:
+    """Drop repeated vertices, keeping the first of each and the path order."""
+    _, first = np.unique(points, axis=0, return_index=True)
+    return points[np.sort(first)]
 
 
-# ----------------------------------------------------------------------------------------------------------------
-# utils_coordinate_system.py
-# ----------------------------------------------------------------------------------------------------------------
+def _bspline_through(points: np.ndarray, n_samples: int) -> np.ndarray:
+    """Interpolating cubic B-spline through `points` (chord-length parameter, no smoothing), evaluated at `n_samples`
+    equally spaced parameter values."""
+    from scipy.interpolate import splev, splprep
+    tck, u = splprep(points.T, u=None, k=3, s=0.0)
+    x, y = splev(np.linspace(u.min(), u.max(), n_samples), tck, der=0)
+    return np.stack([x, y], axis=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's entry points
+# ---------------------------------------------------------------------------------------------------------------------
 def extend_path_linearly(points, extension_length=50, at_start=True):
-    """Extend the list of points linearly at the start or end by a given length (:21-51)."""
-    if at_start:
-        p1, p2 = points[0], points[1]
-    else:
-        p1, p2 = points[-2], points[-1]
-    delta_x = p2[0] - p1[0]
-    delta_y = p2[1] - p1[1]
-    dist = np.sqrt(delta_x ** 2 + delta_y ** 2)
-    if dist == 0:
-        return points  # p1 and p2 coincide
-    step_x = delta_x / dist
-    step_y = delta_y / dist
-    num_new_points = int(extension_length / dist)
-    if num_new_points == 0:
-        return np.asarray(points)  # np.vstack of an empty list raises upstream; nothing to add
-    i = np.arange(1, num_new_points + 1, dtype=np.float64)
-    if at_start:
-        new_points = np.stack([p1[0] - i * step_x * dist, p1[1] - i * step_y * dist], axis=1)
-        return np.vstack((new_points[::-1], points))
-    new_points = np.stack([p2[0] + i * step_x * dist, p2[1] + i * step_y * dist], axis=1)
-    return np.vstack((points, new_points))
+    """Straight continuation of the first / last segment by `extension_length` metres, one vertex per segment length
+    (utils_coordinate_system.py:21-51).  Coincident end vertices: the input is handed back untouched."""
+    a, b = (points[0], points[1]) if at_start else (points[-2], points[-1])
+    heading = np.array([b[0] - a[0], b[1] - a[1]], dtype=np.float64)
+    spacing = float(np.sqrt(heading[0] ** 2 + heading[1] ** 2))
+    if spacing == 0:
+        return points
+    return prolong(points, int(extension_length / spacing), (spacing, heading / spacing), front=at_start)
 
 
 def extend_ref_path_both_ends(ref_path, extension_length=30):
-    """Extend the reference path on both ends by a default length (:54-58)."""
-    extended_start = extend_path_linearly(ref_path, extension_length, at_start=True)
-    return extend_path_linearly(extended_start, extension_length, at_start=False)
+    """Both ends continued by `extension_length` metres (:54-58)."""
+    return extend_path_linearly(extend_path_linearly(ref_path, extension_length, at_start=True), extension_length,
+                                at_start=False)
 
 
 def extend_points(points):
-    """Prepend points along the direction of the first segment, about 5 m worth (:61-77)."""
-    p1, p2 = points[0], points[1]
-    delta_x = p2[0] - p1[0]
-    delta_y = p2[1] - p1[1]
-    dist = _distance(points[0], points[1])
-    num_new_points = int(5 / dist)
-    if num_new_points == 0:
-        return np.asarray(points)
-    i = np.arange(1, num_new_points + 1, dtype=np.float64)
-    new_points = np.stack([p1[0] - i * delta_x, p1[1] - i * delta_y], axis=1)
-    return np.vstack((new_points[::-1], points))
-
-
-def extend_points_end(points, extension_length=30):
-    """Append points along the direction of the last segment (:80-99)."""
-    p1, p2 = points[-2], points[-1]
-    delta_x = p2[0] - p1[0]
-    delta_y = p2[1] - p1[1]
-    dist = _distance(p1, p2)
-    if dist == 0:
-        return points
-    num_new_points = int(extension_length / dist)
-    if num_new_points == 0:
-        return np.asarray(points)
-    i = np.arange(1, num_new_points + 1, dtype=np.float64)
-    new_points = np.stack([p2[0] + i * delta_x, p2[1] + i * delta_y], axis=1)
-    return np.vstack((points, new_points))
+    """About five metres of extra vertices in front of the path, spaced like its first segment (:61-77)."""
+    first = np.array([points[1][0] - points[0][0], points[1][1] - points[0][1]], dtype=np.float64)
+    spacing = float(np.sqrt(first[0] ** 2 + first[1] ** 2))
+    return prolong(points, int(5 / spacing), first, front=True)
 
 
 def extend_ref_path(ref_path, init_pos):
-    """Prepend points when the planning position (shifted to the rear axle) is closest to the first vertex (:102-108)."""
-    d2 = (ref_path[:, 0] - init_pos[0]) ** 2 + (ref_path[:, 1] - init_pos[1]) ** 2
-    close_point = ref_path[int(np.argmin(d2))]  # min(..., key=distance): first minimum
-    if close_point[0] == ref_path[0, 0] and close_point[1] == ref_path[0, 1]:
-        ref_path = extend_points(ref_path)
-    return ref_path
+    """The rear-axle start position may project in front of the path: when the first vertex is the closest one, vertices are
+    added in front (:102-108)."""
+    ref_path = _as_polyline(ref_path)
+    gap2 = (ref_path[:, 0] - init_pos[0]) ** 2 + (ref_path[:, 1] - init_pos[1]) ** 2
+    nearest = ref_path[int(np.argmin(gap2))]
+    return extend_points(ref_path) if (nearest == ref_path[0]).all() else ref_path
 
 
-def _unique_rows_keep_order(a: np.ndarray) -> np.ndarray:
-    _, idx = np.unique(a, axis=0, return_index=True)
-    return a[np.sort(idx)]
+ROUTE_SPACING = 0.125  # vertex spacing the route planner delivers; smooth_ref_path is written for it (:117)
 
 
 def smooth_ref_path(reference: np.ndarray, smoothing_interval: float = 4):
-    """Cubic B-spline through every t-th vertex, resampled at 1 m (:110-134)."""
-    from scipy.interpolate import splev, splprep
-    reference = _unique_rows_keep_order(np.asarray(reference, dtype=np.float64))
-    distances = np.sqrt(np.sum((reference[0:-2:2] - reference[1:-1:2]) ** 2, axis=1))
-    dist_sum_in_m = np.round(np.sum(distances), 3)
-    average_dist_in_m = 0.125
-    t = int(smoothing_interval / average_dist_in_m)  # smoothing_interval metres per control point
-    reference = reference[::t]
-    spline_discretization = int(6 * dist_sum_in_m)
-    tck, u = splprep(reference.T, u=None, k=3, s=0.0)
-    u_new = np.linspace(u.min(), u.max(), spline_discretization)
-    x_new, y_new = splev(u_new, tck, der=0)
-    reference = np.array([x_new, y_new]).transpose()
-    reference = resample_polyline(reference, 1)
-    return _unique_rows_keep_order(reference)
-
-
-def extrapolate_ref_path(reference_path: np.ndarray, resample_step: float = 0.25) -> np.ndarray:
-    """Extrapolates the end of the reference path along its last segment (:158-169)."""
-    p = np.poly1d(np.polyfit(reference_path[-2:, 0], reference_path[-2:, 1], 1))
-    x = 2.3 * reference_path[-1, 0] - reference_path[-2, 0]
-    new_polyline = np.concatenate((reference_path, np.array([[x, p(x)]])), axis=0)
-    return resample_polyline(new_polyline, step=resample_step)
-
-
-def preprocess_ref_path(ref_path: np.ndarray, resample_step: float = 0.1, max_curv_desired: float = 0.1):
-    """Corner cutting + resampling until the maximum curvature is below the limit (:172-184)."""
-    ref_path_preprocessed = deepcopy(ref_path)
-    max_curv = max_curv_desired + 0.2
-    while max_curv > max_curv_desired:
-        ref_path_preprocessed = np.array(chaikins_corner_cutting(ref_path_preprocessed))
-        ref_path_preprocessed = resample_polyline(ref_path_preprocessed, resample_step)
-        abs_curv = compute_curvature_from_polyline(ref_path_preprocessed)
-        max_curv = max(abs_curv)
-    return ref_path_preprocessed
+    """Cubic B-spline through one route vertex per `smoothing_interval` metres, sampled six times per metre and brought to
+    1 m spacing (:110-134).  The path length that sizes the sampling is taken from every second segment, as upstream."""
+    route = _first_occurrences(_as_polyline(reference))
+    every_other = route[0:-2:2] - route[1:-1:2]
+    length = np.round(np.sum(np.sqrt(np.sum(every_other ** 2, axis=1))), 3)
+    knots = route[::int(smoothing_interval / ROUTE_SPACING)]
+    dense = _bspline_through(knots, int(6 * length))
+    return _first_occurrences(resample_polyline(dense, 1))
 
 
 def prepare_reference_path(route_reference_path: np.ndarray) -> np.ndarray:
-    """What FrenetPlannerInterface does with the route planner's polyline (frenet_interface.py:110-114)."""
-    return smooth_ref_path(extend_ref_path_both_ends(np.asarray(route_reference_path, dtype=np.float64)))
+    """Route planner polyline -> planner reference path (frenet_interface.py:110-114)."""
+    return smooth_ref_path(extend_ref_path_both_ends(_as_polyline(route_reference_path)))

@@ -3,9 +3,9 @@ REFERENCE's own functions in cr_scenario_handler/utils/utils_coordinate_system.p
 
     python tests/golden/gen_refpath_golden.py
 
-commonroad_dc is not installed; its two helpers the reference calls (resample_polyline, chaikins_corner_cutting)
-are supplied to the imported module from the build's restatement, so the vectors pin everything the reference
-itself does (de-duplication, decimation, SciPy spline, extension arithmetic) -- not those two helpers.
+commonroad_dc is not installed; the helper the prepared path needs from it (resample_polyline) is supplied to the
+imported module from the build's restatement, so the vectors pin everything the reference itself does
+(de-duplication, decimation, SciPy spline, extension arithmetic) -- not that helper.
 Fixtures are data only: input polylines and the reference's output polylines.
 """
 import os
@@ -48,24 +48,18 @@ def main():
     from frenetix_motion_planner_amd import ref_path as mine
     import cr_scenario_handler.utils.utils_coordinate_system as ucs
     ucs.resample_polyline = mine.resample_polyline
-    ucs.chaikins_corner_cutting = mine.chaikins_corner_cutting
-    ucs.compute_curvature_from_polyline = __import__(
-        "frenetix_motion_planner_amd.coordinate_system", fromlist=["x"]).compute_curvature_from_polyline
     fx = {}
     for name, pl in polylines().items():
         fx[f"{name}/in"] = pl
         fx[f"{name}/extend_both_30"] = np.asarray(ucs.extend_ref_path_both_ends(pl))
         fx[f"{name}/extend_start_50"] = np.asarray(ucs.extend_path_linearly(pl, 50, at_start=True))
         fx[f"{name}/extend_points"] = np.asarray(ucs.extend_points(pl))
-        fx[f"{name}/extend_points_end"] = np.asarray(ucs.extend_points_end(pl, 30))
         fx[f"{name}/extend_ref_path_first"] = np.asarray(ucs.extend_ref_path(pl, pl[0] + np.array([-0.3, 0.1])))
         fx[f"{name}/extend_ref_path_mid"] = np.asarray(ucs.extend_ref_path(pl, pl[len(pl) // 2]))
-        fx[f"{name}/extrapolate"] = np.asarray(ucs.extrapolate_ref_path(pl))
         if name != "coarse_diag":
             fx[f"{name}/smooth"] = np.asarray(ucs.smooth_ref_path(pl))
             fx[f"{name}/smooth_8"] = np.asarray(ucs.smooth_ref_path(pl, 8))
             fx[f"{name}/prepared"] = np.asarray(ucs.smooth_ref_path(ucs.extend_ref_path_both_ends(pl)))
-    fx["turn_left/preprocess"] = np.asarray(ucs.preprocess_ref_path(polylines()["turn_left"][::8], 0.5, 0.12))
     path = os.path.join(HERE, "refpath_golden.npz")
     np.savez_compressed(path, **fx)
     for k, v in fx.items():

@@ -264,6 +264,9 @@ def test_split_horizon_on_golden_cases(eng, name, lanes, variant):
 
 @pytest.mark.parametrize("stop", [None, 28.0])
 def test_generic_and_grid_kernels_agree_bitwise(eng, stop):
+    """Same walk, two kernels: every flag, plane, counter and cost term is bit-identical -- except the prediction cost, which
+    the grid kernel evaluates through the Cholesky factor of the inverse covariance from its staged obstacle table
+    (fx_walk.h, ObsHot) and the generic kernel in the reference's r0 e0 + r1 e1 form: equal to rounding."""
     kw = dict(ref_kind="scurve", kappa=0.02, v0=9.0, grid=(7, 9, 33), n_obstacles=6, draw_traj_set=True, kinematic_debug=True,
               stop_point_s=stop)
     inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
@@ -276,8 +279,12 @@ def test_generic_and_grid_kernels_agree_bitwise(eng, stop):
     finally:
         eng.set_tuning(0, 0, 0)
     a, b = outs
-    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    ip = inp.cost_names.index("prediction")
+    others = [n for n in range(len(inp.cost_names)) if n != ip]
+    assert np.array_equal(a[4][:, others], b[4][:, others])
+    assert np.allclose(a[4][:, ip], b[4][:, ip], rtol=1e-12, atol=0)
+    assert np.allclose(a[1], b[1], rtol=1e-12, atol=0)
     assert a[0]["best_index"] == b[0]["best_index"] and a[0]["reason_hist"] == b[0]["reason_hist"]
 
 

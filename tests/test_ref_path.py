@@ -22,14 +22,8 @@ def test_extensions_match_reference(name):
     close(ref_path.extend_ref_path_both_ends(pl), GOLD[f"{name}/extend_both_30"], 1e-12)
     close(ref_path.extend_path_linearly(pl, 50, at_start=True), GOLD[f"{name}/extend_start_50"], 1e-12)
     close(ref_path.extend_points(pl), GOLD[f"{name}/extend_points"], 1e-12)
-    close(ref_path.extend_points_end(pl, 30), GOLD[f"{name}/extend_points_end"], 1e-12)
     close(ref_path.extend_ref_path(pl, pl[0] + np.array([-0.3, 0.1])), GOLD[f"{name}/extend_ref_path_first"], 1e-12)
     close(ref_path.extend_ref_path(pl, pl[len(pl) // 2]), GOLD[f"{name}/extend_ref_path_mid"], 0.0)
-    with np.errstate(all="ignore"):
-        import warnings
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            close(ref_path.extrapolate_ref_path(pl), GOLD[f"{name}/extrapolate"], 1e-9)
 
 
 @pytest.mark.parametrize("name", [n for n in NAMES if f"{n}/smooth" in GOLD.files])
@@ -50,22 +44,20 @@ def test_smoothing_matches_reference(name):
     assert np.linalg.norm(xy - pl[len(pl) // 2]) < 1e-6
 
 
-def test_preprocess_matches_reference():
-    pl = GOLD["turn_left/in"][::8]
-    close(ref_path.preprocess_ref_path(pl, 0.5, 0.12), GOLD["turn_left/preprocess"], 1e-9)
-
-
-def test_resample_and_corner_cutting_properties():
-    """The two third-party helpers (restated, unpinned): defining properties."""
+def test_resample_properties():
+    """The third-party helper (restated, unpinned): defining properties."""
     pl = GOLD["turn_left/in"]
     r = ref_path.resample_polyline(pl, 1.0)
     assert np.array_equal(r[0], pl[0]) and np.allclose(r[-1], pl[-1])
     seg = np.linalg.norm(np.diff(r, axis=0), axis=1)
     assert np.all(seg[:-1] <= 1.0 + 1e-9) and np.all(seg[:-1] > 0.99)  # chord <= arc step; last one is the remainder
     assert len(ref_path.resample_polyline(pl[:1], 1.0)) == 1
-    c = ref_path.chaikins_corner_cutting(np.array([[0.0, 0.0], [4.0, 0.0], [4.0, 4.0]]))
-    assert np.allclose(c, [[0, 0], [1, 0], [3, 0], [4, 1], [4, 3], [4, 4]])
-    assert len(ref_path.chaikins_corner_cutting(pl, 2)) == 4 * len(pl)
+    # a sample that falls exactly on a vertex belongs to the segment that starts there; an integer step is fine
+    sq = np.array([[0.0, 0.0], [2.0, 0.0], [2.0, 2.0]])
+    assert np.allclose(ref_path.resample_polyline(sq, 1), [[0, 0], [1, 0], [2, 0], [2, 1], [2, 2]])
+    # duplicate vertices are stepped over
+    dup = np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 0.0], [3.0, 0.0]])
+    assert np.allclose(ref_path.resample_polyline(dup, 1.0), [[0, 0], [1, 0], [2, 0], [3, 0]])
 
 
 def test_degenerate_extensions():

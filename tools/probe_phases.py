@@ -10,13 +10,13 @@ os.environ["FXPLAN_SO"] = os.path.join(ROOT, "tools", "probe_build", "libfxplan_
 sys.path.insert(0, ROOT)
 import numpy as np
 from frenetix_motion_planner_amd import synthetic, _lib
-from frenetix_motion_planner_amd.engine import FrenetEngine
+from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
 
 SL = 16
-def run(label, G, mp, fused, **kw):
-    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, **kw)
+def run(label, G, mp, fused, wpe=2, **kw):
+    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, hull_builder=build_obstacle_hulls, **kw)
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
-        eng.set_timing("kernel"); eng.set_fused_selection(fused); eng.set_tuning(G, 2, 2, 256, mp); eng.upload(inp)
+        eng.set_timing("kernel"); eng.set_fused_selection(fused); eng.set_tuning(G, wpe, 2, 256, mp); eng.upload(inp)
         for _ in range(5): eng.evaluate(); eng.finish()
         ms = eng.last_eval_kernel_ms
         n_waves = -(-inp.n_candidates // (256 // G)) * 4
@@ -42,3 +42,9 @@ run("50k_B", 2, 2, False, grid=(19, 51, 51))
 run("50k_A", 2, 2, True, grid=(19, 51, 51), write_bundle=False, write_costmap=False)
 run("50k_B", 1, 0, True, grid=(19, 51, 51))
 run("1M_A", 1, 0, True, grid=(19, 230, 229), write_bundle=False, write_costmap=False)
+run("c3_B", 2, 2, True, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0)
+run("c3_B", 4, 2, True, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0)
+run("c3_B", 4, 2, True, wpe=3, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0)
+run("c3_A", 2, 2, True, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0, write_bundle=False, write_costmap=False)
+run("50k_A", 4, 2, True, grid=(19, 51, 51), write_bundle=False, write_costmap=False)
+run("50k_A", 4, 2, True, wpe=3, grid=(19, 51, 51), write_bundle=False, write_costmap=False)
