@@ -512,7 +512,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         // with the obstacle stage the walk needs ~220 VGPRs: three waves per SIMD (168 VGPRs, few spills) is the best
         // trade at scale, four spill inside the obstacle loop (tools/obst_sweep.py)
         bool obst_any = false;
-        for (int a = 0; a < n_agents; a++) obst_any |= probs[a].K > 0;
+        for (int a = 0; a < n_agents; a++) obst_any |= probs[a].K > 0 || ((probs[a].mode & FX_MODE_ROAD_BOUNDARY) && probs[a].n_bound > 0);
         // a materialised bundle makes the walk store-bound: more resident waves only add spills (1 M candidates, Mode B:
         // 651 us at 2 waves per SIMD, 697 us at 4 -- tools/sweep_1m_modeB.py)
         bool bundle_any = false;
@@ -536,7 +536,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                     const FxProblem *p = &probs[a];
                     const size_t n_pairs = (size_t)(blk / G + p->nD - 2) / p->nD + 1;
                     const size_t S = (size_t)p->N + 1;
-                    need = std::max(need, sizeof(double) * (((5 * S + 1) & ~(size_t)1) + (((size_t)p->M + 1) & ~(size_t)1)) +
+                    need = std::max(need, sizeof(double) * (FX_TP * S + (((size_t)p->M + 1) & ~(size_t)1)) +
                                               128 * n_pairs * S +
                                               (G > 1 ? (size_t)64 * blk : 0));  // + wave-split exchange block (5 f64 + 5 u32 per slot)
                 }
@@ -544,14 +544,15 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                 return need + (size_t)(blk / 64) * hot_block;
             };
             const int want_waves = 4 * c->wpe_step;
-            const size_t lds_cap = (160 * 1024) / 2 - 512;  // two workgroups per CU (static LDS of the kernels: 256 B)
+            const size_t lds_static = 256;  // static LDS of the kernels (reductions)
+            const size_t lds_cap = (160 * 1024) / 2 - 2 * lds_static;  // two workgroups per CU
             block = 0;
             int best_waves = 0;
             const int order_big[3] = {256, 128, 64}, order_small[3] = {128, 256, 64};
             for (int bi = 0; bi < 3; bi++) {
                 const int blk = (G == 8 ? order_small : order_big)[bi];
                 const size_t need = lds_for(blk);
-                const int by_lds = (int)((160 * 1024) / (need + 256));
+                const int by_lds = (int)((160 * 1024) / (need + lds_static));
                 const int waves = by_lds * (blk / 64);
                 if (waves >= want_waves && need <= lds_cap) { block = blk; lds_need = need; break; }
                 // nothing reaches the target (few lateral samples per pair -> many rows): keep the workgroup size that
@@ -565,6 +566,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         if (c->variant_force == 1) grid_ok = false;
         if (c->variant_force == 2 && !grid_ok) return set_err(FX_ERR_INVALID_ARGUMENT, "grid kernel forced but not applicable (G=%d block=%d rows+tables need %zu B of LDS per workgroup)", G, block, lds_need);
         c->use_grid = grid_ok;
+        if (const char *pad = getenv("FX_LDS_PAD")) lds_need = std::max(lds_need, (size_t)atol(pad));  // experiments: occupancy cap through LDS
         c->lds_step = lds_need;
         c->block_step = grid_ok ? block : FX_BLOCK;
         // wave split needs whole waves per part (CPB % 64 == 0) and G in {2, 4}
@@ -596,7 +598,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         if (p->M > c->max_knots) return set_err(FX_ERR_CAPACITY, "M=%d reference knots exceed capacity %d", p->M, c->max_knots);
         if (p->K > c->max_obs || (p->K > 0 && p->P > c->max_pred))
             return set_err(FX_ERR_CAPACITY, "obstacles K=%d P=%d exceed capacity %d x %d", p->K, p->P, c->max_obs, c->max_pred);
-        if (((size_t)p->M * FX_REF_FIELDS + 5 * (size_t)S) * sizeof(double) > 160 * 1024 - 1024)
+        if (((size_t)p->M * FX_REF_FIELDS + FX_TP * (size_t)S) * sizeof(double) > 160 * 1024 - 1024)
             return set_err(FX_ERR_CAPACITY, "reference with %d knots does not fit the 160 KiB LDS", p->M);
         const int64_t ld = (int64_t)align_up((size_t)std::max<int64_t>(C, 1), 64);
         if (cand_off + ld > c->total_ld) return set_err(FX_ERR_CAPACITY, "candidates exceed context capacity %lld", (long long)c->max_cand);
@@ -807,7 +809,7 @@ int32_t fx_evaluate(FxContext *c) {
                                         c->any_bundle, c->any_obst, c->wpe_step, c->wsplit_step, k0, k1, fuse, c->stream));
         else
             HIP_TRY(fx_launch_eval(c->d_probs, c->n_agents, c->max_blocks_step,
-                                   sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + 5 * (size_t)c->S_max_step),
+                                   sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + FX_TP * (size_t)c->S_max_step),
                                    c->G_step, c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, k0, k1, fuse, c->stream));
     }
     if (timed && !attached) HIP_TRY(hipEventRecord(ts->e_eval, c->stream));

@@ -12,6 +12,7 @@
 #define FX_MODE_INT_STORE_WT (1u << 30)  // internal DevProblem.mode bit: write-through plane stores (fx_set_store_mode)
 #define FX_HOT_STRIDE 10        // doubles per (step, obstacle) entry of the hot obstacle table (80 B)
 #define FX_HOT_PRE 4            // table elements per lane prefetched one step ahead (covers K <= 25 obstacles)
+#define FX_TP 12                // doubles per step of the time table in LDS: t .. t^5, then 2t, 3t^2, 4t^3, 5t^4, 6t, 12t^2, 20t^3
 #define FX_REF_FIELDS 8         // per knot: pos, theta, curv, curv_d, x, y, nx, ny  (64 B, AoS in LDS)
 #define FX_MAX_SAMPLES 128      // N+1 <= 128
 
@@ -176,7 +177,6 @@ enum {
 // The device-side counters[] slot FX_CNT_BEST_IDX is free (the winner only exists in the published block): the
 // evaluation kernel's workgroups take completion tickets from it when the selection is fused into the kernel.
 #define FX_DCNT_TICKET FX_CNT_BEST_IDX
-
 // Fused selection (no agent asks for the collision stage): the LAST workgroup of an agent to finish reduces the
 // per-workgroup partials and publishes the step's result block, so the step is one launch.  host_result == nullptr:
 // a separate fx_select_kernel follows.

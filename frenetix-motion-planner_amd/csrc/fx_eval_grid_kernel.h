@@ -75,14 +75,14 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     const int it = (int)(pair / nV), iv = (int)(pair - (int64_t)it * nV);
     const double T = as_global(P.t_samp)[it], v1 = as_global(P.v_samp)[iv], d1 = as_global(P.d_samp)[id];
     // ---- phase 1: one round of global loads -- time powers, knot arc lengths, cost ids / weights -> LDS ----
-    double *__restrict__ tpw = lds_dyn;                                // [5][S]
-    double *__restrict__ rpos = lds_dyn + ((5 * S + 1) & ~1);          // [M] arc length of the knots (binary search)
+    double *__restrict__ tpw = lds_dyn;                                // [S][FX_TP] time table
+    double *__restrict__ rpos = lds_dyn + FX_TP * S;                   // [M] arc length of the knots (binary search)
     LonRow *__restrict__ rows = reinterpret_cast<LonRow *>(rpos + ((M + 1) & ~1));  // 16-byte aligned
     // the knots themselves are only touched once per (pair, step) item: read them through L1/L2
     const FX_GLOBAL double *__restrict__ kn = as_global(P.ref);
     {
         const FX_GLOBAL double *__restrict__ tsrc = as_global(P.tpow);
-        for (int i = tid; i < 5 * S; i += BLK) tpw[i] = tsrc[i];
+        for (int i = tid; i < S; i += BLK) fill_time_row(tpw + i * FX_TP, tsrc[i], tsrc[S + i], tsrc[2 * S + i], tsrc[3 * S + i], tsrc[4 * S + i]);
         for (int i = tid; i < M; i += BLK) rpos[i] = kn[(int64_t)i * FX_REF_FIELDS];
         if (tid < P.n_cost) { sh_cost_id[tid] = Pg.cost_id[tid]; sh_cost_w[tid] = Pg.cost_w[tid]; }
     }
@@ -165,10 +165,10 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     }
 
     auto lat_eval = [&](int i, double u_lowvel, double &d, double &dv, double &da) {
-        double u1, u2, u3, u4, u5;
-        if (low_vel) { u1 = u_lowvel; u2 = u1 * u1; u3 = u2 * u1; u4 = u2 * u2; u5 = u4 * u1; }
-        else { u1 = tp[i]; u2 = tp[S + i]; u3 = tp[2 * S + i]; u4 = tp[3 * S + i]; u5 = tp[4 * S + i]; }
-        L.eval(u1, u2, u3, u4, u5, d, dv, da);
+        LatU U;
+        if (low_vel) U.from_parameter(u_lowvel);
+        else U.from_table(tp + i * FX_TP);
+        L.eval(U, d, dv, da);
     };
     // lateral value the extension holds: d[traj_len-1] (reactive_planner.py:344)
     double d_ext, dv_u, da_u;

@@ -482,7 +482,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
 
 // ---------------------------------------------------------------------------------------------------
 // Generic kernel: arbitrary sampling-matrix rows (or ranges), every lane derives its own longitudinal row.
-// grid = (ceil(maxC / (256/G)), n_agents), block = 256, dynamic LDS = M*64 B + 5*S*8 B.
+// grid = (ceil(maxC / (256/G)), n_agents), block = 256, dynamic LDS = M*64 B + FX_TP*S*8 B.
 //   G      : lanes per candidate (1, 2, 4, 8)
 //   BUNDLE : write the 14-plane SoA TrajectoryBundle + coefficients (FX_MODE_WRITE_BUNDLE)
 //   OBST   : obstacles present (prediction cost and/or collision stage)
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     using namespace fxk;
     static_assert(!EXTRA || G == 1, "windowed costs need the whole horizon in one lane");
     constexpr int CPB = FX_BLOCK / G;  // candidates per workgroup
-    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];  // [M][8] knots, then [5][S] time powers
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];  // [M][8] knots, then the [S][FX_TP] time table
     __shared__ double red_cost[FX_BLOCK / 64];
     __shared__ long long red_idx[FX_BLOCK / 64];
     __shared__ unsigned int red_cnt[2 + FX_NUM_REASONS + 1];  // counters, then the last-workgroup flag
@@ -517,7 +517,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
         const FX_GLOBAL double *__restrict__ src = as_global(P.ref);
         for (int i = tid; i < M * FX_REF_FIELDS; i += FX_BLOCK) lds_dyn[i] = src[i];
         const FX_GLOBAL double *__restrict__ tsrc = as_global(P.tpow);
-        for (int i = tid; i < 5 * S; i += FX_BLOCK) lds_dyn[M * FX_REF_FIELDS + i] = tsrc[i];
+        for (int i = tid; i < S; i += FX_BLOCK)
+            fill_time_row(lds_dyn + M * FX_REF_FIELDS + i * FX_TP, tsrc[i], tsrc[S + i], tsrc[2 * S + i], tsrc[3 * S + i], tsrc[4 * S + i]);
         if (tid < P.n_cost) { sh_cost_id[tid] = Pg.cost_id[tid]; sh_cost_w[tid] = Pg.cost_w[tid]; }
     }
     if (tid < 2 + FX_NUM_REASONS) red_cnt[tid] = 0;
@@ -597,10 +598,10 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
                             want_trig, [&](int k) { return knots[k]; }, [&](int k) { return knots[k].pos; });
     };
     auto lat_eval = [&](int i, double u_lowvel, double &d, double &dv, double &da) {
-        double u1, u2, u3, u4, u5;
-        if (low_vel) { u1 = u_lowvel; u2 = u1 * u1; u3 = u2 * u1; u4 = u2 * u2; u5 = u4 * u1; }
-        else { u1 = tp[i]; u2 = tp[S + i]; u3 = tp[2 * S + i]; u4 = tp[3 * S + i]; u5 = tp[4 * S + i]; }
-        L.eval(u1, u2, u3, u4, u5, d, dv, da);
+        LatU U;
+        if (low_vel) U.from_parameter(u_lowvel);
+        else U.from_table(tp + i * FX_TP);
+        L.eval(U, d, dv, da);
     };
     // lateral value the extension holds: d[traj_len-1] (reactive_planner.py:344)
     double d_ext, dv_u, da_u;

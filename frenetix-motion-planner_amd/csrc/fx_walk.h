@@ -66,6 +66,15 @@ __device__ __forceinline__ double fx_min(double a, double b) {
     return r;
 }
 
+// 1 if the predicate holds in any lane of the wave, as a value in a scalar register (a wave-uniform bool is a lane mask to
+// the compiler and gets widened to 0 / 1 per lane with vector instructions; this keeps bit bookkeeping on the scalar unit)
+__device__ __forceinline__ unsigned wave_any_bit(bool p) {
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(p);
+    unsigned r;
+    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(b) : "scc");
+    return r;
+}
+
 // n / d with one residual correction on the quotient (correctly rounded for the operands of this kernel)
 __device__ __forceinline__ double fdiv(double n, double d) {
     const double r = rcp_nr(d);
@@ -120,7 +129,8 @@ __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, d
                                                double cl3, double cl4, double cl5, int traj_len, const double *tp, double rp_first,
                                                double rp_last, double guess_scale, bool want_trig, KnotFn knot, PosFn kpos) {
     const int ie = i < traj_len ? i : traj_len - 1;  // sample that is evaluated (the last one feeds the extension)
-    const double t1 = tp[ie], t2 = tp[S + ie], t3 = tp[2 * S + ie], t4 = tp[3 * S + ie], t5 = tp[4 * S + ie];
+    const double *te = tp + ie * FX_TP;
+    const double t1 = te[0], t2 = te[1], t3 = te[2], t4 = te[3], t5 = te[4];
     // calc_position / calc_velocity / calc_acceleration (polynomial_trajectory.py:241-273); c5 = 0 for the quartic
     double s_i = cl0 + cl1 * t1 + cl2 * t2 + cl3 * t3 + cl4 * t4 + cl5 * t5;
     double sv_i = cl1 + 2. * cl2 * t1 + 3. * cl3 * t2 + 4. * cl4 * t3 + 5. * cl5 * t4;
@@ -193,22 +203,37 @@ __device__ __forceinline__ double heading_of_moving_step(const LonRow &r, double
     return fxm::atan(dp) + r.th_ref;
 }
 
-// lateral quintic with the derivative coefficients pre-multiplied: (2.*c2)*t etc. are the reference's own
-// products (polynomial_trajectory.py:251-257), the sums are fused left to right
+// Time table row of step i in LDS (FX_TP doubles): the powers t .. t^5 and the derivative factors 2t, 3t^2, 4t^3, 5t^4,
+// 6t, 12t^2, 20t^3.  The factors of the reference's velocity / acceleration polynomials (2. * c2 * t, 3. * c3 * t2, ...,
+// polynomial_trajectory.py:251-257) ride on the wave-uniform powers instead of on eight more per-lane coefficients.
+struct LatU {
+    double u1, u2, u3, u4, u5, w2, w3, w4, w5, z3, z4, z5;
+    __device__ __forceinline__ void from_table(const double *row) {
+        u1 = row[0]; u2 = row[1]; u3 = row[2]; u4 = row[3]; u5 = row[4];
+        w2 = row[5]; w3 = row[6]; w4 = row[7]; w5 = row[8]; z3 = row[9]; z4 = row[10]; z5 = row[11];
+    }
+    __device__ __forceinline__ void from_parameter(double u) {  // LOW_VEL_MODE: the lateral parameter is the arc length s - s0
+        u1 = u; u2 = u1 * u1; u3 = u2 * u1; u4 = u2 * u2; u5 = u4 * u1;
+        w2 = 2. * u1; w3 = 3. * u2; w4 = 4. * u3; w5 = 5. * u4; z3 = 6 * u1; z4 = 12 * u2; z5 = 20 * u3;
+    }
+};
+__device__ __forceinline__ void fill_time_row(double *row, double t1, double t2, double t3, double t4, double t5) {
+    row[0] = t1; row[1] = t2; row[2] = t3; row[3] = t4; row[4] = t5;
+    row[5] = 2. * t1; row[6] = 3. * t2; row[7] = 4. * t3; row[8] = 5. * t4; row[9] = 6 * t1; row[10] = 12 * t2; row[11] = 20 * t3;
+}
+
+// lateral quintic: position, velocity and acceleration by fused sums left to right
 struct LatPoly {
     double c0, c1, c2, c3, c4, c5;
-    double v2, v3, v4, v5;      // 2 c2, 3 c3, 4 c4, 5 c5
-    double a2, a3, a4, a5;      // 2 c2, 6 c3, 12 c4, 20 c5
+    double a2;                  // 2 c2
     __device__ __forceinline__ void set(double k0, double k1, double k2, double k3, double k4, double k5) {
         c0 = k0; c1 = k1; c2 = k2; c3 = k3; c4 = k4; c5 = k5;
-        v2 = 2. * k2; v3 = 3. * k3; v4 = 4. * k4; v5 = 5. * k5;
-        a2 = 2 * k2; a3 = 6 * k3; a4 = 12 * k4; a5 = 20 * k5;
+        a2 = 2 * k2;
     }
-    __device__ __forceinline__ void eval(double u1, double u2, double u3, double u4, double u5, double &d, double &dv,
-                                         double &da) const {
-        d = fma(c5, u5, fma(c4, u4, fma(c3, u3, fma(c2, u2, fma(c1, u1, c0)))));
-        dv = fma(v5, u4, fma(v4, u3, fma(v3, u2, fma(v2, u1, c1))));
-        da = fma(a5, u3, fma(a4, u2, fma(a3, u1, a2)));
+    __device__ __forceinline__ void eval(const LatU &U, double &d, double &dv, double &da) const {
+        d = fma(c5, U.u5, fma(c4, U.u4, fma(c3, U.u3, fma(c2, U.u2, fma(c1, U.u1, c0)))));
+        dv = fma(c5, U.w5, fma(c4, U.w4, fma(c3, U.w3, fma(c2, U.w2, c1))));
+        da = fma(c5, U.z5, fma(c4, U.z4, fma(c3, U.z3, a2)));
     }
 };
 
@@ -347,10 +372,10 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
     // -- lateral polynomial (reactive_planner.py:326-346) --
     double d_i, dv_i, da_i;
     if (i < traj_len) {
-        double u1, u2, u3, u4, u5;
-        if (K.low_vel) { u1 = r.u1; u2 = u1 * u1; u3 = u2 * u1; u4 = u2 * u2; u5 = u4 * u1; }
-        else { u1 = tp[i]; u2 = tp[S + i]; u3 = tp[2 * S + i]; u4 = tp[3 * S + i]; u5 = tp[4 * S + i]; }
-        L.eval(u1, u2, u3, u4, u5, d_i, dv_i, da_i);
+        LatU U;
+        if (K.low_vel) U.from_parameter(r.u1);
+        else U.from_table(tp + i * FX_TP);
+        L.eval(U, d_i, dv_i, da_i);
     } else {
         d_i = d_ext; dv_i = 0.0; da_i = 0.0;
     }
@@ -555,7 +580,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                 };
                 // obstacles some lane of the wave is near (wave-uniform mask): one compare and a few scalar operations per visit
                 unsigned long long nm = 0ULL;
-                auto mark = [&](double g, int k) { nm |= (__any(!(g > K.gap_margin)) ? 1ULL : 0ULL) << k; };
+                auto mark = [&](double g, int k) { nm |= (unsigned long long)wave_any_bit(!(g > K.gap_margin)) << k; };
                 if (hm == full) {
                     fx_d2 ha, ra, hb, rb, hc, rc, hd, rd;
                     int k = 0;
