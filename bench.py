@@ -3,32 +3,44 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): single agent, dense grid 19 x 51 x 52 = 50 388 candidates x 31 samples
-(30-step horizon), no obstacles, constant-curvature reference with 400 knots, default cost weights,
-materialised SoA TrajectoryBundle ("Mode B": every candidate's 14 planes written to HBM, as the reference's
-default `draw_traj_set` configuration keeps them).  `--workload config3` adds 20 predicted obstacles
-(prediction cost + OBB collision stage); `--select-only` drops the bundle ("Mode A").
+Default workload (BASELINE.json configs[2], the largest single-GPU configuration): single agent, dense grid 19 x 51 x 52 =
+50 388 candidates x 31 samples (30-step horizon), 20 predicted obstacles (obstacle 0 a slow lead vehicle so that the cheapest
+candidates collide): prediction cost + OBB collision stage, constant-curvature reference with 400 knots, default cost
+weights, SoA TrajectoryBundle materialised ("Mode B": every candidate's 14 planes written to HBM, as the reference's default
+`draw_traj_set` configuration keeps them).  `--workload config2` drops the obstacles; `--select-only` drops the bundle
+("Mode A").
 
-A step = one plan step of the hot path with the inputs already resident in HBM: evaluation kernel + selection
-kernel + (N > 1) top-k kernel and ONE RCCL all-gather of the per-GPU survivors, finished on the host (the
-winner is in host memory when the step ends).  For N > 1 the global grid is N x 50 388 candidates (the
-velocity range is sampled N times denser) and each rank evaluates a contiguous shard: weak scaling.
+A step = one plan step of the hot path: evaluation kernel + selection kernel + (N > 1) ONE RCCL all-gather of the per-GPU
+survivors, finished on the host (the winner is in host memory when the step ends).  The contract's timed region -- `value`,
+`ms_per_step` -- runs K such steps with the inputs resident in HBM.  A second region of K steps feeds every step a NEW ego
+state and NEW predictions from host buffers (fx_update_step: tables re-packed into the pinned staging block, one host-to-device
+copy, evaluation, result): `plan_step_p50_ms` / `value_with_upload` are that PCIe-inclusive plan step.  For N > 1 the global
+grid is N x 50 388 candidates (the velocity range is sampled N times denser) and each rank evaluates a contiguous shard:
+weak scaling.
 
-Other workloads (parity-test configurations of BASELINE.json, measured on request -- the default line stays config 2):
+In the same run, same JSON line (`north_star`): the target workload of BASELINE.json -- 1 005 100 candidates x 31 samples x
+20 obstacles, select-only (FP64-issue-bound: executed-work roofline) and 1 005 100 x 31 with the 3.49 GB bundle materialised
+(HBM-bound).
+
+`python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run on 127.0.0.1) before anything
+touches the GPU and relays rank 0's line.
+
+Other workloads (parity-test configurations of BASELINE.json, measured on request):
   --workload config1   the ego of ZAM_Tjunction-1_42_T-1, default sampling (630 candidates), 5 predicted obstacles;
   --workload config5   "synthetic stress": `--agents-per-gpu` (default 32 = 256 agents / 8 GPUs) agents per GPU x
                        39 x 51 x 52 = 103 428 candidates x 51 samples (5 s horizon), 20 predicted obstacles per agent,
                        select-only, one batched launch per step, per-agent top-32 survivors all-gathered (agent sharding:
                        N GPUs carry N x 32 agents -- weak scaling);
-  --workload config4   multi-agent ZAM_Tjunction closed loop (5 agents, sampling level 4 = 11 220 candidates per agent,
-                       materialised bundle, collision stage against the other agents' plans): a step = one simulation
-                       step of every agent (host glue + one batched launch when the agents replan).
+  --workload config4   multi-agent ZAM_Tjunction closed loop (5 agents, dense 19 x 23 x 23(+1) grid per agent, materialised
+                       bundle, collision stage against the other agents' plans): a step = one simulation step of every agent.
 
 Prints ONE JSON line (rank 0).  `value` = candidates evaluated by all ranks / wall time of the K timed steps.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,14 +52,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 BYTES_PER_CAND_MODE_A = 40     # 3 x 8 B read + 8 B cost + 4 B flags + 4 B index
 GRID = (19, 51, 51)            # n_t, n_v, n_d (+ d0) -> 50 388
+NORTH_STAR_GRID = (19, 230, 229)  # 19 x 230 x 230 (d0 added) = 1 005 100 candidates
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: FP64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
-LEAD_GAP = 25.0                # config 3: obstacle 0 is a slow lead vehicle 25 m ahead (the cheapest candidates collide)
+LEAD_GAP = 25.0                # obstacle 0 is a slow lead vehicle 25 m ahead (the cheapest candidates collide)
 STRESS_GRID = (39, 51, 51)     # config 5: T = 1.1 .. 4.9 (39) x 51 x 51 (+ d0), 5 s horizon
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r2", "summary.json")  # rocprofv3 summaries of these commands (tools/collect_profiles_r2.sh)
+UPSTREAM_NOTE = "upstream OpenMP C++ handler (frenetix 0.4.0): not run -- not installable offline, not in the reference tree"
 
 
 def algorithmic_flops_per_candidate(n_samples, n_obstacles):
-    """~5.5 kflop per candidate at 31 samples without obstacles (~177 flop per step) plus ~100 flop per
-    (obstacle, step) for the prediction cost and the OBB test (65 kflop at K = 20, N = 30)."""
+    """SURVEY.md 8(d) planning figure: ~5.5 kflop per candidate at 31 samples without obstacles (~177 flop per step) plus
+    ~100 flop per (obstacle, step).  Only used where no executed-work count is available (config 5)."""
     return 177.0 * n_samples + 100.0 * n_obstacles * (n_samples - 1)
 
 
@@ -55,13 +70,45 @@ def bundle_bytes_per_candidate(n_samples):
     return 14 * n_samples * 8  # 3 472 B at 31 samples
 
 
-def make_workload(args, world):
+def profile_summary():
+    try:
+        return json.load(open(PROFILE_SUMMARY))
+    except (OSError, ValueError):
+        return {}
+
+
+def executed_fp64_flops(section):
+    """FP64 flops one launch EXECUTES, from the tracked PMC summary of the same workload: 64 lanes x (ADD + MUL + 2 FMA +
+    transcendental) wave-instructions (SQ_INSTS_VALU_*_F64; an upper bound in that partially masked instructions count
+    whole).  None when the summary has no such section."""
+    pmc = profile_summary().get(section, {}).get("pmc_per_launch_mean", {})
+    try:
+        return 64.0 * (pmc["SQ_INSTS_VALU_ADD_F64"] + pmc["SQ_INSTS_VALU_MUL_F64"] + 2.0 * pmc["SQ_INSTS_VALU_FMA_F64"] +
+                       pmc["SQ_INSTS_VALU_TRANS_F64"])
+    except KeyError:
+        return None
+
+
+def pmc_traffic(section):
+    """HBM bytes per launch from the tracked PMC passes (separate --pmc runs): WRITE_SIZE [KiB] x 1024 + FETCH_SIZE [KiB] x
+    1024 x 2 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half of the bytes read)."""
+    pmc = profile_summary().get(section, {}).get("pmc_per_launch_mean", {})
+    try:
+        return pmc["WRITE_SIZE"] * 1024.0 + 2.0 * pmc["FETCH_SIZE"] * 1024.0
+    except KeyError:
+        return None
+
+
+def make_workload(args, world, grid=GRID, n_obst=None, select_only=None):
     from frenetix_motion_planner_amd import synthetic
     from frenetix_motion_planner_amd.engine import build_obstacle_hulls
-    n_obst = 20 if args.workload == "config3" else 0
-    grid = (GRID[0], GRID[1] * world, GRID[2])
+    if n_obst is None:
+        n_obst = 20 if args.workload == "config3" else 0
+    if select_only is None:
+        select_only = args.select_only
+    grid = (grid[0], grid[1] * world, grid[2])
     return synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=grid, n_obstacles=n_obst, n_pred=30, lead_gap=LEAD_GAP,
-                                 write_bundle=not args.select_only, write_costmap=not args.select_only,
+                                 write_bundle=not select_only, write_costmap=not select_only,
                                  draw_traj_set=False, kinematic_debug=False,
                                  hull_builder=build_obstacle_hulls if n_obst else None)
 
@@ -123,7 +170,7 @@ def cpu_baseline_of(inp, what):
     one, reps1, dt1 = _time_oracle(inp, 5.0, 1)
     out = {"value": one, "unit": "trajectories/s", "cores": 1, "kind": "port",
            "sample": f"{reps1} whole plan steps of {what} in {dt1:.1f} s, oracle/fx_oracle.c single thread",
-           "cpu": _cpu_model(), "host_cores": os.cpu_count()}
+           "cpu": _cpu_model(), "host_cores": os.cpu_count(), "upstream_handler": UPSTREAM_NOTE}
     if threads > 1:
         many, repsN, dtN = _time_oracle(inp, 8.0, threads)
         out.update({"value": many, "cores": threads, "single_thread_value": one,
@@ -140,22 +187,7 @@ def cpu_baseline(args):
     n_obst = 20 if args.workload == "config3" else 0
     inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=GRID, n_obstacles=n_obst, n_pred=30, lead_gap=LEAD_GAP,
                                 hull_builder=oracle.build_obstacle_hulls if n_obst else None)
-    return cpu_baseline_of(inp, f"the same workload ({inp.n_candidates} candidates x {inp.n_samples} samples)")
-
-
-def pmc_traffic(args, world):
-    """HBM bytes per launch of the evaluation kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r1/s2_config2_modeB_rocprof_summary.json; tools/collect_profiles.sh): WRITE_SIZE [KiB] x 1024 +
-    FETCH_SIZE [KiB] x 1024 x 2 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half of the bytes read).  PMC
-    counters cannot be collected from inside the timed run, so other workloads report null."""
-    if args.workload != "config2" or args.select_only or world != 1:
-        return None, None
-    path = os.path.join(ROOT, "profiles", "r1", "s2_config2_modeB_rocprof_summary.json")
-    try:
-        pmc = json.load(open(path))["pmc_per_launch_mean"]
-        return pmc["WRITE_SIZE"] * 1024.0 + 2.0 * pmc["FETCH_SIZE"] * 1024.0, os.path.relpath(path, ROOT)
-    except (OSError, KeyError, ValueError):
-        return None, None
+    return cpu_baseline_of(inp, f"the same workload ({inp.n_candidates} candidates x {inp.n_samples} samples, {n_obst} obstacles)")
 
 
 def _cpu_model():
@@ -168,32 +200,152 @@ def _cpu_model():
     return "unknown"
 
 
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, torch.distributed.run on
+    127.0.0.1) BEFORE this process touches the GPU, relay their output, return their exit code.  (A process that has
+    initialised the GPU must not be replaced by exec on this platform; a child process is always safe.)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(args, world, rank):
+    """CPU-only check of the launch path: the ranks rendezvous over gloo, agree on the world size, rank 0 prints a line."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        t = torch.tensor([1.0])
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"metric": "dry launch", "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup}))
+    return 0
+
+
+def perturbed_updates(eng, inp, n):
+    """n plan-step updates around the workload's state: the ego a little further along the reference each time (new x_cl,
+    new sampling values for the end velocities) and every predicted obstacle shifted along its track -- what a planner
+    hands over from one step to the next.  Pre-built so that the timed loop measures the library, not NumPy."""
+    from frenetix_motion_planner_amd.engine import build_obstacle_hulls
+    from frenetix_motion_planner_amd.problem import pack_predictions
+    ups = []
+    for j in range(n):
+        x0_lon = np.array(inp.x0_lon) + np.array([0.05 * (j + 1), 0.01 * ((j % 3) - 1), 0.0])
+        x0_lat = np.array(inp.x0_lat) + np.array([0.01 * ((j % 5) - 2), 0.0, 0.0])
+        obstacles = None
+        if inp.obstacles["K"] > 0 and getattr(inp, "predictions", None):
+            preds = {}
+            for k, pr in inp.predictions.items():
+                q = dict(pr)
+                step = np.array([np.cos(pr["orientation_list"][0]), np.sin(pr["orientation_list"][0])]) * 0.02 * (j + 1)
+                q["pos_list"] = np.asarray(pr["pos_list"]) + step[None, :]
+                preds[k] = q
+            obstacles = pack_predictions(preds, inp.n_samples, build_obstacle_hulls)
+        ups.append(eng.make_state_update(x0_lon=x0_lon, x0_lat=x0_lat, x0_orientation=inp.x0_orientation, v_des=inp.v_des,
+                                         v_samp=np.asarray(inp.v_samp) + 1e-3 * (j % 4), obstacles=obstacles))
+    return ups
+
+
+def north_star(args, local_rank):
+    """BASELINE.json's target workload in the same run: 1 005 100 x 31 x 20 obstacles (select-only) and 1 005 100 x 31 with
+    the bundle materialised.  Kernel time from HIP events attached to every launch of a short timed region."""
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    out = {}
+    for key, n_obst, select_only in (("obstacles_select_only", 20, True), ("bundle_no_obstacles", 0, False)):
+        inp = make_workload(args, 1, grid=NORTH_STAR_GRID, n_obst=n_obst, select_only=select_only)
+        C, S = inp.n_candidates, inp.n_samples
+        eng = FrenetEngine(max_candidates=C + 64, max_steps=inp.N, max_ref_knots=1024, max_obstacles=32, max_pred_steps=64,
+                           device=local_rank)
+        eng.set_timing("kernel", every=1)
+        eng.upload(inp)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.3:  # a kernel after idle is timed at a lower clock
+            eng.step_raw()
+        n = 24
+        ts = time.perf_counter()
+        for _ in range(n):
+            res = eng.step_raw()[0]
+        step_ms = (time.perf_counter() - ts) / n * 1e3
+        evalk, _ = eng.kernel_times(n)
+        k_ms = float(np.mean(evalk))
+        rec = {"workload": f"{C} candidates x {S} samples, {n_obst} predicted obstacles, "
+                           f"{'select-only (Mode A)' if select_only else 'SoA TrajectoryBundle materialised (Mode B)'}",
+               "candidates": C, "samples": S, "obstacles": n_obst, "eval_kernel_ms": k_ms, "step_ms": step_ms,
+               "value": C / (step_ms * 1e-3), "launches_timed": int(len(evalk)),
+               "winner": {"index": int(res.best_index), "cost": float(res.best_cost), "n_collisions": int(res.n_collisions)},
+               "target": "< 10 ms on one MI355X"}
+        if select_only:
+            fl = executed_fp64_flops("north_star_obstacles")
+            src = PROFILE_SUMMARY if fl else None
+            if fl is None:
+                fl = algorithmic_flops_per_candidate(S, n_obst) * C
+            tf = fl / (k_ms * 1e-3) / 1e12
+            rec["roofline"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_launch": fl,
+                               "flops_source": ("executed FP64 instructions of this kernel (SQ_INSTS_VALU_*_F64 x 64 lanes), "
+                                                + os.path.relpath(src, ROOT)) if src else "SURVEY.md 8(d) planning figure",
+                               "traffic": pmc_traffic("north_star_obstacles")}
+        else:
+            alg = bundle_bytes_per_candidate(S) * C
+            ach = alg / (k_ms * 1e-3) / 1e9
+            rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_launch": alg, "traffic": pmc_traffic("north_star_bundle"),
+                               "note": "3.49 GB per launch: past the 256 MiB Infinity Cache"}
+        out[key] = rec
+        eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["config1", "config2", "config3", "config4", "config5"], default="config2")
+    ap.add_argument("--workload", choices=["config1", "config2", "config3", "config4", "config5"], default="config3")
     ap.add_argument("--agents-per-gpu", type=int, default=32, help="config5: agents evaluated per GPU in one batched launch")
-    ap.add_argument("--sampling-level", type=int, default=4, help="config4: sampling level of every agent (4 -> 11 220 candidates)")
+    ap.add_argument("--sampling-level", type=int, default=-1,
+                    help="config4: reference sampling level of every agent instead of the dense 19 x 23 x 23 grid (4 -> 11 220 candidates)")
     ap.add_argument("--select-only", action="store_true", help="Mode A: no SoA bundle write")
     ap.add_argument("--topk", type=int, default=1, help="survivors per GPU in the exchange (1: the winner, no top-k kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the 1 M-candidate target workloads")
     ap.add_argument("--timing", choices=["stream", "kernel"], default="kernel",
                     help="HIP events around the evaluation kernel: attached to the kernel (hipExtLaunchKernel) or stream events")
-    ap.add_argument("--timing-every", type=int, default=16,
-                    help="attach the events to every n-th launch of the timed region (they are read after it)")
+    ap.add_argument("--timing-every", type=int, default=0,
+                    help="attach the events to every n-th launch of the timed region (0: every launch below 64 steps, else every 8th)")
+    ap.add_argument("--dry-launch", action="store_true", help="CPU-only check of the multi-rank launch path (gloo)")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
+    if args.timing_every <= 0:
+        args.timing_every = 1 if args.steps < 64 else 8
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print(f"bench.py: --gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} ...`",
-              file=sys.stderr)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))  # nothing has touched the GPU yet
+    if args.dry_launch:
+        sys.exit(dry_launch(args, world, rank))
+
+    import torch
+    import torch.distributed as dist
+
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks", file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible -- the engine has no CPU fallback", file=sys.stderr)
@@ -221,6 +373,7 @@ def main():
     ev.shard(inp)
     C_local = inp.n_candidates
     S = inp.n_samples
+    n_obst = int(inp.obstacles["K"])
 
     def barrier():
         if world > 1:
@@ -247,12 +400,37 @@ def main():
     # HIP-event durations of the launches timed inside the region above (event ring, read only now)
     n_timed = min(256, (args.steps + args.timing_every - 1) // args.timing_every)
     evalk, kern = eng.kernel_times(n_timed)
+    winner = {"index": int(res.get("global_best_index", res["best_index"])),
+              "cost": float(res.get("global_best_cost", res["best_cost"])), "n_feasible_local": int(res["n_feasible"]),
+              "n_collisions": int(res["n_collisions"])}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same K steps fed from host buffers: every step a new ego state and new predictions (single-rank steps; with
+    # N > 1 every rank does the same update, the exchange is the one above)
+    eng.set_timing("off")
+    ups = perturbed_updates(eng, inp, 8)
+    upd_step = (lambda u: eng.update_step_raw(u)) if world == 1 else (lambda u: (eng.update_state(u), step()))
+    for j in range(max(4, args.warmup // 2)):
+        upd_step(ups[j % len(ups)])
+    barrier()
+    lat_u = []
+    tu = time.perf_counter()
+    for j in range(args.steps):
+        ts = time.perf_counter()
+        upd_step(ups[j % len(ups)])
+        lat_u.append(time.perf_counter() - ts)
+    barrier()
+    elapsed_u = time.perf_counter() - tu
+    if world > 1:
+        t = torch.tensor([elapsed_u], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_u = float(t.item())
+
     # device-throughput figure: K evaluations enqueued back to back, one sync (informational)
+    eng.upload(inp)
     barrier()
     tq = time.perf_counter()
     for _ in range(args.steps):
@@ -260,17 +438,38 @@ def main():
     eng.finish()
     torch.cuda.synchronize()
     pipelined = time.perf_counter() - tq
+    eng.close()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = C_global * args.steps / elapsed
         eval_ms = float(np.mean(evalk))
-        per_cand = BYTES_PER_CAND_MODE_A + (0 if args.select_only else bundle_bytes_per_candidate(S))
-        if not args.select_only:
-            per_cand = bundle_bytes_per_candidate(S)  # SURVEY 8(d) Mode-B figure: 3 472 B / candidate at 31 samples
+        per_cand = BYTES_PER_CAND_MODE_A if args.select_only else bundle_bytes_per_candidate(S)
         alg_bytes = per_cand * C_local
         achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args, world)
+        section = f"{args.workload}_{'modeA' if args.select_only else 'modeB'}"
+        traffic = pmc_traffic(section) if world == 1 else None
+        hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "traffic": traffic, "traffic_source": os.path.relpath(PROFILE_SUMMARY, ROOT) if traffic else None,
+               "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_candidate": per_cand}
+        common = {"kernel": "fx_eval_grid_kernel" + ("" if n_obst else " (evaluation + fused selection)"),
+                  "avg_launch_ms": eval_ms, "launches_timed": int(len(evalk)),
+                  "timing": (f"HIP events attached to every {args.timing_every}. launch of the timed region (hipExtLaunchKernel "
+                             "start/stop)") if args.timing == "kernel" else "stream events"}
+        if n_obst:
+            # the obstacle stage is FP64-issue-bound: executed work of this kernel against the FP64 vector peak
+            fl = executed_fp64_flops(section) if world == 1 else None
+            fsrc = os.path.relpath(PROFILE_SUMMARY, ROOT) if fl else None
+            if fl is None:
+                fl = algorithmic_flops_per_candidate(S, n_obst) * C_local
+            tf = fl / (eval_ms * 1e-3) / 1e12
+            roofline = dict({"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "flops_per_launch": fl,
+                             "flops_source": ("executed FP64 instructions of this kernel (SQ_INSTS_VALU_*_F64 x 64 lanes), " + fsrc)
+                             if fsrc else "SURVEY.md 8(d) planning figure (no tracked PMC summary for this command)"}, **common)
+            hbm.update(common)
+        else:
+            roofline = dict(hbm, **common)
         out = {
             "metric": "candidate trajectories/sec (30-step horizon)",
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -278,29 +477,31 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE {args.workload}: single agent, {C_local} candidates/GPU x {S} samples "
                                    f"({GRID[0]}x{GRID[1]}x{GRID[2] + 1} grid per GPU), "
-                                   f"{'20 predicted obstacles (prediction cost + OBB collision)' if args.workload == 'config3' else 'no obstacles'}, "
+                                   f"{'20 predicted obstacles (prediction cost + OBB collision)' if n_obst else 'no obstacles'}, "
                                    f"{'select-only (Mode A)' if args.select_only else 'SoA TrajectoryBundle materialised (Mode B)'}",
                        "candidates_global": C_global, "candidates_per_gpu": C_local, "samples": S,
-                       "reference_knots": int(inp.coordinate_system.ref_pos.shape[0]), "obstacles": int(inp.obstacles["K"]),
+                       "reference_knots": int(inp.coordinate_system.ref_pos.shape[0]), "obstacles": n_obst,
                        "parallelism": f"candidate-shard x{world}, all-gather top-{args.topk}" if world > 1 else "single GPU"},
-            "plan_step_p50_ms": float(np.percentile(lat, 50) * 1e3), "plan_step_p95_ms": float(np.percentile(lat, 95) * 1e3),
+            "resident_step_p50_ms": float(np.percentile(lat, 50) * 1e3), "resident_step_p95_ms": float(np.percentile(lat, 95) * 1e3),
+            "plan_step_p50_ms": float(np.percentile(lat_u, 50) * 1e3), "plan_step_p95_ms": float(np.percentile(lat_u, 95) * 1e3),
+            "plan_step_note": "plan_step_* = the step fed a new ego state and new predictions from host buffers every time "
+                              "(fx_update_step: re-packed tables, one host-to-device copy, evaluation, result on the host); "
+                              "resident_step_* and value = inputs resident in HBM",
+            "with_upload_ms_per_step": elapsed_u / args.steps * 1e3, "value_with_upload": C_global * args.steps / elapsed_u,
             "device_ms_per_step": float(np.mean(kern)), "eval_kernel_ms": eval_ms,
             "pipelined_value": C_global * args.steps / pipelined,
-            "winner": {"index": int(res.get("global_best_index", res["best_index"])),
-                       "cost": float(res.get("global_best_cost", res["best_cost"])), "n_feasible_local": int(res["n_feasible"])},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "fx_eval_grid_kernel (evaluation + fused selection)" if not inp.obstacles["K"] else "fx_eval_grid_kernel", "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_candidate": per_cand, "avg_launch_ms": eval_ms,
-                         "launches_timed": int(len(evalk)), "timing": f"HIP events attached to every {args.timing_every}. launch "
-                         "of the timed region (hipExtLaunchKernel start/stop)" if args.timing == "kernel" else "stream events"},
+            "winner": winner,
+            "roofline": roofline,
         }
+        if n_obst:
+            out["roofline_hbm"] = hbm
+        if world == 1 and not args.no_north_star:
+            out["north_star"] = north_star(args, local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    eng.close()
     if world > 1:
         dist.destroy_process_group()
 
@@ -459,7 +660,10 @@ def bench_multiagent(args, world, rank, local_rank, torch, dist):
     from frenetix_motion_planner_amd.reactive_planner import PlannerConfig
     sc = crx.read_scenario_json(os.path.join(ROOT, "tests", "golden", "ZAM_Tjunction-1_42_T-1.scenario.json"))
     lvl = args.sampling_level
-    cfg = PlannerConfig(sampling_min=lvl, sampling_max=lvl + 1)
+    if lvl >= 0:
+        cfg = PlannerConfig(sampling_min=lvl, sampling_max=lvl + 1)
+    else:  # dense 19 x 23 x 23 (+ the current d) grid per agent
+        cfg = PlannerConfig(sampling_min=0, sampling_max=1, dense_grid=(19, 23, 23))
     sim = MultiAgentSimulation(sc, config=cfg, device=local_rank)
     counts = {"cands": 0, "batch_ms": []}
 
@@ -480,7 +684,7 @@ def bench_multiagent(args, world, rank, local_rank, torch, dist):
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "ZAM_Tjunction-1_42_T-1 (scenario fixture), agents' own plans as predictions",
             "config": {"workload": f"BASELINE config4: multi-agent ZAM_Tjunction, {n_agents} agents x {per_agent} candidates x 31 samples "
-                                   f"(sampling level {lvl}), bundle materialised, collision stage; a step = one simulation step "
+                                   f"({'sampling level ' + str(lvl) if lvl >= 0 else 'dense 19 x 23 x 23(+1) grid'}), bundle materialised, collision stage; a step = one simulation step "
                                    "(replanning every 3rd step)",
                        "agents": n_agents, "candidates_per_agent": per_agent, "plan_steps_timed": plan_steps,
                        "parallelism": f"agent round-robin x{world}, one all-gather of the plans per step" if world > 1 else "single GPU"},

@@ -5,7 +5,7 @@ wrapper (oracle/oracle.py) can share the struct definitions.
 """
 import ctypes as C
 
-FX_ABI_VERSION = 2
+FX_ABI_VERSION = 3
 FX_LON_VELOCITY_KEEPING, FX_LON_STOP_POINT = 0, 1
 
 FX_OK = 0
@@ -75,6 +75,15 @@ class FxProblem(C.Structure):
         ("n_dto", C.c_int32), ("dto_pos", _pd),
         ("n_bound", C.c_int32), ("bound_piece", _pd), ("bound_bin", C.POINTER(C.c_int32)), ("bound_item", C.POINTER(C.c_int32)),
         ("bound_d_reach", C.c_double),
+    ]
+
+
+class FxStateUpdate(C.Structure):
+    """what changes between two plan steps of a planner (fx_update_state); NULL / NaN / negative = keep"""
+    _fields_ = [
+        ("x0_lon", _pd), ("x0_lat", _pd), ("x0_orientation", C.c_double), ("v_des", C.c_double), ("low_vel_mode", C.c_int32),
+        ("t_samp", _pd), ("v_samp", _pd), ("d_samp", _pd),
+        ("obs_pos", _pd), ("obs_cov_inv", _pd), ("obs_npred", _pi32), ("obs_hull", _pd), ("obs_nhull", _pi32),
     ]
 
 

@@ -63,6 +63,14 @@ struct FxAgentSlot {
     int64_t C = 0, ld = 0, cand_off = 0;  // cand_off: offset of this agent in the per-candidate arrays
     int32_t S = 0, n_cost = 0, n_blocks = 0;
     uint32_t mode = 0;
+    // where the step-dependent inputs of this agent sit in the pinned staging block (fx_update_state rewrites them in
+    // place); (size_t)-1 = not present
+    size_t off_t = (size_t)-1, off_v = (size_t)-1, off_d = (size_t)-1, off_ref = (size_t)-1;
+    size_t off_pos = (size_t)-1, off_cov = (size_t)-1, off_npred = (size_t)-1, off_hull = (size_t)-1, off_nhull = (size_t)-1;
+    size_t off_rec = (size_t)-1, off_pm = (size_t)-1, off_hm = (size_t)-1, off_hot = (size_t)-1;
+    size_t dyn_end = 0;   // end of this agent's step-dependent inputs that the kernels read
+    int32_t nT = 0, nV = 0, nD = 0, K = 0, P = 0, M = 0;
+    bool have_hull = false, want_collision = false;
 };
 
 struct FxContext {
@@ -89,8 +97,9 @@ struct FxContext {
     char *h_in = nullptr;   // pinned
     char *d_in = nullptr;
     // problems
-    DevProblem *h_probs = nullptr;  // pinned [max_agents]
-    DevProblem *d_probs = nullptr;
+    DevProblem *h_probs = nullptr;  // [max_agents], the front of the pinned staging block h_in ...
+    DevProblem *d_probs = nullptr;  // ... and of its device twin d_in: problems and inputs travel in ONE copy
+    size_t probs_bytes = 0;
     // outputs
     double *d_cost = nullptr;
     uint32_t *d_flags = nullptr;
@@ -127,6 +136,9 @@ struct FxContext {
     int n_agents = 0;
     std::vector<FxAgentSlot> slots;
     bool uploaded = false, evaluated = false;
+    size_t in_used = 0;                    // bytes of the staging block the last upload filled
+    size_t dirty_lo = (size_t)-1, dirty_hi = 0;  // staging range rewritten by fx_update_state, copied by the next evaluation
+    bool probs_dirty = false;
     int max_blocks_step = 0, M_max_step = 0, S_max_step = 0, K_max_step = 0;
     int G_step = 1, wpe_step = 2;          // lanes per candidate / occupancy target of the current step
     int G_force = 0, wpe_force = 0;        // fx_set_tuning overrides (0 = automatic)
@@ -264,6 +276,66 @@ int validate(const FxProblem *p) {
     return FX_OK;
 }
 
+
+// Step-major obstacle tables of one agent: rec[S][K][12] (mu, inverse covariance of prediction i-1; hull i-2), the per-step
+// masks, and the hot table hot[S][K][FX_HOT_STRIDE] in the form the walk consumes (fx_walk.h, ObsHot).  Returns the margin of
+// the broad phase's expanded circle test.
+double pack_obstacle_tables(int S, int K, int P, const double *obs_pos, const double *obs_cov_inv, const int32_t *obs_npred,
+                            const double *obs_hull, const int32_t *obs_nhull, bool have_hull, double ox, double oy,
+                            double *rec, unsigned long long *pm, unsigned long long *hm, double *hot) {
+    double r2_max = 0.0;
+    for (int i = 0; i < S; i++) {
+        pm[i] = hm[i] = 0ULL;
+        for (int k = 0; k < K; k++) {
+            double *q = rec + ((size_t)i * K + k) * 12;
+            for (int e = 0; e < 12; e++) q[e] = 0.0;
+            double *h = hot + ((size_t)i * K + k) * FX_HOT_STRIDE;
+            for (int e = 0; e < FX_HOT_STRIDE; e++) h[e] = 0.0;
+            if (i >= 1 && i < obs_npred[k] && i - 1 < P) {
+                const double *mu = obs_pos + ((size_t)k * P + (i - 1)) * 2;
+                const double *iv = obs_cov_inv + ((size_t)k * P + (i - 1)) * 4;
+                q[0] = mu[0]; q[1] = mu[1]; q[2] = iv[0]; q[3] = iv[1]; q[4] = iv[2]; q[5] = iv[3];
+                pm[i] |= 1ULL << k;
+                // Cholesky factor of the symmetric part of the inverse covariance: A = L^T L, L = [[l11, l12], [0, l22]];
+                // the quadratic form r0 e0 + r1 e1 of the reference only sees that symmetric part.  No factor (not
+                // positive definite, not finite): the entry stays zero, the form evaluates to 0 and the kernel redoes the
+                // step from `rec`.
+                const double a = iv[0], b = 0.5 * (iv[1] + iv[2]), dd = iv[3];
+                const double l11 = std::sqrt(a), l12 = b / l11, l22sq = dd - l12 * l12;
+                if (a > 0.0 && l22sq > 0.0 && std::isfinite(l11) && std::isfinite(l12) && std::isfinite(l22sq)) {
+                    const double l22 = std::sqrt(l22sq), mx = mu[0] - ox, my = mu[1] - oy;
+                    h[0] = l11; h[1] = l12; h[2] = l11 * mx + l12 * my; h[3] = l22; h[4] = l22 * my;
+                }
+            }
+            if (have_hull && i >= 2 && i - 2 < obs_nhull[k]) {
+                const double *oh = obs_hull + ((size_t)k * (P - 1) + (i - 2)) * 6;
+                for (int e = 0; e < 6; e++) q[6 + e] = oh[e];
+                hm[i] |= 1ULL << k;
+                // broad phase: circle that holds the hull (radius h1 + h2, with slack) in expanded form
+                const double hx = oh[0] - ox, hy = oh[1] - oy, hr = (oh[4] + oh[5]) * 1.000001;
+                h[5] = -2.0 * hx; h[6] = -2.0 * hy; h[7] = -2.0 * hr; h[8] = hx * hx + hy * hy - hr * hr;
+                r2_max = std::max(r2_max, hx * hx + hy * hy);
+            }
+        }
+    }
+    // centre-gap values up to this margin go to the exact axis test: covers the rounding of the expanded form for ego hulls
+    // within ~1 km of the origin (the pairs it adds are decided exactly, so decisions do not move)
+    return 1e-6 + 4e-15 * (r2_max + 1e6);
+}
+
+// origin of the hot table's coordinates: the reference knot at the ego's arc length (any point near the ego does; it only
+// keeps the products of the transformed forms small against their differences).  knots = [M][FX_REF_FIELDS] AoS.
+void hot_origin_of(const double *knots, int M, double s0, double *origin) {
+    int lo = 0, hi = M;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (knots[(size_t)mid * FX_REF_FIELDS] > s0) hi = mid; else lo = mid + 1;
+    }
+    const int ko = std::min(std::max(lo - 1, 0), M - 1);
+    origin[0] = knots[(size_t)ko * FX_REF_FIELDS + 4];
+    origin[1] = knots[(size_t)ko * FX_REF_FIELDS + 5];
+}
+
 }  // namespace
 
 extern "C" {
@@ -314,12 +386,14 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     c->max_blocks_total = c->total_ld / 8 + max_agents + 1;  // 64-lane workgroups at G = 8: 8 candidates each
     c->in_bytes = (size_t)max_agents * input_bytes_for(0, S, max_ref_knots, max_obstacles, c->max_pred, false) +
                   align_up(sizeof(double) * 13 * (size_t)max_candidates_total, 256) + 4096;
+    c->probs_bytes = align_up(sizeof(DevProblem) * (size_t)max_agents, 256);
+    c->in_bytes += c->probs_bytes;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_in), c->in_bytes, hipHostMallocDefault));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_in), c->in_bytes));
     c->dev_bytes += (int64_t)c->in_bytes;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_probs), sizeof(DevProblem) * max_agents, hipHostMallocDefault));
+    c->h_probs = reinterpret_cast<DevProblem *>(c->h_in);
+    c->d_probs = reinterpret_cast<DevProblem *>(c->d_in);
     int rc;
-    if ((rc = dev_alloc(c, &c->d_probs, max_agents))) return rc;
     if ((rc = dev_alloc(c, &c->d_cost, c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_flags, c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_costmap, (size_t)FX_NUM_COSTS * c->total_ld))) return rc;
@@ -358,14 +432,14 @@ int32_t fx_destroy(FxContext *c) {
     if (!c) return FX_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_probs, c->d_cost, c->d_flags, c->d_costmap, c->d_coeffs, c->d_trajlen, c->d_planes,
+    void *dev[] = {c->d_in, c->d_cost, c->d_flags, c->d_costmap, c->d_coeffs, c->d_trajlen, c->d_planes,
                    c->d_part_cost, c->d_part_idx, c->d_counters, c->d_topk_cost, c->d_topk_idx, c->d_topk_scr_cost,
                    c->d_topk_scr_idx};
     for (void *p : dev) if (p) (void)hipFree(p);
     if (c->d_bstep) (void)hipFree(c->d_bstep);
     if (c->d_bound) (void)hipFree(c->d_bound);
     if (c->h_bound) (void)hipHostFree(c->h_bound);
-    void *host[] = {c->h_in, c->h_probs, c->h_counters, c->h_topk_cost, c->h_topk_idx, c->h_pub, c->h_cand};
+    void *host[] = {c->h_in, c->h_counters, c->h_topk_cost, c->h_topk_idx, c->h_pub, c->h_cand};
     for (void *p : host) if (p) (void)hipHostFree(p);
     for (auto &t : c->ring) {
         if (t.e0) (void)hipEventDestroy(t.e0);
@@ -462,7 +536,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         c->in_flight = false;
     }
     c->uploaded = c->evaluated = false;
-    Arena ar{c->h_in, c->d_in, 0, c->in_bytes};
+    Arena ar{c->h_in, c->d_in, c->probs_bytes, c->in_bytes};
     // road boundary: its own staging block, grown on demand (maps differ by orders of magnitude in size)
     size_t bound_need = 0;
     for (int a = 0; a < n_agents; a++) {
@@ -621,16 +695,49 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         }
         memcpy(d.simpson_corr, p->simpson_corr, sizeof(d.simpson_corr));
         bool ok = true;
-        d.tpow = ar.put(p->tpow, (size_t)5 * S, &ok);
+        FxAgentSlot &sl = c->slots[a];
+        sl = FxAgentSlot();
+        sl.nT = p->nT; sl.nV = p->nV; sl.nD = p->nD; sl.K = p->K; sl.P = p->P; sl.M = p->M;
+        sl.want_collision = (p->mode & FX_MODE_COLLISION) != 0;
+        // what may change from step to step (fx_update_state) comes first, right behind the problems, so that an update is
+        // one copy of the front of the block; the per-reference constants follow
         if (d.has_matrix) {
             d.matrix = ar.put(p->sampling_matrix, (size_t)13 * C_global, &ok);
         } else {
-            d.t_samp = ar.put(p->t_samp, p->nT, &ok);
-            d.v_samp = ar.put(p->v_samp, p->nV, &ok);
-            d.d_samp = ar.put(p->d_samp, p->nD, &ok);
+            sl.off_t = ar.off; d.t_samp = ar.put(p->t_samp, p->nT, &ok);
+            sl.off_v = ar.off; d.v_samp = ar.put(p->v_samp, p->nV, &ok);
+            sl.off_d = ar.off; d.d_samp = ar.put(p->d_samp, p->nD, &ok);
         }
+        double *rec = nullptr, *hot = nullptr;
+        unsigned long long *pm = nullptr, *hm = nullptr;
+        const bool have_hull = p->K > 0 && p->obs_hull && p->obs_nhull;
+        if (p->K > 0) {
+            sl.off_pos = ar.off; d.obs_pos = ar.put(p->obs_pos, (size_t)2 * p->K * p->P, &ok);
+            sl.off_cov = ar.off; d.obs_cov_inv = ar.put(p->obs_cov_inv, (size_t)4 * p->K * p->P, &ok);
+            sl.off_npred = ar.off; d.obs_npred = ar.put(p->obs_npred, p->K, &ok);
+            sl.have_hull = have_hull;
+            if (!have_hull) d.mode &= ~FX_MODE_COLLISION;
+            // step-major packed records + per-step obstacle masks + hot table (filled below, once the knots are staged)
+            const double *dev = nullptr, *dhot = nullptr;
+            const unsigned long long *dpm = nullptr, *dhm = nullptr;
+            sl.off_rec = ar.off; rec = ar.host_slot<double>((size_t)S * p->K * 12, &dev, &ok);
+            sl.off_pm = ar.off; pm = ar.host_slot<unsigned long long>(S, &dpm, &ok);
+            sl.off_hm = ar.off; hm = ar.host_slot<unsigned long long>(S, &dhm, &ok);
+            sl.off_hot = ar.off; hot = ar.host_slot<double>((size_t)S * p->K * FX_HOT_STRIDE, &dhot, &ok);
+            d.obs_rec = dev; d.obs_pmask = dpm; d.obs_hmask = dhm; d.obs_hot = dhot;
+            sl.dyn_end = ar.off;
+            if (have_hull) {  // kept in the staging block for re-packing; the kernels read the hulls from `rec`
+                sl.off_hull = ar.off; d.obs_hull = ar.put(p->obs_hull, (size_t)6 * p->K * (p->P - 1), &ok);
+                sl.off_nhull = ar.off; d.obs_nhull = ar.put(p->obs_nhull, p->K, &ok);
+            }
+        } else {
+            d.mode &= ~FX_MODE_COLLISION;
+            sl.dyn_end = ar.off;
+        }
+        d.tpow = ar.put(p->tpow, (size_t)5 * S, &ok);
         {   // reference knots, AoS: pos, theta, curv, curv_d, x, y, nx, ny
             const double *dev = nullptr;
+            sl.off_ref = ar.off;
             double *h = ar.host_slot<double>((size_t)p->M * FX_REF_FIELDS, &dev, &ok);
             if (h) {
                 for (int k = 0; k < p->M; k++) {
@@ -638,81 +745,13 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                     q[0] = p->ref_pos[k]; q[1] = p->ref_theta[k]; q[2] = p->ref_curv[k]; q[3] = p->ref_curv_d[k];
                     q[4] = p->ref_x[k]; q[5] = p->ref_y[k]; q[6] = p->ref_nx[k]; q[7] = p->ref_ny[k];
                 }
+                if (rec && pm && hm && hot) {
+                    hot_origin_of(h, p->M, p->x0_lon[0], d.hot_origin);
+                    d.hot_gap_margin = pack_obstacle_tables(S, p->K, p->P, p->obs_pos, p->obs_cov_inv, p->obs_npred, p->obs_hull,
+                                                            p->obs_nhull, have_hull, d.hot_origin[0], d.hot_origin[1], rec, pm, hm, hot);
+                }
             }
             d.ref = dev;
-        }
-        if (p->K > 0) {
-            d.obs_pos = ar.put(p->obs_pos, (size_t)2 * p->K * p->P, &ok);
-            d.obs_cov_inv = ar.put(p->obs_cov_inv, (size_t)4 * p->K * p->P, &ok);
-            d.obs_npred = ar.put(p->obs_npred, p->K, &ok);
-            const bool have_hull = p->obs_hull && p->obs_nhull;
-            if (have_hull) {
-                d.obs_hull = ar.put(p->obs_hull, (size_t)6 * p->K * (p->P - 1), &ok);
-                d.obs_nhull = ar.put(p->obs_nhull, p->K, &ok);
-            } else {
-                d.mode &= ~FX_MODE_COLLISION;
-            }
-            {   // step-major packed records + per-step obstacle masks
-                const double *dev = nullptr;
-                double *rec = ar.host_slot<double>((size_t)S * p->K * 12, &dev, &ok);
-                const unsigned long long *dpm = nullptr, *dhm = nullptr;
-                unsigned long long *pm = ar.host_slot<unsigned long long>(S, &dpm, &ok);
-                unsigned long long *hm = ar.host_slot<unsigned long long>(S, &dhm, &ok);
-                const double *dhot = nullptr;
-                double *hot = ar.host_slot<double>((size_t)S * p->K * FX_HOT_STRIDE, &dhot, &ok);
-                // origin of the hot table's coordinates: the reference knot at the ego's arc length (any point near the
-                // ego does; it only keeps the products of the transformed forms small against their differences)
-                {
-                    int ko = (int)(std::upper_bound(p->ref_pos, p->ref_pos + p->M, p->x0_lon[0]) - p->ref_pos) - 1;
-                    ko = std::min(std::max(ko, 0), p->M - 1);
-                    d.hot_origin[0] = p->ref_x[ko];
-                    d.hot_origin[1] = p->ref_y[ko];
-                }
-                const double ox = d.hot_origin[0], oy = d.hot_origin[1];
-                double r2_max = 0.0;
-                if (rec && pm && hm && hot) {
-                    for (int i = 0; i < S; i++) {
-                        pm[i] = hm[i] = 0ULL;
-                        for (int k = 0; k < p->K; k++) {
-                            double *q = rec + ((size_t)i * p->K + k) * 12;
-                            for (int e = 0; e < 12; e++) q[e] = 0.0;
-                            double *h = hot + ((size_t)i * p->K + k) * FX_HOT_STRIDE;
-                            for (int e = 0; e < FX_HOT_STRIDE; e++) h[e] = 0.0;
-                            if (i >= 1 && i < p->obs_npred[k] && i - 1 < p->P) {
-                                const double *mu = p->obs_pos + ((size_t)k * p->P + (i - 1)) * 2;
-                                const double *iv = p->obs_cov_inv + ((size_t)k * p->P + (i - 1)) * 4;
-                                q[0] = mu[0]; q[1] = mu[1]; q[2] = iv[0]; q[3] = iv[1]; q[4] = iv[2]; q[5] = iv[3];
-                                pm[i] |= 1ULL << k;
-                                // Cholesky factor of the symmetric part of the inverse covariance: A = L^T L,
-                                // L = [[l11, l12], [0, l22]]; the quadratic form r0 e0 + r1 e1 of the reference only
-                                // sees that symmetric part.  No factor (not positive definite, not finite): the entry
-                                // stays zero, the form evaluates to 0 and the kernel redoes the step from `rec`.
-                                const double a = iv[0], b = 0.5 * (iv[1] + iv[2]), dd = iv[3];
-                                const double l11 = std::sqrt(a), l12 = b / l11, l22sq = dd - l12 * l12;
-                                if (a > 0.0 && l22sq > 0.0 && std::isfinite(l11) && std::isfinite(l12) && std::isfinite(l22sq)) {
-                                    const double l22 = std::sqrt(l22sq), mx = mu[0] - ox, my = mu[1] - oy;
-                                    h[0] = l11; h[1] = l12; h[2] = l11 * mx + l12 * my; h[3] = l22; h[4] = l22 * my;
-                                }
-                            }
-                            if (have_hull && i >= 2 && i - 2 < p->obs_nhull[k]) {
-                                const double *oh = p->obs_hull + ((size_t)k * (p->P - 1) + (i - 2)) * 6;
-                                for (int e = 0; e < 6; e++) q[6 + e] = oh[e];
-                                hm[i] |= 1ULL << k;
-                                // broad phase: circle that holds the hull (radius h1 + h2, with slack) in expanded form
-                                const double hx = oh[0] - ox, hy = oh[1] - oy, hr = (oh[4] + oh[5]) * 1.000001;
-                                h[5] = -2.0 * hx; h[6] = -2.0 * hy; h[7] = -2.0 * hr; h[8] = hx * hx + hy * hy - hr * hr;
-                                r2_max = std::max(r2_max, hx * hx + hy * hy);
-                            }
-                        }
-                    }
-                }
-                // centre-gap values up to this margin go to the exact axis test: covers the rounding of the expanded form
-                // for ego hulls within ~1 km of the origin (the pairs it adds are decided exactly, so decisions do not move)
-                d.hot_gap_margin = 1e-6 + 4e-15 * (r2_max + 1e6);
-                d.obs_rec = dev; d.obs_pmask = dpm; d.obs_hmask = dhm; d.obs_hot = dhot;
-            }
-        } else {
-            d.mode &= ~FX_MODE_COLLISION;
         }
         if (p->n_dto > 0) d.dto_pos = ar.put(p->dto_pos, (size_t)2 * p->n_dto, &ok);
         if ((p->mode & FX_MODE_ROAD_BOUNDARY) && p->n_bound > 0) {
@@ -747,7 +786,6 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         c->M_max_step = std::max(c->M_max_step, p->M);
         c->K_max_step = std::max(c->K_max_step, std::max(p->K, 0));
         c->S_max_step = std::max(c->S_max_step, S);
-        FxAgentSlot &sl = c->slots[a];
         sl.C = C; sl.ld = ld; sl.cand_off = cand_off; sl.S = S; sl.n_cost = p->n_cost; sl.n_blocks = d.n_blocks; sl.mode = d.mode;
         cand_off += ld;
         block_off += d.n_blocks;
@@ -767,9 +805,10 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                                                                   reinterpret_cast<size_t>(c->h_probs[a].planes));
     }
     c->n_agents = n_agents;
-    HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, ar.off, hipMemcpyHostToDevice, c->stream));
+    c->in_used = ar.off;
+    c->dirty_lo = (size_t)-1; c->dirty_hi = 0; c->probs_dirty = false;
+    HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, ar.off, hipMemcpyHostToDevice, c->stream));  // problems + inputs
     if (br.off) HIP_TRY(hipMemcpyAsync(c->d_bound, c->h_bound, br.off, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_probs, c->h_probs, sizeof(DevProblem) * n_agents, hipMemcpyHostToDevice, c->stream));
     c->uploaded = true;
     c->in_flight = true;
     return FX_OK;
@@ -781,6 +820,15 @@ int32_t fx_evaluate(FxContext *c) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     if (!c->uploaded) return set_err(FX_ERR_NOT_READY, "fx_evaluate before fx_upload");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->probs_dirty || c->dirty_hi > c->dirty_lo) {
+        // inputs rewritten by fx_update_state since the last evaluation: ONE copy of the front of the staging block (the
+        // problems, then whatever changed behind them)
+        const size_t lo = c->probs_dirty ? 0 : c->dirty_lo;
+        const size_t hi = std::max(c->dirty_hi > c->dirty_lo ? c->dirty_hi : 0, c->probs_dirty ? sizeof(DevProblem) * (size_t)c->n_agents : 0);
+        HIP_TRY(hipMemcpyAsync(c->d_in + lo, c->h_in + lo, hi - lo, hipMemcpyHostToDevice, c->stream));
+        c->dirty_lo = (size_t)-1; c->dirty_hi = 0;
+        c->probs_dirty = false;
+    }
     // timing (every timing_every-th step): FX_TIMING_KERNEL attaches start/stop events to the evaluation kernel
     // itself (hipExtLaunchKernel), so its duration is the kernel's, not launch latency; FX_TIMING_STREAM brackets
     // with stream events instead (includes the dispatch gap before the kernel).  Events live in a ring and are
@@ -876,6 +924,74 @@ int32_t fx_finish(FxContext *c, FxResult *res) { return fx_finish_batch(c, res);
 int32_t fx_step(FxContext *c, FxResult *res) {
     const int rc = fx_evaluate(c);
     return rc ? rc : fx_finish_batch(c, res);
+}
+
+// Per-step state of one agent of the uploaded batch (header: fxplan.h).
+int32_t fx_update_state(FxContext *c, int32_t agent, const FxStateUpdate *u) {
+    if (!c || !u) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_update_state: NULL argument");
+    if (!c->uploaded) return set_err(FX_ERR_NOT_READY, "fx_update_state before fx_upload");
+    if (agent < 0 || agent >= c->n_agents) return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d out of range", agent);
+    if (c->in_flight) {  // a copy out of the staging block may still be running: let it land before rewriting its source
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->in_flight = false;
+    }
+    FxAgentSlot &sl = c->slots[agent];
+    DevProblem &d = c->h_probs[agent];
+    auto touch = [&](size_t off, size_t bytes) {
+        c->dirty_lo = std::min(c->dirty_lo, off);
+        c->dirty_hi = std::max(c->dirty_hi, off + bytes);
+    };
+    bool origin_moved = false;
+    if (u->x0_lon) {
+        origin_moved = d.x0_lon[0] != u->x0_lon[0];
+        memcpy(d.x0_lon, u->x0_lon, sizeof(d.x0_lon));
+    }
+    if (u->x0_lat) memcpy(d.x0_lat, u->x0_lat, sizeof(d.x0_lat));
+    if (u->x0_orientation == u->x0_orientation) d.x0_orientation = u->x0_orientation;
+    if (u->v_des == u->v_des) d.v_des = u->v_des;
+    if (u->low_vel_mode >= 0) d.low_vel_mode = u->low_vel_mode;
+    if (u->t_samp || u->v_samp || u->d_samp) {
+        if (sl.off_t == (size_t)-1) return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d was uploaded with a sampling matrix: upload again", agent);
+        if (u->t_samp) { memcpy(c->h_in + sl.off_t, u->t_samp, sizeof(double) * sl.nT); touch(sl.off_t, sizeof(double) * sl.nT); }
+        if (u->v_samp) { memcpy(c->h_in + sl.off_v, u->v_samp, sizeof(double) * sl.nV); touch(sl.off_v, sizeof(double) * sl.nV); }
+        if (u->d_samp) { memcpy(c->h_in + sl.off_d, u->d_samp, sizeof(double) * sl.nD); touch(sl.off_d, sizeof(double) * sl.nD); }
+    }
+    const bool new_obs = u->obs_pos || u->obs_cov_inv || u->obs_npred || u->obs_hull || u->obs_nhull;
+    if (new_obs && sl.K <= 0) return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d was uploaded without obstacles: upload again", agent);
+    if (new_obs || (origin_moved && sl.K > 0)) {
+        const int K = sl.K, P = sl.P, S = sl.S;
+        double *pos = reinterpret_cast<double *>(c->h_in + sl.off_pos), *cov = reinterpret_cast<double *>(c->h_in + sl.off_cov);
+        int32_t *npred = reinterpret_cast<int32_t *>(c->h_in + sl.off_npred);
+        if (u->obs_pos) memcpy(pos, u->obs_pos, sizeof(double) * 2 * K * P);
+        if (u->obs_cov_inv) memcpy(cov, u->obs_cov_inv, sizeof(double) * 4 * K * P);
+        if (u->obs_npred) memcpy(npred, u->obs_npred, sizeof(int32_t) * K);
+        double *hull = nullptr;
+        int32_t *nhull = nullptr;
+        if (sl.have_hull) {
+            hull = reinterpret_cast<double *>(c->h_in + sl.off_hull);
+            nhull = reinterpret_cast<int32_t *>(c->h_in + sl.off_nhull);
+            if (u->obs_hull) memcpy(hull, u->obs_hull, sizeof(double) * 6 * K * (P - 1));
+            if (u->obs_nhull) memcpy(nhull, u->obs_nhull, sizeof(int32_t) * K);
+        } else if (u->obs_hull || u->obs_nhull) {
+            return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d was uploaded without obstacle hulls: upload again", agent);
+        }
+        hot_origin_of(reinterpret_cast<const double *>(c->h_in + sl.off_ref), sl.M, d.x0_lon[0], d.hot_origin);
+        d.hot_gap_margin = pack_obstacle_tables(S, K, P, pos, cov, npred, hull, nhull, sl.have_hull, d.hot_origin[0], d.hot_origin[1],
+                                                reinterpret_cast<double *>(c->h_in + sl.off_rec),
+                                                reinterpret_cast<unsigned long long *>(c->h_in + sl.off_pm),
+                                                reinterpret_cast<unsigned long long *>(c->h_in + sl.off_hm),
+                                                reinterpret_cast<double *>(c->h_in + sl.off_hot));
+        touch(sl.off_pos, sl.dyn_end - sl.off_pos);
+    }
+    c->probs_dirty = true;
+    return FX_OK;
+}
+
+int32_t fx_update_step(FxContext *c, const FxStateUpdate *u, FxResult *res) {
+    int rc = fx_update_state(c, 0, u);
+    if (rc) return rc;
+    return fx_step(c, res);
 }
 
 int32_t fx_plan_step(FxContext *c, const FxProblem *prob, FxResult *res) {

@@ -157,6 +157,50 @@ class FrenetEngine:
         self._structs = arr  # keep pointers alive until the copy has been enqueued (h2d staging is synchronous memcpy)
         check(lib().fx_upload_batch(self._ctx, len(batch), arr))
 
+    @staticmethod
+    def make_state_update(x0_lon=None, x0_lat=None, x0_orientation=None, v_des=None, low_vel_mode=None, t_samp=None,
+                          v_samp=None, d_samp=None, obstacles=None):
+        """FxStateUpdate (+ the arrays it points into) for `update_state`: what changes between two plan steps of a
+        planner that keeps its reference path, grid shape and cost function.  `obstacles` = a packed predictions dict
+        (problem.pack_predictions) with the K and P of the upload.  Build it once, reuse it as often as wanted."""
+        u = _abi.FxStateUpdate()
+        keep = []
+        pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+
+        def arr(a, typ=np.float64):
+            a = np.ascontiguousarray(a, dtype=typ)
+            keep.append(a)
+            return a.ctypes.data_as(pd if typ == np.float64 else pi)
+
+        if x0_lon is not None: u.x0_lon = arr(x0_lon)
+        if x0_lat is not None: u.x0_lat = arr(x0_lat)
+        u.x0_orientation = float("nan") if x0_orientation is None else float(x0_orientation)
+        u.v_des = float("nan") if v_des is None else float(v_des)
+        u.low_vel_mode = -1 if low_vel_mode is None else int(bool(low_vel_mode))
+        if t_samp is not None: u.t_samp = arr(t_samp)
+        if v_samp is not None: u.v_samp = arr(v_samp)
+        if d_samp is not None: u.d_samp = arr(d_samp)
+        if obstacles is not None and obstacles["K"] > 0:
+            u.obs_pos, u.obs_cov_inv = arr(obstacles["pos"]), arr(obstacles["cov_inv"])
+            u.obs_npred = arr(obstacles["npred"], np.int32)
+            if obstacles.get("hull") is not None and obstacles["nhull"].any():
+                u.obs_hull, u.obs_nhull = arr(obstacles["hull"]), arr(obstacles["nhull"], np.int32)
+        u._keep = keep
+        return u
+
+    def update_state(self, update, agent: int = 0):
+        """Rewrite the step-dependent inputs of one uploaded agent in place (fx_update_state): one small host-to-device
+        copy in front of the next evaluation instead of a full upload."""
+        check(lib().fx_update_state(self._ctx, int(agent), C.byref(update)))
+
+    def update_step_raw(self, update):
+        """update_state(agent 0) + step_raw() in ONE call across the boundary"""
+        res = getattr(self, "_res_buf", None)
+        if res is None or len(res) != len(self._inputs):
+            res = self._res_buf = (_abi.FxResult * len(self._inputs))()
+        check(lib().fx_update_step(self._ctx, C.byref(update), res))
+        return res
+
     def evaluate(self):
         check(lib().fx_evaluate(self._ctx))
 

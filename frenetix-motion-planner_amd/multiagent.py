@@ -168,12 +168,12 @@ class MultiAgentSimulation:
                            if i in scenario.obstacles else dict(length=self.vehicle.length, width=self.vehicle.width))
                        for i in self.agent_ids}
         self.my_slots = agents_of_rank(len(self.agent_ids), self.rank, self.world)
-        n = 2 ** (self.config.sampling_max) + 1
-        cap = max_candidates or max(16 * (n + 1) * (n + 1), 4096)
         mine = [FrenetPlannerInterfaceHip(self.agent_ids[k], scenario, self.problems[self.agent_ids[k]], config=self._cfg(),
                                           vehicle=self.vehicle, device=device, use_road_boundary=use_road_boundary,
                                           engine=engine_factory() if engine_factory else None)
                 for k in self.my_slots]
+        # per-agent capacity from the sampling sets the planners can really reach (the time set is not bounded by 16 values)
+        cap = max_candidates or max([4096] + [a.planner.max_candidates_per_step() for a in mine])
         self.batch = AgentBatchHip(mine, max_candidates=cap, device=device,
                                    engine=engine_factory() if engine_factory else None)
         self.S = self.batch.agents[0].planner.N + 1 if mine else int(self.config.planning_horizon / self.config.dt) + 1

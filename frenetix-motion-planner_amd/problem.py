@@ -85,6 +85,9 @@ def _dict_ptrs(d: dict, spec):
     return c
 
 
+MAX_OBSTACLES = 64  # obstacles per agent (64-bit per-step masks of the obstacle stage)
+
+
 def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
     """predictions dict {id: {'pos_list' [P,2], 'cov_list' [P,2,2], 'orientation_list' [P],
     'shape': {'length','width'}}} (prediction_helpers.py:209-261) -> packed arrays.
@@ -98,7 +101,12 @@ def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
         return dict(K=0, P=0, pos=z, cov_inv=z, npred=np.zeros(0, np.int32), hull=z, nhull=np.zeros(0, np.int32))
     keys = list(predictions.keys())
     K = len(keys)
-    P = max(2, max(len(predictions[k]["pos_list"]) for k in keys))
+    if K > MAX_OBSTACLES:
+        raise ValueError(f"{K} predicted obstacles: the engine's per-step obstacle masks hold {MAX_OBSTACLES} -- cull the "
+                         "predictions on the host (e.g. by distance to the reachable set, get_obstacles_in_radius) before packing")
+    # only the first n_samples predictions are ever read (prediction i-1 pairs with ego step i <= N, hulls use min(S, n)):
+    # a 100-step predictor does not enlarge the tables
+    P = max(2, min(n_samples, max(len(predictions[k]["pos_list"]) for k in keys)))
     pos = np.zeros((K, P, 2))
     cov_inv = np.zeros((K, P, 4))
     npred = np.zeros(K, np.int32)
@@ -107,12 +115,16 @@ def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
     for i, k in enumerate(keys):
         pr = predictions[k]
         pl = np.asarray(pr["pos_list"], dtype=np.float64).reshape(-1, 2)
-        n = len(pl)
-        npred[i] = n
-        if n == 0:
+        n_all = len(pl)
+        # len(pos_list) decides which ego steps see the obstacle (i < len, collision_probability.py:287): keep the real
+        # length, store what can be read
+        npred[i] = n_all
+        if n_all == 0:
             continue
+        n = min(n_all, P)
+        pl = pl[:n]
         pos[i, :n] = pl
-        cov_inv[i, :n] = np.linalg.inv(np.asarray(pr["cov_list"], dtype=np.float64)).reshape(n, 4)
+        cov_inv[i, :n] = np.linalg.inv(np.asarray(pr["cov_list"], dtype=np.float64)[:n]).reshape(n, 4)
         n_use = min(n_samples, n)
         if build_hulls is not None and "orientation_list" in pr and "shape" in pr:
             yaw = _f64(pr["orientation_list"])[:n_use]

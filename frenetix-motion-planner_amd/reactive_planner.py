@@ -67,6 +67,9 @@ class PlannerConfig:
     kinematic_debug: bool = True     # debug.yaml:20
     save_all_traj: bool = False
     survivors: int = 16              # top-k kept for the host-side road-boundary walk
+    # dense grid (n_t, n_v, n_d) in natural order instead of the reference's sampling levels (BASELINE configs 2 - 5): T from
+    # t_min in steps of dt, V over the planner's velocity range, D over [d_min, d_max] plus the current d
+    dense_grid: Optional[Tuple[int, int, int]] = None
 
 
 class ReactivePlannerHip:
@@ -127,12 +130,19 @@ class ReactivePlannerHip:
     def engine(self):
         if self._engine is None:
             from .engine import FrenetEngine
-            lvl = max(self._sampling_max - 1, 0)
-            n = 2 ** (lvl + 1) + 1
-            cap = 16 * (n + 1) * (n + 1)
+            cap = self.max_candidates_per_step()
             self._engine = FrenetEngine(max_candidates=max(cap, 4096), max_steps=self.N, max_ref_knots=4096,
                                         max_obstacles=64, max_pred_steps=max(64, self.N + 2), device=self._device)
         return self._engine
+
+    def max_candidates_per_step(self) -> int:
+        """Candidates of the densest sampling level this planner can reach (or of its dense grid): the capacity its engine
+        needs so that the level escalation of plan() never outgrows it."""
+        if self.config.dense_grid is not None:
+            n_t, n_v, n_d = self.config.dense_grid
+            return int(n_t * n_v * (n_d + 1))
+        return self.sampling_handler.max_candidates(range(min(self._sampling_min, self._sampling_max - 1), self._sampling_max),
+                                                    cpp_style=True)
 
     @property
     def infeasible_count_collision(self):
@@ -233,7 +243,14 @@ class ReactivePlannerHip:
     def _inputs_for_level(self, samp_level: int, stop_point_s: Optional[float] = None) -> PlanInputs:
         from .engine import build_obstacle_hulls
         x_lon, x_lat = self.x_cl
-        t, v, d = self.sampling_handler.ordered_ranges(samp_level, x_lat[0])
+        if self.config.dense_grid is not None and stop_point_s is None:
+            from .sampling import dense_ranges
+            n_t, n_v, n_d = self.config.dense_grid
+            vs = self.sampling_handler.v_sampling
+            t, v, d = dense_ranges(n_t, n_v, n_d, vs.minimum, vs.maximum, self.horizon, self.dT, x_lat[0], self.config.t_min,
+                                   self.config.d_min, self.config.d_max)
+        else:
+            t, v, d = self.sampling_handler.ordered_ranges(samp_level, x_lat[0])
         if stop_point_s is not None:
             # stop-point sampling: end positions in [(s0 + s_stop) / 2, s_stop] (reactive_planner.py:637-643)
             self.sampling_handler.set_s_sampling((x_lon[0] + stop_point_s) / 2, stop_point_s)

@@ -124,6 +124,32 @@ class SamplingHandler:
         return t, v, d
 
 
+    def max_candidates(self, levels=None, cpp_style: bool = False) -> int:
+        """Largest |T| x |V| x (|D| + 1) over the sampling levels (|T| + 1, |V| + 1 with the C++ handler's extra values):
+        what an engine must hold so that every level of the escalation fits.  The time set is not bounded by 16:
+        horizon 5 s at level 3 has 20 values."""
+        levels = range(self.max_sampling_number) if levels is None else levels
+        extra = 1 if cpp_style else 0
+        best = 0
+        for lvl in levels:
+            n = 2 ** (lvl + 1) + 1
+            best = max(best, (len(self.t_sampling.to_range(lvl)) + extra) * (n + extra) * (n + 1))
+        return best
+
+
+def dense_ranges(n_t: int, n_v: int, n_d: int, v_lo: float, v_hi: float, horizon: float, dt: float, d0: float,
+                 t_min: float = 1.1, d_min: float = -3.0, d_max: float = 3.0):
+    """Dense grid in natural (ascending) order: T = t_min .. horizon step dt (first n_t), V = linspace(v_lo, v_hi, n_v),
+    D = linspace(d_min, d_max, n_d) plus d0 appended if absent (BASELINE configs 2 - 5)."""
+    t = np.round(t_min + dt * np.arange(n_t), 2)
+    t = t[t <= horizon + 1e-9]
+    v = np.linspace(v_lo, v_hi, n_v)
+    d = np.linspace(d_min, d_max, n_d)
+    if d0 not in d:
+        d = np.append(d, d0)
+    return t, v, d
+
+
 def generate_sampling_matrix(*, t0_range, t1_range, s0_range, ss0_range, sss0_range, ss1_range, sss1_range,
                              d0_range, dd0_range, ddd0_range, d1_range, dd1_range, ddd1_range):
     """Cartesian product of the 13 ranges, row-major, rows in itertools.product order

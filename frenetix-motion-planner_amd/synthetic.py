@@ -11,6 +11,7 @@ import numpy as np
 from .coordinate_system import CoordinateSystem
 from .problem import DEFAULT_COST_WEIGHTS, PlanInputs, VehicleParams, pack_predictions
 from .sampling import SamplingHandler, v_sampling_bounds
+from .sampling import dense_ranges as _dense_ranges
 
 SEED = 20241008
 
@@ -35,17 +36,10 @@ def reference_polyline(kind: str = "arc", n_knots: int = 400, spacing: float = 0
 
 def dense_ranges(n_t: int, n_v: int, n_d: int, v0: float, veh: VehicleParams, horizon: float, dt: float, d0: float,
                  t_min: float = 1.1, d_min: float = -3.0, d_max: float = 3.0):
-    """Dense grid in natural (ascending) order: T = t_min .. horizon-dt step dt (first n_t),
-    V = linspace(v-range, n_v), D = linspace(d_min, d_max, n_d) plus d0 appended if absent.
+    """Dense grid of sampling.dense_ranges over the planner's velocity range for v0 (planner.py:304-306).
     BASELINE config 2: n_t=19, n_v=51, n_d=51 -> 19 x 51 x 52 = 50 388 candidates."""
-    t = np.round(t_min + dt * np.arange(n_t), 2)
-    t = t[t <= horizon + 1e-9]
     v_lo, v_hi = v_sampling_bounds(v0, veh.a_max, horizon, veh.v_max)
-    v = np.linspace(v_lo, v_hi, n_v)
-    d = np.linspace(d_min, d_max, n_d)
-    if d0 not in d:
-        d = np.append(d, d0)
-    return t, v, d
+    return _dense_ranges(n_t, n_v, n_d, v_lo, v_hi, horizon, dt, d0, t_min, d_min, d_max)
 
 
 def synthetic_predictions(cs: CoordinateSystem, n_obstacles: int, n_pred: int, dt: float, s_center: float,

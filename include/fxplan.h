@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 2
+#define FX_ABI_VERSION 3
 
 /* ---- status codes (planner.py / reactive_planner_cpp.py raise Python exceptions; the shim maps
  *      <0 -> ValueError, >0 -> RuntimeError, see SURVEY 8b "Error conventions") ---- */
@@ -236,6 +236,24 @@ int32_t fx_plan_step(FxContext *ctx, const FxProblem *prob, FxResult *res);
 /* evaluate + finish for inputs that are already resident (the handler re-evaluating its current trajectory set,
  * reactive_planner_cpp.py:345-349): one call across the boundary per plan step; res[n_agents] */
 int32_t fx_step(FxContext *ctx, FxResult *res);
+
+/* ---- per-step update of a planner that keeps its reference path, grid shape and cost function: the new ego state,
+ *      desired velocity, sampling values and predictions of planner.py:172-217 (update_externals) / reactive_planner_cpp.py:
+ *      56-86 (set_predictions) rewritten in place in the context's pinned staging block, ONE host-to-device copy of what
+ *      changed in front of the next evaluation.  NULL pointers, NaN doubles and a negative low_vel_mode keep the uploaded
+ *      value; array lengths (nT, nV, nD, K, P) are those of the upload.  fx_update_step = fx_update_state(agent 0) + fx_step. */
+typedef struct FxStateUpdate {
+    const double *x0_lon, *x0_lat;             /* [3] each */
+    double x0_orientation, v_des;
+    int32_t low_vel_mode;
+    const double *t_samp, *v_samp, *d_samp;
+    const double *obs_pos, *obs_cov_inv;       /* [K][P][2], [K][P][4] */
+    const int32_t *obs_npred;                  /* [K] */
+    const double *obs_hull;                    /* [K][P-1][6] */
+    const int32_t *obs_nhull;                  /* [K] */
+} FxStateUpdate;
+int32_t fx_update_state(FxContext *ctx, int32_t agent, const FxStateUpdate *upd);
+int32_t fx_update_step(FxContext *ctx, const FxStateUpdate *upd, FxResult *res);
 
 /* ---- read-back (TrajectorySample views are materialised lazily from the SoA bundle;
  *      reactive_planner_cpp.py:353 get_sorted_trajectories, trajectories.py:337-477) ---- */

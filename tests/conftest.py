@@ -15,3 +15,22 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def _gpu_available() -> bool:
+    """A usable engine: the HIP library loads and sees a device (counting devices does not initialise the GPU)."""
+    try:
+        from frenetix_motion_planner_amd.engine import device_count
+        return device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` tests need an MI355X: on a host without one they are skipped, not failed (a plain `pytest` stays green)."""
+    if _gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible (libfxplan.so has no CPU fallback)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

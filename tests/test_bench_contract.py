@@ -1,4 +1,5 @@
-"""bench.py prints ONE JSON line with the fields the driver and the judge read (GPU box)."""
+"""bench.py prints ONE JSON line with the fields the driver and the judge read (GPU box); its multi-rank launch path is
+checked on the CPU."""
 import json
 import os
 import subprocess
@@ -12,30 +13,59 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "traffic")
 
 
-def run(*args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, cwd=ROOT)
+def run(*args, timeout=600):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-1500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-500:]
     return json.loads(lines[0])
 
 
+def test_gpus_n_starts_its_own_ranks_dry():
+    """`python bench.py --gpus 2` without a launcher starts two rank processes that rendezvous (gloo, 127.0.0.1) -- no GPU
+    involved: the launch path the driver uses for the scaling runs."""
+    d = run("--gpus", "2", "--dry-launch", "--steps", "3", "--warmup", "1", timeout=300)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    one = run("--dry-launch")
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
+
+
 @pytest.mark.gpu
-def test_default_line_has_the_contract_fields():
-    d = run("--steps", "24", "--warmup", "4", "--timing-every", "4", "--no-cpu-baseline")
+def test_default_line_is_config3_with_north_star():
+    d = run("--steps", "24", "--warmup", "4", "--no-cpu-baseline")
     for k in REQUIRED:
         assert k in d, k
     for k in ROOFLINE:
         assert k in d["roofline"], k
     assert d["n_gpus"] == 1 and d["steps"] == 24 and d["warmup"] == 4 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and d["unit"] == "trajectories/s"
-    assert "workload" in d["config"] and "config2" in d["config"]["workload"] and d["config"]["candidates_global"] == 50388
+    assert "config3" in d["config"]["workload"] and d["config"]["candidates_global"] == 50388 and d["config"]["obstacles"] == 20
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and 0.2 < rf["frac"] < 1.0
-    assert rf["achieved"] == pytest.approx(rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9)
-    assert rf["algorithmic_bytes_per_launch"] == 50388 * 3472 and rf["launches_timed"] == 6
+    assert rf["bound"] == "fp64_valu" and rf["peak"] == 78.6 and rf["unit"] == "TFLOP/s" and 0.02 < rf["frac"] < 1.0
+    assert rf["achieved"] == pytest.approx(rf["flops_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e12)
+    assert rf["launches_timed"] == 24  # every launch is timed below 64 steps
+    hb = d["roofline_hbm"]
+    assert hb["bound"] == "hbm" and hb["peak"] == 8000.0 and hb["algorithmic_bytes_per_launch"] == 50388 * 3472
+    assert hb["achieved"] == pytest.approx(hb["algorithmic_bytes_per_launch"] / (hb["avg_launch_ms"] * 1e-3) / 1e9)
     assert d["value"] == pytest.approx(50388 * 24 / (d["ms_per_step"] * 1e-3 * 24), rel=1e-9) and d["value"] > 1e8
-    assert d["winner"]["index"] >= 0 and d["cpu_baseline"] is None
+    assert d["winner"]["index"] >= 0 and d["winner"]["n_collisions"] > 0 and d["cpu_baseline"] is None
+    # the step fed from host buffers is reported next to the resident one
+    assert d["plan_step_p50_ms"] > 0 and d["resident_step_p50_ms"] > 0 and d["value_with_upload"] > 1e8
+    ns = d["north_star"]
+    a, b = ns["obstacles_select_only"], ns["bundle_no_obstacles"]
+    assert a["candidates"] == 1005100 and a["obstacles"] == 20 and a["samples"] == 31 and a["eval_kernel_ms"] < 10.0 and a["step_ms"] < 10.0
+    assert a["roofline"]["bound"] == "fp64_valu" and 0 < a["roofline"]["frac"] < 1
+    assert b["candidates"] == 1005100 and b["roofline"]["bound"] == "hbm" and b["roofline"]["algorithmic_bytes_per_launch"] == 1005100 * 3472
+    assert 0.2 < b["roofline"]["frac"] < 1.0
+
+
+@pytest.mark.gpu
+def test_config2_line_keeps_the_hbm_roofline():
+    d = run("--workload", "config2", "--steps", "24", "--warmup", "4", "--no-cpu-baseline", "--no-north-star")
+    rf = d["roofline"]
+    assert "config2" in d["config"]["workload"] and rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.2 < rf["frac"] < 1.0
+    assert rf["achieved"] == pytest.approx(rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9)
+    assert rf["algorithmic_bytes_per_launch"] == 50388 * 3472 and rf["launches_timed"] == 24 and "north_star" not in d
 
 
 @pytest.mark.gpu
@@ -45,5 +75,6 @@ def test_cpu_baseline_object_and_other_workloads():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e4 and d["config"]["candidates"] == 630
+    assert "not run" in cb["upstream_handler"]
     d5 = run("--workload", "config5", "--agents-per-gpu", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert d5["config"]["agents_per_gpu"] == 2 and d5["config"]["candidates_per_gpu"] == 2 * 103428 and "compute" in d5

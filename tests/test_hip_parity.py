@@ -624,3 +624,53 @@ def test_maximum_obstacle_count_and_long_horizon(lanes, mapping, horizon):
         if np.all(out["margin"] >= FRAGILE):
             assert res["best_index"] == out["result"]["best_index"] and res["n_collisions"] == out["result"]["n_collisions"]
     assert out["collision"].sum() > 20 and out["result"]["n_feasible"] > 20
+
+
+def test_update_state_equals_fresh_upload(eng):
+    """fx_update_state (new ego state, sampling values and predictions rewritten in place, one small copy) gives bit for bit
+    what a full upload of the same inputs gives -- flags, costs, planes, winner, counters."""
+    kw = dict(ref_kind="arc", v0=10.0, grid=(7, 13, 13), n_obstacles=6, lead_gap=20.0)
+    base = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    eng.plan_step(base)
+    from frenetix_motion_planner_amd.problem import pack_predictions
+    for j in range(3):
+        moved = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+        moved.x0_lon = moved.x0_lon + np.array([0.4 * (j + 1), 0.1 * j, -0.05 * j])
+        moved.x0_lat = moved.x0_lat + np.array([0.03 * (j + 1), 0.01, 0.0])
+        moved.v_des = 11.0 + j
+        moved.v_samp = moved.v_samp + 0.01 * (j + 1)
+        preds = {k: dict(p, pos_list=np.asarray(p["pos_list"]) + 0.1 * (j + 1)) for k, p in moved.predictions.items()}
+        moved.obstacles = pack_predictions(preds, moved.n_samples, hip_hulls())
+        # in place
+        eng.upload(base)
+        up = eng.make_state_update(x0_lon=moved.x0_lon, x0_lat=moved.x0_lat, x0_orientation=moved.x0_orientation, v_des=moved.v_des,
+                                   v_samp=moved.v_samp, obstacles=moved.obstacles)
+        eng.update_state(up)
+        eng.evaluate()
+        ra = eng.finish()[0]
+        ca, fa = eng.costs()
+        pa = eng.bundle()
+        # fresh
+        rb = eng.plan_step(moved)
+        cb, fb = eng.costs()
+        pb = eng.bundle()
+        assert np.array_equal(fa, fb) and np.array_equal(ca, cb) and np.array_equal(pa, pb)
+        for k in ("best_index", "best_cost", "n_returned", "n_feasible", "n_collisions", "reason_hist"):
+            assert ra[k] == rb[k], k
+    # the combined call, state only (obstacles kept)
+    eng.upload(base)
+    up = eng.make_state_update(x0_lon=base.x0_lon + np.array([0.2, 0.0, 0.0]), v_des=12.5)
+    r1 = eng.update_step_raw(up)[0]
+    moved = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    moved.x0_lon = moved.x0_lon + np.array([0.2, 0.0, 0.0])
+    moved.v_des = 12.5
+    r2 = eng.plan_step(moved)
+    assert r1.best_index == r2["best_index"] and r1.best_cost == r2["best_cost"] and r1.n_collisions == r2["n_collisions"]
+
+
+def test_update_state_rejects_what_needs_a_new_upload(eng):
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), ref_kind="arc", v0=10.0, grid=(3, 5, 5))
+    eng.plan_step(inp)
+    with_obs = synthetic.make_inputs(hull_builder=hip_hulls(), ref_kind="arc", v0=10.0, grid=(3, 5, 5), n_obstacles=2)
+    with pytest.raises(ValueError):
+        eng.update_state(eng.make_state_update(obstacles=with_obs.obstacles))  # uploaded without obstacles
