@@ -39,6 +39,35 @@
 #define EPS 1e-5 /* reactive_planner.py:26 */
 #define TWO_PI 6.283185307179586
 
+/* ---------------------------------------------------------------- decisions taken by the last ulp (test bookkeeping)
+ *
+ * The reference compares quantities that are constructed to equal a threshold (the slowest sampled end velocity is
+ * max(0.001, ..) and is tested with "> 0.001", reactive_planner.py:393): such a comparison is decided by rounding noise and
+ * differs between machines running the reference itself.  Every comparison of the per-candidate evaluation goes through
+ * decide(): it records the smallest distance of any decision from its threshold ("margin"), the set of code sites that took
+ * a decision closer than FXO_FRAGILE to its threshold, and -- for the parity tests -- can be told to take all such
+ * decisions of chosen sites one way or the other, so that a device result can be checked against BOTH admissible outcomes
+ * instead of being skipped. */
+#define FXO_FRAGILE 1e-9
+enum { SITE_LON_GOAL = 0, SITE_NEG, SITE_CLAMP, SITE_ACC_PRE, SITE_MOVING, SITE_V_NEG, SITE_KAPPA, SITE_YAW, SITE_KAPPA_RATE,
+       SITE_A_LO, SITE_A_HI, SITE_DOM_LO, SITE_DOM_HI, SITE_COLLISION, SITE_BOUND_REACH, SITE_BOUND_HIT, SITE_COUNT };
+typedef struct {
+    double margin;          /* smallest |distance to threshold| seen */
+    uint32_t fragile;       /* sites with a decision closer than FXO_FRAGILE */
+    uint32_t force_mask;    /* sites whose fragile decisions are forced ... */
+    uint32_t force_vals;    /* ... to this outcome (bit = 1: the comparison holds) */
+} Decisions;
+static inline int decide(Decisions *D, int site, int cond, double dist) {
+    if (!D) return cond;
+    double m = fabs(dist);
+    if (m < D->margin) D->margin = m;
+    if (m < FXO_FRAGILE) {
+        D->fragile |= 1u << site;
+        if (D->force_mask & (1u << site)) return (D->force_vals >> site) & 1u;
+    }
+    return cond;
+}
+
 /* ---------------------------------------------------------------- numpy helpers */
 
 /* numpy/core/src/umath/loops_utils.h.src DOUBLE_pairwise_sum; np.sum(a) == 0.0 + this */
@@ -163,9 +192,9 @@ static int argmax_gt(const double *ref_pos, int M, double s) {
 
 /* (s,d) -> (x,y): foot point on segment k at s, offset d along the normalised interpolated vertex
  * normal.  Returns 0 outside the projection domain [ref_pos[0], ref_pos[M-1]]. */
-static int project(const FxProblem *p, double s, double d, double *x, double *y) {
+static int project_in(const FxProblem *p, double s, double d, double *x, double *y, int in_domain) {
     int M = p->M;
-    if (!(s >= p->ref_pos[0] && s <= p->ref_pos[M - 1])) return 0;
+    if (!in_domain) return 0;
     int lo = 0, hi = M;
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
@@ -183,6 +212,9 @@ static int project(const FxProblem *p, double s, double d, double *x, double *y)
     *x = px + d * (nx / nn);
     *y = py + d * (ny / nn);
     return 1;
+}
+static int project(const FxProblem *p, double s, double d, double *x, double *y) {
+    return project_in(p, s, d, x, y, s >= p->ref_pos[0] && s <= p->ref_pos[p->M - 1]);
 }
 
 /* ---------------------------------------------------------------- OBB hull + SAT (normative) */
@@ -219,7 +251,7 @@ static void obb_hull(double c0x, double c0y, double u0x, double u0y, double c1x,
 }
 
 /* separating-axis test of two OBBs a,b = (cx,cy,ex,ey,h1,h2); touching counts as collision */
-static int obb_overlap_m(const double *a, const double *b, double *margin) {
+static int obb_overlap_m(const double *a, const double *b, Decisions *D) {
     double tx = b[0] - a[0], ty = b[1] - a[1];
     double c = a[2] * b[2] + a[3] * b[3];  /* e_a . e_b */
     double s = a[2] * b[3] - a[3] * b[2];  /* e_a x e_b */
@@ -228,12 +260,9 @@ static int obb_overlap_m(const double *a, const double *b, double *margin) {
     double g1 = fabs(-tx * a[3] + ty * a[2]) - (a[5] + (b[4] * as + b[5] * ac));
     double g2 = fabs(tx * b[2] + ty * b[3]) - (b[4] + (a[4] * ac + a[5] * as));
     double g3 = fabs(-tx * b[3] + ty * b[2]) - (b[5] + (a[4] * as + a[5] * ac));
-    if (margin) {
-        /* the decision is max(g) > 0 <=> separated; it is fragile when that maximum is near zero */
-        double gm = fmax(fmax(g0, g1), fmax(g2, g3));
-        if (fabs(gm) < *margin) *margin = fabs(gm);
-    }
-    return !(g0 > 0 || g1 > 0 || g2 > 0 || g3 > 0);
+    /* the decision is max(g) > 0 <=> separated; it is fragile when that maximum is near zero */
+    double gm = fmax(fmax(g0, g1), fmax(g2, g3));
+    return !decide(D, SITE_COLLISION, g0 > 0 || g1 > 0 || g2 > 0 || g3 > 0, gm);
 }
 static int obb_overlap(const double *a, const double *b) { return obb_overlap_m(a, b, NULL); }
 
@@ -251,7 +280,7 @@ int32_t fxo_build_obstacle_hulls(int32_t n_pred, const double *pos, const double
 /* planner.py:342-357 + collision_check.py:110-200: ego boxes (centre = rear axle + wb_rear_axle along
  * heading, half extents length/2 x width/2) at time t0+i, OBB-sum hull of steps (i,i+1) at time t0+i;
  * obstacle hull j covers predictions (j,j+1) at time t0+1+j.  Equal time index <=> j = i-1. */
-static int ego_collides(const FxProblem *p, const double *x, const double *y, const double *th, double *margin) {
+static int ego_collides(const FxProblem *p, const double *x, const double *y, const double *th, Decisions *margin) {
     int S = p->N + 1;
     double hull[6];
     for (int i = 1; i + 1 < S; i++) {
@@ -276,14 +305,13 @@ static int ego_collides(const FxProblem *p, const double *x, const double *y, co
  * (mid, half vector).  Separating axes: the two box axes and the piece's normal; touching intersects.  Returns the
  * first step that meets any piece, -1 if none.  Steps from the first out-of-domain step on are not tested. */
 static int ego_leaves_road(const FxProblem *p, const double *x, const double *y, const double *th, const double *s,
-                           const double *d, double *margin) {
+                           const double *d, Decisions *D) {
     const int S = p->N + 1, M = p->M;
     const double hl = p->veh.length / 2, hw = p->veh.width / 2, wb = p->veh.wb_rear_axle;
     for (int i = 0; i < S; i++) {
         if (!(s[i] >= p->ref_pos[0] && s[i] <= p->ref_pos[M - 1])) break; /* projection failed: loop breaks, :537-547 */
         /* beyond the lateral reach the boundary structure was built for: off the road by definition */
-        if (margin && fabs(fabs(d[i]) - p->bound_d_reach) < *margin) *margin = fabs(fabs(d[i]) - p->bound_d_reach);
-        if (fabs(d[i]) > p->bound_d_reach) return i;
+        if (decide(D, SITE_BOUND_REACH, fabs(d[i]) > p->bound_d_reach, fabs(d[i]) - p->bound_d_reach)) return i;
         const double ux = cos(th[i]), uy = sin(th[i]);
         const double cx = x[i] + wb * ux, cy = y[i] + wb * uy;
         int hit = 0;
@@ -295,13 +323,10 @@ static int ego_leaves_road(const FxProblem *p, const double *x, const double *y,
             const double m1 = fabs(ex) - (hl + fabs(hx));
             const double m2 = fabs(ey) - (hw + fabs(hy));
             const double m3 = fabs(ex * hy - ey * hx) - (hl * fabs(hy) + hw * fabs(hx));
-            if (margin) {
-                /* the decision is max(m1, m2, m3) > 0 */
-                double mx = m1 > m2 ? m1 : m2;
-                mx = mx > m3 ? mx : m3;
-                if (fabs(mx) < *margin) *margin = fabs(mx);
-            }
-            if (!(m1 > 0 || m2 > 0 || m3 > 0)) hit = 1;
+            /* the decision is max(m1, m2, m3) > 0 */
+            double mx = m1 > m2 ? m1 : m2;
+            mx = mx > m3 ? mx : m3;
+            if (!decide(D, SITE_BOUND_HIT, m1 > 0 || m2 > 0 || m3 > 0, mx)) hit = 1;
         }
         if (hit) return i;
     }
@@ -336,10 +361,8 @@ static void candidate_params(const FxProblem *p, int64_t g, double *T, double *l
 }
 
 /* evaluates candidate g; pl = 14 x S planes (zero-initialised by the caller) */
-#define MARGIN(expr) do { double m_ = fabs(expr); if (m_ < mg) mg = m_; } while (0)
 static uint32_t eval_candidate(const FxProblem *p, int64_t g, Cand *cd, double *pl, double *cost_raw, double *cost_total,
-                               double *margin_out) {
-    double mg = 1e300; /* smallest distance of any discrete decision from its threshold (test bookkeeping) */
+                               Decisions *DC) {
     const int S = p->N + 1;
     const int D = (p->mode & FX_MODE_DRAW_TRAJ_SET) != 0, KD = (p->mode & FX_MODE_KINEMATIC_DEBUG) != 0;
     double *x = pl + FX_PL_X * S, *y = pl + FX_PL_Y * S, *theta_gl = pl + FX_PL_THETA * S, *v = pl + FX_PL_V * S;
@@ -361,8 +384,7 @@ static uint32_t eval_candidate(const FxProblem *p, int64_t g, Cand *cd, double *
     if (p->low_vel_mode) {
         double t2 = T * T, t3 = t2 * T, t4 = t2 * t2, t5 = t3 * t2; /* evaluate_state_at_tau :213-216 */
         double s_lon_goal = poly_pos(cd->cl, T, t2, t3, t4, t5) - lon0[0];
-        MARGIN(s_lon_goal);
-        if (s_lon_goal <= 0) s_lon_goal = T;
+        if (decide(DC, SITE_LON_GOAL, s_lon_goal <= 0, s_lon_goal)) s_lon_goal = T;
         tau = s_lon_goal;
     }
     quintic_coeffs(lat0[0], lat0[1], lat0[2], lat1[0], lat1[1], lat1[2], tau, cd->ct);
@@ -405,28 +427,26 @@ static uint32_t eval_candidate(const FxProblem *p, int64_t g, Cand *cd, double *
 
     /* :350-355 */
     int neg = 0;
-    for (int i = 0; i < S; i++) { MARGIN(sv[i] + EPS); MARGIN(fabs(sv[i]) - EPS); if (sv[i] < -EPS) neg = 1; }
+    for (int i = 0; i < S; i++) if (decide(DC, SITE_NEG, sv[i] < -EPS, sv[i] + EPS)) neg = 1;
     if (neg) {
         flags &= ~FX_FLAG_VALID;
         reasons |= 1u << 10;
-        if (!D && !KD) { if (margin_out) *margin_out = mg; return flags | (reasons << FX_REASON_SHIFT); }
+        if (!D && !KD) return flags | (reasons << FX_REASON_SHIFT);
     }
-    for (int i = 0; i < S; i++) if (fabs(sv[i]) < EPS) sv[i] = 0.0;
+    for (int i = 0; i < S; i++) if (decide(DC, SITE_CLAMP, fabs(sv[i]) < EPS, fabs(sv[i]) - EPS)) sv[i] = 0.0;
 
     /* :373-386 */
     if (!D) {
         int acc = 0;
-        for (int i = 0; i < S; i++) { MARGIN(fabs(sa[i]) - p->veh.a_max); if (fabs(sa[i]) > p->veh.a_max) acc = 1; }
+        for (int i = 0; i < S; i++) if (decide(DC, SITE_ACC_PRE, fabs(sa[i]) > p->veh.a_max, fabs(sa[i]) - p->veh.a_max)) acc = 1;
         if (acc) {
             flags &= ~FX_FLAG_FEASIBLE;
             reasons |= 1u << 1;
-            if (margin_out) *margin_out = mg;
             return flags | FX_FLAG_RETURNED | (reasons << FX_REASON_SHIFT);
         }
         if (neg) {
             flags &= ~FX_FLAG_FEASIBLE;
             reasons |= 1u << 2;
-            if (margin_out) *margin_out = mg;
             return flags | FX_FLAG_RETURNED | (reasons << FX_REASON_SHIFT);
         }
     }
@@ -437,11 +457,12 @@ static uint32_t eval_candidate(const FxProblem *p, int64_t g, Cand *cd, double *
     const double kappa_max = p->veh.kappa_max;
     for (int i = 0; i < S; i++) {
         double dp, dpp;
-        if (!p->low_vel_mode) MARGIN(sv[i] - 0.001);
+        /* the three "s_dot > 0.001" tests of a step (:393, :403, :423) see the same number: one decision */
+        const int moving = p->low_vel_mode ? 1 : decide(DC, SITE_MOVING, sv[i] > 0.001, sv[i] - 0.001);
         if (!p->low_vel_mode) {
-            dp = sv[i] > 0.001 ? dv[i] / sv[i] : 0.;
+            dp = moving ? dv[i] / sv[i] : 0.;
             double ddot = da[i] - dp * sa[i];
-            dpp = sv[i] > 0.001 ? ddot / (sv[i] * sv[i]) : 0.;
+            dpp = moving ? ddot / (sv[i] * sv[i]) : 0.;
         } else {
             dp = dv[i];
             dpp = da[i];
@@ -451,7 +472,7 @@ static uint32_t eval_candidate(const FxProblem *p, int64_t g, Cand *cd, double *
         if (i0 < 0) i0 = M - 1;
         double s_lambda = (s[i] - rp[i0]) / (rp[i1] - rp[i0]);
 
-        if (sv[i] > 0.001 || p->low_vel_mode) {
+        if (moving) {
             theta_cl[i] = atan2(dp, 1.0);
             theta_gl[i] = theta_cl[i] + interpolate_angle(s[i], rp[i0], rp[i1], rth[i0], rth[i1]);
         } else {
@@ -472,36 +493,36 @@ static uint32_t eval_candidate(const FxProblem *p, int64_t g, Cand *cd, double *
                ((sv[i] * sv[i]) / cosTheta) *
                    (oneKrD * tanTheta * (kappa_gl[i] * (oneKrD / cosTheta) - k_r) - (k_r_d * d[i] + k_r * dp));
 
-        MARGIN(v[i] + EPS);
-        if (v[i] < -EPS) { reasons |= 1u << 4; if (!D && !KD) break; }
-        MARGIN(fabs(kappa_gl[i]) - kappa_max);
-        if (fabs(kappa_gl[i]) > kappa_max) { reasons |= 1u << 5; if (!D && !KD) break; }
+        if (decide(DC, SITE_V_NEG, v[i] < -EPS, v[i] + EPS)) { reasons |= 1u << 4; if (!D && !KD) break; }
+        if (decide(DC, SITE_KAPPA, fabs(kappa_gl[i]) > kappa_max, fabs(kappa_gl[i]) - kappa_max)) { reasons |= 1u << 5; if (!D && !KD) break; }
         double yaw_rate = i > 0 ? (theta_gl[i] - theta_gl[i - 1]) / dt : 0.;
         double theta_dot_max = kappa_max * v[i];
         double yr5 = fabs(np_round5(yaw_rate));
-        /* the 5-decimal rounding moves the value by up to 5e-6: near the limit the rint tie matters too */
-        if (fabs(yr5 - theta_dot_max) < 2e-5) MARGIN((fabs(fabs(yaw_rate * 1e5) - floor(fabs(yaw_rate * 1e5)) - 0.5)) * 1e-5);
-        /* 0 > 0 is exact, not noise: wherever the clamped velocity is exactly 0 the limit kappa_max * 0 is exactly 0,
-         * and a yaw rate that rounds to 0.00000 stays there under perturbation (its rint tie is tracked above) */
-        if (!(theta_dot_max == 0.0 && yr5 == 0.0)) MARGIN(yr5 - theta_dot_max);
-        if (yr5 > theta_dot_max) { reasons |= 1u << 6; if (!D && !KD) break; }
+        /* distance of the yaw-rate decision from flipping: to the limit itself, or -- the 5-decimal rounding moves the value
+         * by up to 5e-6, so near the limit -- to the rint tie.  0 > 0 is exact, not noise: wherever the clamped velocity is
+         * exactly 0 the limit kappa_max * 0 is exactly 0, and a yaw rate that rounds to 0.00000 stays there. */
+        double yaw_dist = (theta_dot_max == 0.0 && yr5 == 0.0) ? 1e300 : fabs(yr5 - theta_dot_max);
+        if (fabs(yr5 - theta_dot_max) < 2e-5) {
+            double tie = (fabs(fabs(yaw_rate * 1e5) - floor(fabs(yaw_rate * 1e5)) - 0.5)) * 1e-5;
+            if (tie < yaw_dist) yaw_dist = tie;
+        }
+        if (decide(DC, SITE_YAW, yr5 > theta_dot_max, yaw_dist)) { reasons |= 1u << 6; if (!D && !KD) break; }
         double kd = i > 0 ? (kappa_gl[i] - kappa_gl[i - 1]) / dt : 0.;
-        MARGIN(fabs(kd) - 0.4);
-        if (fabs(kd) > 0.4) { reasons |= 1u << 7; if (!D && !KD) break; }
+        if (decide(DC, SITE_KAPPA_RATE, fabs(kd) > 0.4, fabs(kd) - 0.4)) { reasons |= 1u << 7; if (!D && !KD) break; }
         double a_hi = v[i] > p->veh.v_switch ? p->veh.a_max * p->veh.v_switch / v[i] : p->veh.a_max;
         double a_lo = -p->veh.a_max;
-        MARGIN(a[i] - a_lo);
-        MARGIN(a[i] - a_hi);
-        if (!(a_lo <= a[i] && a[i] <= a_hi)) { reasons |= 1u << 8; if (!D && !KD) break; }
+        const int lo_ok = decide(DC, SITE_A_LO, a_lo <= a[i], a[i] - a_lo);
+        const int hi_ok = decide(DC, SITE_A_HI, a[i] <= a_hi, a[i] - a_hi);
+        if (!(lo_ok && hi_ok)) { reasons |= 1u << 8; if (!D && !KD) break; }
     }
     if (reasons & 0x1F8u) flags &= ~FX_FLAG_FEASIBLE; /* reasons 3..8 */
 
     /* :536-567 */
     if ((flags & FX_FLAG_FEASIBLE) || D) {
         for (int i = 0; i < S; i++) {
-            MARGIN(s[i] - p->ref_pos[0]);
-            MARGIN(s[i] - p->ref_pos[M - 1]);
-            if (!project(p, s[i], d[i], &x[i], &y[i])) {
+            const int ge_lo = decide(DC, SITE_DOM_LO, s[i] >= p->ref_pos[0], s[i] - p->ref_pos[0]);
+            const int le_hi = decide(DC, SITE_DOM_HI, s[i] <= p->ref_pos[M - 1], s[i] - p->ref_pos[M - 1]);
+            if (!project_in(p, s[i], d[i], &x[i], &y[i], ge_lo && le_hi)) {
                 flags &= ~FX_FLAG_VALID;
                 reasons |= 1u << 9;
                 break;
@@ -522,7 +543,6 @@ static uint32_t eval_candidate(const FxProblem *p, int64_t g, Cand *cd, double *
         costed = (flags & FX_FLAG_RETURNED) && (flags & FX_FLAG_VALID) && (flags & FX_FLAG_FEASIBLE);
         selectable = costed;
     }
-    if (margin_out) *margin_out = mg;
     if (!costed) return flags;
     flags |= FX_FLAG_COSTED;
     if (selectable) flags |= FX_FLAG_SELECTABLE;
@@ -597,6 +617,25 @@ static uint32_t eval_candidate(const FxProblem *p, int64_t g, Cand *cd, double *
     return flags;
 }
 
+/* candidate g end to end: evaluation, collision walk, road boundary */
+static uint32_t eval_one(const FxProblem *p, int64_t g, Cand *cd, double *pl, double *raw, double *total, int *bstep, Decisions *dc) {
+    const int S = p->N + 1;
+    uint32_t f = eval_candidate(p, g, cd, pl, raw, total, dc);
+    if ((f & FX_FLAG_SELECTABLE) && (p->mode & FX_MODE_COLLISION) && p->K > 0) {
+        if (ego_collides(p, pl + FX_PL_X * S, pl + FX_PL_Y * S, pl + FX_PL_THETA * S, dc)) f |= FX_FLAG_COLLISION;
+    }
+    *bstep = -1;
+    if ((f & FX_FLAG_SELECTABLE) && (p->mode & FX_MODE_ROAD_BOUNDARY) && p->n_bound > 0) {
+        *bstep = ego_leaves_road(p, pl + FX_PL_X * S, pl + FX_PL_Y * S, pl + FX_PL_THETA * S, pl + FX_PL_S * S, pl + FX_PL_D * S, dc);
+        if (*bstep >= 0) f |= FX_FLAG_BOUNDARY;
+    }
+    return f;
+}
+
+/* sites that took a decision closer than FXO_FRAGILE to its threshold, per candidate of the next fxo_plan_step_b call (NULL:
+ * not wanted); set by fxo_plan_step_c */
+static __thread uint32_t *g_frag_out = NULL;
+
 /* ---------------------------------------------------------------- whole plan step */
 
 typedef struct { double c; int64_t i; } CostIdx;
@@ -649,18 +688,12 @@ int32_t fxo_plan_step_b(const FxProblem *p, double *coeff_lon, double *coeff_lat
         memset(pl, 0, sizeof(double) * FX_NUM_PLANES * S);
         Cand cd;
         double raw[FX_NUM_COSTS], total = 0.0;
-        double mg = 1e300;
-        uint32_t f = eval_candidate(p, g0 + g, &cd, pl, raw, &total, &mg);
-        if ((f & FX_FLAG_SELECTABLE) && (p->mode & FX_MODE_COLLISION) && p->K > 0) {
-            if (ego_collides(p, pl + FX_PL_X * S, pl + FX_PL_Y * S, pl + FX_PL_THETA * S, &mg)) f |= FX_FLAG_COLLISION;
-        }
+        Decisions dc = {1e300, 0u, 0u, 0u};
         int bstep = -1;
-        if ((f & FX_FLAG_SELECTABLE) && (p->mode & FX_MODE_ROAD_BOUNDARY) && p->n_bound > 0) {
-            bstep = ego_leaves_road(p, pl + FX_PL_X * S, pl + FX_PL_Y * S, pl + FX_PL_THETA * S, pl + FX_PL_S * S, pl + FX_PL_D * S, &mg);
-            if (bstep >= 0) f |= FX_FLAG_BOUNDARY;
-        }
+        uint32_t f = eval_one(p, g0 + g, &cd, pl, raw, &total, &bstep, &dc);
         if (bound_step) bound_step[g] = bstep;
-        if (margin) margin[g] = mg;
+        if (margin) margin[g] = dc.margin;
+        if (g_frag_out) g_frag_out[g] = dc.fragile;
         flags[g] = f;
         cost[g] = (f & FX_FLAG_COSTED) ? total : 0.0;
         if (coeff_lon) memcpy(coeff_lon + 6 * g, cd.cl, sizeof(cd.cl));
@@ -817,6 +850,38 @@ int32_t fxo_plan_range_mt(const FxProblem *p, int64_t g0, int64_t g1, int32_t n_
     free(jobs);
     free(th);
     return rc;
+}
+
+/* fxo_plan_step_b plus frag_sites[C]: bit k set <=> site k (enum SITE_*) took a decision of this candidate by less than
+ * FXO_FRAGILE */
+int32_t fxo_plan_step_c(const FxProblem *p, double *coeff_lon, double *coeff_lat, int32_t *traj_len, double *planes,
+                        uint32_t *flags, double *cost, double *costmap, int64_t *order, double *margin, int32_t *bound_step,
+                        uint32_t *frag_sites, FxResult *res) {
+    g_frag_out = frag_sites;
+    int32_t rc = fxo_plan_step_b(p, coeff_lon, coeff_lat, traj_len, planes, flags, cost, costmap, order, margin, bound_step, res);
+    g_frag_out = NULL;
+    return rc;
+}
+
+/* One candidate (global index g) with every fragile decision of the sites in force_mask taken as force_vals says
+ * (bit = 1: the comparison holds).  planes [14][S], raw [n_cost].  The parity tests use it to check a device result of a
+ * fragile candidate against both admissible outcomes. */
+int32_t fxo_eval_forced(const FxProblem *p, int64_t g, uint32_t force_mask, uint32_t force_vals, double *planes, uint32_t *flags,
+                        double *cost, double *raw, int32_t *bound_step, uint32_t *frag_sites) {
+    const int S = p->N + 1;
+    if (S > 255 || p->n_cost > FX_NUM_COSTS) return FX_ERR_INVALID_ARGUMENT;
+    memset(planes, 0, sizeof(double) * FX_NUM_PLANES * S);
+    Cand cd;
+    double total = 0.0, rawl[FX_NUM_COSTS];
+    Decisions dc = {1e300, 0u, force_mask, force_vals};
+    int bstep = -1;
+    uint32_t f = eval_one(p, g, &cd, planes, rawl, &total, &bstep, &dc);
+    *flags = f;
+    *cost = (f & FX_FLAG_COSTED) ? total : 0.0;
+    if (raw) for (int n = 0; n < p->n_cost; n++) raw[n] = (f & FX_FLAG_COSTED) ? rawl[n] : 0.0;
+    if (bound_step) *bound_step = bstep;
+    if (frag_sites) *frag_sites = dc.fragile;
+    return FX_OK;
 }
 
 /* exported for tests of the normative pieces */

@@ -35,6 +35,11 @@ def lib():
         L.fxo_plan_step_b.argtypes = [C.POINTER(_abi.FxProblem), pd, pd, pi32, pd, pu32, pd, pd, pi64, pd, pi32,
                                       C.POINTER(_abi.FxResult)]
         L.fxo_plan_step_b.restype = C.c_int32
+        L.fxo_plan_step_c.argtypes = [C.POINTER(_abi.FxProblem), pd, pd, pi32, pd, pu32, pd, pd, pi64, pd, pi32, pu32,
+                                      C.POINTER(_abi.FxResult)]
+        L.fxo_plan_step_c.restype = C.c_int32
+        L.fxo_eval_forced.argtypes = [C.POINTER(_abi.FxProblem), C.c_int64, C.c_uint32, C.c_uint32, pd, pu32, pd, pd, pi32, pu32]
+        L.fxo_eval_forced.restype = C.c_int32
         L.fxo_plan_range.argtypes = [C.POINTER(_abi.FxProblem), C.c_int64, C.c_int64, pu32, pd, pi64, pd]
         L.fxo_plan_range.restype = C.c_int32
         L.fxo_plan_range_mt.argtypes = [C.POINTER(_abi.FxProblem), C.c_int64, C.c_int64, C.c_int32, C.c_int32, pu32, pd, pi64, pd]
@@ -81,12 +86,13 @@ def plan_step(inputs, want_planes=True):
         coeff_lon=np.zeros((Cn, 6)), coeff_lat=np.zeros((Cn, 6)), traj_len=np.zeros(Cn, np.int32),
         planes=np.zeros((Cn, _abi.FX_NUM_PLANES, S)) if want_planes else None,
         flags=np.zeros(Cn, np.uint32), cost=np.zeros(Cn), costmap=np.zeros((Cn, max(nc, 1))),
-        order=np.zeros(Cn, np.int64), margin=np.zeros(Cn), boundary_step=np.full(Cn, -1, np.int32))
+        order=np.zeros(Cn, np.int64), margin=np.zeros(Cn), boundary_step=np.full(Cn, -1, np.int32),
+        frag_sites=np.zeros(Cn, np.uint32))
     res = _abi.FxResult()
-    rc = lib().fxo_plan_step_b(C.byref(prob), _p(out["coeff_lon"]), _p(out["coeff_lat"]), _p(out["traj_len"], C.c_int32),
+    rc = lib().fxo_plan_step_c(C.byref(prob), _p(out["coeff_lon"]), _p(out["coeff_lat"]), _p(out["traj_len"], C.c_int32),
                                _p(out["planes"]) if want_planes else None, _p(out["flags"], C.c_uint32),
                                _p(out["cost"]), _p(out["costmap"]), _p(out["order"], C.c_int64), _p(out["margin"]),
-                               _p(out["boundary_step"], C.c_int32), C.byref(res))
+                               _p(out["boundary_step"], C.c_int32), _p(out["frag_sites"], C.c_uint32), C.byref(res))
     if rc != 0:
         raise ValueError(f"fxo_plan_step failed: {rc}")
     out["costmap"] = out["costmap"][:, :nc]
@@ -99,6 +105,40 @@ def plan_step(inputs, want_planes=True):
         out[name] = (f & bit) != 0
     out["reasons"] = (f >> _abi.FX_REASON_SHIFT) & 0x7FF
     return out
+
+
+FRAGILE = 1e-9  # FXO_FRAGILE of fx_oracle.c: decisions closer than this to their threshold are taken by rounding noise
+SITES = ("lon_goal", "neg", "clamp", "acc_pre", "moving", "v_neg", "kappa", "yaw", "kappa_rate", "a_lo", "a_hi", "dom_lo",
+         "dom_hi", "collision", "bound_reach", "bound_hit")
+
+
+def eval_forced(inputs, g, force_mask=0, force_vals=0):
+    """One candidate (index within the evaluated shard) with every fragile decision of the sites in `force_mask` taken the way
+    `force_vals` says.  Returns dict(planes [14, S], flags, cost, raw [n_cost], boundary_step, frag_sites)."""
+    prob = inputs.as_struct()
+    S, nc = inputs.n_samples, len(inputs.cost_names)
+    planes = np.zeros((_abi.FX_NUM_PLANES, S))
+    raw = np.zeros(max(nc, 1))
+    flags, frag, bstep, cost = C.c_uint32(0), C.c_uint32(0), C.c_int32(-1), C.c_double(0.0)
+    rc = lib().fxo_eval_forced(C.byref(prob), int(g) + inputs.shard_begin, int(force_mask), int(force_vals), _p(planes),
+                               C.byref(flags), C.byref(cost), _p(raw), C.byref(bstep), C.byref(frag))
+    if rc != 0:
+        raise ValueError(f"fxo_eval_forced failed: {rc}")
+    return dict(planes=planes, flags=flags.value, cost=cost.value, raw=raw[:nc], boundary_step=bstep.value, frag_sites=frag.value)
+
+
+def admissible_outcomes(inputs, g, frag_sites, max_sites=4):
+    """Every outcome the reference's arithmetic admits for a candidate whose decisions at the sites `frag_sites` are taken
+    by the last ulp: all 2^n assignments of those sites (n capped; beyond the cap the unforced evaluation alone)."""
+    sites = [k for k in range(len(SITES)) if (int(frag_sites) >> k) & 1]
+    if not sites or len(sites) > max_sites:
+        return [eval_forced(inputs, g)]
+    mask = sum(1 << k for k in sites)
+    outs = []
+    for combo in range(1 << len(sites)):
+        vals = sum(((combo >> j) & 1) << k for j, k in enumerate(sites))
+        outs.append(eval_forced(inputs, g, mask, vals))
+    return outs
 
 
 def plan_range(inputs, g0, g1, n_threads=1, reps=1):

@@ -1,0 +1,68 @@
+"""Candidates whose decisions the reference takes by the last ulp (oracle margin < FRAGILE) are not skipped: a result is
+accepted iff it equals ONE of the outcomes the reference's arithmetic admits -- the oracle re-evaluated with the fragile
+decisions forced each way (oracle.admissible_outcomes)."""
+import numpy as np
+
+from frenetix_motion_planner_amd import _abi
+
+FRAGILE = 1e-9
+# planes of a fragile candidate against the matching admissible outcome: at the step where s_dot sits on the 0.001 literal,
+# d'' = (d_ddot - d' s_ddot) / s_dot^2 amplifies last-digit differences by 1e6 and the difference cancels (measured: up to
+# 1.2e-7 of the plane's peak between device and oracle on the SAME branch): the north star's 1e-6 is the bound there
+FRAGILE_STATE_TOL = 1e-6
+_BITS = (_abi.FX_FLAG_VALID, _abi.FX_FLAG_FEASIBLE, _abi.FX_FLAG_RETURNED, _abi.FX_FLAG_COSTED, _abi.FX_FLAG_SELECTABLE,
+         _abi.FX_FLAG_COLLISION, _abi.FX_FLAG_BOUNDARY)
+
+
+def plane_error(got, ref):
+    """error of a [14, S] block, absolute for ordinary magnitudes and relative to each plane's peak otherwise"""
+    return float((np.abs(got - ref) / (1.0 + np.abs(ref).max(axis=1, keepdims=True))).max())
+
+
+def sec_max(planes):
+    """largest 1 / cos(theta_cl) of a candidate: how many digits cos(atan(d')) and tan(atan(d')) lose in the reference"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sec = np.abs(1.0 / np.cos(planes[9]))
+    return float(np.nan_to_num(sec, nan=np.inf).max())
+
+
+def conditioning(planes):
+    """sec(theta_cl) of the candidate, capped: the factor by which the reference's cos(arctan(d')) loses relative accuracy"""
+    return min(sec_max(planes), 1e12)
+
+
+def state_tolerance(ref_planes, base=1e-9):
+    """Plane tolerance of one candidate.  The reference forms cos(theta_cl) = cos(arctan(d')) and tan(arctan(d')): an absolute
+    error of one ulp in theta_cl is a RELATIVE error of sec(theta_cl) ulps in both, and v, a, kappa carry one to three such
+    factors.  The device takes cos = 1 / sqrt(1 + d'^2) and tan = d' (relative error one ulp), so the two may differ by about
+    sec * 1e-16 * (a few) relative to the plane's peak: 2e-14 * sec on top of `base` -- nothing up to sec ~ 1e4, growing
+    linearly beyond (sec = 1e7, "velocities" of 1e7 m/s: 2e-7)."""
+    return base + 2e-14 * conditioning(ref_planes)
+
+
+def cost_tolerance(ref_planes, base=1e-9):
+    """relative cost tolerance: the costs are sums of (squares of) those planes"""
+    return base + 4e-14 * conditioning(ref_planes)
+
+
+def same_decisions(flags_a, flags_b):
+    mask = 0
+    for b in _BITS:
+        mask |= b
+    mask |= 0x7FF << _abi.FX_REASON_SHIFT
+    return (int(flags_a) & mask) == (int(flags_b) & mask)
+
+
+def matches_one_outcome(outcomes, flags, cost=None, planes=None, *, cost_rtol=1e-9, state_tol=1e-9, planes_stored=True):
+    """True iff (flags, cost, planes) equals one of the admissible outcomes: decisions exactly, cost and planes to tolerance"""
+    for o in outcomes:
+        if not same_decisions(o["flags"], flags):
+            continue
+        if cost is not None and (o["flags"] & _abi.FX_FLAG_COSTED):
+            if abs(cost - o["cost"]) > cost_tolerance(o["planes"], cost_rtol) * max(abs(o["cost"]), 1e-12):
+                continue
+        if planes is not None and planes_stored and (o["flags"] & _abi.FX_FLAG_RETURNED):
+            if plane_error(planes, o["planes"]) > state_tolerance(o["planes"], state_tol):
+                continue
+        return True
+    return False

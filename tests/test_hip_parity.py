@@ -1,8 +1,10 @@
 """Parity of the HIP engine (through the C-ABI, libfxplan.so) against the CPU oracle on a real MI355X.
 
-Bit-exact on every index / mask / counter for candidates whose decisions are not taken by the last ulp
-(oracle margin >= FRAGILE, see tests/test_oracle_golden.py); floating-point planes within 1e-9 (the
-north-star bound on Cartesian states is 1e-6), costs within 1e-9 relative.
+Bit-exact on every index / mask / counter, floating-point planes within 1e-9 (the north-star bound on Cartesian states is
+1e-6), costs within 1e-9 relative -- for EVERY candidate.  Two refinements instead of exclusions (tests/admissible.py):
+candidates whose decisions the reference takes by the last ulp (oracle margin < FRAGILE) must equal one of the outcomes those
+decisions admit, and where the reference's own cos(arctan(d')) loses digits (theta_cl next to pi/2) the tolerances grow with
+sec(theta_cl).
 """
 import numpy as np
 import pytest
@@ -31,8 +33,14 @@ def hip_hulls():
     return build_obstacle_hulls
 
 
-def compare(eng, inp, out, res, *, check_planes=True, agent=0):
-    """out = oracle.plan_step(inp) ; res = engine result of the same inputs."""
+def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
+    """out = oracle.plan_step(ref_inp or inp) ; res = engine result of the same inputs.  EVERY candidate is checked:
+      * decisions (flag word: masks + reasons) exactly, planes to STATE_TOL, costs to COST_RTOL -- where the reference itself
+        loses digits (cos(arctan(d')) next to pi/2) the two tolerances grow with sec(theta_cl), tests/admissible.py;
+      * candidates whose decisions the reference takes by the last ulp (oracle margin < FRAGILE) against every outcome those
+        decisions admit: the device result must equal ONE of them."""
+    from oracle import oracle
+    from tests.admissible import FRAGILE_STATE_TOL, conditioning, matches_one_outcome
     robust = out["margin"] >= FRAGILE
     n_frag = int((~robust).sum())
     cost, flags = eng.costs(agent)
@@ -52,24 +60,21 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0):
     assert abs(res["n_feasible"] - ref["n_feasible"]) <= n_frag
     assert np.abs(np.array(res["reason_hist"]) - np.array(ref["reason_hist"])).max() <= n_frag
     assert res["n_candidates"] == ref["n_candidates"]
-    # A candidate whose theta_cl comes within 1e-3 of pi/2 (d' = d_dot / s_dot with s_dot ~ 1e-3, or a lateral polynomial over a
-    # few centimetres of arc length in LOW_VEL_MODE: 1 / cos > 1e3, "velocities" of 1e7 m/s, costs of 1e22) carries no digits in
-    # the reference either -- cos(atan(d')) and tan(atan(d')) lose them.  Such candidates are infeasible by orders of magnitude
-    # and only exist under the debug flag sets; their decisions (flags, reasons, counters) are compared, their numbers are not.
-    degenerate = np.zeros(len(flags), dtype=bool)
+    # per-candidate conditioning of the reference's own arithmetic (1 for ordinary candidates)
+    cond = np.ones(len(flags))
     if out.get("planes") is not None:
         with np.errstate(divide="ignore", invalid="ignore"):
             sec = np.abs(1.0 / np.cos(out["planes"][:, 9, :]))
-        degenerate = ~(np.nan_to_num(sec, nan=np.inf).max(axis=1) <= 1e3)
+        cond = np.minimum(np.nan_to_num(sec, nan=np.inf).max(axis=1), 1e12)
     # costs
-    c = out["costed"] & robust & ((flags & _abi.FX_FLAG_COSTED) != 0) & ~degenerate
+    c = out["costed"] & robust & ((flags & _abi.FX_FLAG_COSTED) != 0)
+    cm = eng.costmap(agent) if inp.write_costmap and len(inp.cost_names) else None
     if c.any():
         rel = np.abs(cost[c] - out["cost"][c]) / np.maximum(np.abs(out["cost"][c]), 1e-12)
-        assert rel.max() < COST_RTOL, f"cost rel err {rel.max()}"
-        if inp.write_costmap and len(inp.cost_names):
-            cm = eng.costmap(agent)
+        assert (rel < COST_RTOL + 4e-14 * cond[c]).all(), f"cost rel err {rel.max()}"
+        if cm is not None:
             relm = np.abs(cm[c] - out["costmap"][c]) / np.maximum(np.abs(out["costmap"][c]), 1e-9)
-            assert relm.max() < 1e-8, f"costmap rel err {relm.max()}"
+            assert (relm < 1e-8 + 4e-14 * cond[c][:, None]).all(), f"costmap rel err {relm.max()}"
     # winner: identical unless a fragile candidate or a sub-tolerance cost gap is involved
     if res["best_index"] != ref["best_index"]:
         a, b = res["best_index"], ref["best_index"]
@@ -81,14 +86,15 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0):
             assert abs(res["best_cost"] - ref["best_cost"]) <= COST_RTOL * max(1.0, abs(ref["best_cost"]))
         assert res["n_collisions"] == ref["n_collisions"] or n_frag > 0
     # planes
+    got = None
     if check_planes and inp.write_bundle:
         stored = out["returned"] & robust & (out["costed"] | (inp.draw_traj_set))
         got = eng.bundle(agent)
         refp = out["planes"]
-        err = np.abs(got - refp) / (1.0 + np.abs(refp).max(axis=2, keepdims=True))
+        err = (np.abs(got - refp) / (1.0 + np.abs(refp).max(axis=2, keepdims=True))).max(axis=(1, 2))
         err[~stored] = 0
-        err[degenerate] = 0
-        assert err.max() < STATE_TOL, f"plane err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}"
+        tol = STATE_TOL + 2e-14 * cond
+        assert (err < tol).all(), f"plane err {err.max()} (tolerance {tol[err.argmax()]}) at candidate {err.argmax()}"
         # coefficients / traj_len of a few candidates
         for g in np.linspace(0, inp.n_candidates - 1, 5).astype(int):
             lon, lat, tl = eng.coeffs(int(g), agent)
@@ -96,6 +102,17 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0):
             assert np.allclose(lat, out["coeff_lat"][g], rtol=1e-13, atol=0)
             assert tl == out["traj_len"][g]
             assert np.array_equal(eng.sample(int(g), agent), got[g])
+    # fragile candidates: one of the admissible outcomes, nothing skipped
+    src = ref_inp if ref_inp is not None else inp
+    for g in np.nonzero(~robust)[0]:
+        outs = oracle.admissible_outcomes(src, int(g), out["frag_sites"][g])
+        stored = bool(flags[g] & _abi.FX_FLAG_RETURNED) and (bool(flags[g] & _abi.FX_FLAG_COSTED) or inp.draw_traj_set)
+        ok = matches_one_outcome(outs, flags[g], cost[g] if flags[g] & _abi.FX_FLAG_COSTED else None,
+                                 got[g] if got is not None else None, cost_rtol=COST_RTOL, state_tol=FRAGILE_STATE_TOL,
+                                 planes_stored=stored)
+        assert ok, (f"fragile candidate {g} (sites {[oracle.SITES[k] for k in range(len(oracle.SITES)) if (out['frag_sites'][g] >> k) & 1]}): "
+                    f"device flags {hex(int(flags[g]))} match none of {[hex(o['flags']) for o in outs]}")
+    del conditioning
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -108,29 +125,45 @@ def test_golden_cases_vs_oracle(eng, name):
         assert np.allclose(inp.obstacles["hull"], ref_inp.obstacles["hull"], rtol=0, atol=1e-12)
     out = oracle.plan_step(ref_inp)
     res = eng.plan_step(inp)
-    compare(eng, inp, out, res)
+    compare(eng, inp, out, res, ref_inp=ref_inp)
 
 
-@pytest.mark.parametrize("name", ["arc_hv_l2_debug_obs5", "arc_lv_l1_debug", "short_ref_hv_l1_prod"])
+@pytest.mark.parametrize("name", golden_names())
 def test_golden_cases_vs_reference_vectors(eng, name):
-    """HIP output against the reference's own vectors directly (not via the oracle)."""
+    """HIP output against the reference's own vectors directly (not via the oracle), every stored candidate: within 1e-6 of the
+    reference's planes (the north-star bound; 1e-9 for all but a handful) -- or, where the reference took a decision by the
+    last ulp, equal to the oracle's outcome with that decision taken the other way."""
+    from oracle import oracle
+    from tests.admissible import FRAGILE_STATE_TOL, matches_one_outcome
     fx = load_golden(name)
     inp = inputs_from_fixture(fx, hip_hulls(), collision=False)
+    ref_inp = inputs_from_fixture(fx, oracle.build_obstacle_hulls, collision=False)
     res = eng.plan_step(inp)
     cost, flags = eng.costs()
     ids = fx["plane_ids"]
-    got = eng.bundle()[ids]
+    bundle = eng.bundle()
+    got = bundle[ids]
     stored = fx["has_cart"][ids]
-    err = np.abs(got - fx["planes"]) / (1.0 + np.abs(fx["planes"]).max(axis=2, keepdims=True))
+    err = (np.abs(got - fx["planes"]) / (1.0 + np.abs(fx["planes"]).max(axis=2, keepdims=True))).max(axis=(1, 2))
     err[~stored] = 0
-    # a fragile candidate (decision taken by the last ulp, see test_oracle_golden) shows up as a heading
-    # difference of up to O(1e-4) at one step; everything else is far inside the north-star bound of 1e-6
-    per_cand = err.max(axis=(1, 2))
-    fragile_share = 1.0 / len(fx["v_order"]) + 0.05
-    assert (per_cand > 1e-6).mean() <= fragile_share
-    assert (per_cand > 1e-9).mean() <= fragile_share
-    agree = ((flags & _abi.FX_FLAG_FEASIBLE) != 0)[fx["returned"]] == fx["feasible"][fx["returned"]]
-    assert agree.mean() >= 1 - (1.0 / len(fx["v_order"]) + 0.05)
+    feas_gpu = (flags & _abi.FX_FLAG_FEASIBLE) != 0
+    ret = fx["returned"]
+    out = oracle.plan_step(ref_inp)
+    robust = out["margin"] >= FRAGILE
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sec = np.abs(1.0 / np.cos(fx["planes"][:, 9, :]))
+    cond = np.minimum(np.nan_to_num(sec, nan=np.inf).max(axis=1), 1e12)
+    # candidates without a fragile decision: the reference's own vectors to 1e-9 (scaled where the reference loses digits)
+    rb = robust[ids]
+    assert (err[rb] < STATE_TOL + 2e-14 * cond[rb]).all(), f"robust candidate off the reference's vectors by {err[rb].max()}"
+    assert np.array_equal(feas_gpu[ret & robust], fx["feasible"][ret & robust])
+    # fragile ones: same branch as the reference took (1e-6: the step on the threshold is ill-conditioned) or the other one
+    suspects = set(int(g) for g in ids[(err > 1e-6) & ~rb]) | set(int(g) for g in np.nonzero(ret & ~robust & (feas_gpu != fx["feasible"]))[0])
+    for g in sorted(suspects):
+        outs = oracle.admissible_outcomes(ref_inp, g, out["frag_sites"][g])
+        st = bool(flags[g] & _abi.FX_FLAG_RETURNED) and (bool(flags[g] & _abi.FX_FLAG_COSTED) or inp.draw_traj_set)
+        assert matches_one_outcome(outs, flags[g], cost[g] if flags[g] & _abi.FX_FLAG_COSTED else None, bundle[g],
+                                   state_tol=FRAGILE_STATE_TOL, planes_stored=st), g
     if len(fx["walk_ids"]):
         assert res["best_index"] == int(fx["walk_ids"][0])
 
@@ -166,7 +199,7 @@ def test_synthetic_cases_vs_oracle(eng, name):
     ref_inp = synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw)
     out = oracle.plan_step(ref_inp)
     res = eng.plan_step(inp)
-    compare(eng, inp, out, res)
+    compare(eng, inp, out, res, ref_inp=ref_inp)
     if name == "dense_prod_obs":
         # a meaningful share of otherwise-best candidates must collide
         assert out["collision"].sum() > 0

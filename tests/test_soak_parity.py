@@ -1,0 +1,43 @@
+"""Parity soak (GPU): 240 seeded random scenarios -- reference shapes, speeds from standstill to 22 m/s, horizons 2 / 3 / 5 s,
+sampling levels and dense grids, 0-8 obstacles, flag sets, stop-point sampling, road boundary -- each under a randomly forced
+work decomposition / kernel variant / store mode, EVERY candidate against the oracle (tests/test_hip_parity.py::compare:
+fragile candidates against their admissible outcomes, nothing skipped)."""
+import numpy as np
+import pytest
+
+from frenetix_motion_planner_amd import synthetic
+from tests.test_hip_parity import FRAGILE, _random_case, compare, hip_hulls
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_soak_block(block):
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    from oracle import oracle
+    n_fragile = n_cands = 0
+    for case in range(5000 + 30 * block, 5000 + 30 * (block + 1)):
+        rng = np.random.default_rng([20241008, case])
+        kw = _random_case(rng)
+        inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+        ref_inp = synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw)
+        out = oracle.plan_step(ref_inp)
+        with FrenetEngine(max_candidates=max(inp.n_candidates, 64), max_steps=inp.N, max_pred_steps=max(64, inp.N + 2)) as e:
+            tn = (int(rng.choice([0, 1, 2, 4, 8])), int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 1, 2])),
+                  int(rng.choice([0, 64, 128, 256])), int(rng.choice([0, 1, 2])))
+            e.set_tuning(*tn)
+            e.set_store_mode(int(rng.integers(0, 3)))
+            try:
+                res = e.plan_step(inp)
+            except ValueError:  # a forced variant that does not apply to this case
+                e.set_tuning(0, 0, 0, 0, 0)
+                res = e.plan_step(inp)
+            try:
+                compare(e, inp, out, res, ref_inp=ref_inp)
+                if np.all(out["margin"] >= FRAGILE):
+                    assert res["best_index"] == out["result"]["best_index"] and res["n_collisions"] == out["result"]["n_collisions"]
+            except AssertionError as ex:
+                raise AssertionError(f"case {case} tuning {tn}: {ex}\n{kw}") from ex
+        n_fragile += int((out["margin"] < FRAGILE).sum())
+        n_cands += inp.n_candidates
+    assert n_cands > 0
