@@ -116,6 +116,51 @@ class CoordinateSystem:
     ref_theta = property(lambda self: self._ref_theta)
     normals = property(lambda self: self._normals)
 
+    def reference_at(self, s: float):
+        """(theta_ref unwrapped, kappa_ref, kappa_ref') linearly interpolated at arc length s -- the segment is the one the
+        reference's `argmax(ref_pos > s) - 1` picks (planner.py:580-597)."""
+        rp = self._ref_pos
+        k = int(np.argmax(rp > s)) - 1
+        lam = (s - rp[k]) / (rp[k + 1] - rp[k])
+        th = np.unwrap(self.ref_theta)
+        theta = interpolate_angle(s, rp[k], rp[k + 1], th[k], th[k + 1])
+        return theta, (self.ref_curv[k + 1] - self.ref_curv[k]) * lam + self.ref_curv[k], \
+            (self.ref_curv_d[k + 1] - self.ref_curv_d[k]) * lam + self.ref_curv_d[k]
+
+    def frenet_state(self, x: float, y: float, heading: float, speed: float, acceleration: float, curvature: float,
+                     arc_length_lateral: bool):
+        """Cartesian vehicle state -> ([s, s', s''], [d, d', d'']) along this reference (Werling, A.3 / A.5; behaviour of
+        planner.py:567-635).  With the heading error e = heading - theta_ref, the lateral scale w = 1 - kappa_ref d and the
+        curvature mismatch m = curvature * w / cos e - kappa_ref:
+
+            dd/ds   = w tan e                       d2d/ds2 = -(kappa_ref' d + kappa_ref dd/ds) tan e + w m / cos^2 e
+            ds/dt   = speed cos e / w               d2s/dt2 = (acceleration - (ds/dt)^2 / cos e * (w tan e m - (kappa_ref' d +
+                                                               kappa_ref dd/ds))) * cos e / w
+
+        The lateral derivatives are returned per arc length (LOW_VEL_MODE, `arc_length_lateral`) or per time
+        (d' = speed sin e, d'' = s'' dd/ds + s'^2 d2d/ds2).  Raises ValueError outside the projection domain and when the
+        vehicle faces against the reference (s' < 0)."""
+        import math
+        s, d = self.convert_to_curvilinear_coords(x, y)
+        theta_ref, k_ref, k_ref_s = self.reference_at(s)
+        e = heading - theta_ref
+        tan_e, cos_e = np.tan(e), math.cos(e)
+        w = 1 - k_ref * d
+        d_s = w * tan_e
+        bend = k_ref_s * d + k_ref * d_s          # d/ds of (kappa_ref d)
+        mismatch = curvature * w / cos_e - k_ref
+        d_ss = -bend * tan_e + (w / cos_e ** 2) * mismatch
+        s_t = speed * cos_e / w
+        if s_t < 0:
+            raise ValueError("the vehicle faces against the reference path (negative s'): initial state or reference incorrect")
+        s_tt = acceleration - (s_t ** 2 / cos_e) * (w * tan_e * mismatch - bend)
+        s_tt /= w / cos_e
+        if arc_length_lateral:
+            lat = [float(d), float(d_s), float(d_ss)]
+        else:
+            lat = [float(d), float(speed * math.sin(e)), float(s_tt * d_s + s_t ** 2 * d_ss)]
+        return [float(s), float(s_t), float(s_tt)], lat
+
     def segment_of(self, s: float) -> int:
         k = int(np.searchsorted(self._ref_pos, s, side="right")) - 1
         return min(max(k, 0), len(self._ref_pos) - 2)

@@ -208,36 +208,15 @@ class ReactivePlannerHip:
 
     # ------------------------------------------------------------------ initial Frenet state (planner.py:567-635)
     def _compute_initial_states(self, x_0: ReactivePlannerState):
-        cs = self.coordinate_system
+        """x_0 -> x_cl along the current reference; the ego curvature comes from the steering angle, tan(delta) / wheelbase"""
         try:
-            s, d = cs.convert_to_curvilinear_coords(x_0.position[0], x_0.position[1])
-        except ValueError:
-            raise ValueError("Initial state could not be transformed.")
-        s_idx = int(np.argmax(cs.ref_pos > s)) - 1
-        s_lambda = (s - cs.ref_pos[s_idx]) / (cs.ref_pos[s_idx + 1] - cs.ref_pos[s_idx])
-        ref_theta = np.unwrap(cs.ref_theta)
-        theta_cl = x_0.orientation - interpolate_angle(s, cs.ref_pos[s_idx], cs.ref_pos[s_idx + 1], ref_theta[s_idx],
-                                                       ref_theta[s_idx + 1])
-        kr = (cs.ref_curv[s_idx + 1] - cs.ref_curv[s_idx]) * s_lambda + cs.ref_curv[s_idx]
-        kr_d = (cs.ref_curv_d[s_idx + 1] - cs.ref_curv_d[s_idx]) * s_lambda + cs.ref_curv_d[s_idx]
-        kappa_0 = np.tan(x_0.steering_angle) / self.vehicle_params.wheelbase
-        d_p = (1 - kr * d) * np.tan(theta_cl)
-        d_pp = -(kr_d * d + kr * d_p) * np.tan(theta_cl) + ((1 - kr * d) / (math.cos(theta_cl) ** 2)) * (
-            kappa_0 * (1 - kr * d) / math.cos(theta_cl) - kr)
-        s_velocity = x_0.velocity * math.cos(theta_cl) / (1 - kr * d)
-        if s_velocity < 0:
-            raise Exception("Initial state or reference incorrect! Curvilinear velocity is negative which indicates"
-                            "that the ego vehicle is not driving in the same direction as specified by the reference")
-        s_acceleration = x_0.acceleration
-        s_acceleration -= (s_velocity ** 2 / math.cos(theta_cl)) * (
-            (1 - kr * d) * np.tan(theta_cl) * (kappa_0 * (1 - kr * d) / (math.cos(theta_cl)) - kr) - (kr_d * d + kr * d_p))
-        s_acceleration /= ((1 - kr * d) / (math.cos(theta_cl)))
-        if self._LOW_VEL_MODE:
-            d_velocity, d_acceleration = d_p, d_pp
-        else:
-            d_velocity = x_0.velocity * math.sin(theta_cl)
-            d_acceleration = s_acceleration * d_p + s_velocity ** 2 * d_pp
-        return [float(s), float(s_velocity), float(s_acceleration)], [float(d), float(d_velocity), float(d_acceleration)]
+            return self.coordinate_system.frenet_state(
+                x_0.position[0], x_0.position[1], x_0.orientation, x_0.velocity, x_0.acceleration,
+                np.tan(x_0.steering_angle) / self.vehicle_params.wheelbase, arc_length_lateral=self._LOW_VEL_MODE)
+        except ValueError as ex:
+            if "faces against" in str(ex):
+                raise
+            raise ValueError("Initial state could not be transformed.") from ex
 
     # ------------------------------------------------------------------ plan (reactive_planner.py:67-130)
     def _inputs_for_level(self, samp_level: int, stop_point_s: Optional[float] = None) -> PlanInputs:

@@ -26,9 +26,22 @@ def sec_max(planes):
     return float(np.nan_to_num(sec, nan=np.inf).max())
 
 
+def conditioning_many(planes):
+    """Per candidate ([C, 14, S] planes of the oracle): how much relative accuracy the reference's own arithmetic loses.
+      * sec(theta_cl): cos(arctan(d')) and tan(arctan(d')) carry sec ulps of relative error next to pi/2;
+      * the dynamic range of the lateral derivatives: a lateral polynomial over a few centimetres of arc length (LOW_VEL_MODE)
+        or a division by s_dot^2 ~ 1e-6 gives d', d'' of 1e4 ... 1e7 whose evaluation noise (1e-16 of THEIR peak) lands
+        unattenuated in kappa / a at the steps where cos(theta_cl) is 1 -- measured against those planes' own small peaks.
+    1 for ordinary candidates; capped at 1e12."""
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        sec = np.nan_to_num(np.abs(1.0 / np.cos(planes[:, 9, :])), nan=np.inf).max(axis=1)
+        lat = np.nan_to_num(np.abs(planes[:, 12:14, :]), nan=np.inf).max(axis=(1, 2))
+        kin = 1.0 + np.nan_to_num(np.abs(planes[:, 3:7, :]), nan=0.0).max(axis=2).min(axis=1)
+    return np.minimum(np.maximum(np.maximum(sec, lat / kin), 1.0), 1e12)
+
+
 def conditioning(planes):
-    """sec(theta_cl) of the candidate, capped: the factor by which the reference's cos(arctan(d')) loses relative accuracy"""
-    return min(sec_max(planes), 1e12)
+    return float(conditioning_many(planes[None])[0])
 
 
 def state_tolerance(ref_planes, base=1e-9):

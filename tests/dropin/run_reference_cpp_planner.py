@@ -82,11 +82,16 @@ class O:
         self.__dict__.update(kw)
 
 
-def main(use_hip: bool, blocked: bool):
+def main(use_hip: bool, blocked: bool, record: str = None):
     ref_harness.install()
     install_container_shims()
     from frenetix_motion_planner_amd import VehicleParams, frenetix_compat, synthetic
     frenetix_compat.install(force=True)
+    recorder = None
+    if record:  # write the adapter's call trace (data only) for the replay test on the GPU box
+        from tests.dropin.trace_recorder import CLASSES, Recorder
+        recorder = Recorder()
+        recorder.wrap({n: sys.modules[n] for n in CLASSES})
     import frenetix
     import frenetix_motion_planner.planner as refplanner
     import frenetix_motion_planner.reactive_planner_cpp as rpc
@@ -166,8 +171,11 @@ def main(use_hip: bool, blocked: bool):
                    last=[float(cart[-1].position[0]), float(cart[-1].position[1]), float(cart[-1].velocity)],
                    sampling_parameters=[float(v) for v in opt.sampling_parameters],
                    costmap={k: [float(v[0]), float(v[1])] for k, v in opt.costMap.items()})
+    if recorder is not None:
+        recorder.save(record, out)
     print(json.dumps(out))
 
 
 if __name__ == "__main__":
-    main("--hip" in sys.argv, "--blocked" in sys.argv)
+    rec = sys.argv[sys.argv.index("--record") + 1] if "--record" in sys.argv else None
+    main("--hip" in sys.argv, "--blocked" in sys.argv, rec)

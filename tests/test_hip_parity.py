@@ -40,7 +40,7 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
       * candidates whose decisions the reference takes by the last ulp (oracle margin < FRAGILE) against every outcome those
         decisions admit: the device result must equal ONE of them."""
     from oracle import oracle
-    from tests.admissible import FRAGILE_STATE_TOL, conditioning, matches_one_outcome
+    from tests.admissible import FRAGILE_STATE_TOL, conditioning_many, matches_one_outcome
     robust = out["margin"] >= FRAGILE
     n_frag = int((~robust).sum())
     cost, flags = eng.costs(agent)
@@ -61,11 +61,7 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
     assert np.abs(np.array(res["reason_hist"]) - np.array(ref["reason_hist"])).max() <= n_frag
     assert res["n_candidates"] == ref["n_candidates"]
     # per-candidate conditioning of the reference's own arithmetic (1 for ordinary candidates)
-    cond = np.ones(len(flags))
-    if out.get("planes") is not None:
-        with np.errstate(divide="ignore", invalid="ignore"):
-            sec = np.abs(1.0 / np.cos(out["planes"][:, 9, :]))
-        cond = np.minimum(np.nan_to_num(sec, nan=np.inf).max(axis=1), 1e12)
+    cond = conditioning_many(out["planes"]) if out.get("planes") is not None else np.ones(len(flags))
     # costs
     c = out["costed"] & robust & ((flags & _abi.FX_FLAG_COSTED) != 0)
     cm = eng.costmap(agent) if inp.write_costmap and len(inp.cost_names) else None
@@ -112,7 +108,6 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
                                  planes_stored=stored)
         assert ok, (f"fragile candidate {g} (sites {[oracle.SITES[k] for k in range(len(oracle.SITES)) if (out['frag_sites'][g] >> k) & 1]}): "
                     f"device flags {hex(int(flags[g]))} match none of {[hex(o['flags']) for o in outs]}")
-    del conditioning
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -150,9 +145,8 @@ def test_golden_cases_vs_reference_vectors(eng, name):
     ret = fx["returned"]
     out = oracle.plan_step(ref_inp)
     robust = out["margin"] >= FRAGILE
-    with np.errstate(divide="ignore", invalid="ignore"):
-        sec = np.abs(1.0 / np.cos(fx["planes"][:, 9, :]))
-    cond = np.minimum(np.nan_to_num(sec, nan=np.inf).max(axis=1), 1e12)
+    from tests.admissible import conditioning_many
+    cond = conditioning_many(fx["planes"])
     # candidates without a fragile decision: the reference's own vectors to 1e-9 (scaled where the reference loses digits)
     rb = robust[ids]
     assert (err[rb] < STATE_TOL + 2e-14 * cond[rb]).all(), f"robust candidate off the reference's vectors by {err[rb].max()}"
