@@ -34,6 +34,38 @@ def agents_of_rank(n_agents: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_agents, world))
 
 
+def hybrid_assignment(n_agents: int, world: int) -> List[List[Tuple[int, int, int]]]:
+    """Work items of every rank: a list over ranks of (agent, part, n_parts) triples.
+
+    n_agents >= world: agents round-robin over the ranks, every item the whole agent (part 0 of 1) -- the reference's agent
+    batches (simulation.py:449-470).  n_agents < world (BASELINE config 4: 5 agents on 8 GPUs): every rank still gets exactly
+    one item; the ranks are dealt to the agents as evenly as possible (the first `world % n_agents` agents get one more) and
+    the ranks of an agent split its candidates into contiguous parts (shard_range), so no GPU idles."""
+    if n_agents < 1 or world < 1:
+        raise ValueError("bad n_agents/world")
+    if n_agents >= world:
+        return [[(a, 0, 1) for a in agents_of_rank(n_agents, r, world)] for r in range(world)]
+    base, extra = divmod(world, n_agents)
+    items: List[List[Tuple[int, int, int]]] = []
+    for a in range(n_agents):
+        n_parts = base + (1 if a < extra else 0)
+        items.extend([[(a, p, n_parts)] for p in range(n_parts)])
+    return items
+
+
+def merge_agent_parts(n_agents: int, gathered) -> List[Tuple[float, int]]:
+    """gathered: iterable of (agent, cost, global index) rows from every rank's items (index < 0: that part found nothing).
+    Returns per agent the lexicographic (cost, index) minimum -- (0.0, -1) when no part of the agent has a survivor."""
+    best: List[Optional[Tuple[float, int]]] = [None] * n_agents
+    for a, c, i in gathered:
+        a, i = int(a), int(i)
+        if a < 0 or i < 0:
+            continue
+        if best[a] is None or (c, i) < best[a]:
+            best[a] = (float(c), i)
+    return [b if b is not None else (0.0, -1) for b in best]
+
+
 def merge_survivors(cost: np.ndarray, index: np.ndarray):
     """Lexicographic (cost, index) minimum over gathered survivors; index < 0 marks an empty slot.
     Returns (best_cost, best_index, order) with order = all valid survivors sorted."""
@@ -210,15 +242,26 @@ class ShardedEvaluator:
         return res, surv
 
     def plan_agents(self, agent_inputs: Sequence) -> List[Optional[dict]]:
-        """Agent sharding: rank r evaluates agents r, r+W, ... in one batched launch; winners are
-        all-gathered so every rank knows every agent's (cost, index).  Returns a list over ALL agents of
-        dicts {best_cost, best_index} (plus the full local result for the rank's own agents)."""
+        """Agent sharding with the candidate split for small agent counts (hybrid_assignment): every rank evaluates its items
+        -- whole agents, or its contiguous part of an agent's candidates -- in ONE batched launch; ONE all-gather of
+        (agent, cost, global index) per item; every rank takes the same lexicographic minimum per agent.  Returns a list over
+        ALL agents of dicts {best_cost, best_index} (global winner), plus the full local result under "local" for the
+        agents (or agent parts) this rank evaluated."""
+        import copy
         n = len(agent_inputs)
-        mine = agents_of_rank(n, self.rank, self.world)
-        local = self.engine.plan_batch([agent_inputs[a] for a in mine]) if mine else []
-        per = (n + self.world - 1) // self.world
+        items = hybrid_assignment(n, self.world)
+        mine = items[self.rank]
+        local_inputs = []
+        for a, part, n_parts in mine:
+            inp = agent_inputs[a]
+            if n_parts > 1:
+                inp = copy.copy(inp)  # shallow: the arrays are shared, only the shard differs
+                inp.shard = shard_range(agent_inputs[a].n_candidates_global, part, n_parts)
+            local_inputs.append(inp)
+        local = self.engine.plan_batch(local_inputs) if mine else []
+        per = max(len(it) for it in items)
         buf = np.full((per, 3), -1.0)
-        for j, a in enumerate(mine):
+        for j, (a, _, _) in enumerate(mine):
             buf[j] = (a, local[j]["best_cost"], local[j]["best_index"])
         if self.world == 1:
             gathered = buf
@@ -233,11 +276,11 @@ class ShardedEvaluator:
                 gl = [self.torch.empty_like(t) for _ in range(self.world)]
                 self.dist.all_gather(gl, t, group=self.group)
                 gathered = self.torch.cat(gl).numpy()
-        out: List[Optional[dict]] = [None] * n
-        for row in gathered:
-            a = int(row[0])
-            if a >= 0:
-                out[a] = dict(best_cost=float(row[1]), best_index=int(row[2]))
-        for j, a in enumerate(mine):
-            out[a] = dict(local[j], **out[a])
+        winners = merge_agent_parts(n, gathered)
+        out: List[Optional[dict]] = [dict(best_cost=c, best_index=i) for c, i in winners]
+        for j, (a, part, n_parts) in enumerate(mine):
+            out[a]["local"] = local[j]
+            out[a]["part"] = (part, n_parts)
+            if n_parts == 1:
+                out[a] = dict(local[j], **out[a])
         return out

@@ -134,8 +134,9 @@ def _gpu_worker(rank, world, port, q):
             agents = [synthetic.make_inputs(hull_builder=build_obstacle_hulls, ref_kind="arc", v0=6.0 + 2 * a, grid=(3, 5, 7),
                                             n_obstacles=a % 3, seed=a) for a in range(5)]
             ares = ev.plan_agents(agents)
+            hyb = ev.plan_agents(agents[3:4])   # one agent on two ranks: its candidates are split (hybrid_assignment)
             q.put((rank, res["global_best_index"], res["global_best_cost"], list(res["survivors"][:8]), inp.shard,
-                   [(r["best_index"], r["best_cost"]) for r in ares]))
+                   [(r["best_index"], r["best_cost"]) for r in ares], (hyb[0]["best_index"], hyb[0]["best_cost"], hyb[0]["part"])))
     finally:
         dist.destroy_process_group()
 
@@ -163,8 +164,9 @@ def test_sharded_path_with_real_engine_world2():
         tc, ti = eng.topk(8)
         singles = [eng.plan_step(synthetic.make_inputs(hull_builder=build_obstacle_hulls, ref_kind="arc", v0=6.0 + 2 * a,
                                                        grid=(3, 5, 7), n_obstacles=a % 3, seed=a)) for a in range(5)]
-    for rank, bi, bc, surv, shard, ares in got:
+    for rank, bi, bc, surv, shard, ares, hyb in got:
         assert bi == full["best_index"] and bc == full["best_cost"]
+        assert hyb == (singles[3]["best_index"], singles[3]["best_cost"], (rank, 2))
         assert surv[:4] == list(ti[0][:4])   # merged survivors == single-GPU top-k
         for a, (abi, abc) in enumerate(ares):
             assert abi == singles[a]["best_index"] and abc == singles[a]["best_cost"]
@@ -257,3 +259,96 @@ def test_agent_sharded_topk_gather_single_rank():
                 assert res[a]["best_index"] == ref[a]["best_index"] == (ti[a, 0] if ti[a, 0] >= 0 else -1)
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Hybrid agent x candidate sharding (fewer agents than ranks: BASELINE config 4 has 5 agents on 8 GPUs)
+# ---------------------------------------------------------------------------------------------------------
+def test_hybrid_assignment_gives_every_rank_work():
+    from frenetix_motion_planner_amd.distributed import hybrid_assignment, shard_range
+    items = hybrid_assignment(5, 8)                       # config 4
+    assert len(items) == 8 and all(len(it) == 1 for it in items)
+    parts = {}
+    for (a, p, n), in items:
+        parts.setdefault(a, []).append((p, n))
+    assert sorted(parts) == [0, 1, 2, 3, 4]
+    assert [len(parts[a]) for a in range(5)] == [2, 2, 2, 1, 1]   # 8 = 3 x 2 + 2 x 1
+    for a, pl in parts.items():
+        assert sorted(p for p, _ in pl) == list(range(len(pl))) and all(n == len(pl) for _, n in pl)
+    # the parts of an agent tile its candidates
+    assert [shard_range(10051, p, 2) for p in range(2)] == [(0, 5026), (5026, 5025)]
+    # at least as many agents as ranks: plain round-robin
+    assert hybrid_assignment(5, 2) == [[(0, 0, 1), (2, 0, 1), (4, 0, 1)], [(1, 0, 1), (3, 0, 1)]]
+    assert hybrid_assignment(1, 1) == [[(0, 0, 1)]]
+    with pytest.raises(ValueError):
+        hybrid_assignment(0, 4)
+
+
+def _agents(n):
+    from frenetix_motion_planner_amd import synthetic
+    from oracle import oracle
+    return [synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, ref_kind="arc", v0=6.0 + 2 * a, grid=(4, 7, 9),
+                                  n_obstacles=1 + a % 3, seed=a, lead_gap=18.0 if a % 2 else 0.0) for a in range(n)]
+
+
+def test_five_agents_on_eight_emulated_ranks_match_single_rank():
+    """config 4's shape without eight processes: every 'rank' evaluates its item with the oracle stand-in, the gathered
+    rows are merged the way every rank merges them -- the winners equal the single-rank winners of the whole agents."""
+    import copy
+    from frenetix_motion_planner_amd.distributed import hybrid_assignment, merge_agent_parts, shard_range
+    from oracle import oracle
+    agents = _agents(5)
+    rows = []
+    for rank_items in hybrid_assignment(5, 8):
+        for a, part, n_parts in rank_items:
+            inp = copy.copy(agents[a])
+            if n_parts > 1:
+                inp.shard = shard_range(agents[a].n_candidates_global, part, n_parts)
+            res = oracle.plan_step(inp, want_planes=False)["result"]
+            rows.append((a, res["best_cost"], res["best_index"]))
+    winners = merge_agent_parts(5, rows)
+    for a in range(5):
+        ref = oracle.plan_step(agents[a], want_planes=False)["result"]
+        assert winners[a] == (ref["best_cost"], ref["best_index"]) or (ref["best_index"] < 0 and winners[a][1] < 0)
+    assert any(w[1] >= 0 for w in winners)
+
+
+def _hybrid_worker(rank, world, port, q, n_agents):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ev = ShardedEvaluator(OracleEngine(), k=1)
+        ares = ev.plan_agents(_agents(n_agents))
+        q.put((rank, [(r["best_index"], r["best_cost"]) for r in ares], [r.get("part") for r in ares]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,n_agents", [(2, 1), (3, 2)])
+def test_hybrid_sharding_gloo(world, n_agents):
+    """1 agent on 2 ranks, 2 agents on 3 ranks: the candidates of an agent are split over its ranks, one all-gather, the
+    same winners on every rank, equal to the single-rank winners"""
+    from oracle import oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hybrid_worker, args=(r, world, port, q, n_agents)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    agents = _agents(n_agents)
+    for rank, winners, parts in got:
+        assert winners == got[0][1]
+        for a, (bi, bc) in enumerate(winners):
+            ref = oracle.plan_step(agents[a], want_planes=False)["result"]
+            assert (bi, bc) == (ref["best_index"], ref["best_cost"])
+    # every rank evaluated a part: with fewer agents than ranks nobody idles
+    assert all(any(p is not None for p in parts) for _, _, parts in got)
