@@ -5,7 +5,7 @@ wrapper (oracle/oracle.py) can share the struct definitions.
 """
 import ctypes as C
 
-FX_ABI_VERSION = 3
+FX_ABI_VERSION = 4
 FX_LON_VELOCITY_KEEPING, FX_LON_STOP_POINT = 0, 1
 
 FX_OK = 0
@@ -84,6 +84,21 @@ class FxStateUpdate(C.Structure):
         ("x0_lon", _pd), ("x0_lat", _pd), ("x0_orientation", C.c_double), ("v_des", C.c_double), ("low_vel_mode", C.c_int32),
         ("t_samp", _pd), ("v_samp", _pd), ("d_samp", _pd),
         ("obs_pos", _pd), ("obs_cov_inv", _pd), ("obs_npred", _pi32), ("obs_hull", _pd), ("obs_nhull", _pi32),
+    ]
+
+
+FX_PKG_ROWS = FX_NUM_PLANES + 3
+PKG_ROW_YAW_RATE, PKG_ROW_STEERING, PKG_ROW_ORIENTATION = FX_NUM_PLANES, FX_NUM_PLANES + 1, FX_NUM_PLANES + 2
+
+
+class FxPackage(C.Structure):
+    """the chosen trajectory of a plan step (fx_read_package / fx_plan_and_package)"""
+    _fields_ = [
+        ("found", C.c_int32), ("S", C.c_int32), ("traj_len", C.c_int32), ("flags", C.c_uint32),
+        ("index", C.c_int64), ("cost", C.c_double),
+        ("coeff_lon", C.c_double * 6), ("coeff_lat", C.c_double * 6),
+        ("n_cost", C.c_int32), ("reserved", C.c_int32),
+        ("raw_costs", C.c_double * FX_NUM_COSTS),
     ]
 
 

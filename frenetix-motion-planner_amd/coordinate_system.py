@@ -107,6 +107,7 @@ class CoordinateSystem:
         self._ref_curv_d = np.gradient(self._ref_curv, self._ref_pos)
         self._ref_curv_dd = np.gradient(self._ref_curv_d, self._ref_pos)
         self._normals = vertex_normals(ref)
+        self._c_args = None
 
     reference = property(lambda self: self._reference)
     ref_pos = property(lambda self: self._ref_pos)
@@ -122,7 +123,7 @@ class CoordinateSystem:
         rp = self._ref_pos
         k = int(np.argmax(rp > s)) - 1
         lam = (s - rp[k]) / (rp[k + 1] - rp[k])
-        th = np.unwrap(self.ref_theta)
+        th = self._ref_theta   # unwrapped at construction
         theta = interpolate_angle(s, rp[k], rp[k + 1], th[k], th[k + 1])
         return theta, (self.ref_curv[k + 1] - self.ref_curv[k]) * lam + self.ref_curv[k], \
             (self.ref_curv_d[k + 1] - self.ref_curv_d[k]) * lam + self.ref_curv_d[k]
@@ -179,36 +180,16 @@ class CoordinateSystem:
     def convert_to_curvilinear_coords(self, x: float, y: float) -> np.ndarray:
         """Inverse of convert_to_cartesian_coords: the (s, d) with smallest |d| whose foot point and
         interpolated normal pass through (x, y).  Raises ValueError outside the projection domain
-        (planner.py:574-578 expects that)."""
-        P, Nrm, rp = self._reference, self._normals, self._ref_pos
-        q = np.array([x, y], dtype=np.float64)
-        best = None
-        for k in range(len(P) - 1):
-            a = P[k] - q
-            b = P[k + 1] - P[k]
-            n0 = Nrm[k]
-            dn = Nrm[k + 1] - Nrm[k]
-            # cross(a + lam b, n0 + lam dn) = 0
-            c2 = b[0] * dn[1] - b[1] * dn[0]
-            c1 = a[0] * dn[1] - a[1] * dn[0] + b[0] * n0[1] - b[1] * n0[0]
-            c0 = a[0] * n0[1] - a[1] * n0[0]
-            if abs(c2) < 1e-14:
-                roots = [] if abs(c1) < 1e-300 else [-c0 / c1]
-            else:
-                disc = c1 * c1 - 4 * c2 * c0
-                if disc < 0:
-                    continue
-                sq = math.sqrt(disc)
-                roots = [(-c1 + sq) / (2 * c2), (-c1 - sq) / (2 * c2)]
-            for lam in roots:
-                if -1e-12 <= lam <= 1 + 1e-12:
-                    lam = min(max(lam, 0.0), 1.0)
-                    foot = P[k] + lam * b
-                    n = n0 + lam * dn
-                    n = n / math.sqrt(n[0] * n[0] + n[1] * n[1])
-                    d = float((q - foot) @ n)
-                    if best is None or abs(d) < abs(best[1]):
-                        best = (float(rp[k] + lam * (rp[k + 1] - rp[k])), d)
-        if best is None:
+        (planner.py:574-578 expects that).  Host geometry of the library (fx_cs_to_curvilinear): on every segment the
+        collinearity of foot point, interpolated normal and the point is a quadratic in the segment parameter."""
+        import ctypes as C
+        from ._lib import lib
+        pd = C.POINTER(C.c_double)
+        if self._c_args is None:   # contiguous views, kept alive with the object
+            keep = (np.ascontiguousarray(self._reference), np.ascontiguousarray(self._normals), np.ascontiguousarray(self._ref_pos))
+            self._c_args = (keep, len(keep[0]), *[a.ctypes.data_as(pd) for a in keep])
+        _, M, p_ref, p_nrm, p_pos = self._c_args
+        out = (C.c_double * 2)()
+        if lib().fx_cs_to_curvilinear(M, p_ref, p_nrm, p_pos, float(x), float(y), out) != 0:
             raise ValueError("<CoordinateSystem>: point outside projection domain")
-        return np.array(best)
+        return np.array([out[0], out[1]])

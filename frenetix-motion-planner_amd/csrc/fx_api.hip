@@ -28,6 +28,9 @@ extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, 
 extern "C" hipError_t fx_launch_math_test(int n, const double *x, double *at, double *sn, double *cs, hipStream_t stream);
 extern "C" hipError_t fx_launch_publish(const double *src, int n, double *host_dst, unsigned long long *host_seq,
                                         unsigned long long seq, hipStream_t stream);
+extern "C" hipError_t fx_launch_stage(const void *src_mapped, void *dst, size_t bytes, hipStream_t stream);
+extern "C" hipError_t fx_launch_package(const DevProblem *d_probs, int n_agents, const double *winner, double *host_pkg, int stride,
+                                        int plane_rows, unsigned long long seq, hipStream_t stream);
 extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int k, double *scr_cost, long long *scr_idx,
                                      double *out_cost, long long *out_idx, hipStream_t stream);
 
@@ -57,6 +60,8 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // bundles up to this size use write-through plane stores.  tools/store_sweep.py on MI355X: write-through is faster up to
 // ~0.5 GB (41 vs 45 us at 175 MB) and equal beyond (740 vs 746 us at 3.5 GB), so there is no upper limit by default.
 #define FX_STORE_WT_MAX_BYTES (~(size_t)0)
+// state updates up to this many bytes are staged by a copy kernel reading the mapped pinned block, larger ones by the DMA engine
+#define FX_STAGE_KERNEL_MAX ((size_t)1 << 20)
 #define FX_PUB_MAX 16384  // doubles: 8 ranks x 64 survivors x 2 x 16 agents
 
 struct FxAgentSlot {
@@ -94,7 +99,9 @@ struct FxContext {
     int32_t max_steps = 0, max_knots = 0, max_obs = 0, max_pred = 0, max_agents = 1;
     // input arena
     size_t in_bytes = 0;
-    char *h_in = nullptr;   // pinned
+    char *h_in = nullptr;   // pinned + mapped
+    char *h_in_dev = nullptr;  // device address of the same block (the staging kernel reads it)
+    int stage_mode = 0;        // 0 auto: kernel copy up to FX_STAGE_KERNEL_MAX bytes, DMA above; 1 DMA; 2 kernel (FX_STAGE=dma|kernel)
     char *d_in = nullptr;
     // problems
     DevProblem *h_probs = nullptr;  // [max_agents], the front of the pinned staging block h_in ...
@@ -127,6 +134,11 @@ struct FxContext {
     double *d_topk_scr_cost = nullptr;     // [max_agents][64 slices][64]
     long long *d_topk_scr_idx = nullptr;
     double *h_topk_cost = nullptr;
+    // winner package (fx_set_package): pinned + mapped [max_agents][pkg_stride] doubles the package kernel fills behind the selection
+    double *h_pkg = nullptr, *h_pkg_dev = nullptr;
+    int pkg_stride = 0, pkg_plane_rows = 0;
+    double *d_winner_own = nullptr;        // [max_agents][2]: the winner stays device-resident for the package kernel
+    bool package_enabled = false, pkg_step = false;
     double *h_cand = nullptr;  // pinned staging of fx_read_candidate_agent: planes | coeffs | raw costs | cost | traj_len | flags
     size_t h_cand_doubles = 0;
     long long *h_topk_idx = nullptr;
@@ -388,7 +400,9 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
                   align_up(sizeof(double) * 13 * (size_t)max_candidates_total, 256) + 4096;
     c->probs_bytes = align_up(sizeof(DevProblem) * (size_t)max_agents, 256);
     c->in_bytes += c->probs_bytes;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_in), c->in_bytes, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_in), c->in_bytes, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_in_dev), c->h_in, 0));
+    if (const char *sm = getenv("FX_STAGE")) c->stage_mode = !strcmp(sm, "dma") ? 1 : (!strcmp(sm, "kernel") ? 2 : 0);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_in), c->in_bytes));
     c->dev_bytes += (int64_t)c->in_bytes;
     c->h_probs = reinterpret_cast<DevProblem *>(c->h_in);
@@ -416,6 +430,13 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     if ((rc = dev_alloc(c, &c->d_topk_scr_cost, (size_t)max_agents * 64 * 64))) return rc;
     if ((rc = dev_alloc(c, &c->d_topk_scr_idx, (size_t)max_agents * 64 * 64))) return rc;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_topk_cost), sizeof(double) * max_agents * 64, hipHostMallocDefault));
+    c->pkg_plane_rows = FX_NUM_PLANES * (max_steps + 1);
+    c->pkg_stride = (c->pkg_plane_rows + FX_PKG_TAIL + 1 + 7) & ~7;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_pkg), sizeof(double) * (size_t)max_agents * c->pkg_stride,
+                          hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_pkg, 0, sizeof(double) * (size_t)max_agents * c->pkg_stride);
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_pkg_dev), c->h_pkg, 0));
+    if ((rc = dev_alloc(c, &c->d_winner_own, (size_t)max_agents * 2))) return rc;
     c->h_cand_doubles = (size_t)FX_NUM_PLANES * (max_steps + 1) + 12 + FX_NUM_COSTS + 4;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_cand), sizeof(double) * c->h_cand_doubles, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_topk_idx), sizeof(long long) * max_agents * 64, hipHostMallocDefault));
@@ -439,7 +460,8 @@ int32_t fx_destroy(FxContext *c) {
     if (c->d_bstep) (void)hipFree(c->d_bstep);
     if (c->d_bound) (void)hipFree(c->d_bound);
     if (c->h_bound) (void)hipHostFree(c->h_bound);
-    void *host[] = {c->h_in, c->h_counters, c->h_topk_cost, c->h_topk_idx, c->h_pub, c->h_cand};
+    if (c->d_winner_own) (void)hipFree(c->d_winner_own);
+    void *host[] = {c->h_in, c->h_counters, c->h_topk_cost, c->h_topk_idx, c->h_pub, c->h_cand, c->h_pkg};
     for (void *p : host) if (p) (void)hipHostFree(p);
     for (auto &t : c->ring) {
         if (t.e0) (void)hipEventDestroy(t.e0);
@@ -825,7 +847,12 @@ int32_t fx_evaluate(FxContext *c) {
         // problems, then whatever changed behind them)
         const size_t lo = c->probs_dirty ? 0 : c->dirty_lo;
         const size_t hi = std::max(c->dirty_hi > c->dirty_lo ? c->dirty_hi : 0, c->probs_dirty ? sizeof(DevProblem) * (size_t)c->n_agents : 0);
-        HIP_TRY(hipMemcpyAsync(c->d_in + lo, c->h_in + lo, hi - lo, hipMemcpyHostToDevice, c->stream));
+        // (offsets inside the block are multiples of 256, so the 16-byte lanes of the staging kernel line up)
+        const size_t lo16 = lo & ~(size_t)15, hi16 = (hi + 15) & ~(size_t)15;
+        if (c->stage_mode == 2 || (c->stage_mode == 0 && hi16 - lo16 <= FX_STAGE_KERNEL_MAX))
+            HIP_TRY(fx_launch_stage(c->h_in_dev + lo16, c->d_in + lo16, hi16 - lo16, c->stream));
+        else
+            HIP_TRY(hipMemcpyAsync(c->d_in + lo, c->h_in + lo, hi - lo, hipMemcpyHostToDevice, c->stream));
         c->dirty_lo = (size_t)-1; c->dirty_hi = 0;
         c->probs_dirty = false;
     }
@@ -849,7 +876,9 @@ int32_t fx_evaluate(FxContext *c) {
     // last workgroup reduces and publishes (fx_eval_kernel.h, "fused selection")
     c->seq++;
     c->fused_step = c->fuse_enabled && c->fusable_step && c->eval_launched;
-    FuseArgs fuse{c->fused_step ? c->h_counters_dev : nullptr, c->seq, c->dev_winner, c->K_max_step};
+    c->pkg_step = c->package_enabled && c->any_bundle;
+    double *winner = c->dev_winner ? c->dev_winner : (c->pkg_step ? c->d_winner_own : nullptr);
+    FuseArgs fuse{c->fused_step ? c->h_counters_dev : nullptr, c->seq, winner, c->K_max_step};
     if (c->eval_launched)
     {
         if (c->use_grid)
@@ -862,10 +891,12 @@ int32_t fx_evaluate(FxContext *c) {
     }
     if (timed && !attached) HIP_TRY(hipEventRecord(ts->e_eval, c->stream));
     if (!c->fused_step) {
-        HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, c->dev_winner, c->stream));
-        if (timed) HIP_TRY(hipEventRecord(ts->e_end, c->stream));
+        HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, winner, c->stream));
     }
-    if (timed) { ts->fused = c->fused_step; c->n_timed++; }
+    if (c->pkg_step)  // the winner's arrays follow the result block into pinned host memory: fx_finish waits for them
+        HIP_TRY(fx_launch_package(c->d_probs, c->n_agents, winner, c->h_pkg_dev, c->pkg_stride, c->pkg_plane_rows, c->seq, c->stream));
+    if (timed && (!c->fused_step || c->pkg_step)) HIP_TRY(hipEventRecord(ts->e_end, c->stream));
+    if (timed) { ts->fused = c->fused_step && !c->pkg_step; c->n_timed++; }
     c->timed_step = timed;
     c->evaluated = true;
     c->in_flight = true;
@@ -881,7 +912,10 @@ int32_t fx_finish_batch(FxContext *c, FxResult *res) {
         for (long spin = 0; spin < 20000000L && !done; spin++) {
             done = true;
             for (int a = 0; a < c->n_agents; a++) {
-                const volatile unsigned long long *sq = c->h_counters + (size_t)a * (FX_CNT_COUNT + 1) + FX_CNT_COUNT;
+                // with a winner package the last word to arrive is the package's (its kernel runs behind the selection)
+                const volatile unsigned long long *sq = c->pkg_step
+                    ? reinterpret_cast<const unsigned long long *>(c->h_pkg + (size_t)a * c->pkg_stride + c->pkg_stride - 1)
+                    : c->h_counters + (size_t)a * (FX_CNT_COUNT + 1) + FX_CNT_COUNT;
                 if (__atomic_load_n(sq, __ATOMIC_ACQUIRE) != c->seq) { done = false; break; }
             }
         }
@@ -992,6 +1026,140 @@ int32_t fx_update_step(FxContext *c, const FxStateUpdate *u, FxResult *res) {
     int rc = fx_update_state(c, 0, u);
     if (rc) return rc;
     return fx_step(c, res);
+}
+
+static int check_agent(FxContext *c, int a);
+
+// ---- winner package (header: fxplan.h) ----
+int32_t fx_set_package(FxContext *c, int32_t enabled) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    c->package_enabled = enabled != 0;
+    return FX_OK;
+}
+
+int32_t fx_read_package(FxContext *c, int32_t agent, double yaw_rate0, FxPackage *pkg, double *block) {
+    int rc = check_agent(c, agent);
+    if (rc) return rc;
+    if (!pkg) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_read_package: NULL argument");
+    if (!c->pkg_step) return set_err(FX_ERR_NOT_READY, "the last step ran without a winner package (fx_set_package, FX_MODE_WRITE_BUNDLE)");
+    if (c->in_flight) {  // fx_finish has not been called for this step: wait for the package word here
+        const volatile unsigned long long *sq =
+            reinterpret_cast<const unsigned long long *>(c->h_pkg + (size_t)agent * c->pkg_stride + c->pkg_stride - 1);
+        bool done = false;
+        for (long spin = 0; spin < 20000000L && !done; spin++) done = __atomic_load_n(sq, __ATOMIC_ACQUIRE) == c->seq;
+        if (!done) HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    const FxAgentSlot &sl = c->slots[agent];
+    const DevProblem &d = c->h_probs[agent];
+    const double *src = c->h_pkg + (size_t)agent * c->pkg_stride, *tail = src + c->pkg_plane_rows;
+    const int S = sl.S;
+    memset(pkg, 0, sizeof(*pkg));
+    pkg->S = S;
+    pkg->n_cost = sl.n_cost;
+    pkg->index = -1;
+    pkg->found = tail[16 + FX_NUM_COSTS] != 0.0;
+    if (!pkg->found) return FX_OK;
+    memcpy(pkg->coeff_lon, tail, sizeof(double) * 6);
+    memcpy(pkg->coeff_lat, tail + 6, sizeof(double) * 6);
+    memcpy(pkg->raw_costs, tail + 12, sizeof(double) * FX_NUM_COSTS);
+    pkg->cost = tail[12 + FX_NUM_COSTS];
+    pkg->traj_len = (int32_t)tail[13 + FX_NUM_COSTS];
+    pkg->flags = (uint32_t)tail[14 + FX_NUM_COSTS];
+    pkg->index = (int64_t)tail[15 + FX_NUM_COSTS];
+    if (!block) return FX_OK;
+    memcpy(block, src, sizeof(double) * FX_NUM_PLANES * S);
+    // the derived columns of planner.py:394-447 (_compute_trajectory_pair): yaw rate by backward differences of the heading,
+    // steering angle of the kinematic single-track model, heading shifted into [x0_orientation - pi, x0_orientation + pi]
+    const double *theta = block + 2 * (size_t)S, *kappa = block + 5 * (size_t)S;
+    double *yaw = block + (size_t)FX_NUM_PLANES * S, *steer = yaw + S, *orient = steer + S;
+    const double lo = d.x0_orientation - M_PI, hi = d.x0_orientation + M_PI, wb = d.veh.wheelbase;
+    for (int i = 0; i < S; i++) {
+        yaw[i] = i == 0 ? yaw_rate0 : (theta[i] - theta[i - 1]) / d.dt;
+        steer[i] = std::atan2(wb * kappa[i], 1.0);
+        double o = theta[i];
+        for (int r = 0; r < 4; r++) {
+            if (o < lo) o += 2 * M_PI;
+            if (o > hi) o -= 2 * M_PI;
+        }
+        orient[i] = o;
+    }
+    return FX_OK;
+}
+
+int32_t fx_plan_and_package(FxContext *c, const FxStateUpdate *upd, double yaw_rate0, FxResult *res, FxPackage *pkg, double *block) {
+    if (!c || !res || !pkg) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_plan_and_package: NULL argument");
+    int rc;
+    if (upd && (rc = fx_update_state(c, 0, upd))) return rc;
+    const bool was = c->package_enabled;
+    c->package_enabled = true;
+    rc = fx_evaluate(c);
+    c->package_enabled = was;
+    if (rc) return rc;
+    if ((rc = fx_finish_batch(c, res))) return rc;
+    return fx_read_package(c, 0, yaw_rate0, pkg, block);
+}
+
+// ---- host geometry of the callers either side of the path ----
+// (s, d) of a Cartesian point along the reference polyline (planner.py:574-578 convert_to_curvilinear_coords): on every
+// segment k the foot point P_k + lam b and the interpolated normal n_k + lam dn are collinear with the point where
+// cross(a + lam b, n_k + lam dn) = 0, a quadratic in lam; of all roots in [0, 1] the one with the smallest |d| wins.
+int32_t fx_cs_to_curvilinear(int32_t M, const double *ref_xy, const double *normals, const double *ref_pos, double x, double y, double *sd) {
+    if (M < 2 || !ref_xy || !normals || !ref_pos || !sd) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_cs_to_curvilinear: bad argument");
+    bool have = false;
+    double best_s = 0, best_d = 0;
+    for (int k = 0; k + 1 < M; k++) {
+        const double ax = ref_xy[2 * k] - x, ay = ref_xy[2 * k + 1] - y;
+        const double bx = ref_xy[2 * k + 2] - ref_xy[2 * k], by = ref_xy[2 * k + 3] - ref_xy[2 * k + 1];
+        const double n0x = normals[2 * k], n0y = normals[2 * k + 1];
+        const double dnx = normals[2 * k + 2] - n0x, dny = normals[2 * k + 3] - n0y;
+        const double c2 = bx * dny - by * dnx;
+        const double c1 = ax * dny - ay * dnx + bx * n0y - by * n0x;
+        const double c0 = ax * n0y - ay * n0x;
+        double roots[2];
+        int nr = 0;
+        if (std::fabs(c2) < 1e-14) {
+            if (!(std::fabs(c1) < 1e-300)) roots[nr++] = -c0 / c1;
+        } else {
+            const double disc = c1 * c1 - 4 * c2 * c0;
+            if (disc < 0) continue;
+            const double sq = std::sqrt(disc);
+            roots[nr++] = (-c1 + sq) / (2 * c2);
+            roots[nr++] = (-c1 - sq) / (2 * c2);
+        }
+        for (int r = 0; r < nr; r++) {
+            double lam = roots[r];
+            if (!(lam >= -1e-12 && lam <= 1 + 1e-12)) continue;
+            lam = std::fmin(std::fmax(lam, 0.0), 1.0);
+            const double fx = ref_xy[2 * k] + lam * bx, fy = ref_xy[2 * k + 1] + lam * by;
+            double nx = n0x + lam * dnx, ny = n0y + lam * dny;
+            const double nn = std::sqrt(nx * nx + ny * ny);
+            nx = nx / nn; ny = ny / nn;
+            const double dd = (x - fx) * nx + (y - fy) * ny;
+            if (!have || std::fabs(dd) < std::fabs(best_d)) {
+                have = true;
+                best_d = dd;
+                best_s = ref_pos[k] + lam * (ref_pos[k + 1] - ref_pos[k]);
+            }
+        }
+    }
+    if (!have) return set_err(FX_ERR_INVALID_ARGUMENT, "point outside projection domain");
+    sd[0] = best_s; sd[1] = best_d;
+    return FX_OK;
+}
+
+// fx_build_obstacle_hulls for K obstacles in one call: pos [K][P][2], yaw [K][P], n_use [K] predictions that count,
+// length / width [K]; hull [K][P-1][6], n_hull [K].
+int32_t fx_build_obstacle_hulls_batch(int32_t K, int32_t P, const int32_t *n_use, const double *pos, const double *yaw,
+                                      const double *length, const double *width, double *hull, int32_t *n_hull) {
+    if (K < 0 || P < 2 || (K > 0 && (!n_use || !pos || !yaw || !length || !width || !hull || !n_hull)))
+        return set_err(FX_ERR_INVALID_ARGUMENT, "fx_build_obstacle_hulls_batch: bad argument");
+    for (int k = 0; k < K; k++) {
+        if (n_use[k] > P) return set_err(FX_ERR_INVALID_ARGUMENT, "obstacle %d: %d predictions, stride %d", k, n_use[k], P);
+        int rc = fx_build_obstacle_hulls(n_use[k], pos + (size_t)2 * P * k, yaw + (size_t)P * k, length[k], width[k],
+                                         hull + (size_t)6 * (P - 1) * k, n_hull + k);
+        if (rc) return rc;
+    }
+    return FX_OK;
 }
 
 int32_t fx_plan_step(FxContext *c, const FxProblem *prob, FxResult *res) {

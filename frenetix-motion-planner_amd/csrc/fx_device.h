@@ -168,6 +168,9 @@ extern __device__ unsigned long long fx_probe_stamps[FX_PROBE_WAVES * FX_PROBE_S
 #define FX_STAMP(k) do { } while (0)
 #endif
 
+// winner package tail behind the [14][S] planes (doubles): lon6 lat6 | raw[FX_NUM_COSTS] | cost | traj_len | flags | index | found
+#define FX_PKG_TAIL (12 + FX_NUM_COSTS + 5)
+
 // counters[] layout
 enum {
     FX_CNT_RETURNED = 0, FX_CNT_FEASIBLE, FX_CNT_HIST0, /* 11 entries */

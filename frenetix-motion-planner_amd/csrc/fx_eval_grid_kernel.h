@@ -180,13 +180,16 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     const int i_end = min(S, i_begin + CH);
     const int i_first = (G > 1 && part > 0) ? i_begin - 1 : i_begin;
 
+    // The walk's wave-uniform doubles live in VGPRs (KV): the loop keeps ~50 lane masks and pointers in scalar registers and
+    // the allocator otherwise parks these constants in VGPR lanes and reads them back (v_readlane) every step.
+    auto KV = [](double x) { return WPE <= 2 ? fxk::uniform_to_vgpr(x) : x; };  // 256 VGPRs to spend only at two waves per SIMD
     StepConst K;
-    K.dt = dt; K.r_dt = 1.0 / dt; K.kappa_max = P.veh.kappa_max; K.a_max = a_max; K.v_switch = P.veh.v_switch;
-    K.av_switch = a_max * P.veh.v_switch; K.v_des = P.v_des; K.wb = P.veh.wb_rear_axle; K.half_len = P.veh.length / 2;
-    K.half_wid = P.veh.width / 2; K.S = S; K.half = S / 2; K.K = P.K; K.low_vel = low_vel; K.dbg = dbg;
+    K.dt = KV(dt); K.r_dt = KV(1.0 / dt); K.kappa_max = KV(P.veh.kappa_max); K.a_max = KV(a_max); K.v_switch = KV(P.veh.v_switch);
+    K.av_switch = KV(a_max * P.veh.v_switch); K.v_des = KV(P.v_des); K.wb = KV(P.veh.wb_rear_axle); K.half_len = KV(P.veh.length / 2);
+    K.half_wid = KV(P.veh.width / 2); K.S = S; K.half = S / 2; K.K = P.K; K.low_vel = low_vel; K.dbg = dbg;
     K.do_collision = do_collision; K.store_wt = (P.mode & FX_MODE_INT_STORE_WT) != 0;
     K.n_bound = (OBST && (P.mode & FX_MODE_ROAD_BOUNDARY)) ? P.n_bound : 0; K.bound_d_reach = P.bound_d_reach;
-    K.ox = P.hot_origin[0]; K.oy = P.hot_origin[1]; K.gap_margin = P.hot_gap_margin;
+    K.ox = KV(P.hot_origin[0]); K.oy = KV(P.hot_origin[1]); K.gap_margin = KV(P.hot_gap_margin);
     const BoundView Bv{as_global(P.bound_piece), as_global(P.bound_bin), as_global(P.bound_item)};
     const FX_GLOBAL double *__restrict__ obs_rec = as_global(P.obs_rec);
     const FX_GLOBAL unsigned long long *__restrict__ obs_pmask = as_global(P.obs_pmask);

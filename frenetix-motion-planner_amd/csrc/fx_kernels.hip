@@ -219,9 +219,9 @@ __global__ __launch_bounds__(256) void fx_topk_merge_kernel(int k, const double 
 __global__ __launch_bounds__(256) void fx_publish_kernel(const double *__restrict__ src, int n, double *host_dst,
                                                          unsigned long long *host_seq, unsigned long long seq) {
     for (int i = threadIdx.x; i < n; i += 256) host_dst[i] = src[i];
+    __threadfence_system();  // per wave: its stores are performed before the barrier lets thread 0 release the sequence word
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence_system();
         __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -229,6 +229,65 @@ __global__ __launch_bounds__(256) void fx_publish_kernel(const double *__restric
 extern "C" hipError_t fx_launch_publish(const double *src, int n, double *host_dst, unsigned long long *host_seq,
                                         unsigned long long seq, hipStream_t stream) {
     hipLaunchKernelGGL(fx_publish_kernel, dim3(1), dim3(256), 0, stream, src, n, host_dst, host_seq, seq);
+    return hipGetLastError();
+}
+
+// Staging copy of a plan step's rewritten inputs: the kernel reads the pinned (mapped) staging block over the bus and writes
+// the device copy, 16 B per lane.  For the 1 - 150 KB a state update touches this lands in a few microseconds behind the
+// launch, where a DMA-engine copy of the same bytes costs its submission latency first (measured: tools/upload_step.py).
+__global__ __launch_bounds__(256) void fx_stage_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" hipError_t fx_launch_stage(const void *src_mapped, void *dst, size_t bytes, hipStream_t stream) {
+    const int n16 = (int)(bytes / 16);
+    const int blocks = std::min(256, std::max(1, (n16 + 255) / 256));
+    hipLaunchKernelGGL(fx_stage_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(src_mapped),
+                       reinterpret_cast<uint4 *>(dst), n16);
+    return hipGetLastError();
+}
+
+// Winner package: everything the planner reads of the chosen trajectory -- planes [14][S], coefficients, raw partial costs,
+// cost, horizon, flag word -- gathered from the SoA outputs straight into pinned host memory behind the selection, so that a
+// plan step ends with ONE wait instead of a second round of strided copies and a stream synchronisation
+// (reactive_planner_cpp.py:355-357 reads the optimal trajectory's arrays, planner.py:394-447 packages them).
+// grid = n_agents, block = 256.  Layout per agent (doubles): planes | lon6 lat6 | raw[FX_NUM_COSTS] | cost | traj_len | flags |
+// index | found, then the sequence word at stride - 1.
+__global__ __launch_bounds__(256) void fx_package_kernel(const DevProblem *__restrict__ probs, const double *__restrict__ winner,
+                                                         double *host_pkg, int stride, int plane_rows, unsigned long long seq) {
+    const DevProblem &P = probs[blockIdx.x];
+    double *out = host_pkg + (size_t)blockIdx.x * stride;
+    double *tail = out + plane_rows;
+    const long long gi = reinterpret_cast<const long long *>(winner)[2 * blockIdx.x + 1];
+    const bool found = gi >= 0 && (P.mode & FX_MODE_WRITE_BUNDLE);
+    const int tid = threadIdx.x;
+    if (found) {
+        const int64_t l = gi - P.g_base, ld = P.ld;
+        const int n_pl = FX_NUM_PLANES * P.S;
+        const FX_GLOBAL double *pl = as_global(P.planes);
+        for (int t = tid; t < n_pl; t += 256) out[t] = pl[(size_t)t * ld + l];
+        if (tid < 12) tail[tid] = as_global(P.coeffs)[(size_t)tid * ld + l];
+        if (tid >= 64 && tid < 64 + FX_NUM_COSTS)
+            tail[12 + tid - 64] = (tid - 64 < P.n_cost && (P.mode & FX_MODE_WRITE_COSTMAP)) ? as_global(P.costmap)[(size_t)(tid - 64) * ld + l] : 0.0;
+        if (tid == 128) {
+            tail[12 + FX_NUM_COSTS] = as_global(P.cost)[l];
+            tail[13 + FX_NUM_COSTS] = (double)as_global(P.traj_len)[l];
+            tail[14 + FX_NUM_COSTS] = (double)as_global(P.flags)[l];
+            tail[15 + FX_NUM_COSTS] = (double)gi;
+        }
+    }
+    if (tid == 129) tail[16 + FX_NUM_COSTS] = found ? 1.0 : 0.0;
+    // every wave waits for its own stores to be performed at system scope; the barrier then orders them before the sequence word
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(out + stride - 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+extern "C" hipError_t fx_launch_package(const DevProblem *d_probs, int n_agents, const double *winner, double *host_pkg, int stride,
+                                        int plane_rows, unsigned long long seq, hipStream_t stream) {
+    hipLaunchKernelGGL(fx_package_kernel, dim3(n_agents), dim3(256), 0, stream, d_probs, winner, host_pkg, stride, plane_rows, seq);
     return hipGetLastError();
 }
 

@@ -27,6 +27,13 @@
 
 namespace fxk {
 
+// a wave-uniform double pinned into a vector register pair (see fx_eval_grid_kernel.h, StepConst)
+__device__ __forceinline__ double uniform_to_vgpr(double x) {
+    double r;
+    asm volatile("v_mov_b64 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+}
+
 struct alignas(16) LonRow {  // longitudinal quantities of one (pair, step); 128 B
     double s, sv, sa;        // s, clamped s_dot, s_ddot
     double th_ref, k_r, k_r_d;
@@ -73,6 +80,27 @@ __device__ __forceinline__ unsigned wave_any_bit(bool p) {
     unsigned r;
     asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(b) : "scc");
     return r;
+}
+
+// first active lane's double as a wave-uniform value (two v_readfirstlane)
+__device__ __forceinline__ double uniform_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(b & 0xffffffffu)), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// max over the wave of an unsigned value, wave-uniform result: four row shifts and two row broadcasts in the data-parallel
+// primitives of the vector unit (no LDS crossbar), then lane 63
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define FX_DPP_MAX(ctrl, rows) v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rows, 0xf, false))
+    FX_DPP_MAX(0x111, 0xf);  // row_shr:1
+    FX_DPP_MAX(0x112, 0xf);  // row_shr:2
+    FX_DPP_MAX(0x114, 0xf);  // row_shr:4
+    FX_DPP_MAX(0x118, 0xf);  // row_shr:8   -> lane 15 of every row holds the row's maximum
+    FX_DPP_MAX(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    FX_DPP_MAX(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef FX_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // n / d with one residual correction on the quotient (correctly rounded for the operands of this kernel)
@@ -488,11 +516,20 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
         // -- prediction cost (collision_probability.py:283-292): sum over the obstacles of 1 / m^2 --
         if (pm) {
             const double xr = x_i - K.ox, yr = y_i - K.oy;
-            auto term = [&](fx_d2 l, fx_d2 c, double cw) {  // l = (l11, l12), c = (cu, l22)
+            auto msq = [&](fx_d2 l, fx_d2 c, double cw) {  // m^2 of one obstacle; l = (l11, l12), c = (cu, l22)
                 const double u = fma(l.x, xr, fma(l.y, yr, -c.x));
                 const double w = fma(c.y, yr, -cw);
                 const double m = fma(u, u, w * w);
-                return rcp_pred(m * m);
+                return m * m;
+            };
+            auto term = [&](fx_d2 l, fx_d2 c, double cw) { return rcp_pred(msq(l, c, cw)); };
+            // 1/a + 1/b + 1/c + 1/d over ONE reciprocal: ((a + b) cd + (c + d) ab) / (ab cd) -- 11 operations for four terms
+            // instead of 16, one quarter-rate reciprocal instead of four.  The products stay far inside the exponent range
+            // (a term is a squared Mahalanobis form); a zero or non-finite term surfaces in the sum and takes the exact path.
+            auto four = [&](double a, double b, double c, double d) {
+                const double ab = a * b, cd = c * d;
+                const double num = fma(a + b, cd, (c + d) * ab);
+                return num * rcp_pred(ab * cd);
             };
             auto ld = [&](int k, fx_d2 &l, fx_d2 &c, double &cw) {
                 const double *q = hot + (size_t)k * FX_HOT_STRIDE;
@@ -511,9 +548,9 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                 if (nK > 1) ld(1, lb, cb, wb);
                 for (; k + 5 < nK; k += 4) {
                     ld(k + 2, lc, cc, wc); ld(k + 3, ld_, cd, wd);
-                    s0 += term(la, ca, wa); s1 += term(lb, cb, wb);
+                    const double qa = msq(la, ca, wa), qb = msq(lb, cb, wb);
                     ld(k + 4, la, ca, wa); ld(k + 5, lb, cb, wb);
-                    s0 += term(lc, cc, wc); s1 += term(ld_, cd, wd);
+                    s0 += four(qa, qb, msq(lc, cc, wc), msq(ld_, cd, wd));
                 }
                 // entries k (a) and k + 1 (b) are loaded; up to five remain
                 for (; k + 3 < nK; k += 2) {
@@ -578,37 +615,37 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                     hxy = fx_d2{q[FX_HOT_HX2], q[FX_HOT_HY2]};
                     hrk = fx_d2{q[FX_HOT_HR2], q[FX_HOT_CK]};
                 };
-                // obstacles some lane of the wave is near (wave-uniform mask): one compare and a few scalar operations per visit
+                // Wave-level cull, all obstacles at once: the ego hulls of the wave's 64 candidates at this step lie inside the
+                // circle around the first lane's hull centre c0 with radius R = max over the lanes of (|c - c0| + r_e); lane k
+                // tests obstacle k's circle against that one (a pair of boxes that overlap has |h - c| <= r_o + r_e, hence
+                // |h - c0| <= r_o + R: nothing that the exact test would report is dropped; the slack covers the single-precision
+                // square root and conversions).  Candidates of a wave are neighbours in the sampling grid, R is a few metres, and
+                // for most steps no obstacle survives -- the per-lane test below then does not run at all.
+                unsigned long long cand;
+                {
+                    const double c0x = uniform_f64(cxr), c0y = uniform_f64(cyr);
+                    const double dx = cxr - c0x, dy = cyr - c0y;
+                    const double q = fma(dx, dx, dy * dy);
+                    const bool bad = !(q + re < 1e300);   // a hull that is not finite keeps every obstacle on the per-lane path
+                    const float reach = fmaf(__builtin_amdgcn_sqrtf((float)q), 1.00001f, (float)re * 1.00001f);
+                    const unsigned rb = wave_max_u32(bad ? 0u : __float_as_uint(reach));  // reach >= 0: the bit patterns order like the values
+                    const double R = (double)__uint_as_float(rb);
+                    const int kl = min(H->lane, nK - 1);
+                    const double *qo = hot + (size_t)kl * FX_HOT_STRIDE;
+                    const double ex = fma(-0.5, qo[FX_HOT_HX2], -c0x), ey = fma(-0.5, qo[FX_HOT_HY2], -c0y);  // h - c0
+                    const double rr = fma(-0.5, qo[FX_HOT_HR2], R) * 1.00001;                                 // r_o + R
+                    cand = __builtin_amdgcn_ballot_w64(!(fma(ex, ex, ey * ey) > rr * rr)) & hm;
+                    if (wave_any_bit(bad)) cand = hm;
+                }
+                // obstacles some lane of the wave is near (wave-uniform mask): the circle test per lane, for the survivors
                 unsigned long long nm = 0ULL;
                 auto mark = [&](double g, int k) { nm |= (unsigned long long)wave_any_bit(!(g > K.gap_margin)) << k; };
-                if (hm == full) {
-                    fx_d2 ha, ra, hb, rb, hc, rc, hd, rd;
-                    int k = 0;
-                    ldh(0, ha, ra);
-                    if (nK > 1) ldh(1, hb, rb);
-                    for (; k + 5 < nK; k += 4) {
-                        ldh(k + 2, hc, rc); ldh(k + 3, hd, rd);
-                        mark(gap(ha, ra), k); mark(gap(hb, rb), k + 1);
-                        ldh(k + 4, ha, ra); ldh(k + 5, hb, rb);
-                        mark(gap(hc, rc), k + 2); mark(gap(hd, rd), k + 3);
-                    }
-                    for (; k + 3 < nK; k += 2) {
-                        ldh(k + 2, hc, rc); ldh(k + 3, hd, rd);
-                        mark(gap(ha, ra), k); mark(gap(hb, rb), k + 1);
-                        ha = hc; ra = rc; hb = hd; rb = rd;
-                    }
-                    mark(gap(ha, ra), k);
-                    if (k + 1 < nK) mark(gap(hb, rb), k + 1);
-                    if (k + 2 < nK) { ldh(k + 2, hc, rc); mark(gap(hc, rc), k + 2); }
-                } else {
-                    unsigned long long m = hm;
-                    while (m) {
-                        const int k = __builtin_ctzll(m);
-                        m &= m - 1;
-                        fx_d2 hxy, hrk;
-                        ldh(k, hxy, hrk);
-                        mark(gap(hxy, hrk), k);
-                    }
+                while (cand) {
+                    const int k = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    fx_d2 hxy, hrk;
+                    ldh(k, hxy, hrk);
+                    mark(gap(hxy, hrk), k);
                 }
                 while (nm) {  // exact axis test for whatever is near (rare; the hull comes in through scalar loads)
                     const int k = __builtin_ctzll(nm);

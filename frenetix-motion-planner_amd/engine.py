@@ -27,6 +27,19 @@ def build_obstacle_hulls(n_pred, pos, yaw, length, width) -> np.ndarray:
     return out[:n.value]
 
 
+def _build_obstacle_hulls_batch(n_use, pos, yaw, length, width, hull, nhull):
+    """fx_build_obstacle_hulls_batch: pos [K][P][2], yaw [K][P] -> hull [K][P-1][6], nhull [K] (in place)"""
+    K, P = pos.shape[0], pos.shape[1]
+    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    length, width = np.ascontiguousarray(length, dtype=np.float64), np.ascontiguousarray(width, dtype=np.float64)
+    check(lib().fx_build_obstacle_hulls_batch(K, P, n_use.ctypes.data_as(pi), pos.ctypes.data_as(pd), yaw.ctypes.data_as(pd),
+                                              length.ctypes.data_as(pd), width.ctypes.data_as(pd), hull.ctypes.data_as(pd),
+                                              nhull.ctypes.data_as(pi)))
+
+
+build_obstacle_hulls.batch = _build_obstacle_hulls_batch
+
+
 def build_boundary_bins(ref_xy, segments, max_len: float, reach: float):
     """fx_build_boundary_bins (host geometry of the library): pieces [n][4], bins [M+1], items."""
     ref = np.ascontiguousarray(ref_xy, dtype=np.float64)
@@ -52,6 +65,25 @@ def build_boundary_bins(ref_xy, segments, max_len: float, reach: float):
     check(rc)
 
 
+class WinnerPackage:
+    """The chosen trajectory as the library packaged it (fx_read_package): `block` [FX_PKG_ROWS][S] = the 14 planes, yaw rate,
+    steering angle, shifted heading; coefficients, raw partial costs, cost, flag word, horizon, global index."""
+
+    def __init__(self, pkg: _abi.FxPackage, block: np.ndarray, inputs: PlanInputs):
+        self.block = block
+        self.index = int(pkg.index)
+        self.cost = float(pkg.cost)
+        self.flags = int(pkg.flags)
+        self.traj_len = int(pkg.traj_len)
+        self.lon = np.array(pkg.coeff_lon)
+        self.lat = np.array(pkg.coeff_lat)
+        self.raw_costs = np.array(pkg.raw_costs[:pkg.n_cost]) if inputs.write_costmap else None
+
+    @property
+    def planes(self) -> np.ndarray:
+        return self.block[:_abi.FX_NUM_PLANES]
+
+
 def math_selftest(x: np.ndarray):
     """(atan, sin, cos) of the device math kernels for the values in x."""
     x = np.ascontiguousarray(x, dtype=np.float64)
@@ -72,6 +104,8 @@ class FrenetEngine:
                  max_pred_steps: int = 64, device: int = 0, max_agents: int = 1):
         self._ctx = C.c_void_p()
         self._inputs: List[PlanInputs] = []
+        self._resident_key = None
+        self.packaging = False
         check(lib().fx_create_batch(C.byref(self._ctx), device, max_agents, int(max_candidates), int(max_steps),
                                     int(max_ref_knots), int(max_obstacles), int(max_pred_steps)))
         self.device = device
@@ -153,6 +187,7 @@ class FrenetEngine:
     def upload(self, inputs):
         batch = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
         self._inputs = batch
+        self._resident_key = None
         arr = (_abi.FxProblem * len(batch))(*[b.as_struct() for b in batch])
         self._structs = arr  # keep pointers alive until the copy has been enqueued (h2d staging is synchronous memcpy)
         check(lib().fx_upload_batch(self._ctx, len(batch), arr))
@@ -183,7 +218,7 @@ class FrenetEngine:
         if obstacles is not None and obstacles["K"] > 0:
             u.obs_pos, u.obs_cov_inv = arr(obstacles["pos"]), arr(obstacles["cov_inv"])
             u.obs_npred = arr(obstacles["npred"], np.int32)
-            if obstacles.get("hull") is not None and obstacles["nhull"].any():
+            if obstacles.get("hull") is not None and obstacles["hull"].size:  # also when no hull is left: the old ones must go
                 u.obs_hull, u.obs_nhull = arr(obstacles["hull"]), arr(obstacles["nhull"], np.int32)
         u._keep = keep
         return u
@@ -225,6 +260,40 @@ class FrenetEngine:
         self.upload(inputs)
         self.evaluate()
         return self.finish()[0]
+
+    def plan_step_packaged(self, inputs: PlanInputs, yaw_rate0: float = 0.0):
+        """A planner's closed-loop plan step in ONE call across the boundary (fx_plan_and_package): when the resident upload
+        has the structure of `inputs` (PlanInputs.structure_key) only the ego state, sampling values and predictions are
+        rewritten in place, else everything is uploaded; evaluation; result; the winner's arrays, which the device gathers
+        into pinned host memory behind the selection.  Returns (result dict, WinnerPackage or None)."""
+        key = inputs.structure_key()
+        upd = None
+        if inputs.sampling_matrix is None and self._resident_key == key and len(self._inputs) == 1:
+            upd = self.make_state_update(inputs.x0_lon, inputs.x0_lat, inputs.x0_orientation, inputs.v_des, inputs.low_vel_mode,
+                                         inputs.t_samp, inputs.v_samp, inputs.d_samp, inputs.obstacles)
+            self._inputs = [inputs]
+        else:
+            self.upload(inputs)
+            self._resident_key = key
+        res = (_abi.FxResult * 1)()
+        pkg = _abi.FxPackage()
+        block = np.empty((_abi.FX_PKG_ROWS, inputs.n_samples))
+        check(lib().fx_plan_and_package(self._ctx, C.byref(upd) if upd is not None else None, float(yaw_rate0), res,
+                                        C.byref(pkg), block.ctypes.data_as(C.POINTER(C.c_double))))
+        return res[0].as_dict(), (WinnerPackage(pkg, block, inputs) if pkg.found else None)
+
+    def set_package(self, enabled: bool):
+        """Gather the winner's arrays into pinned host memory behind every evaluation that writes the bundle (fx_set_package);
+        read them with `package(agent)` after finish()."""
+        check(lib().fx_set_package(self._ctx, int(bool(enabled))))
+        self.packaging = bool(enabled)
+
+    def package(self, agent: int = 0, yaw_rate0: float = 0.0):
+        pkg = _abi.FxPackage()
+        inp = self._inputs[agent]
+        block = np.empty((_abi.FX_PKG_ROWS, inp.n_samples))
+        check(lib().fx_read_package(self._ctx, int(agent), float(yaw_rate0), C.byref(pkg), block.ctypes.data_as(C.POINTER(C.c_double))))
+        return WinnerPackage(pkg, block, inp) if pkg.found else None
 
     def plan_batch(self, inputs: Sequence[PlanInputs]) -> List[dict]:
         self.upload(list(inputs))

@@ -98,6 +98,8 @@ class AgentBatchHip:
                                   max_obstacles=max_obstacles, max_pred_steps=max(64, N + 2), device=device,
                                   max_agents=max(len(self.agents), 1))
         self.engine = engine
+        if hasattr(engine, "set_package"):   # every agent's winner arrives packaged with the result block: no read-back per agent
+            engine.set_package(True)
         self.launches = 0
         self.escalations = 0
         self.last_batch_ms = 0.0

@@ -112,6 +112,10 @@ def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
     npred = np.zeros(K, np.int32)
     hull = np.zeros((K, P - 1, 6))
     nhull = np.zeros(K, np.int32)
+    yaw = np.zeros((K, P))
+    n_use = np.zeros(K, np.int32)
+    shape = np.zeros((2, K))
+    covs, rows = [], []
     for i, k in enumerate(keys):
         pr = predictions[k]
         pl = np.asarray(pr["pos_list"], dtype=np.float64).reshape(-1, 2)
@@ -122,15 +126,28 @@ def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
         if n_all == 0:
             continue
         n = min(n_all, P)
-        pl = pl[:n]
-        pos[i, :n] = pl
-        cov_inv[i, :n] = np.linalg.inv(np.asarray(pr["cov_list"], dtype=np.float64)[:n]).reshape(n, 4)
-        n_use = min(n_samples, n)
+        pos[i, :n] = pl[:n]
+        covs.append(np.asarray(pr["cov_list"], dtype=np.float64)[:n].reshape(n, 2, 2))
+        rows.append((i, n))
         if build_hulls is not None and "orientation_list" in pr and "shape" in pr:
-            yaw = _f64(pr["orientation_list"])[:n_use]
-            h = build_hulls(n_use, _f64(pl[:n_use]), yaw, float(pr["shape"]["length"]), float(pr["shape"]["width"]))
-            nhull[i] = len(h)
-            hull[i, :len(h)] = h
+            n_use[i] = min(n_samples, n)
+            yaw[i, :n_use[i]] = _f64(pr["orientation_list"])[:n_use[i]]
+            shape[0, i], shape[1, i] = float(pr["shape"]["length"]), float(pr["shape"]["width"])
+    if covs:  # ONE stacked inversion (gesv per matrix, as np.linalg.inv of each list gives)
+        inv = np.linalg.inv(np.concatenate(covs)).reshape(-1, 4)
+        o = 0
+        for i, n in rows:
+            cov_inv[i, :n] = inv[o:o + n]
+            o += n
+    if build_hulls is not None and n_use.any():
+        batch = getattr(build_hulls, "batch", None)
+        if batch is not None:   # the library builds every obstacle's hulls in one call
+            batch(n_use, pos, yaw, shape[0], shape[1], hull, nhull)
+        else:
+            for i in np.nonzero(n_use)[0]:
+                h = build_hulls(int(n_use[i]), _f64(pos[i, :n_use[i]]), _f64(yaw[i, :n_use[i]]), shape[0, i], shape[1, i])
+                nhull[i] = len(h)
+                hull[i, :len(h)] = h
     return dict(K=K, P=P, pos=_f64(pos), cov_inv=_f64(cov_inv), npred=npred, hull=_f64(hull), nhull=nhull)
 
 
@@ -271,6 +288,16 @@ class PlanInputs:
         if self._bound is not None and self._bound["n"] > 0:
             m |= _abi.FX_MODE_ROAD_BOUNDARY
         return m
+
+    def structure_key(self):
+        """Everything of a plan step that fx_update_state cannot change: two inputs with equal keys differ only in the ego
+        state, the desired velocity, the sampling values and the obstacle predictions (same counts)."""
+        o = self.obstacles
+        return (self.N, self.dt, self.mode, bool(self.stop_point), (self.vehicle.length, self.vehicle.width, self.vehicle.wheelbase, self.vehicle.wb_rear_axle, self.vehicle.a_max,
+                 self.vehicle.v_switch, self.vehicle.delta_max), id(self.coordinate_system),
+                None if self.sampling_matrix is not None else (len(self.t_samp), len(self.v_samp), len(self.d_samp)),
+                tuple(self.cost_names), self._cost_w.tobytes(), int(o["K"]), int(o["P"]), self._dto.tobytes(),
+                None if self._bound is None else id(self._bound), self.shard)
 
     def candidate_params(self, g: int):
         """(t0, t1, s0, ss0, sss0, ss1, sss1, d0, dd0, ddd0, d1, dd1, ddd1) of candidate g -- the

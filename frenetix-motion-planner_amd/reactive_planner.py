@@ -303,7 +303,8 @@ class ReactivePlannerHip:
     def plan_consume(self, inputs: PlanInputs, res: dict, engine, agent: int = 0):
         """Take this planner's share of a batched launch (first sampling level); returns the chosen trajectory
         (materialised -- the batch engine's buffers are reused) or None when the level has to escalate."""
-        best = self._consume_result(inputs, res, engine, agent)
+        package = engine.package(agent, self.x_0.yaw_rate) if getattr(engine, "packaging", False) else None
+        best = self._consume_result(inputs, res, engine, agent, package)
         if best is not None:
             best.materialise()
         return best
@@ -383,13 +384,19 @@ class ReactivePlannerHip:
         """reactive_planner.py:184-272: feasibility, costs, stable sort, collision walk -- one fused launch."""
         if self.last_step is not None:
             self.last_step.invalidate()
-        res = self.engine.plan_step(inputs)
-        return self._consume_result(inputs, res, self.engine, 0)
+        pkg = None
+        if hasattr(self.engine, "plan_step_packaged"):
+            # one call across the boundary: in-place update of the resident inputs, evaluation, result, the winner packaged
+            res, pkg = self.engine.plan_step_packaged(inputs, self.x_0.yaw_rate)
+        else:
+            res = self.engine.plan_step(inputs)
+        return self._consume_result(inputs, res, self.engine, 0, pkg)
 
-    def _consume_result(self, inputs: PlanInputs, res: dict, engine, agent: int):
+    def _consume_result(self, inputs: PlanInputs, res: dict, engine, agent: int, package=None):
         if self.last_step is not None:
             self.last_step.invalidate()
         step = PlanStepResult(engine, inputs, res, agent)
+        step.package = package
         lr = self.params_harm["log_reg"]["ignore_angle"]
         step.harm_coeff = (lr["const"], lr["speed"])
         self.last_step = step
@@ -443,6 +450,19 @@ class ReactivePlannerHip:
 
     # ------------------------------------------------------------------ output packaging (planner.py:394-447)
     def _compute_trajectory_pair(self, trajectory) -> tuple:
+        pkg = getattr(trajectory, "_pkg", None)
+        if pkg is not None:
+            # packaged by the library (fx_read_package): yaw rate, steering angle and shifted heading are rows of the block;
+            # the state objects are built when they are indexed
+            b = pkg.block
+            n, t0 = b.shape[1], self.x_0.time_step
+            x, y, th, v, a, kap = (b[r].tolist() for r in (0, 1, 2, 3, 4, 5))
+            yr, st, orl = (b[r].tolist() for r in (_abi.PKG_ROW_YAW_RATE, _abi.PKG_ROW_STEERING, _abi.PKG_ROW_ORIENTATION))
+            s_, d_ = b[7].tolist(), b[8].tolist()
+            cart_list = _LazyStates(n, lambda i: ReactivePlannerState(t0 + i, np.array((x[i], y[i])), orl[i], v[i], a[i], yr[i], st[i]))
+            cl_list = _LazyStates(n, lambda i: dict(time_step=t0 + i, position=np.array((s_[i], d_[i])), velocity=v[i],
+                                                    acceleration=a[i], orientation=th[i], yaw_rate=kap[i]))
+            return cart_list, cl_list, b[[7, 10, 11]].T.tolist(), b[[8, 12, 13]].T.tolist()
         c, k = trajectory.cartesian, trajectory.curvilinear
         n = len(c.x)
         theta = np.asarray(c.theta, dtype=np.float64)
@@ -489,6 +509,32 @@ class ReactivePlannerHip:
         if self._engine is not None:
             self._engine.close()
             self._engine = None
+
+
+class _LazyStates:
+    """Read-only sequence whose items are built on first access and then kept (the state lists of a trajectory pair: a
+    closed-loop step reads one or two of the 31 states)."""
+
+    def __init__(self, n: int, make):
+        self._make = make
+        self._items = [None] * n
+
+    def __len__(self):
+        return len(self._items)
+
+    def _get(self, i):
+        it = self._items[i]
+        if it is None:
+            it = self._items[i] = self._make(i if i >= 0 else i + len(self._items))
+        return it
+
+    def __getitem__(self, j):
+        if isinstance(j, slice):
+            return [self._get(i) for i in range(*j.indices(len(self._items)))]
+        return self._get(j)
+
+    def __iter__(self):
+        return (self._get(i) for i in range(len(self._items)))
 
 
 class _LazySortedList:

@@ -77,7 +77,19 @@ class TrajectorySample:
         self._planes = None
         self._costmap = None
         self._coeffs = None
-        if step.have_arrays:
+        self._pkg = None
+        pkg = step.package
+        if pkg is not None and pkg.index == int(index) + step.inputs.shard_begin:
+            # the winner: the library has already delivered everything (fx_read_package), nothing is fetched
+            flags, self._cost = pkg.flags, pkg.cost
+            self._planes = pkg.planes
+            self._coeffs = (pkg.lon, pkg.lat, pkg.traj_len)
+            self._pkg = pkg
+            if pkg.raw_costs is not None:
+                names, w = step.inputs.cost_names, step.inputs.cost_weights
+                raw = pkg.raw_costs.tolist()
+                self._costmap = {n: (raw[k], float(w[n] * raw[k])) for k, n in enumerate(names)}
+        elif step.have_arrays:
             flags = int(step.flags[index])
             self._cost = float(step.cost[index])
         else:
@@ -230,6 +242,7 @@ class PlanStepResult:
 
     def __init__(self, engine, inputs, result: dict, agent: int = 0):
         self.engine, self.inputs, self.result, self.agent = engine, inputs, result, agent
+        self.package = None               # engine.WinnerPackage of the step's winner when the library packaged it
         self._cost = self._flags = None   # [C] arrays, read back on first use (all_traj, masks, sorted lists)
         self._stale = False
         self._samples = {}

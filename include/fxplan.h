@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 3
+#define FX_ABI_VERSION 4
 
 /* ---- status codes (planner.py / reactive_planner_cpp.py raise Python exceptions; the shim maps
  *      <0 -> ValueError, >0 -> RuntimeError, see SURVEY 8b "Error conventions") ---- */
@@ -254,6 +254,39 @@ typedef struct FxStateUpdate {
 } FxStateUpdate;
 int32_t fx_update_state(FxContext *ctx, int32_t agent, const FxStateUpdate *upd);
 int32_t fx_update_step(FxContext *ctx, const FxStateUpdate *upd, FxResult *res);
+
+/* ---- the chosen trajectory, packaged (planner.py:394-447 _compute_trajectory_pair; reactive_planner_cpp.py:355-357 reads the
+ *      optimal trajectory's arrays; frenet_interface.py:243-277 consumes the pair) ----
+ *      With fx_set_package(ctx, 1) every evaluation that writes the bundle is followed by a gather of the winner's data into
+ *      pinned host memory on the same stream, and fx_finish returns once it has arrived: no strided read-back, no second
+ *      synchronisation.  fx_read_package hands it out: `pkg` = index (global), cost, flag word, horizon, coefficients, raw
+ *      partial costs; `block` (may be NULL) = [FX_PKG_ROWS][S] doubles: the FX_NUM_PLANES planes in PLANE order, then
+ *      yaw_rate (yaw_rate0, then backward differences of theta over dt), steering_angle atan2(wheelbase * kappa, 1) and the
+ *      heading shifted into [x0_orientation - pi, x0_orientation + pi].  found = 0: no selectable collision-free candidate.
+ *      fx_plan_and_package = fx_update_state(agent 0, upd; upd may be NULL) + fx_evaluate + fx_finish + fx_read_package in ONE
+ *      call: a planner's closed-loop plan step. */
+#define FX_PKG_ROWS (FX_NUM_PLANES + 3)
+typedef struct FxPackage {
+    int32_t found, S, traj_len;
+    uint32_t flags;
+    int64_t index;
+    double cost;
+    double coeff_lon[6], coeff_lat[6];
+    int32_t n_cost, reserved;
+    double raw_costs[FX_NUM_COSTS];
+} FxPackage;
+int32_t fx_set_package(FxContext *ctx, int32_t enabled);
+int32_t fx_read_package(FxContext *ctx, int32_t agent, double yaw_rate0, FxPackage *pkg, double *block /*[FX_PKG_ROWS][S] or NULL*/);
+int32_t fx_plan_and_package(FxContext *ctx, const FxStateUpdate *upd, double yaw_rate0, FxResult *res, FxPackage *pkg, double *block);
+
+/* ---- host geometry of the callers either side of the path (plain C, no device) ----
+ *      fx_cs_to_curvilinear: (s, d) of a Cartesian point along a reference polyline with per-vertex normals (the projection
+ *      behind planner.py:574-578); ref_xy / normals [M][2], ref_pos [M]; FX_ERR_INVALID_ARGUMENT outside the projection domain.
+ *      fx_build_obstacle_hulls_batch: fx_build_obstacle_hulls for K obstacles stored with stride P. */
+int32_t fx_cs_to_curvilinear(int32_t M, const double *ref_xy, const double *normals, const double *ref_pos, double x, double y,
+                             double *sd /*[2]*/);
+int32_t fx_build_obstacle_hulls_batch(int32_t K, int32_t P, const int32_t *n_use, const double *pos, const double *yaw,
+                                      const double *length, const double *width, double *hull, int32_t *n_hull);
 
 /* ---- read-back (TrajectorySample views are materialised lazily from the SoA bundle;
  *      reactive_planner_cpp.py:353 get_sorted_trajectories, trajectories.py:337-477) ---- */

@@ -1,0 +1,131 @@
+"""The winner package (fx_set_package / fx_read_package / fx_plan_and_package, include/fxplan.h): what the planner reads of
+the chosen trajectory, gathered by the device behind the selection -- against the classic read-back of the same candidate
+and against the oracle; the planner's packaged trajectory pair against planner.py:394-447 computed the long way."""
+import numpy as np
+import pytest
+
+from frenetix_motion_planner_amd import _abi, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(**kw):
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    return FrenetEngine(**kw)
+
+
+def _inputs(**kw):
+    from frenetix_motion_planner_amd.engine import build_obstacle_hulls
+    base = dict(ref_kind="arc", v0=9.0, grid=(5, 9, 11), n_obstacles=3, hull_builder=build_obstacle_hulls)
+    base.update(kw)
+    return synthetic.make_inputs(**base)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_obstacles=0), dict(grid=(9, 21, 21), n_obstacles=8, ref_kind="scurve"),
+                                dict(lead_gap=18.0), dict(v0=0.5)])
+def test_package_equals_read_back_and_oracle(kw):
+    from oracle import oracle
+    inp = _inputs(**kw)
+    with _engine(max_candidates=8192) as eng:
+        ref = eng.plan_step(inp)
+        res, pkg = eng.plan_step_packaged(inp, yaw_rate0=0.125)
+        assert res["best_index"] == ref["best_index"] and res["best_cost"] == ref["best_cost"]
+        if ref["best_index"] < 0:
+            assert pkg is None
+            return
+        cand = eng.candidate(ref["best_index"])
+        assert pkg.index == ref["best_index"] and pkg.cost == ref["best_cost"] == cand["cost"]
+        assert pkg.flags == cand["flags"] and pkg.traj_len == cand["traj_len"]
+        assert np.array_equal(pkg.planes, cand["planes"])
+        assert np.array_equal(pkg.lon, cand["lon"]) and np.array_equal(pkg.lat, cand["lat"])
+        assert np.array_equal(pkg.raw_costs, cand["raw_costs"])
+        # derived rows: planner.py:394-447
+        th, kap = pkg.planes[2], pkg.planes[5]
+        yaw = np.concatenate([[0.125], np.diff(th) / inp.dt])
+        assert np.array_equal(pkg.block[_abi.PKG_ROW_YAW_RATE], yaw)
+        assert np.allclose(pkg.block[_abi.PKG_ROW_STEERING], np.arctan2(inp.vehicle.wheelbase * kap, 1.0), rtol=0, atol=1e-15)
+        orl = pkg.block[_abi.PKG_ROW_ORIENTATION]
+        assert np.all(np.abs(orl - inp.x0_orientation) <= np.pi + 1e-12)
+        assert np.allclose(np.cos(orl), np.cos(th), atol=1e-12) and np.allclose(np.sin(orl), np.sin(th), atol=1e-12)
+    out = oracle.plan_step(inp)
+    assert out["result"]["best_index"] == ref["best_index"]
+    err = np.abs(out["planes"][ref["best_index"]] - pkg.planes) / (1.0 + np.abs(pkg.planes).max(axis=1, keepdims=True))
+    assert err.max() < 1e-9
+
+
+def test_resident_update_path_equals_fresh_upload():
+    """plan_step_packaged rewrites the resident inputs in place when only the state changed: same result as a new engine"""
+    a = _inputs(seed=3)
+    b = _inputs(seed=4, v0=7.5)           # same structure: other ego state, other predictions
+    b.coordinate_system = a.coordinate_system
+    b._ref = a._ref
+    assert a.structure_key() == b.structure_key()
+    with _engine(max_candidates=8192) as eng:
+        eng.plan_step_packaged(a)
+        res, pkg = eng.plan_step_packaged(b)       # in-place update
+        assert eng._resident_key is not None
+    with _engine(max_candidates=8192) as eng2:
+        ref, rpkg = eng2.plan_step_packaged(b)     # full upload
+    assert res["best_index"] == ref["best_index"] and res["best_cost"] == ref["best_cost"]
+    for k in ("n_feasible", "n_returned", "n_collisions", "reason_hist"):
+        assert res[k] == ref[k]
+    if pkg is not None:
+        assert np.array_equal(pkg.block, rpkg.block)
+    c = _inputs(seed=4, grid=(5, 9, 13))   # other grid: new upload, transparently
+    c.coordinate_system, c._ref = a.coordinate_system, a._ref
+    assert c.structure_key() != a.structure_key()
+
+
+def test_batched_packages():
+    from frenetix_motion_planner_amd.engine import build_obstacle_hulls
+    agents = [synthetic.make_inputs(hull_builder=build_obstacle_hulls, ref_kind="arc", v0=6.0 + 2 * a, grid=(3, 5, 7), n_obstacles=a % 3,
+                                    seed=a) for a in range(4)]
+    with _engine(max_candidates=4096, max_agents=4) as eng:
+        eng.set_package(True)
+        res = eng.plan_batch(agents)
+        for a, r in enumerate(res):
+            pkg = eng.package(a)
+            if r["best_index"] < 0:
+                assert pkg is None
+                continue
+            cand = eng.candidate(r["best_index"], a)
+            assert pkg.index == r["best_index"] and np.array_equal(pkg.planes, cand["planes"])
+            assert np.array_equal(pkg.raw_costs, cand["raw_costs"]) and pkg.cost == cand["cost"]
+        eng.set_package(False)
+        eng.evaluate(); eng.finish()
+        with pytest.raises(Exception):
+            eng.package(0)
+
+
+def test_planner_pair_from_package_equals_the_long_way():
+    from frenetix_motion_planner_amd.coordinate_system import CoordinateSystem
+    from frenetix_motion_planner_amd.reactive_planner import PlannerConfig, ReactivePlannerHip, ReactivePlannerState
+    ref = synthetic.reference_polyline("arc", 400, 0.5, 0.01)
+    cs = CoordinateSystem(ref)
+    s0 = float(cs.ref_pos[40] + 0.1)
+    x0 = ReactivePlannerState(0, np.asarray(cs.convert_to_cartesian_coords(s0, 0.2)), float(cs.ref_theta[40]), 10.0, 0.0, 0.07, 0.01)
+    preds = synthetic.synthetic_predictions(cs, 5, 30, 0.1, s0, np.random.default_rng(1))
+    p = ReactivePlannerHip(PlannerConfig(sampling_min=2, sampling_max=3))
+    try:
+        p.update_externals(reference_path=ref, x_0=x0, desired_velocity=12.0, predictions=preds)
+        for step in range(3):   # the second and third step take the in-place update
+            pair = p.plan()
+            best = p.optimal_trajectory
+            assert best._pkg is not None
+            best._pkg, keep = None, best._pkg
+            long_way = p._compute_trajectory_pair(best)
+            best._pkg = keep
+            assert len(pair[0]) == len(long_way[0]) == 31
+            for i in (0, 1, 7, 30, -1):
+                s1, s2 = pair[0][i], long_way[0][i]
+                assert s1.time_step == s2.time_step and np.array_equal(s1.position, s2.position)
+                assert s1.velocity == s2.velocity and s1.acceleration == s2.acceleration and s1.yaw_rate == s2.yaw_rate
+                assert abs(s1.orientation - s2.orientation) < 1e-15 and abs(s1.steering_angle - s2.steering_angle) < 1e-15
+                assert pair[1][i]["yaw_rate"] == long_way[1][i]["yaw_rate"] and np.array_equal(pair[1][i]["position"], long_way[1][i]["position"])
+            assert pair[2] == long_way[2] and pair[3] == long_way[3]
+            t0 = p.x_0.time_step
+            assert [s.time_step for s in pair[0][2:5]] == [t0 + 2, t0 + 3, t0 + 4]
+            x1 = pair[0][1]
+            p.update_externals(x_0=x1, x_cl=(pair[2][1], pair[3][1]), predictions=preds)
+    finally:
+        p.close()

@@ -37,14 +37,17 @@ def run(label, G, mp, fused, wpe=2, **kw):
     print("   median cycles per phase:", {n: int(np.median(d[:, i])) for i, n in enumerate(names)})
     print("   p95    cycles per phase:", {n: int(np.percentile(d[:, i], 95)) for i, n in enumerate(names)})
 
-run("50k_B", 2, 2, True, grid=(19, 51, 51))
-run("50k_B", 2, 2, False, grid=(19, 51, 51))
-run("50k_A", 2, 2, True, grid=(19, 51, 51), write_bundle=False, write_costmap=False)
-run("50k_B", 1, 0, True, grid=(19, 51, 51))
-run("1M_A", 1, 0, True, grid=(19, 230, 229), write_bundle=False, write_costmap=False)
-run("c3_B", 2, 2, True, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0)
-run("c3_B", 4, 2, True, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0)
-run("c3_B", 4, 2, True, wpe=3, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0)
-run("c3_A", 2, 2, True, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0, write_bundle=False, write_costmap=False)
-run("50k_A", 4, 2, True, grid=(19, 51, 51), write_bundle=False, write_costmap=False)
-run("50k_A", 4, 2, True, wpe=3, grid=(19, 51, 51), write_bundle=False, write_costmap=False)
+RUNS = dict(
+    c2B=lambda: run("50k_B", 2, 2, True, grid=(19, 51, 51)),
+    c2B_sel=lambda: run("50k_B", 2, 2, False, grid=(19, 51, 51)),
+    c2A=lambda: run("50k_A", 2, 2, True, grid=(19, 51, 51), write_bundle=False, write_costmap=False),
+    c2B_g1=lambda: run("50k_B", 1, 0, True, grid=(19, 51, 51)),
+    m1A=lambda: run("1M_A", 1, 0, True, grid=(19, 230, 229), write_bundle=False, write_costmap=False),
+    c3B=lambda: run("c3_B", 2, 2, True, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0),
+    c3B_g4=lambda: run("c3_B", 4, 2, True, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0),
+    c3B_g4w3=lambda: run("c3_B", 4, 2, True, wpe=3, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0),
+    c3A=lambda: run("c3_A", 2, 2, True, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0, write_bundle=False, write_costmap=False),
+    c2A_g4=lambda: run("50k_A", 4, 2, True, grid=(19, 51, 51), write_bundle=False, write_costmap=False),
+)
+for name in sys.argv[1:] or list(RUNS):
+    RUNS[name]()
