@@ -646,7 +646,10 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             int best_waves = 0;
             const int order_big[3] = {256, 128, 64}, order_small[3] = {128, 256, 64};
             for (int bi = 0; bi < 3; bi++) {
-                const int blk = (G == 8 ? order_small : order_big)[bi];
+                // two parts on two waves (G = 2, wave split) with the obstacle stage: 128-lane workgroups -- one wave per part --
+                // finish 3 - 8 % earlier than 256-lane ones (config 3: 88 - 95 vs 96 us); without obstacles they are slower
+                // (config 2: 48.6 vs 42.1 us, select-only 38.4 vs 29.1) -- tools/sweep_tuning.py, tools/c3.py
+                const int blk = (G == 8 || (G == 2 && obst_any) ? order_small : order_big)[bi];
                 const size_t need = lds_for(blk);
                 const int by_lds = (int)((160 * 1024) / (need + lds_static));
                 const int waves = by_lds * (blk / 64);
@@ -797,6 +800,8 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         d.part_idx = c->d_part_idx + block_off;
         d.counters = c->d_counters + (size_t)a * FX_CNT_COUNT;
         if (d.mode & FX_MODE_WRITE_BUNDLE) {
+            if ((uint64_t)ld * 8u >= (1ull << 32))  // the walk addresses a row with a 32-bit byte offset per lane
+                return set_err(FX_ERR_CAPACITY, "agent %d: %lld candidates with a materialised bundle (rows are limited to 4 GiB)", a, (long long)C);
             d.planes = reinterpret_cast<double *>(planes_need);  // offset for now, patched below
             planes_need += sizeof(double) * FX_NUM_PLANES * (size_t)S * (size_t)ld;
             c->any_bundle = true;
@@ -1144,6 +1149,32 @@ int32_t fx_cs_to_curvilinear(int32_t M, const double *ref_xy, const double *norm
     }
     if (!have) return set_err(FX_ERR_INVALID_ARGUMENT, "point outside projection domain");
     sd[0] = best_s; sd[1] = best_d;
+    return FX_OK;
+}
+
+// Inverses of n 2x2 matrices with the arithmetic of np.linalg.inv (LAPACK gesv on the identity as OpenBLAS executes it:
+// partial pivoting, the multiplier and both divisions through reciprocals, one fused multiply-add in the back substitution)
+// -- bit-identical to NumPy's result (collision_probability.py:281 inverts the prediction covariances with it; the CPU
+// suite compares the two on random matrices).  Returns FX_ERR_INVALID_ARGUMENT for a singular matrix (NumPy: LinAlgError).
+int32_t fx_invert_cov2(int32_t n, const double *m, double *out) {
+    if (n < 0 || (n > 0 && (!m || !out))) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_invert_cov2: bad argument");
+    for (int i = 0; i < n; i++) {
+        const double a = m[4 * i], b = m[4 * i + 1], c = m[4 * i + 2], d = m[4 * i + 3];
+        const bool sw = std::fabs(c) > std::fabs(a);
+        const double p0a = sw ? c : a, p0b = sw ? d : b, p1a = sw ? a : c, p1b = sw ? b : d;
+        if (p0a == 0.0) return set_err(FX_ERR_INVALID_ARGUMENT, "singular matrix (%d)", i);
+        const double rp = 1.0 / p0a;
+        const double l = p1a * rp;
+        const double u11 = p1b - l * p0b;
+        if (u11 == 0.0) return set_err(FX_ERR_INVALID_ARGUMENT, "singular matrix (%d)", i);
+        const double ru = 1.0 / u11;
+        for (int col = 0; col < 2; col++) {
+            const double r0 = sw ? (col == 1) : (col == 0), r1 = sw ? (col == 0) : (col == 1);
+            const double x1 = (r1 - l * r0) * ru;
+            out[4 * i + col] = std::fma(-p0b, x1, r0) * rp;
+            out[4 * i + 2 + col] = x1;
+        }
+    }
     return FX_OK;
 }
 

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     if ((int64_t)blockIdx.x * CPB >= C) return;
     FX_STAMP(0);
     // parts of a candidate: adjacent lanes (lane split) or the same lane of G lane-groups (wave split, CPB % 64 == 0)
-    const int part = G == 1 ? 0 : (WSPLIT ? tid / CPB : (tid & (G - 1)));
+    // wave split: the part is the same for the 64 lanes of a wave -- say so (scalar loop control, scalar row base of the stores)
+    const int part = G == 1 ? 0 : (WSPLIT ? __builtin_amdgcn_readfirstlane(tid / CPB) : (tid & (G - 1)));
     const int cand_local = G == 1 ? tid : (WSPLIT ? tid - part * CPB : tid / G);
     const int64_t c0 = (int64_t)blockIdx.x * CPB;  // first local candidate of this workgroup
     const int64_t g_raw = c0 + cand_local;
@@ -227,13 +228,17 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
         if (i_first < i_end) Hs.prefetch(i_first);
     }
 
+    // wave-uniform step index: scalar row base + the lane's 32-bit byte offset for the plane stores (the host refuses bundles
+    // whose rows exceed 4 GiB)
+    constexpr bool USTEP32 = (G == 1 || WSPLIT);
     FX_STAMP(3);
 #pragma unroll 1
     for (int i = i_first; i < i_end; i++) {
         const bool emit = i >= i_begin;
         const LonRow r = my[i];
         walk_step<OBST, (G == 1 || WSPLIT), HOT>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit,
-                                                 planes + (int64_t)i * ld + g, ps, Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv,
+                                                 USTEP32 ? planes + (int64_t)i * ld : planes + (int64_t)i * ld + g,
+                                                 USTEP32 ? (uint32_t)g * 8u : 0u, ps, Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv,
                                                  &Hs, i + 1 < i_end ? i + 1 : -1);
     }
 

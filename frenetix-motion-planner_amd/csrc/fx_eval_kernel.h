@@ -661,7 +661,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     for (int i = i_first; i < i_end; i++) {
         const bool emit = i >= i_begin;  // false only for the carry-in step of parts > 0
         const LonRow r = row_at(i);
-        walk_step<OBST, G == 1>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit, planes + (int64_t)i * ld + g, ps,
+        walk_step<OBST, G == 1>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit, planes + (int64_t)i * ld + g, 0u, ps,
                                 Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv);
         if (EXTRA) {
             sim_acc.push(O.a * O.a, S);                                 // partial_cost_functions.py:29-31

@@ -19,11 +19,11 @@
 
 // Plane stores of the bundle: plain write-back stores, or agent-scope (write-through) stores that leave nothing dirty in
 // the XCD's L2 for the end-of-kernel write-back (StepConst::store_wt, chosen by the host from the bundle size)
-#define FX_PLANE_STORE(ptr, val)                                                                        \
-    do {                                                                                                \
-        if (K.store_wt) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   \
-        else *(ptr) = (val);                                                                            \
-    } while (0)
+#define FX_ST_WT(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define FX_ST_WB(ptr, val) (*(ptr) = (val))
+// plane p of this step: the base of the step's row (wave-uniform when the step index is: scalar base + the lane's 32-bit byte
+// offset, one address register for all 14 stores instead of a 64-bit add per plane)
+#define FX_PLANE_AT(p) reinterpret_cast<FX_GLOBAL double *>(reinterpret_cast<FX_GLOBAL char *>(planes_i + (p) * ps) + lane_off)
 
 namespace fxk {
 
@@ -299,7 +299,7 @@ struct StepOut {  // per-step values the windowed (EXTRA) costs of the generic k
     double a, v, th_cl, x, y;
 };
 
-// One step of one candidate.  `planes_i` = address of plane 0 at (step i, this candidate); ps = plane stride.
+// One step of one candidate.  `planes_i` + `lane_off` bytes = address of plane 0 at (step i, this candidate); ps = plane stride.
 // USTEP: the step index is wave-uniform (one lane per candidate, or parts on different waves), so the obstacle
 // records of the step come in through scalar loads; otherwise every lane reads its own step's records.
 // Road boundary of the agent as the walk sees it (address-space-1 pointers; n_bound lives in StepConst).
@@ -391,7 +391,7 @@ __device__ __forceinline__ void heading_trig(const LonRow &r, double cosTheta, d
 
 template <bool OBST, bool USTEP, bool HOT = false, typename PlanePtr, typename ObsD, typename ObsM>
 __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, const LatPoly &L, const double *tp, int i,
-                                          int traj_len, double d_ext, bool emit, bool store, PlanePtr planes_i, int64_t ps,
+                                          int traj_len, double d_ext, bool emit, bool store, PlanePtr planes_i, uint32_t lane_off, int64_t ps,
                                           StepCarry &C, StepAcc &A, StepOut &O, ObsD obs_rec, ObsM obs_pmask, ObsM obs_hmask,
                                           const BoundView &B, ObsHot *H = nullptr, int i_next = -1) {
     const int S = K.S;
@@ -480,20 +480,40 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
 
     // -- SoA bundle (trajectories.py:56-334) --
     if (store) {
-        FX_PLANE_STORE(planes_i + FX_PL_X * ps, x_i);
-        FX_PLANE_STORE(planes_i + FX_PL_Y * ps, y_i);
-        FX_PLANE_STORE(planes_i + FX_PL_THETA * ps, th_gl);
-        FX_PLANE_STORE(planes_i + FX_PL_V * ps, v_i);
-        FX_PLANE_STORE(planes_i + FX_PL_A * ps, a_i);
-        FX_PLANE_STORE(planes_i + FX_PL_KAPPA * ps, kap);
-        FX_PLANE_STORE(planes_i + FX_PL_KAPPA_DOT * ps, kap_dot);
-        FX_PLANE_STORE(planes_i + FX_PL_S * ps, s_i);
-        FX_PLANE_STORE(planes_i + FX_PL_D * ps, d_i);
-        FX_PLANE_STORE(planes_i + FX_PL_THETA_CL * ps, th_cl);
-        FX_PLANE_STORE(planes_i + FX_PL_S_DOT * ps, sv_i);
-        FX_PLANE_STORE(planes_i + FX_PL_S_DDOT * ps, sa_i);
-        FX_PLANE_STORE(planes_i + FX_PL_D_DOT * ps, dv_i);
-        FX_PLANE_STORE(planes_i + FX_PL_D_DDOT * ps, da_i);
+        // the offset's widening has to happen next to the stores for them to take the scalar-base + 32-bit-offset form
+        asm volatile("" : "+v"(lane_off));
+        // ONE wave-uniform branch for the store mode, then fourteen straight stores
+        if (K.store_wt) {
+            FX_ST_WT(FX_PLANE_AT(FX_PL_X), x_i);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_Y), y_i);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_THETA), th_gl);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_V), v_i);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_A), a_i);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_KAPPA), kap);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_KAPPA_DOT), kap_dot);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_S), s_i);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_D), d_i);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_THETA_CL), th_cl);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_S_DOT), sv_i);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_S_DDOT), sa_i);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_D_DOT), dv_i);
+            FX_ST_WT(FX_PLANE_AT(FX_PL_D_DDOT), da_i);
+        } else {
+            FX_ST_WB(FX_PLANE_AT(FX_PL_X), x_i);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_Y), y_i);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_THETA), th_gl);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_V), v_i);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_A), a_i);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_KAPPA), kap);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_KAPPA_DOT), kap_dot);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_S), s_i);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_D), d_i);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_THETA_CL), th_cl);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_S_DOT), sv_i);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_S_DDOT), sa_i);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_D_DOT), dv_i);
+            FX_ST_WB(FX_PLANE_AT(FX_PL_D_DDOT), da_i);
+        }
     }
 
     // -- partial costs, streamed --

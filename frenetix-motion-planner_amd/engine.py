@@ -37,7 +37,18 @@ def _build_obstacle_hulls_batch(n_use, pos, yaw, length, width, hull, nhull):
                                               nhull.ctypes.data_as(pi)))
 
 
+def invert_cov2(m: np.ndarray) -> np.ndarray:
+    """[n, 2, 2] -> [n, 4]: np.linalg.inv of every matrix, bit for bit (fx_invert_cov2); LinAlgError for a singular one"""
+    m = np.ascontiguousarray(m, dtype=np.float64).reshape(-1, 4)
+    out = np.empty_like(m)
+    pd = C.POINTER(C.c_double)
+    if lib().fx_invert_cov2(len(m), m.ctypes.data_as(pd), out.ctypes.data_as(pd)) != 0:
+        raise np.linalg.LinAlgError("Singular matrix")
+    return out
+
+
 build_obstacle_hulls.batch = _build_obstacle_hulls_batch
+build_obstacle_hulls.invert_cov2 = invert_cov2
 
 
 def build_boundary_bins(ref_xy, segments, max_len: float, reach: float):

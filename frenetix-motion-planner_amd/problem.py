@@ -133,8 +133,11 @@ def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
             n_use[i] = min(n_samples, n)
             yaw[i, :n_use[i]] = _f64(pr["orientation_list"])[:n_use[i]]
             shape[0, i], shape[1, i] = float(pr["shape"]["length"]), float(pr["shape"]["width"])
-    if covs:  # ONE stacked inversion (gesv per matrix, as np.linalg.inv of each list gives)
-        inv = np.linalg.inv(np.concatenate(covs)).reshape(-1, 4)
+    if covs:  # ONE stacked inversion (gesv per matrix, as np.linalg.inv of each list gives; the library's fx_invert_cov2 is
+        # that arithmetic bit for bit without the LAPACK call overhead)
+        inv2 = getattr(build_hulls, "invert_cov2", None)
+        stacked = np.concatenate(covs)
+        inv = inv2(stacked) if inv2 is not None else np.linalg.inv(stacked).reshape(-1, 4)
         o = 0
         for i, n in rows:
             cov_inv[i, :n] = inv[o:o + n]

@@ -285,6 +285,8 @@ int32_t fx_plan_and_package(FxContext *ctx, const FxStateUpdate *upd, double yaw
  *      fx_build_obstacle_hulls_batch: fx_build_obstacle_hulls for K obstacles stored with stride P. */
 int32_t fx_cs_to_curvilinear(int32_t M, const double *ref_xy, const double *normals, const double *ref_pos, double x, double y,
                              double *sd /*[2]*/);
+/* n 2x2 matrices (row-major, 4 doubles each) inverted with the arithmetic of np.linalg.inv, bit for bit (collision_probability.py:281) */
+int32_t fx_invert_cov2(int32_t n, const double *m, double *out);
 int32_t fx_build_obstacle_hulls_batch(int32_t K, int32_t P, const int32_t *n_use, const double *pos, const double *yaw,
                                       const double *length, const double *width, double *hull, int32_t *n_hull);
 
