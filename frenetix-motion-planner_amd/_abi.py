@@ -80,10 +80,11 @@ class FxProblem(C.Structure):
 
 class FxStateUpdate(C.Structure):
     """what changes between two plan steps of a planner (fx_update_state); NULL / NaN / negative = keep"""
+    # the pointers as plain addresses (array.ctypes.data): this struct is filled once per plan step
     _fields_ = [
-        ("x0_lon", _pd), ("x0_lat", _pd), ("x0_orientation", C.c_double), ("v_des", C.c_double), ("low_vel_mode", C.c_int32),
-        ("t_samp", _pd), ("v_samp", _pd), ("d_samp", _pd),
-        ("obs_pos", _pd), ("obs_cov_inv", _pd), ("obs_npred", _pi32), ("obs_hull", _pd), ("obs_nhull", _pi32),
+        ("x0_lon", C.c_void_p), ("x0_lat", C.c_void_p), ("x0_orientation", C.c_double), ("v_des", C.c_double), ("low_vel_mode", C.c_int32),
+        ("t_samp", C.c_void_p), ("v_samp", C.c_void_p), ("d_samp", C.c_void_p),
+        ("obs_pos", C.c_void_p), ("obs_cov_inv", C.c_void_p), ("obs_npred", C.c_void_p), ("obs_hull", C.c_void_p), ("obs_nhull", C.c_void_p),
     ]
 
 

@@ -184,12 +184,10 @@ class CoordinateSystem:
         collinearity of foot point, interpolated normal and the point is a quadratic in the segment parameter."""
         import ctypes as C
         from ._lib import lib
-        pd = C.POINTER(C.c_double)
         if self._c_args is None:   # contiguous views, kept alive with the object
             keep = (np.ascontiguousarray(self._reference), np.ascontiguousarray(self._normals), np.ascontiguousarray(self._ref_pos))
-            self._c_args = (keep, len(keep[0]), *[a.ctypes.data_as(pd) for a in keep])
-        _, M, p_ref, p_nrm, p_pos = self._c_args
-        out = (C.c_double * 2)()
-        if lib().fx_cs_to_curvilinear(M, p_ref, p_nrm, p_pos, float(x), float(y), out) != 0:
+            self._c_args = (keep, len(keep[0]), *[a.ctypes.data for a in keep], (C.c_double * 2)())
+        _, M, p_ref, p_nrm, p_pos, out = self._c_args
+        if lib().fx_cs_to_curvilinear(M, p_ref, p_nrm, p_pos, float(x), float(y), C.addressof(out)) != 0:
             raise ValueError("<CoordinateSystem>: point outside projection domain")
         return np.array([out[0], out[1]])

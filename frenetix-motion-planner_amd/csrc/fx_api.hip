@@ -24,7 +24,8 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
                                           size_t lds_bytes, int G, bool bundle, bool obst, int wpe, bool wsplit,
                                           hipEvent_t ev_start, hipEvent_t ev_stop, FuseArgs fuse, hipStream_t stream);
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
-                                       unsigned long long seq, double *dev_winner, hipStream_t stream);
+                                       unsigned long long seq, double *dev_winner, double *host_pkg, int pkg_stride, int pkg_plane_rows,
+                                       hipStream_t stream);
 extern "C" hipError_t fx_launch_math_test(int n, const double *x, double *at, double *sn, double *cs, hipStream_t stream);
 extern "C" hipError_t fx_launch_publish(const double *src, int n, double *host_dst, unsigned long long *host_seq,
                                         unsigned long long seq, hipStream_t stream);
@@ -896,10 +897,14 @@ int32_t fx_evaluate(FxContext *c) {
     }
     if (timed && !attached) HIP_TRY(hipEventRecord(ts->e_eval, c->stream));
     if (!c->fused_step) {
-        HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, winner, c->stream));
-    }
-    if (c->pkg_step)  // the winner's arrays follow the result block into pinned host memory: fx_finish waits for them
+        // with a package the selection's publishing workgroup gathers the winner's arrays itself (no further launch)
+        HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, winner, c->pkg_step ? c->h_pkg_dev : nullptr,
+                                 c->pkg_stride, c->pkg_plane_rows, c->stream));
+    } else if (c->pkg_step) {
+        // fused selection publishes while other waves' plane stores may still be in flight: the gather runs as its own small
+        // kernel behind the evaluation; fx_finish waits for its sequence word
         HIP_TRY(fx_launch_package(c->d_probs, c->n_agents, winner, c->h_pkg_dev, c->pkg_stride, c->pkg_plane_rows, c->seq, c->stream));
+    }
     if (timed && (!c->fused_step || c->pkg_step)) HIP_TRY(hipEventRecord(ts->e_end, c->stream));
     if (timed) { ts->fused = c->fused_step && !c->pkg_step; c->n_timed++; }
     c->timed_step = timed;
@@ -1173,6 +1178,39 @@ int32_t fx_invert_cov2(int32_t n, const double *m, double *out) {
             const double x1 = (r1 - l * r0) * ru;
             out[4 * i + col] = std::fma(-p0b, x1, r0) * rp;
             out[4 * i + 2 + col] = x1;
+        }
+    }
+    return FX_OK;
+}
+
+// Packing of K predicted obstacles (prediction_helpers.py:209-261 dict entries) into the arrays FxProblem / FxStateUpdate take,
+// in one call: obstacle k has n[k] predictions at pos[k] ([n][2]), cov[k] ([n][4]) and -- when yaw[k] is not NULL -- headings
+// yaw[k] ([n]) with the box length[k] x width[k].  Outputs with stride P (zero-filled here): pos_out [K][P][2], cov_inv_out
+// [K][P][4] (fx_invert_cov2), npred [K] = n[k] (the real length decides which ego steps see the obstacle,
+// collision_probability.py:287), hull [K][P-1][6], nhull [K] (hulls over the first min(n_samples, n[k], P) boxes,
+// collision_check.py:150).
+int32_t fx_pack_predictions(int32_t K, int32_t P, int32_t n_samples, const int32_t *n, const double *const *pos, const double *const *cov,
+                            const double *const *yaw, const double *length, const double *width, double *pos_out, double *cov_inv_out,
+                            int32_t *npred, double *hull, int32_t *nhull) {
+    if (K < 0 || P < 2 || (K > 0 && (!n || !pos || !cov || !yaw || !length || !width || !pos_out || !cov_inv_out || !npred || !hull || !nhull)))
+        return set_err(FX_ERR_INVALID_ARGUMENT, "fx_pack_predictions: bad argument");
+    memset(pos_out, 0, sizeof(double) * 2 * (size_t)K * P);
+    memset(cov_inv_out, 0, sizeof(double) * 4 * (size_t)K * P);
+    memset(hull, 0, sizeof(double) * 6 * (size_t)K * (P - 1));
+    std::vector<double> yaw_k((size_t)P);
+    for (int k = 0; k < K; k++) {
+        npred[k] = n[k];
+        nhull[k] = 0;
+        const int m = std::min(n[k], P);
+        if (m <= 0) continue;
+        if (!pos[k] || !cov[k]) return set_err(FX_ERR_INVALID_ARGUMENT, "obstacle %d: NULL arrays", k);
+        memcpy(pos_out + (size_t)2 * P * k, pos[k], sizeof(double) * 2 * m);
+        int rc = fx_invert_cov2(m, cov[k], cov_inv_out + (size_t)4 * P * k);
+        if (rc) return rc;
+        if (yaw[k]) {
+            rc = fx_build_obstacle_hulls(std::min(n_samples, m), pos_out + (size_t)2 * P * k, yaw[k], length[k], width[k],
+                                         hull + (size_t)6 * (P - 1) * k, nhull + k);
+            if (rc) return rc;
         }
     }
     return FX_OK;

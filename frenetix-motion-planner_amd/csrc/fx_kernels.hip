@@ -35,6 +35,52 @@ extern "C" int fx_probe_read(unsigned long long *out, size_t n_words) {
 }
 #endif
 
+// Winner package: everything the planner reads of the chosen trajectory -- planes [14][S], coefficients, raw partial costs,
+// cost, horizon, flag word -- gathered from the SoA outputs straight into pinned host memory behind the selection, so that a
+// plan step ends with ONE wait instead of a second round of strided copies and a stream synchronisation
+// (reactive_planner_cpp.py:355-357 reads the optimal trajectory's arrays, planner.py:394-447 packages them).
+// grid = n_agents, block = 256.  Layout per agent (doubles): planes | lon6 lat6 | raw[FX_NUM_COSTS] | cost | traj_len | flags |
+// index | found, then the sequence word at stride - 1.
+// The gather itself, for one agent, by the 256 threads of a workgroup; every wave leaves with its stores performed at system
+// scope (the caller orders the sequence word behind a barrier).
+__device__ __forceinline__ void fx_package_gather(const DevProblem &P, long long gi, double *out, int plane_rows) {
+    double *tail = out + plane_rows;
+    const bool found = gi >= 0 && (P.mode & FX_MODE_WRITE_BUNDLE);
+    const int tid = threadIdx.x;
+    if (found) {
+        const int64_t l = gi - P.g_base, ld = P.ld;
+        const int n_pl = FX_NUM_PLANES * P.S;
+        const FX_GLOBAL double *pl = as_global(P.planes);
+        for (int t = tid; t < n_pl; t += 256) out[t] = pl[(size_t)t * ld + l];
+        if (tid < 12) tail[tid] = as_global(P.coeffs)[(size_t)tid * ld + l];
+        if (tid >= 64 && tid < 64 + FX_NUM_COSTS)
+            tail[12 + tid - 64] = (tid - 64 < P.n_cost && (P.mode & FX_MODE_WRITE_COSTMAP)) ? as_global(P.costmap)[(size_t)(tid - 64) * ld + l] : 0.0;
+        if (tid == 128) {
+            tail[12 + FX_NUM_COSTS] = as_global(P.cost)[l];
+            tail[13 + FX_NUM_COSTS] = (double)as_global(P.traj_len)[l];
+            tail[14 + FX_NUM_COSTS] = (double)as_global(P.flags)[l];
+            tail[15 + FX_NUM_COSTS] = (double)gi;
+        }
+    }
+    if (tid == 129) tail[16 + FX_NUM_COSTS] = found ? 1.0 : 0.0;
+    __threadfence_system();
+}
+
+__global__ __launch_bounds__(256) void fx_package_kernel(const DevProblem *__restrict__ probs, const double *__restrict__ winner,
+                                                         double *host_pkg, int stride, int plane_rows, unsigned long long seq) {
+    double *out = host_pkg + (size_t)blockIdx.x * stride;
+    fx_package_gather(probs[blockIdx.x], reinterpret_cast<const long long *>(winner)[2 * blockIdx.x + 1], out, plane_rows);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(out + stride - 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" hipError_t fx_launch_package(const DevProblem *d_probs, int n_agents, const double *winner, double *host_pkg, int stride,
+                                        int plane_rows, unsigned long long seq, hipStream_t stream) {
+    hipLaunchKernelGGL(fx_package_kernel, dim3(n_agents), dim3(256), 0, stream, d_probs, winner, host_pkg, stride, plane_rows, seq);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Selection kernel: one workgroup per agent.  Reduces the per-workgroup partials to the winner and
 // counts the colliding candidates that the reference's cost-ordered walk would have visited before it
@@ -46,7 +92,8 @@ extern "C" int fx_probe_read(unsigned long long *out, size_t n_words) {
 // publishes the result block.  One workgroup scanning 50 000 candidates took ~30 us; the slices take ~5.
 #define FX_SELECT_SLICES 32
 __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__restrict__ probs, unsigned long long *host_result,
-                                                        unsigned long long seq, double *dev_winner) {
+                                                        unsigned long long seq, double *dev_winner, double *host_pkg, int pkg_stride,
+                                                        int pkg_plane_rows) {
     __shared__ double sc[4];
     __shared__ long long si[4];
     __shared__ unsigned int scnt;
@@ -121,10 +168,15 @@ __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__rest
         out[FX_CNT_COLLISIONS] = atomicExch(&P.counters[FX_CNT_COLLISIONS], 0ULL);
         __hip_atomic_store(&P.counters[FX_DCNT_TICKET], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // the winner package (fx_set_package): the evaluation kernel is complete, so the publishing workgroup gathers the chosen
+    // trajectory right here -- no further launch; its sequence word goes out behind the result block's
+    double *pkg = host_pkg ? host_pkg + (size_t)blockIdx.y * pkg_stride : nullptr;
+    if (pkg) fx_package_gather(P, none ? -1LL : bi, pkg, pkg_plane_rows);
     __syncthreads();
     if (tid == 0) {
         __threadfence_system();
         __hip_atomic_store(&out[FX_CNT_COUNT], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (pkg) __hip_atomic_store(reinterpret_cast<unsigned long long *>(pkg + pkg_stride - 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -247,50 +299,6 @@ extern "C" hipError_t fx_launch_stage(const void *src_mapped, void *dst, size_t 
     return hipGetLastError();
 }
 
-// Winner package: everything the planner reads of the chosen trajectory -- planes [14][S], coefficients, raw partial costs,
-// cost, horizon, flag word -- gathered from the SoA outputs straight into pinned host memory behind the selection, so that a
-// plan step ends with ONE wait instead of a second round of strided copies and a stream synchronisation
-// (reactive_planner_cpp.py:355-357 reads the optimal trajectory's arrays, planner.py:394-447 packages them).
-// grid = n_agents, block = 256.  Layout per agent (doubles): planes | lon6 lat6 | raw[FX_NUM_COSTS] | cost | traj_len | flags |
-// index | found, then the sequence word at stride - 1.
-__global__ __launch_bounds__(256) void fx_package_kernel(const DevProblem *__restrict__ probs, const double *__restrict__ winner,
-                                                         double *host_pkg, int stride, int plane_rows, unsigned long long seq) {
-    const DevProblem &P = probs[blockIdx.x];
-    double *out = host_pkg + (size_t)blockIdx.x * stride;
-    double *tail = out + plane_rows;
-    const long long gi = reinterpret_cast<const long long *>(winner)[2 * blockIdx.x + 1];
-    const bool found = gi >= 0 && (P.mode & FX_MODE_WRITE_BUNDLE);
-    const int tid = threadIdx.x;
-    if (found) {
-        const int64_t l = gi - P.g_base, ld = P.ld;
-        const int n_pl = FX_NUM_PLANES * P.S;
-        const FX_GLOBAL double *pl = as_global(P.planes);
-        for (int t = tid; t < n_pl; t += 256) out[t] = pl[(size_t)t * ld + l];
-        if (tid < 12) tail[tid] = as_global(P.coeffs)[(size_t)tid * ld + l];
-        if (tid >= 64 && tid < 64 + FX_NUM_COSTS)
-            tail[12 + tid - 64] = (tid - 64 < P.n_cost && (P.mode & FX_MODE_WRITE_COSTMAP)) ? as_global(P.costmap)[(size_t)(tid - 64) * ld + l] : 0.0;
-        if (tid == 128) {
-            tail[12 + FX_NUM_COSTS] = as_global(P.cost)[l];
-            tail[13 + FX_NUM_COSTS] = (double)as_global(P.traj_len)[l];
-            tail[14 + FX_NUM_COSTS] = (double)as_global(P.flags)[l];
-            tail[15 + FX_NUM_COSTS] = (double)gi;
-        }
-    }
-    if (tid == 129) tail[16 + FX_NUM_COSTS] = found ? 1.0 : 0.0;
-    // every wave waits for its own stores to be performed at system scope; the barrier then orders them before the sequence word
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(out + stride - 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-extern "C" hipError_t fx_launch_package(const DevProblem *d_probs, int n_agents, const double *winner, double *host_pkg, int stride,
-                                        int plane_rows, unsigned long long seq, hipStream_t stream) {
-    hipLaunchKernelGGL(fx_package_kernel, dim3(n_agents), dim3(256), 0, stream, d_probs, winner, host_pkg, stride, plane_rows, seq);
-    return hipGetLastError();
-}
-
 // element-wise check of the fx_math kernels (tests/test_hip_math.py)
 __global__ void fx_math_test_kernel(int n, const double *__restrict__ x, double *__restrict__ at, double *__restrict__ sn,
                                     double *__restrict__ cs) {
@@ -400,8 +408,10 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
 }
 
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
-                                       unsigned long long seq, double *dev_winner, hipStream_t stream) {
-    hipLaunchKernelGGL(fx_select_kernel, dim3(FX_SELECT_SLICES, n_agents), dim3(256), 0, stream, d_probs, host_result, seq, dev_winner);
+                                       unsigned long long seq, double *dev_winner, double *host_pkg, int pkg_stride, int pkg_plane_rows,
+                                       hipStream_t stream) {
+    hipLaunchKernelGGL(fx_select_kernel, dim3(FX_SELECT_SLICES, n_agents), dim3(256), 0, stream, d_probs, host_result, seq, dev_winner,
+                       host_pkg, pkg_stride, pkg_plane_rows);
     return hipGetLastError();
 }
 

@@ -30,23 +30,43 @@ def build_obstacle_hulls(n_pred, pos, yaw, length, width) -> np.ndarray:
 def _build_obstacle_hulls_batch(n_use, pos, yaw, length, width, hull, nhull):
     """fx_build_obstacle_hulls_batch: pos [K][P][2], yaw [K][P] -> hull [K][P-1][6], nhull [K] (in place)"""
     K, P = pos.shape[0], pos.shape[1]
-    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     length, width = np.ascontiguousarray(length, dtype=np.float64), np.ascontiguousarray(width, dtype=np.float64)
-    check(lib().fx_build_obstacle_hulls_batch(K, P, n_use.ctypes.data_as(pi), pos.ctypes.data_as(pd), yaw.ctypes.data_as(pd),
-                                              length.ctypes.data_as(pd), width.ctypes.data_as(pd), hull.ctypes.data_as(pd),
-                                              nhull.ctypes.data_as(pi)))
+    check(lib().fx_build_obstacle_hulls_batch(K, P, n_use.ctypes.data, pos.ctypes.data, yaw.ctypes.data, length.ctypes.data,
+                                              width.ctypes.data, hull.ctypes.data, nhull.ctypes.data))
 
 
 def invert_cov2(m: np.ndarray) -> np.ndarray:
     """[n, 2, 2] -> [n, 4]: np.linalg.inv of every matrix, bit for bit (fx_invert_cov2); LinAlgError for a singular one"""
     m = np.ascontiguousarray(m, dtype=np.float64).reshape(-1, 4)
     out = np.empty_like(m)
-    pd = C.POINTER(C.c_double)
-    if lib().fx_invert_cov2(len(m), m.ctypes.data_as(pd), out.ctypes.data_as(pd)) != 0:
+    if lib().fx_invert_cov2(len(m), m.ctypes.data, out.ctypes.data) != 0:
         raise np.linalg.LinAlgError("Singular matrix")
     return out
 
 
+def _pack_predictions_c(entries, P: int, n_samples: int):
+    """fx_pack_predictions: entries = [(pos [n,2], cov [n,2,2], yaw [n] or None, length, width)] -> packed arrays"""
+    K = len(entries)
+    # inputs: counts, three pointer columns, box sizes in ONE int64 / float64 block each; outputs in one block, handed out as views
+    meta = np.array([[len(e[0]) for e in entries], [e[0].ctypes.data for e in entries], [e[1].ctypes.data for e in entries],
+                     [0 if e[2] is None else e[2].ctypes.data for e in entries]], dtype=np.int64)
+    n32 = meta[0].astype(np.int32)
+    lw = np.array([[e[3] for e in entries], [e[4] for e in entries]])
+    sizes = (2 * K * P, 4 * K * P, 6 * K * (P - 1))
+    out = np.empty(sum(sizes))
+    cnt = np.empty((2, K), np.int32)
+    o0, m0, l0, c0 = out.ctypes.data, meta.ctypes.data, lw.ctypes.data, cnt.ctypes.data
+    rc = lib().fx_pack_predictions(K, P, int(n_samples), n32.ctypes.data, m0 + 8 * K, m0 + 16 * K, m0 + 24 * K, l0, l0 + 8 * K,
+                                   o0, o0 + 8 * sizes[0], c0, o0 + 8 * (sizes[0] + sizes[1]), c0 + 4 * K)
+    if rc != 0:
+        if b"singular" in lib().fx_last_error():
+            raise np.linalg.LinAlgError("Singular matrix")
+        check(rc)
+    return dict(K=K, P=P, pos=out[:sizes[0]].reshape(K, P, 2), cov_inv=out[sizes[0]:sizes[0] + sizes[1]].reshape(K, P, 4),
+                npred=cnt[0], hull=out[sizes[0] + sizes[1]:].reshape(K, P - 1, 6), nhull=cnt[1])
+
+
+build_obstacle_hulls.pack = _pack_predictions_c
 build_obstacle_hulls.batch = _build_obstacle_hulls_batch
 build_obstacle_hulls.invert_cov2 = invert_cov2
 
@@ -211,12 +231,11 @@ class FrenetEngine:
         (problem.pack_predictions) with the K and P of the upload.  Build it once, reuse it as often as wanted."""
         u = _abi.FxStateUpdate()
         keep = []
-        pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
 
         def arr(a, typ=np.float64):
             a = np.ascontiguousarray(a, dtype=typ)
             keep.append(a)
-            return a.ctypes.data_as(pd if typ == np.float64 else pi)
+            return a.ctypes.data
 
         if x0_lon is not None: u.x0_lon = arr(x0_lon)
         if x0_lat is not None: u.x0_lat = arr(x0_lat)

@@ -107,6 +107,16 @@ def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
     # only the first n_samples predictions are ever read (prediction i-1 pairs with ego step i <= N, hulls use min(S, n)):
     # a 100-step predictor does not enlarge the tables
     P = max(2, min(n_samples, max(len(predictions[k]["pos_list"]) for k in keys)))
+    pack = getattr(build_hulls, "pack", None)
+    if pack is not None:   # the library pads, inverts and builds the hulls in one call (fx_pack_predictions)
+        entries = []
+        for k in keys:
+            pr = predictions[k]
+            pl = _f64(pr["pos_list"]).reshape(-1, 2)
+            hulls = "orientation_list" in pr and "shape" in pr
+            entries.append((pl, _f64(pr["cov_list"]) if len(pl) else pl, _f64(pr["orientation_list"]) if hulls else None,
+                            float(pr["shape"]["length"]) if hulls else 0.0, float(pr["shape"]["width"]) if hulls else 0.0))
+        return pack(entries, P, n_samples)
     pos = np.zeros((K, P, 2))
     cov_inv = np.zeros((K, P, 4))
     npred = np.zeros(K, np.int32)

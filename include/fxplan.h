@@ -287,6 +287,11 @@ int32_t fx_cs_to_curvilinear(int32_t M, const double *ref_xy, const double *norm
                              double *sd /*[2]*/);
 /* n 2x2 matrices (row-major, 4 doubles each) inverted with the arithmetic of np.linalg.inv, bit for bit (collision_probability.py:281) */
 int32_t fx_invert_cov2(int32_t n, const double *m, double *out);
+/* K predicted obstacles -> the obstacle arrays of FxProblem / FxStateUpdate in one call (covariance inverses, hulls, padding
+ * to the stride P); pos[k] [n[k]][2], cov[k] [n[k]][4], yaw[k] [n[k]] or NULL (no hulls for that obstacle). */
+int32_t fx_pack_predictions(int32_t K, int32_t P, int32_t n_samples, const int32_t *n, const double *const *pos, const double *const *cov,
+                            const double *const *yaw, const double *length, const double *width, double *pos_out, double *cov_inv_out,
+                            int32_t *npred, double *hull, int32_t *nhull);
 int32_t fx_build_obstacle_hulls_batch(int32_t K, int32_t P, const int32_t *n_use, const double *pos, const double *yaw,
                                       const double *length, const double *width, double *hull, int32_t *n_hull);
 
