@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <dlfcn.h>
 
 #include "fx_device.h"
 
@@ -125,6 +126,10 @@ struct FxContext {
     unsigned long long *h_counters = nullptr;  // pinned + mapped: [max_agents][FX_CNT_COUNT + 1], last word = sequence
     unsigned long long *h_counters_dev = nullptr;  // device address of the same block
     unsigned long long seq = 0;
+    // survivor exchange inside the library (fx_comm_init): an RCCL communicator of this context's own, the gathered winners
+    void *comm = nullptr;                  // ncclComm_t
+    int comm_rank = 0, comm_world = 0;
+    double *d_gather = nullptr;            // [world][max_agents][2]
     double *h_pub = nullptr, *h_pub_dev = nullptr;   // pinned + mapped [FX_PUB_MAX + 1]: published buffer, last word = sequence
     unsigned long long pub_seq = 0;
     int pub_n = 0;
@@ -461,6 +466,7 @@ int32_t fx_destroy(FxContext *c) {
     if (c->d_bstep) (void)hipFree(c->d_bstep);
     if (c->d_bound) (void)hipFree(c->d_bound);
     if (c->h_bound) (void)hipHostFree(c->h_bound);
+    if (c->comm) (void)fx_comm_destroy(c);
     if (c->d_winner_own) (void)hipFree(c->d_winner_own);
     void *host[] = {c->h_in, c->h_counters, c->h_topk_cost, c->h_topk_idx, c->h_pub, c->h_cand, c->h_pkg};
     for (void *p : host) if (p) (void)hipHostFree(p);
@@ -1039,6 +1045,109 @@ int32_t fx_update_step(FxContext *c, const FxStateUpdate *u, FxResult *res) {
 }
 
 static int check_agent(FxContext *c, int a);
+
+// ---- survivor exchange inside the library (header: fxplan.h) ----
+// RCCL is bound at run time (dlopen of librccl.so.1: the copy the process already has -- torch's -- or the system one), so the
+// library loads and plans on a single GPU without it.
+namespace {
+struct Rccl {
+    typedef struct { char internal[128]; } UniqueId;
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+Rccl *rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (h) {
+            r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+            r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+            r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+            r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+            r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+            r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
+        }
+    }
+    return &r;
+}
+#define RCCL_TRY(expr)                                                                                             \
+    do {                                                                                                            \
+        const int e_ = (expr);                                                                                      \
+        if (e_ != 0) return set_err(FX_ERR_HIP, "%s failed: %s", #expr, rccl()->GetErrorString(e_));              \
+    } while (0)
+}  // namespace
+
+int32_t fx_comm_unique_id(uint8_t *id128) {
+    if (!id128) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_comm_unique_id: NULL argument");
+    if (!rccl()->ok) return set_err(FX_ERR_NOT_READY, "librccl.so.1 not available");
+    Rccl::UniqueId id;
+    RCCL_TRY(rccl()->GetUniqueId(&id));
+    memcpy(id128, id.internal, 128);
+    return FX_OK;
+}
+
+int32_t fx_comm_init(FxContext *c, const uint8_t *id128, int32_t rank, int32_t world) {
+    if (!c || !id128) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_comm_init: NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_comm_init: rank %d of %d", rank, world);
+    if ((size_t)world * c->max_agents * 2 > FX_PUB_MAX) return set_err(FX_ERR_CAPACITY, "%d ranks x %d agents exceed the publication block", world, c->max_agents);
+    if (!rccl()->ok) return set_err(FX_ERR_NOT_READY, "librccl.so.1 not available");
+    if (c->comm) return set_err(FX_ERR_INVALID_ARGUMENT, "this context already has a communicator");
+    HIP_TRY(hipSetDevice(c->device));
+    Rccl::UniqueId id;
+    memcpy(id.internal, id128, 128);
+    RCCL_TRY(rccl()->CommInitRank(&c->comm, world, id, rank));
+    c->comm_rank = rank; c->comm_world = world;
+    int rc = dev_alloc(c, &c->d_gather, (size_t)world * c->max_agents * 2);
+    if (rc) return rc;
+    if (!c->d_winner_own && (rc = dev_alloc(c, &c->d_winner_own, (size_t)c->max_agents * 2))) return rc;
+    return FX_OK;
+}
+
+int32_t fx_comm_destroy(FxContext *c) {
+    if (!c || !c->comm) return FX_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)rccl()->CommDestroy(c->comm);
+    c->comm = nullptr;
+    if (c->d_gather) { (void)hipFree(c->d_gather); c->d_gather = nullptr; }
+    return FX_OK;
+}
+
+// One plan step of every rank: evaluation (+ selection), ONE all-gather of the ranks' winners (cost f64, global index i64 per
+// agent; 16 B per rank and agent) on the context's stream, publication to pinned host memory -- enqueued back to back, then the
+// host takes the local result block while the collective runs and polls for the gathered winners.
+int32_t fx_step_exchange(FxContext *c, FxResult *res, double *cost, int64_t *index) {
+    if (!c || !res || !cost || !index) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_step_exchange: NULL argument");
+    if (!c->comm) return set_err(FX_ERR_NOT_READY, "fx_step_exchange before fx_comm_init");
+    double *saved = c->dev_winner;
+    if (!saved) c->dev_winner = c->d_winner_own;   // the selection leaves (cost, index) of every agent here
+    int rc = fx_evaluate(c);
+    const double *send = c->dev_winner;
+    c->dev_winner = saved;
+    if (rc) return rc;
+    const int n = c->n_agents * 2, total = n * c->comm_world;
+    RCCL_TRY(rccl()->AllGather(send, c->d_gather, (size_t)n, /*ncclDouble*/ 8, c->comm, c->stream));
+    if ((rc = fx_publish(c, c->d_gather, total))) return rc;
+    if ((rc = fx_finish_batch(c, res))) return rc;
+    const volatile unsigned long long *sq = reinterpret_cast<const unsigned long long *>(c->h_pub + FX_PUB_MAX);
+    bool done = false;
+    for (long spin = 0; spin < 20000000L && !done; spin++) done = __atomic_load_n(sq, __ATOMIC_ACQUIRE) == c->pub_seq;
+    if (!done) HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < c->comm_world; r++)
+        for (int a = 0; a < c->n_agents; a++) {
+            const double *q = c->h_pub + (size_t)r * n + 2 * a;
+            cost[(size_t)r * c->n_agents + a] = q[0];
+            memcpy(&index[(size_t)r * c->n_agents + a], &q[1], sizeof(int64_t));
+        }
+    return FX_OK;
+}
 
 // ---- winner package (header: fxplan.h) ----
 int32_t fx_set_package(FxContext *c, int32_t enabled) {

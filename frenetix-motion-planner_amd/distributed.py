@@ -110,6 +110,24 @@ class _RawStepResult:
         return d
 
 
+class _ExchangedStepResult(_RawStepResult):
+    """local FxResult + the global winner of the in-library exchange"""
+
+    def __init__(self, raw, best_cost, best_index, survivors):
+        super().__init__(raw)
+        self._g = {"global_best_cost": best_cost, "global_best_index": best_index, "survivors": survivors}
+
+    def __getitem__(self, key):
+        if key in self._g:
+            return self._g[key]
+        return getattr(self._raw, key) if key != "reason_hist" else list(self._raw.reason_hist)
+
+    def as_dict(self) -> dict:
+        d = self._raw.as_dict()
+        d.update(self._g)
+        return d
+
+
 class ShardedEvaluator:
     """Candidate-sharded plan step.  `engine` is a FrenetEngine (or anything with plan_step / topk /
     topk_to_device / set_stream); `group` a torch.distributed process group (None = default group, or
@@ -135,6 +153,44 @@ class ShardedEvaluator:
             self._gath = torch.empty(self.world * 2 * self.k, dtype=torch.float64, device=dev)
             if self.k == 1:  # the selection kernel itself leaves (cost, index) in the exchange buffer: no top-k launch
                 engine.set_winner_buffer(self._surv.data_ptr())
+        # k = 1: the exchange runs inside the library on a communicator of the engine's own (fx_step_exchange: evaluation,
+        # all-gather, publication and result in ONE call, no Python between the launches); FX_EXCHANGE=torch keeps the
+        # torch.distributed path
+        self.lib_exchange = False
+        import os
+        if self.on_device and self.k == 1 and hasattr(engine, "comm_init") and (self.world > 1 or self.force_exchange) \
+                and os.environ.get("FX_EXCHANGE", "lib") != "torch":
+            self.lib_exchange = self._init_library_exchange(dev)
+
+    def _init_library_exchange(self, dev) -> bool:
+        """Every rank ends with the same answer: rank 0 draws the id (a flag byte says whether it could), it is broadcast over
+        the torch group, every rank initialises its communicator and the ranks agree (MIN) on whether all of them succeeded."""
+        torch, dist = self.torch, self.dist
+        uid = torch.zeros(129, dtype=torch.uint8, device=dev)
+        if self.rank == 0:
+            try:
+                raw = self.engine.comm_unique_id()
+                uid = torch.tensor(list(raw) + [1], dtype=torch.uint8, device=dev)
+            except Exception:
+                pass
+        if self.world > 1:
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast(uid, src=src, group=self.group)
+        host = uid.cpu().numpy()
+        ok = bool(host[128])
+        if ok:
+            try:
+                self.engine.comm_init(bytes(host[:128]), self.rank, self.world)
+            except Exception:
+                ok = False
+        if self.world > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            all_ok = bool(flag.item())
+            if ok and not all_ok:
+                self.engine.comm_destroy()
+            ok = all_ok
+        return ok
 
     def shard(self, inputs):
         begin, count = shard_range(inputs.n_candidates_global, self.rank, self.world)
@@ -150,6 +206,10 @@ class ShardedEvaluator:
             res = self.engine.finish()[0]
             res["global_best_index"], res["global_best_cost"] = res["best_index"], res["best_cost"]
             return res
+        if self.lib_exchange:
+            raw, gc, gi = self.engine.step_exchange_raw()
+            best_c, best_i, order = merge_survivors(gc[:, 0], gi[:, 0])
+            return _ExchangedStepResult(raw[0], best_c, best_i, order)
         self.engine.evaluate()
         self._enqueue_exchange()
         # the local result block is published by the evaluation kernel itself: unpack it while the all-gather runs
@@ -184,6 +244,9 @@ class ShardedEvaluator:
             res = self.engine.plan_step(inputs)
             res["global_best_index"], res["global_best_cost"] = res["best_index"], res["best_cost"]
             return res
+        if self.lib_exchange:
+            self.engine.upload(inputs)
+            return self.step_enqueued().as_dict()
         if self.on_device:
             self.engine.upload(inputs)
             self.engine.evaluate()

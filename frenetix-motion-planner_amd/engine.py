@@ -312,6 +312,35 @@ class FrenetEngine:
                                         C.byref(pkg), block.ctypes.data_as(C.POINTER(C.c_double))))
         return res[0].as_dict(), (WinnerPackage(pkg, block, inputs) if pkg.found else None)
 
+    # -- survivor exchange inside the library (fx_comm_*) --
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """rank 0: the 128-byte id every rank hands to comm_init (broadcast it with whatever the program has)"""
+        buf = (C.c_uint8 * 128)()
+        check(lib().fx_comm_unique_id(C.addressof(buf)))
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(lib().fx_comm_init(self._ctx, C.addressof(buf), int(rank), int(world)))
+        self._comm_world = int(world)
+
+    def comm_destroy(self):
+        check(lib().fx_comm_destroy(self._ctx))
+        self._comm_world = 0
+
+    def step_exchange_raw(self):
+        """evaluate + all-gather of every rank's winner(s) + finish in ONE call: (FxResult array, cost [W, n], index [W, n])"""
+        n = len(self._inputs)
+        res = getattr(self, "_res_buf", None)
+        if res is None or len(res) != n:
+            res = self._res_buf = (_abi.FxResult * n)()
+        x = getattr(self, "_xchg_buf", None)
+        if x is None or x[0].shape != (self._comm_world, n):
+            x = self._xchg_buf = (np.empty((self._comm_world, n)), np.empty((self._comm_world, n), np.int64))
+        check(lib().fx_step_exchange(self._ctx, res, x[0].ctypes.data, x[1].ctypes.data))
+        return res, x[0], x[1]
+
     def set_package(self, enabled: bool):
         """Gather the winner's arrays into pinned host memory behind every evaluation that writes the bundle (fx_set_package);
         read them with `package(agent)` after finish()."""

@@ -255,6 +255,18 @@ typedef struct FxStateUpdate {
 int32_t fx_update_state(FxContext *ctx, int32_t agent, const FxStateUpdate *upd);
 int32_t fx_update_step(FxContext *ctx, const FxStateUpdate *upd, FxResult *res);
 
+/* ---- multi-GPU survivor exchange inside the library (one process per GPU; the reference fans candidate chunks / agent batches
+ *      out to processes and pickles results back through Queues, reactive_planner.py:197-224, simulation.py:449-470) ----
+ *      The context gets an RCCL communicator of its own: rank 0 draws the 128-byte id (fx_comm_unique_id), the host program
+ *      broadcasts it by whatever means it has, every rank calls fx_comm_init.  fx_step_exchange = fx_evaluate + ONE all-gather of
+ *      every rank's winner (cost f64, global index i64) per agent on the context's stream + publication to pinned host memory +
+ *      fx_finish_batch: cost / index [world][n_agents], index -1 where a rank found nothing.  RCCL is bound at run time
+ *      (librccl.so.1); without it these return FX_ERR_NOT_READY and everything else works. */
+int32_t fx_comm_unique_id(uint8_t *id128);
+int32_t fx_comm_init(FxContext *ctx, const uint8_t *id128, int32_t rank, int32_t world);
+int32_t fx_comm_destroy(FxContext *ctx);
+int32_t fx_step_exchange(FxContext *ctx, FxResult *res, double *cost /*[world][n_agents]*/, int64_t *index /*[world][n_agents]*/);
+
 /* ---- the chosen trajectory, packaged (planner.py:394-447 _compute_trajectory_pair; reactive_planner_cpp.py:355-357 reads the
  *      optimal trajectory's arrays; frenet_interface.py:243-277 consumes the pair) ----
  *      With fx_set_package(ctx, 1) every evaluation that writes the bundle is followed by a gather of the winner's data into

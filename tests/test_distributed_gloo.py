@@ -230,6 +230,47 @@ def test_rccl_exchange_k1_uses_selection_result():
 
 
 @pytest.mark.gpu
+def test_library_side_exchange_single_rank():
+    """fx_comm_init / fx_step_exchange: the all-gather of the winners issued by the library on a communicator of its own (one
+    rank here): same winner as the plain step and as the torch.distributed exchange, collisions counted, repeated steps"""
+    import torch
+    import torch.distributed as dist
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator
+    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for kw in (dict(n_obstacles=8), dict(n_obstacles=0), dict(n_obstacles=6, lead_gap=15.0)):
+            inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(9, 21, 21), hull_builder=build_obstacle_hulls, **kw)
+            with FrenetEngine(max_candidates=8192, device=0) as eng:
+                ref = eng.plan_step(inp)
+                ev = ShardedEvaluator(eng, k=1, force_exchange=True)
+                assert ev.lib_exchange
+                res = ev.plan_step(inp)
+                assert res["global_best_index"] == ref["best_index"] and res["global_best_cost"] == ref["best_cost"]
+                assert res["n_collisions"] == ref["n_collisions"] and res["n_feasible"] == ref["n_feasible"]
+                assert list(res["survivors"]) == ([ref["best_index"]] if ref["best_index"] >= 0 else [])
+                for _ in range(3):
+                    r2 = ev.step_enqueued()
+                assert r2["global_best_index"] == ref["best_index"] and r2["best_index"] == ref["best_index"]
+                eng.set_winner_buffer(0)
+        os.environ["FX_EXCHANGE"] = "torch"
+        try:
+            with FrenetEngine(max_candidates=8192, device=0) as eng:
+                ev = ShardedEvaluator(eng, k=1, force_exchange=True)
+                assert not ev.lib_exchange
+                assert ev.plan_step(inp)["global_best_index"] == ref["best_index"]
+                eng.set_winner_buffer(0)
+        finally:
+            del os.environ["FX_EXCHANGE"]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 def test_agent_sharded_topk_gather_single_rank():
     """BASELINE config 5's exchange: per-agent top-k written into one torch buffer, ONE all-gather, published to the
     host -- with a one-rank nccl group, compared with the engine's own top-k read-back."""

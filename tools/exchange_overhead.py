@@ -10,15 +10,20 @@ os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29517"
 torch.cuda.set_device(0); dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(19, 51, 51))
 with FrenetEngine(max_candidates=inp.n_candidates + 64) as eng:
-    ev = ShardedEvaluator(eng, k=int(os.environ.get('FXK', '1')), force_exchange=True); eng.upload(inp)
-    for _ in range(20): ev.step_enqueued()
-    t = []
-    for _ in range(200):
-        t0 = time.perf_counter(); ev.step_enqueued(); t.append(time.perf_counter() - t0)
-    print("step with top-k + 1-rank RCCL all-gather + D2H: p50 %.1f us" % (np.median(t) * 1e6), flush=True)
+    for mode in ("lib", "torch"):
+        os.environ["FX_EXCHANGE"] = mode
+        ev = ShardedEvaluator(eng, k=int(os.environ.get('FXK', '1')), force_exchange=True); eng.upload(inp)
+        for _ in range(20): ev.step_enqueued()
+        t = []
+        for _ in range(400):
+            t0 = time.perf_counter(); ev.step_enqueued(); t.append(time.perf_counter() - t0)
+        print("step + 1-rank RCCL all-gather of the winner, exchange driven by %s (lib_exchange=%s): p50 %.1f us" % (mode, ev.lib_exchange, np.median(t) * 1e6), flush=True)
+        if ev.lib_exchange: eng.comm_destroy()
+        eng.set_winner_buffer(0)
     ev2 = ShardedEvaluator(eng, k=8); eng.upload(inp)
     t = []
-    for _ in range(200):
+    for _ in range(20): ev2.step_enqueued()
+    for _ in range(400):
         t0 = time.perf_counter(); ev2.step_enqueued(); t.append(time.perf_counter() - t0)
     print("plain step p50 %.1f us" % (np.median(t) * 1e6), flush=True)
 dist.destroy_process_group()
