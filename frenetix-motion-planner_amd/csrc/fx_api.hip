@@ -704,8 +704,11 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         if (p->M > c->max_knots) return set_err(FX_ERR_CAPACITY, "M=%d reference knots exceed capacity %d", p->M, c->max_knots);
         if (p->K > c->max_obs || (p->K > 0 && p->P > c->max_pred))
             return set_err(FX_ERR_CAPACITY, "obstacles K=%d P=%d exceed capacity %d x %d", p->K, p->P, c->max_obs, c->max_pred);
-        if (((size_t)p->M * FX_REF_FIELDS + FX_TP * (size_t)S) * sizeof(double) > 160 * 1024 - 1024)
-            return set_err(FX_ERR_CAPACITY, "reference with %d knots does not fit the 160 KiB LDS", p->M);
+        // only the generic kernel stages the whole knot records (64 B each) in LDS; the grid kernel keeps 8 B per knot and its
+        // LDS need was checked when it was chosen above
+        if (!c->use_grid && ((size_t)p->M * FX_REF_FIELDS + FX_TP * (size_t)S) * sizeof(double) > 160 * 1024 - 1024)
+            return set_err(FX_ERR_CAPACITY, "reference with %d knots does not fit the 160 KiB LDS of the generic kernel (sampling matrix / "
+                           "windowed costs); resample the reference or use sampling ranges", p->M);
         const int64_t ld = (int64_t)align_up((size_t)std::max<int64_t>(C, 1), 64);
         if (cand_off + ld > c->total_ld) return set_err(FX_ERR_CAPACITY, "candidates exceed context capacity %lld", (long long)c->max_cand);
         DevProblem &d = c->h_probs[a];

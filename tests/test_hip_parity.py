@@ -701,3 +701,17 @@ def test_update_state_rejects_what_needs_a_new_upload(eng):
     with_obs = synthetic.make_inputs(hull_builder=hip_hulls(), ref_kind="arc", v0=10.0, grid=(3, 5, 5), n_obstacles=2)
     with pytest.raises(ValueError):
         eng.update_state(eng.make_state_update(obstacles=with_obs.obstacles))  # uploaded without obstacles
+
+
+@pytest.mark.gpu
+def test_long_reference_runs_on_the_grid_kernel():
+    """4 000 reference knots: the grid kernel keeps 8 B per knot in LDS (only the generic kernel stages the 64-byte records)"""
+    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+    from oracle import oracle
+    inp = synthetic.make_inputs(ref_kind="arc", v0=9.0, grid=(5, 9, 11), n_obstacles=2, n_knots=4000, spacing=0.25, kappa=0.002,
+                                hull_builder=build_obstacle_hulls)
+    assert len(inp.coordinate_system.ref_pos) >= 3900
+    with FrenetEngine(max_candidates=4096, max_ref_knots=4096) as eng:
+        res = eng.plan_step(inp)
+    ref = oracle.plan_step(inp, want_planes=False)["result"]
+    assert res["best_index"] == ref["best_index"] and res["n_feasible"] == ref["n_feasible"]
