@@ -194,6 +194,11 @@ class FrenetEngine:
         """Selection fused into the evaluation kernel (default on; applies when no agent runs the collision stage)."""
         check(lib().fx_set_fused_selection(self._ctx, int(bool(enabled))))
 
+    def set_grid_sync(self, enabled: bool):
+        """Collision count behind a grid barrier inside the evaluation kernel instead of a selection launch (default on; applies
+        when the whole launch is resident at once)."""
+        check(lib().fx_set_grid_sync(self._ctx, 2 if enabled == "force" else int(bool(enabled))))
+
     TIMING = {"off": 0, "stream": 1, "kernel": 2}
 
     def set_timing(self, mode, every: int = 1):
