@@ -23,8 +23,7 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
                                      FuseArgs fuse, hipStream_t stream);
 extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, int block_size,
                                           size_t lds_bytes, int G, bool bundle, bool obst, int wpe, bool wsplit,
-                                          hipEvent_t ev_start, hipEvent_t ev_stop, FuseArgs fuse, hipStream_t stream,
-                                          long long *sync_capacity, bool query_only);
+                                          hipEvent_t ev_start, hipEvent_t ev_stop, FuseArgs fuse, hipStream_t stream);
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
                                        unsigned long long seq, double *dev_winner, double *host_pkg, int pkg_stride, int pkg_plane_rows,
                                        hipStream_t stream);
@@ -173,10 +172,6 @@ struct FxContext {
     int timing = FX_TIMING_OFF;
     bool timed_step = false, eval_launched = false;
     bool fuse_enabled = true, fusable_step = false, fused_step = false;
-    // grid-synchronised selection (collision stage without a selection launch): needs every workgroup of the launch resident
-    bool sync_enabled = true, sync_step = false, sync_forced = false;   // forced: skip the residency check (test hook)
-    long long sync_capacity = 0;           // workgroups of the step's kernel variant the device holds at once (0: unknown)
-    int min_blocks_step = 0;
     int64_t dev_bytes = 0;
 };
 
@@ -825,7 +820,6 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         if ((d.mode & FX_MODE_COLLISION) || d.n_blocks == 0) c->fusable_step = false;
         c->any_extra |= extra;
         c->max_blocks_step = std::max(c->max_blocks_step, d.n_blocks);
-        c->min_blocks_step = a == 0 ? d.n_blocks : std::min(c->min_blocks_step, d.n_blocks);
         c->M_max_step = std::max(c->M_max_step, p->M);
         c->K_max_step = std::max(c->K_max_step, std::max(p->K, 0));
         c->S_max_step = std::max(c->S_max_step, S);
@@ -852,13 +846,6 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     c->dirty_lo = (size_t)-1; c->dirty_hi = 0; c->probs_dirty = false;
     HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, ar.off, hipMemcpyHostToDevice, c->stream));  // problems + inputs
     if (br.off) HIP_TRY(hipMemcpyAsync(c->d_bound, c->h_bound, br.off, hipMemcpyHostToDevice, c->stream));
-    // how many workgroups of this step's kernel variant fit the device at once (decides on the grid-synchronised selection)
-    c->sync_capacity = 0;
-    if (c->use_grid && !c->fusable_step && c->max_blocks_step > 0 && c->min_blocks_step > 0) {
-        FuseArgs none{nullptr, 0, nullptr, c->K_max_step, 0};
-        HIP_TRY(fx_launch_eval_grid(c->d_probs, n_agents, c->max_blocks_step, c->block_step, c->lds_step, c->G_step, c->any_bundle,
-                                    c->any_obst, c->wpe_step, c->wsplit_step, nullptr, nullptr, none, c->stream, &c->sync_capacity, true));
-    }
     c->uploaded = true;
     c->in_flight = true;
     return FX_OK;
@@ -906,24 +893,19 @@ int32_t fx_evaluate(FxContext *c) {
     c->fused_step = c->fuse_enabled && c->fusable_step && c->eval_launched;
     c->pkg_step = c->package_enabled && c->any_bundle;
     double *winner = c->dev_winner ? c->dev_winner : (c->pkg_step ? c->d_winner_own : nullptr);
-    // collision stage: when every workgroup of the launch is resident at once (3/4 of the occupancy bound as margin) the count
-    // of colliders ordered before the winner is taken behind a grid barrier inside the evaluation kernel -- no selection launch
-    c->sync_step = c->sync_enabled && !c->fused_step && c->eval_launched && c->use_grid && c->sync_capacity > 0 &&
-                   (c->sync_forced || (long long)c->max_blocks_step * c->n_agents * 4 <= c->sync_capacity * 3);
-    const bool publishes = c->fused_step || c->sync_step;
-    FuseArgs fuse{publishes ? c->h_counters_dev : nullptr, c->seq, winner, c->K_max_step, c->sync_step ? 1 : 0};
+    FuseArgs fuse{c->fused_step ? c->h_counters_dev : nullptr, c->seq, winner, c->K_max_step};
     if (c->eval_launched)
     {
         if (c->use_grid)
             HIP_TRY(fx_launch_eval_grid(c->d_probs, c->n_agents, c->max_blocks_step, c->block_step, c->lds_step, c->G_step,
-                                        c->any_bundle, c->any_obst, c->wpe_step, c->wsplit_step, k0, k1, fuse, c->stream, nullptr, false));
+                                        c->any_bundle, c->any_obst, c->wpe_step, c->wsplit_step, k0, k1, fuse, c->stream));
         else
             HIP_TRY(fx_launch_eval(c->d_probs, c->n_agents, c->max_blocks_step,
                                    sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + FX_TP * (size_t)c->S_max_step),
                                    c->G_step, c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, k0, k1, fuse, c->stream));
     }
     if (timed && !attached) HIP_TRY(hipEventRecord(ts->e_eval, c->stream));
-    if (!publishes) {
+    if (!c->fused_step) {
         // with a package the selection's publishing workgroup gathers the winner's arrays itself (no further launch)
         HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, winner, c->pkg_step ? c->h_pkg_dev : nullptr,
                                  c->pkg_stride, c->pkg_plane_rows, c->stream));
@@ -932,8 +914,8 @@ int32_t fx_evaluate(FxContext *c) {
         // kernel behind the evaluation; fx_finish waits for its sequence word
         HIP_TRY(fx_launch_package(c->d_probs, c->n_agents, winner, c->h_pkg_dev, c->pkg_stride, c->pkg_plane_rows, c->seq, c->stream));
     }
-    if (timed && (!publishes || c->pkg_step)) HIP_TRY(hipEventRecord(ts->e_end, c->stream));
-    if (timed) { ts->fused = publishes && !c->pkg_step; c->n_timed++; }
+    if (timed && (!c->fused_step || c->pkg_step)) HIP_TRY(hipEventRecord(ts->e_end, c->stream));
+    if (timed) { ts->fused = c->fused_step && !c->pkg_step; c->n_timed++; }
     c->timed_step = timed;
     c->evaluated = true;
     c->in_flight = true;
@@ -943,7 +925,6 @@ int32_t fx_evaluate(FxContext *c) {
 int32_t fx_finish_batch(FxContext *c, FxResult *res) {
     if (!c || !res) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_finish: NULL argument");
     if (!c->evaluated) return set_err(FX_ERR_NOT_READY, "fx_finish before fx_evaluate");
-poll_again:
     {   // poll the sequence words the selection kernel publishes; fall back to a stream sync (which also surfaces
         // a faulted kernel) if they do not arrive
         bool done = false;
@@ -980,16 +961,6 @@ poll_again:
         r.n_feasible = (int64_t)cn[FX_CNT_FEASIBLE];
         r.n_infeasible = r.n_returned - r.n_feasible;
         for (int k = 0; k < FX_NUM_REASONS; k++) r.reason_hist[k] = (int64_t)cn[FX_CNT_HIST0 + k];
-        if (cn[FX_CNT_BEST_IDX] == FX_SYNC_FAILED) {
-            // the grid barrier of the evaluation kernel gave up (its workgroups were not resident together -- another kernel
-            // held compute units): this context goes back to the selection launch for good and the step is evaluated again
-            if (!c->sync_step) return set_err(FX_ERR_HIP, "agent %d: inconsistent result block", a);
-            c->sync_enabled = c->sync_forced = false;
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            const int rc2 = fx_evaluate(c);
-            if (rc2) return rc2;
-            goto poll_again;
-        }
         r.best_index = cn[FX_CNT_BEST_IDX] == ~0ULL ? -1 : (int64_t)cn[FX_CNT_BEST_IDX];
         double bc;
         memcpy(&bc, &cn[FX_CNT_BEST_COST], sizeof(bc));
@@ -1667,11 +1638,14 @@ int32_t fx_set_timing_interval(FxContext *c, int32_t every) {
     c->timing_every = every;
     return FX_OK;
 }
-int32_t fx_set_grid_sync(FxContext *c, int32_t enabled) {
-    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
-    c->sync_enabled = enabled != 0;
-    c->sync_forced = enabled == 2;   // 2: also for launches that are NOT resident at once -- the barrier then gives up and the step
-                                     // falls back to the selection launch (exercises that path; tests only)
+// How the last evaluation was launched (tests and tools): out[0] grid kernel, [1] lanes per candidate, [2] waves per SIMD,
+// [3] workgroup size, [4] wave split, [5] fused selection, [6] workgroups per agent (max), [7] agents, [8] winner package,
+// [9] dynamic LDS bytes
+int32_t fx_step_info(const FxContext *c, int64_t *out10) {
+    if (!c || !out10) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_step_info: NULL argument");
+    const int64_t v[10] = {c->use_grid, c->G_step, c->wpe_step, c->block_step, c->wsplit_step, c->fused_step, c->max_blocks_step,
+                           c->n_agents, c->pkg_step, (int64_t)c->lds_step};
+    memcpy(out10, v, sizeof(v));
     return FX_OK;
 }
 

@@ -188,16 +188,7 @@ struct FuseArgs {
     unsigned long long seq;           // sequence word the host polls for
     double *dev_winner;               // optional device copy of (cost, index) per agent
     int32_t k_max;                    // largest obstacle count of the launch's agents (sizes the per-wave hot blocks)
-    int32_t grid_sync;                // 1: every workgroup of the launch is resident at once (the host checked) and the collision
-                                      // stage's count of colliders ordered before the winner is taken behind a grid-wide barrier
-                                      // inside this kernel -- no selection launch
 };
-// device-side counters[] slots that are free on the device (their published values are produced by the publishing workgroup)
-#define FX_DCNT_TICKET2 FX_CNT_BEST_COST
-// the grid barrier gives up after this many polls (a launch that is not co-resident after all must not hang the device); the
-// step then reports an error through the published block
-#define FX_SYNC_SPIN_LIMIT (1 << 22)
-#define FX_SYNC_FAILED (~0ULL - 1)
 
 // Pointers stored inside DevProblem are loaded from memory, so the compiler only knows them as generic ("flat")
 // pointers: every access would be a flat_load/flat_store and wave-uniform reads could not become scalar loads.

@@ -416,92 +416,18 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     if (lane == 0) { red_cost[wave] = bc; red_idx[wave] = bi; }
     FX_STAMP(9);
     __syncthreads();
-    // Only the first wave goes on (it owns the lanes that publish); the others are done -- unless the launch is grid-synchronised:
-    // then every candidate still has to be compared with the winner.
-    const bool grid_sync = fuse.grid_sync != 0;
-    if (wave != 0 && !grid_sync) return;
-    if (wave == 0)
+    // Only the first wave goes on (it owns the lanes that publish); the others are done.
+    if (wave != 0) return;
     for (int w = 1; w < (int)blockDim.x / 64; w++)
         if (red_cost[w] < bc || (red_cost[w] == bc && red_idx[w] < bi)) { bc = red_cost[w]; bi = red_idx[w]; }
-    if (wave == 0 && lane == 0) {
+    if (lane == 0) {
         // agent-scope stores: visible to whichever XCD runs the reducing workgroup without an L2 write-back
         __hip_atomic_store(as_global(P.part_cost) + blockIdx.x, bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(as_global(P.part_idx) + blockIdx.x, (int64_t)bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (wave == 0 && lane < 2 + FX_NUM_REASONS && red_cnt[lane]) atomicAdd(&P.counters[lane], (unsigned long long)red_cnt[lane]);
+    if (lane < 2 + FX_NUM_REASONS && red_cnt[lane]) atomicAdd(&P.counters[lane], (unsigned long long)red_cnt[lane]);
     FX_STAMP(10);
     if (fuse.host_result == nullptr) return;  // a selection kernel follows
-
-    if (grid_sync) {
-        // ---- grid-synchronised selection (collision stage; every workgroup of the launch is resident) ----
-        // 1. arrive, wait for every workgroup's partial; 2. every workgroup reduces the partials to the winner; 3. every
-        // candidate that collides and is ordered before the winner is counted (planner.py:336-357 `_collision_counter`);
-        // 4. second ticket, the last workgroup publishes.
-        bool failed = false;
-        if (wave == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial and counters are performed
-            if (lane == 0) {
-                atomicAdd(&P.counters[FX_DCNT_TICKET], 1ULL);
-                int spins = 0;
-                while (__hip_atomic_load(&P.counters[FX_DCNT_TICKET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)P.n_blocks) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > FX_SYNC_SPIN_LIMIT) { failed = true; break; }
-                }
-            }
-            failed = __shfl((int)failed, 0) != 0;
-            double wc = INFINITY;
-            long long wi = 0x7fffffffffffffffLL;
-            for (int b = lane; b < P.n_blocks; b += 64) {
-                const double c = __hip_atomic_load(as_global(P.part_cost) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const long long ix = __hip_atomic_load(as_global(P.part_idx) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (c < wc || (c == wc && ix < wi)) { wc = c; wi = ix; }
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double oc = __shfl_xor(wc, off);
-                const long long oi = __shfl_xor(wi, off);
-                if (oc < wc || (oc == wc && oi < wi)) { wc = oc; wi = oi; }
-            }
-            if (lane == 0) { red_cost[0] = wc; red_idx[0] = wi; red_cnt[2 + FX_NUM_REASONS] = 0; }
-        }
-        __syncthreads();
-        const double wc = red_cost[0];
-        const long long wi = red_idx[0];
-        const bool none = wi == 0x7fffffffffffffffLL;
-        const bool before = own && selectable && (flags & FX_FLAG_COLLISION) &&
-                            (none || total < wc || (total == wc && (long long)(g + P.g_base) < wi));
-        const unsigned int nb = wave_count(before);
-        if (lane == 0 && nb) atomicAdd(&red_cnt[2 + FX_NUM_REASONS], nb);
-        __syncthreads();
-        if (wave != 0) return;
-        if (lane == 0 && red_cnt[2 + FX_NUM_REASONS]) atomicAdd(&P.counters[FX_CNT_COLLISIONS], (unsigned long long)red_cnt[2 + FX_NUM_REASONS]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // second ticket; a workgroup whose barrier gave up marks the upper half, so the publisher knows about every failure
-        unsigned long long t2 = 0;
-        const unsigned long long inc = failed ? (1ULL << 32) + 1ULL : 1ULL;
-        if (lane == 0) t2 = atomicAdd(&P.counters[FX_DCNT_TICKET2], inc);
-        t2 = __shfl(t2, 0);
-        if ((t2 & 0xffffffffULL) != (unsigned long long)(P.n_blocks - 1)) return;
-        failed = ((t2 + inc) >> 32) != 0;
-        unsigned long long *out = fuse.host_result + (size_t)blockIdx.y * (FX_CNT_COUNT + 1);
-        unsigned long long cnt = 0ULL;
-        if (lane < FX_CNT_BEST_IDX) cnt = atomicExch(&P.counters[lane], 0ULL);
-        if (lane < FX_CNT_BEST_IDX) out[lane] = cnt;
-        if (lane == 0) {
-            if (fuse.dev_winner) {
-                fuse.dev_winner[2 * blockIdx.y] = none ? INFINITY : wc;
-                reinterpret_cast<long long *>(fuse.dev_winner)[2 * blockIdx.y + 1] = none ? -1 : wi;
-            }
-            out[FX_CNT_BEST_IDX] = failed ? FX_SYNC_FAILED : (none ? ~0ULL : (unsigned long long)wi);
-            out[FX_CNT_BEST_COST] = none ? 0ULL : (unsigned long long)__double_as_longlong(wc);
-            out[FX_CNT_COLLISIONS] = atomicExch(&P.counters[FX_CNT_COLLISIONS], 0ULL);
-            __hip_atomic_store(&P.counters[FX_DCNT_TICKET], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&P.counters[FX_DCNT_TICKET2], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&out[FX_CNT_COUNT], fuse.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
 
     // ---- fused selection: the last workgroup of this agent to arrive reduces and publishes ----
     // Partials and counters above are agent-scope atomics issued by THIS wave; once they are acknowledged

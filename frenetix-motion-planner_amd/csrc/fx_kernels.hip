@@ -363,30 +363,17 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
 }
 
 // Grid (t x v x d) specialisation with the shared longitudinal table; lds_bytes includes the rows.
-// `sync_capacity` (may be NULL): workgroups of this launch's kernel the device holds at once (occupancy of the chosen
-// instantiation x compute units) -- what the host needs to decide on a grid-synchronised selection; with query_only nothing is
-// launched.
 extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, int block_size,
                                           size_t lds_bytes, int G, bool bundle, bool obst, int wpe, bool wsplit,
-                                          hipEvent_t ev_start, hipEvent_t ev_stop, FuseArgs fuse, hipStream_t stream,
-                                          long long *sync_capacity, bool query_only) {
+                                          hipEvent_t ev_start, hipEvent_t ev_stop, FuseArgs fuse, hipStream_t stream) {
     dim3 grid(max_blocks, n_agents), block(block_size);
 #define FX_LAUNCH(Gv, B, O, W, WS)                                                                                 \
     do {                                                                                                          \
-        const void *fn_ = reinterpret_cast<const void *>(&fx_eval_grid_kernel<Gv, B, O, W, WS>);                  \
         if (lds_bytes > 48 * 1024) {                                                                              \
-            hipError_t e_ = hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fx_eval_grid_kernel<Gv, B, O, W, WS>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);      \
             if (e_ != hipSuccess) return e_;                                                                      \
         }                                                                                                         \
-        if (sync_capacity) {                                                                                      \
-            int per_cu_ = 0, dev_ = 0, cus_ = 0;                                                                  \
-            hipError_t e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_, fx_eval_grid_kernel<Gv, B, O, W, WS>, block_size, lds_bytes); \
-            if (e_ == hipSuccess) e_ = hipGetDevice(&dev_);                                                       \
-            if (e_ == hipSuccess) e_ = hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_); \
-            if (e_ != hipSuccess) return e_;                                                                      \
-            *sync_capacity = (long long)per_cu_ * cus_;                                                           \
-        }                                                                                                         \
-        if (query_only) return hipSuccess;                                                                        \
         hipExtLaunchKernelGGL((fx_eval_grid_kernel<Gv, B, O, W, WS>), grid, block, lds_bytes, stream, ev_start, ev_stop, 0, d_probs, fuse); \
         return hipGetLastError();                                                                                 \
     } while (0)

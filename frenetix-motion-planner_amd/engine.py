@@ -194,10 +194,13 @@ class FrenetEngine:
         """Selection fused into the evaluation kernel (default on; applies when no agent runs the collision stage)."""
         check(lib().fx_set_fused_selection(self._ctx, int(bool(enabled))))
 
-    def set_grid_sync(self, enabled: bool):
-        """Collision count behind a grid barrier inside the evaluation kernel instead of a selection launch (default on; applies
-        when the whole launch is resident at once)."""
-        check(lib().fx_set_grid_sync(self._ctx, 2 if enabled == "force" else int(bool(enabled))))
+    def step_info(self) -> dict:
+        """how the last evaluation was launched (fx_step_info)"""
+        v = np.zeros(10, np.int64)
+        check(lib().fx_step_info(self._ctx, v.ctypes.data))
+        keys = ("grid_kernel", "lanes_per_candidate", "waves_per_simd", "block", "wave_split", "fused_selection", "blocks", "agents",
+                "package", "lds_bytes")
+        return dict(zip(keys, (int(x) for x in v)))
 
     TIMING = {"off": 0, "stream": 1, "kernel": 2}
 

@@ -378,10 +378,9 @@ double fx_last_eval_kernel_ms(const FxContext *ctx);
  * evaluation kernel's last workgroup reduces the partial arg-mins and publishes the result, so a plan step is a
  * single launch; off = always run the separate selection kernel (same results; used by the parity tests) */
 int32_t fx_set_fused_selection(FxContext *ctx, int32_t enabled);
-/* Collision stage without a selection launch (default on): when every workgroup of the step's launch is resident at once the
- * colliders ordered before the winner (planner.py:336-357 `_collision_counter`) are counted behind a grid-wide barrier inside
- * the evaluation kernel; larger launches keep the selection kernel.  Results are unaffected. */
-int32_t fx_set_grid_sync(FxContext *ctx, int32_t enabled);
+/* how the last evaluation was launched: grid kernel, lanes per candidate, waves per SIMD, workgroup size, wave split, fused
+ * selection, workgroups per agent, agents, winner package, dynamic LDS bytes */
+int32_t fx_step_info(const FxContext *ctx, int64_t *out10);
 /* per-step HIP-event timing (default FX_TIMING_OFF: fx_finish only polls the result block the kernel publishes
  * into pinned host memory).  FX_TIMING_STREAM -- stream events around the kernels (the evaluation figure includes
  * the dispatch gap in front of the kernel); FX_TIMING_KERNEL -- start/stop events attached to the evaluation

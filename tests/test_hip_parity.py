@@ -715,59 +715,3 @@ def test_long_reference_runs_on_the_grid_kernel():
         res = eng.plan_step(inp)
     ref = oracle.plan_step(inp, want_planes=False)["result"]
     assert res["best_index"] == ref["best_index"] and res["n_feasible"] == ref["n_feasible"]
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("kw", [dict(grid=(9, 21, 21), n_obstacles=8, lead_gap=15.0), dict(grid=(5, 9, 11), n_obstacles=3),
-                                dict(grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0), dict(grid=(3, 5, 7), n_obstacles=2, v0=1.0),
-                                dict(grid=(9, 21, 21), n_obstacles=8, lead_gap=15.0, write_bundle=False, write_costmap=False)])
-def test_grid_synchronised_selection_equals_selection_kernel(kw):
-    """The collision count behind the grid barrier of the evaluation kernel (fx_set_grid_sync, default on) against the
-    selection launch: same winner, counters, collisions; repeated steps leave the device counters clean"""
-    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
-    inp = synthetic.make_inputs(ref_kind="arc", v0=kw.pop("v0", 10.0), hull_builder=build_obstacle_hulls, **kw)
-    keys = ("best_index", "best_cost", "n_collisions", "n_feasible", "n_returned", "reason_hist")
-    with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
-        eng.set_grid_sync(False)
-        ref = eng.plan_step(inp)
-        eng.set_grid_sync(True)
-        for _ in range(3):
-            res = eng.plan_step(inp)
-            assert {k: res[k] for k in keys} == {k: ref[k] for k in keys}
-        tc, ti = eng.topk(4)
-        assert ti[0][0] == ref["best_index"] or ref["best_index"] < 0
-
-
-@pytest.mark.gpu
-def test_grid_synchronised_selection_in_a_batch():
-    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
-    agents = [synthetic.make_inputs(hull_builder=build_obstacle_hulls, ref_kind="arc", v0=6.0 + 2 * a, grid=(3 + a, 5, 7), n_obstacles=a % 3,
-                                    seed=a, lead_gap=12.0 if a == 2 else 0.0) for a in range(5)]
-    with FrenetEngine(max_candidates=8192, max_agents=5) as eng:
-        eng.set_grid_sync(False)
-        ref = eng.plan_batch(agents)
-        eng.set_grid_sync(True)
-        for _ in range(2):
-            res = eng.plan_batch(agents)
-            for a in range(5):
-                for k in ("best_index", "best_cost", "n_collisions", "n_feasible", "n_returned"):
-                    assert res[a][k] == ref[a][k], (a, k)
-
-
-@pytest.mark.gpu
-@pytest.mark.timeout(300)
-def test_grid_barrier_gives_up_and_the_step_falls_back():
-    """A launch far larger than the device holds at once, forced onto the grid barrier: the barrier times out instead of
-    hanging, the step is evaluated again through the selection launch and the context stays on that path"""
-    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
-    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(19, 160, 160), n_obstacles=4, lead_gap=20.0, write_bundle=False,
-                                write_costmap=False, hull_builder=build_obstacle_hulls)
-    with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
-        eng.set_grid_sync(False)
-        ref = eng.plan_step(inp)
-        eng.set_grid_sync("force")
-        res = eng.plan_step(inp)
-        for k in ("best_index", "best_cost", "n_collisions", "n_feasible"):
-            assert res[k] == ref[k]
-        res2 = eng.plan_step(inp)     # stays on the selection launch
-        assert res2["best_index"] == ref["best_index"] and res2["n_collisions"] == ref["n_collisions"]

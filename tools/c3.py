@@ -22,16 +22,14 @@ out = {}
 for name in which:
     inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, ref_kind="arc", v0=10.0, **W[name])
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
-        eng.set_timing("kernel")
-        if os.environ.get("FX_GRID_SYNC") == "0": eng.set_grid_sync(False)
-        eng.upload(inp)
+        eng.set_timing("kernel"); eng.upload(inp)
         import time
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.4:   # warm clocks: short runs after idle are timed at a lower clock
             eng.evaluate(); eng.finish()
-        ts, tw = [], []
+        ts = []
         for _ in range(60 if inp.n_candidates < 200000 else 20):
-            t0 = time.perf_counter(); eng.evaluate(); r = eng.finish()[0]; tw.append(time.perf_counter() - t0); ts.append(eng.last_eval_kernel_ms)
+            eng.evaluate(); r = eng.finish()[0]; ts.append(eng.last_eval_kernel_ms)
     out[name] = round(float(np.median(ts)) * 1e3, 1)
-    print(name, out[name], "us  step (wall, timed launches) %.1f us  winner" % (np.median(tw) * 1e6), r["best_index"], "coll", r["n_collisions"], flush=True)
+    print(name, out[name], "us  winner", r["best_index"], "coll", r["n_collisions"], flush=True)
 print(json.dumps(out))
