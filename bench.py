@@ -689,7 +689,7 @@ def bench_multiagent(args, world, rank, local_rank, torch, dist):
                        "agents": n_agents, "candidates_per_agent": per_agent, "plan_steps_timed": plan_steps,
                        "parallelism": f"agent round-robin x{world}, one all-gather of the plans per step" if world > 1 else "single GPU"},
             "sim_step_p50_ms": float(np.percentile(lat, 50) * 1e3), "sim_step_p95_ms": float(np.percentile(lat, 95) * 1e3),
-            "batched_plan_launch_ms": float(np.mean(counts["batch_ms"])) if plan_steps else None,
+            "batched_plan_launch_ms": float(np.median(counts["batch_ms"])) if plan_steps else None,
             "escalations": sim.batch.escalations,
         }
         print(json.dumps(out))

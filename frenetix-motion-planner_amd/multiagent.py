@@ -183,34 +183,46 @@ class MultiAgentSimulation:
         # planned trajectories of ALL agents, identical on every rank after the exchange: [agents][S][FIELDS]
         self.plans = np.zeros((len(self.agent_ids), self.S, self.FIELDS))
         self.history: Dict[int, list] = {i: [] for i in self.agent_ids}
+        self._shared = None
 
     def _cfg(self) -> PlannerConfig:
         import copy
         return copy.deepcopy(self.config)
 
     # -- predictions of one agent: everything but itself ---------------------------------------------------------
-    def predictions_for(self, agent_id: int) -> dict:
+    def _shared_predictions(self):
+        """What every agent's predictions have in common at this time step, built ONCE per simulation step: the recorded
+        futures of the non-agent obstacles and one entry per agent (its plan, or its recorded future before the first plan)."""
         t = self.time_step
+        if self._shared is not None and self._shared[0] == t:
+            return self._shared[1], self._shared[2]
         horizon = self.S - 1
         others = [o for o in self.scenario.obstacles if o not in self.problems]
-        preds = self.scenario.ground_truth_predictions(t, horizon, obstacle_ids=others)
-        preds = {k: v for k, v in preds.items() if len(v["pos_list"])}
+        base = {k: v for k, v in self.scenario.ground_truth_predictions(t, horizon, obstacle_ids=others).items() if len(v["pos_list"])}
+        own = {}
+        cov = np.eye(2) * 0.1
         for k, aid in enumerate(self.agent_ids):
-            if aid == agent_id:
-                continue
             rows = self.plans[k]
             valid = rows[:, 4] > 0
             if valid.any():
                 r = rows[valid]
                 th = r[:, 2]
                 pos = r[:, :2] + self.vehicle.wb_rear_axle * np.stack([np.cos(th), np.sin(th)], axis=1)
-                m = len(r)
-                preds[aid] = dict(pos_list=pos, cov_list=np.tile(np.eye(2) * 0.1, (m, 1, 1)), orientation_list=th.copy(),
-                                  v_list=r[:, 3].copy(), shape=dict(self.shapes[aid]))
+                own[aid] = dict(pos_list=pos, cov_list=np.tile(cov, (len(r), 1, 1)), orientation_list=th.copy(),
+                                v_list=r[:, 3].copy(), shape=dict(self.shapes[aid]))
             elif aid in self.scenario.obstacles:  # no plan yet: the recorded future (first step)
                 gt = self.scenario.ground_truth_predictions(t, horizon, obstacle_ids=[aid])[aid]
                 if len(gt["pos_list"]):
-                    preds[aid] = gt
+                    own[aid] = gt
+        self._shared = (t, base, own)
+        return base, own
+
+    def predictions_for(self, agent_id: int) -> dict:
+        base, own = self._shared_predictions()
+        preds = dict(base)
+        for aid in self.agent_ids:   # agent order, as before
+            if aid != agent_id and aid in own:
+                preds[aid] = own[aid]
         return preds
 
     def _exchange(self, local_rows: np.ndarray) -> np.ndarray:

@@ -41,6 +41,11 @@ class ReactivePlannerState:
     yaw_rate: float = 0.0
     steering_angle: float = 0.0
 
+    def __deepcopy__(self, memo=None) -> "ReactivePlannerState":
+        # the only mutable member is the position array (copy.deepcopy's generic walk costs 100 us per state)
+        return ReactivePlannerState(self.time_step, np.array(self.position, dtype=np.float64), self.orientation, self.velocity,
+                                    self.acceleration, self.yaw_rate, self.steering_angle)
+
     def shift_positions_to_center(self, wb_rear_axle: float) -> "ReactivePlannerState":
         o = self.orientation
         return ReactivePlannerState(self.time_step, np.asarray(self.position) + wb_rear_axle * np.array([np.cos(o), np.sin(o)]),

@@ -129,3 +129,33 @@ def test_planner_pair_from_package_equals_the_long_way():
             p.update_externals(x_0=x1, x_cl=(pair[2][1], pair[3][1]), predictions=preds)
     finally:
         p.close()
+
+
+def test_plan_batch_in_place_update_equals_fresh_upload():
+    """plan_batch rewrites the resident agents in place when their structures are unchanged (fx_update_state per agent)"""
+    from frenetix_motion_planner_amd.engine import build_obstacle_hulls
+
+    def agents(shift):
+        out = []
+        for a in range(4):
+            inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, ref_kind="arc", v0=6.0 + 2 * a + shift, grid=(3, 5, 7),
+                                        n_obstacles=1 + a % 3, seed=a + 10 * int(shift > 0), d0=0.1 * a + 0.05 * shift)
+            out.append(inp)
+        return out
+
+    first, second = agents(0.0), agents(0.7)
+    for a in range(4):     # same reference objects -> same structure
+        second[a].coordinate_system, second[a]._ref = first[a].coordinate_system, first[a]._ref
+    with _engine(max_candidates=4096, max_agents=4) as eng:
+        eng.plan_batch(first)
+        assert eng._resident_keys is not None
+        res = eng.plan_batch(second)           # in place
+        assert [i.structure_key() for i in second] == eng._resident_keys
+        cands = [eng.candidate(r["best_index"], a) if r["best_index"] >= 0 else None for a, r in enumerate(res)]
+    with _engine(max_candidates=4096, max_agents=4) as eng2:
+        eng2.upload(second); eng2.evaluate(); ref = eng2.finish()
+        for a in range(4):
+            for k in ("best_index", "best_cost", "n_feasible", "n_returned", "n_collisions", "reason_hist"):
+                assert res[a][k] == ref[a][k], (a, k)
+            if cands[a] is not None:
+                assert np.array_equal(cands[a]["planes"], eng2.candidate(ref[a]["best_index"], a)["planes"])
