@@ -102,10 +102,24 @@ __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double bc = INFINITY;
     long long bi = 0x7fffffffffffffffLL;
-    for (int b = tid; b < P.n_blocks; b += 256) {
-        const double c = __hip_atomic_load(as_global(P.part_cost) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long ix = __hip_atomic_load(as_global(P.part_idx) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c < bc || (c == bc && ix < bi)) { bc = c; bi = ix; }
+    {
+        // the partials were written by the evaluation kernel, which is complete: plain loads, four per thread in flight
+        // (device-coherent atomic loads, as the in-kernel selection needs them, serialise at ~1 us each)
+        const FX_GLOBAL double *__restrict__ pc = as_global(P.part_cost);
+        const FX_GLOBAL int64_t *__restrict__ pi = as_global(P.part_idx);
+        for (int b0 = tid; b0 < P.n_blocks; b0 += 4 * 256) {
+            double c[4];
+            long long ix[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int b = b0 + u * 256;
+                c[u] = b < P.n_blocks ? pc[b] : INFINITY;
+                ix[u] = b < P.n_blocks ? (long long)pi[b] : 0x7fffffffffffffffLL;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (c[u] < bc || (c[u] == bc && ix[u] < bi)) { bc = c[u]; bi = ix[u]; }
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
