@@ -102,13 +102,27 @@ class WinnerPackage:
 
     def __init__(self, pkg: _abi.FxPackage, block: np.ndarray, inputs: PlanInputs):
         self.block = block
-        self.index = int(pkg.index)
-        self.cost = float(pkg.cost)
-        self.flags = int(pkg.flags)
-        self.traj_len = int(pkg.traj_len)
-        self.lon = np.array(pkg.coeff_lon)
-        self.lat = np.array(pkg.coeff_lat)
-        self.raw_costs = np.array(pkg.raw_costs[:pkg.n_cost]) if inputs.write_costmap else None
+        self.index = pkg.index
+        self.cost = pkg.cost
+        self.flags = pkg.flags
+        self.traj_len = pkg.traj_len
+        self._pkg = pkg
+        self._costmap = bool(inputs.write_costmap)
+
+    @property
+    def lon(self) -> np.ndarray:
+        return np.array(self._pkg.coeff_lon)
+
+    @property
+    def lat(self) -> np.ndarray:
+        return np.array(self._pkg.coeff_lat)
+
+    @property
+    def raw_costs(self):
+        return np.array(self._pkg.raw_costs[:self._pkg.n_cost]) if self._costmap else None
+
+    def raw_cost_list(self):
+        return list(self._pkg.raw_costs[:self._pkg.n_cost]) if self._costmap else None
 
     @property
     def planes(self) -> np.ndarray:
@@ -263,6 +277,21 @@ class FrenetEngine:
         u._keep = keep
         return u
 
+    @staticmethod
+    def _state_update_of(inp: PlanInputs):
+        """FxStateUpdate straight from a PlanInputs (its arrays are contiguous float64 / int32 already: no conversions)"""
+        u = _abi.FxStateUpdate()
+        u.x0_lon, u.x0_lat = inp.x0_lon.ctypes.data, inp.x0_lat.ctypes.data
+        u.x0_orientation, u.v_des, u.low_vel_mode = float(inp.x0_orientation), float(inp.v_des), int(bool(inp.low_vel_mode))
+        u.t_samp, u.v_samp, u.d_samp = inp.t_samp.ctypes.data, inp.v_samp.ctypes.data, inp.d_samp.ctypes.data
+        o = inp.obstacles
+        if o["K"] > 0:
+            u.obs_pos, u.obs_cov_inv, u.obs_npred = o["pos"].ctypes.data, o["cov_inv"].ctypes.data, o["npred"].ctypes.data
+            if o["hull"].size:
+                u.obs_hull, u.obs_nhull = o["hull"].ctypes.data, o["nhull"].ctypes.data
+        u._keep = inp   # the arrays live as long as the inputs do
+        return u
+
     def update_state(self, update, agent: int = 0):
         """Rewrite the step-dependent inputs of one uploaded agent in place (fx_update_state): one small host-to-device
         copy in front of the next evaluation instead of a full upload."""
@@ -309,8 +338,7 @@ class FrenetEngine:
         key = inputs.structure_key()
         upd = None
         if inputs.sampling_matrix is None and self._resident_key == key and len(self._inputs) == 1:
-            upd = self.make_state_update(inputs.x0_lon, inputs.x0_lat, inputs.x0_orientation, inputs.v_des, inputs.low_vel_mode,
-                                         inputs.t_samp, inputs.v_samp, inputs.d_samp, inputs.obstacles)
+            upd = self._state_update_of(inputs)
             self._inputs = [inputs]
         else:
             self.upload(inputs)
@@ -372,8 +400,7 @@ class FrenetEngine:
         keys = [inp.structure_key() if inp.sampling_matrix is None else None for inp in inputs]
         if self._resident_keys is not None and keys == self._resident_keys and None not in keys:
             for a, inp in enumerate(inputs):
-                self.update_state(self.make_state_update(inp.x0_lon, inp.x0_lat, inp.x0_orientation, inp.v_des, inp.low_vel_mode,
-                                                         inp.t_samp, inp.v_samp, inp.d_samp, inp.obstacles), a)
+                self.update_state(self._state_update_of(inp), a)
             self._inputs = inputs
         else:
             self.upload(inputs)

@@ -85,9 +85,9 @@ class TrajectorySample:
             self._planes = pkg.planes
             self._coeffs = (pkg.lon, pkg.lat, pkg.traj_len)
             self._pkg = pkg
-            if pkg.raw_costs is not None:
+            raw = pkg.raw_cost_list()
+            if raw is not None:
                 names, w = step.inputs.cost_names, step.inputs.cost_weights
-                raw = pkg.raw_costs.tolist()
                 self._costmap = {n: (raw[k], float(w[n] * raw[k])) for k, n in enumerate(names)}
         elif step.have_arrays:
             flags = int(step.flags[index])

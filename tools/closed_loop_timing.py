@@ -35,5 +35,5 @@ for lvl in (2, 4):
         for _ in range(200):
             p.update_externals(x_0=x0, predictions=preds); p.plan()
         pr.disable()
-        pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+        pstats.Stats(pr).sort_stats("tottime").print_stats(45)
     p.close()
