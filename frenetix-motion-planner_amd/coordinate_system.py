@@ -19,6 +19,8 @@ import math
 
 import numpy as np
 
+_UIDS = __import__("itertools").count(1)
+
 
 def compute_pathlength_from_polyline(polyline: np.ndarray) -> np.ndarray:
     seg = np.diff(np.asarray(polyline, dtype=np.float64), axis=0)
@@ -108,6 +110,7 @@ class CoordinateSystem:
         self._ref_curv_dd = np.gradient(self._ref_curv_d, self._ref_pos)
         self._normals = vertex_normals(ref)
         self._c_args = None
+        self.uid = next(_UIDS)   # identity that is never reused (id() of a collected object can be)
 
     reference = property(lambda self: self._reference)
     ref_pos = property(lambda self: self._ref_pos)

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 #include <dlfcn.h>
@@ -1064,9 +1065,8 @@ struct Rccl {
 };
 Rccl *rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] {
         void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (h) {
@@ -1077,7 +1077,7 @@ Rccl *rccl() {
             r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
             r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
         }
-    }
+    });
     return &r;
 }
 #define RCCL_TRY(expr)                                                                                             \

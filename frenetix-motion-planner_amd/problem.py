@@ -85,6 +85,7 @@ def _dict_ptrs(d: dict, spec):
     return c
 
 
+_BOUND_UIDS = __import__("itertools").count(1)
 MAX_OBSTACLES = 64  # obstacles per agent (64-bit per-step masks of the obstacle stage)
 
 
@@ -307,10 +308,10 @@ class PlanInputs:
         state, the desired velocity, the sampling values and the obstacle predictions (same counts)."""
         o = self.obstacles
         return (self.N, self.dt, self.mode, bool(self.stop_point), (self.vehicle.length, self.vehicle.width, self.vehicle.wheelbase, self.vehicle.wb_rear_axle, self.vehicle.a_max,
-                 self.vehicle.v_switch, self.vehicle.delta_max), id(self.coordinate_system),
+                 self.vehicle.v_switch, self.vehicle.delta_max), getattr(self.coordinate_system, "uid", None) or id(self.coordinate_system),
                 None if self.sampling_matrix is not None else (len(self.t_samp), len(self.v_samp), len(self.d_samp)),
                 tuple(self.cost_names), self._cost_w.tobytes(), int(o["K"]), int(o["P"]), self._dto.tobytes(),
-                None if self._bound is None else id(self._bound), self.shard)
+                None if self._bound is None else self._bound.setdefault("uid", next(_BOUND_UIDS)), self.shard)
 
     def candidate_params(self, g: int):
         """(t0, t1, s0, ss0, sss0, ss1, sss1, d0, dd0, ddd0, d1, dd1, ddd1) of candidate g -- the
