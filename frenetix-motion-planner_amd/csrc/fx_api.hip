@@ -1309,7 +1309,6 @@ int32_t fx_pack_predictions(int32_t K, int32_t P, int32_t n_samples, const int32
     memset(pos_out, 0, sizeof(double) * 2 * (size_t)K * P);
     memset(cov_inv_out, 0, sizeof(double) * 4 * (size_t)K * P);
     memset(hull, 0, sizeof(double) * 6 * (size_t)K * (P - 1));
-    std::vector<double> yaw_k((size_t)P);
     for (int k = 0; k < K; k++) {
         npred[k] = n[k];
         nhull[k] = 0;

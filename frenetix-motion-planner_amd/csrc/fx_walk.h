@@ -468,14 +468,11 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
 
     // -- (s, d) -> (x, y): foot point + d * unit normal, 0 from the first step outside the domain on (:537-547) --
     double x_i = 0.0, y_i = 0.0;
-    bool xy_is_model = true;  // (x, y) = foot + d n inside the domain / (0, 0) outside: what the obstacle tables assume
     if (!(r.flags & LON_INDOMAIN)) {
         if (emit && A.fail_step == 0x7fffffff) A.fail_step = i;
     } else if (A.fail_step == 0x7fffffff) {
         x_i = fma(d_i, r.nhx, r.px);
         y_i = fma(d_i, r.nhy, r.py);
-    } else {
-        xy_is_model = false;
     }
 
     // -- SoA bundle (trajectories.py:56-334) --
