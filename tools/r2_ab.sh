@@ -1,8 +1,7 @@
 #!/bin/bash
-O=gpurun_out/r2ab; mkdir -p $O; rm -f $O/ab.txt
-for v in "$@"; do
-  if [ $v = cur ]; then unset FXPLAN_SO; else export FXPLAN_SO=$PWD/tools/probe_build/libfxplan_$v.so; fi
-  echo "== $v" >> $O/ab.txt
-  timeout 300 python3 tools/c3.py c3B c3A m1o >> $O/ab.txt 2>&1
-done
-cat $O/ab.txt
+# same-box A/B of the current build against tools/probe_build/libfxplan_prev.so
+cd $GRAFT_REPO_ROOT 2>/dev/null || true
+W="${@:-c3B c3A c2B c2A}"
+echo "--- new build"; timeout 300 python tools/c3.py $W 2>&1 | grep -v "^ " | tail -7
+echo "--- previous build"; FXPLAN_SO=$PWD/tools/probe_build/libfxplan_prev.so timeout 300 python tools/c3.py $W 2>&1 | grep -v "^ " | tail -7
+echo "--- new build again"; timeout 300 python tools/c3.py $W 2>&1 | grep -v "^ " | tail -7

@@ -23,12 +23,15 @@ for name in sys.argv[1:] or ["c3B"]:
         while time.perf_counter() - t0 < 0.4:
             eng.evaluate(); eng.finish()
         base = None
-        for G, wpe, blk, mp in [(0, 0, 0, 0)] + list(itertools.product((1, 2, 4, 8), (2, 3), (0, 128, 64), (1, 2))):
+        combos = [(0, 0, 0, 0)] + list(itertools.product((1, 2, 4, 8), (2, 3), (0, 128, 64), (1, 2)))
+        if inp.n_candidates > 300000:   # large grids: one lane per candidate, the occupancy target and the workgroup size
+            combos = [(0, 0, 0, 0)] + [(1, w, b, 0) for w in (2, 3, 4) for b in (0, 128)] + [(2, w, 0, 2) for w in (2, 3)]
+        for G, wpe, blk, mp in combos:
             try:
                 eng.set_tuning(G, wpe, 2 if G else 0, blk, mp)
                 eng.upload(inp)
                 ts = []
-                for _ in range(30):
+                for _ in range(30 if inp.n_candidates < 300000 else 8):
                     eng.evaluate(); r = eng.finish()[0]; ts.append(eng.last_eval_kernel_ms)
                 t = round(float(np.median(ts)) * 1e3, 1)
             except Exception as e:
