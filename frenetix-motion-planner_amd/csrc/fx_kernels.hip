@@ -159,19 +159,24 @@ __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__rest
         for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
         if (lane == 0 && cnt) atomicAdd(&scnt, cnt);
         __syncthreads();
-        if (tid == 0 && scnt) atomicAdd(&P.counters[FX_CNT_COLLISIONS], (unsigned long long)scnt);
     }
-    // the workgroup that draws the last ticket of this agent publishes
-    if (tid == 0) {
-        __threadfence();
-        s_ticket = atomicAdd(&P.counters[FX_DCNT_TICKET], 1ULL);
-    }
+    // The workgroup that draws the last ticket of this agent publishes.  ONE device-scope atomic per workgroup carries both
+    // the ticket (low byte) and the slice's count (upper bits): no second atomic, no fence between them -- the chain of
+    // device-coherent round trips is what this kernel's 8 us are made of.
+    static_assert(FX_SELECT_SLICES < 256, "the ticket lives in the low byte");
+    if (tid == 0) s_ticket = atomicAdd(&P.counters[FX_DCNT_TICKET], ((unsigned long long)scnt << 8) | 1ULL);
     __syncthreads();
-    if (s_ticket != (unsigned long long)(FX_SELECT_SLICES - 1)) return;
+    if ((s_ticket & 0xffULL) != (unsigned long long)(FX_SELECT_SLICES - 1)) return;
+    const unsigned long long collisions = (s_ticket >> 8) + scnt;
     // Publish the step's result straight into pinned host memory (the host polls the sequence word instead of
-    // paying for a D2H copy and a stream synchronisation) and leave the device counters zeroed for the next step.
+    // paying for a D2H copy and a stream synchronisation) and leave the device counters zeroed for the next step.  The
+    // counters were accumulated by the evaluation kernel, which is complete: plain loads and stores.
     unsigned long long *out = host_result + (size_t)blockIdx.y * (FX_CNT_COUNT + 1);
-    if (tid < FX_CNT_BEST_IDX) out[tid] = atomicExch(&P.counters[tid], 0ULL);
+    if (tid < FX_CNT_BEST_IDX) {
+        FX_GLOBAL unsigned long long *cn = as_global(P.counters);
+        out[tid] = cn[tid];
+        cn[tid] = 0ULL;
+    }
     if (tid == 0 && dev_winner) {  // (cost, index bits) of the winner, device-resident for the multi-GPU exchange
         dev_winner[2 * blockIdx.y] = none ? INFINITY : bc;
         reinterpret_cast<long long *>(dev_winner)[2 * blockIdx.y + 1] = none ? -1 : bi;
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__rest
     if (tid == 0) {
         out[FX_CNT_BEST_IDX] = none ? ~0ULL : (unsigned long long)bi;
         out[FX_CNT_BEST_COST] = none ? 0ULL : (unsigned long long)__double_as_longlong(bc);
-        out[FX_CNT_COLLISIONS] = atomicExch(&P.counters[FX_CNT_COLLISIONS], 0ULL);
+        out[FX_CNT_COLLISIONS] = collisions;
         __hip_atomic_store(&P.counters[FX_DCNT_TICKET], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // the winner package (fx_set_package): the evaluation kernel is complete, so the publishing workgroup gathers the chosen
