@@ -217,3 +217,30 @@ def test_library_cov_inverse_is_numpys_bit_for_bit():
         invert_cov2(np.array([[[1.0, 2.0], [2.0, 4.0]]]))
     with pytest.raises(np.linalg.LinAlgError):
         invert_cov2(np.zeros((1, 2, 2)))
+
+
+def test_library_prediction_packing_equals_the_python_path():
+    """fx_pack_predictions (padding, covariance inverses, hulls in one call) against the per-obstacle Python path with the
+    oracle's hull builder: ragged lengths, an obstacle without headings, one with two predictions, an empty one"""
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.engine import build_obstacle_hulls
+    from frenetix_motion_planner_amd.problem import pack_predictions
+    from oracle import oracle
+    cs = CoordinateSystem(synthetic.reference_polyline("arc", 400, 0.5, 0.01))
+    rng = np.random.default_rng(1)
+    preds = synthetic.synthetic_predictions(cs, 5, 30, 0.1, float(cs.ref_pos[40]), rng)
+    preds[99] = dict(pos_list=rng.normal(size=(50, 2)), cov_list=np.tile(np.eye(2) * 0.3, (50, 1, 1)))
+    preds[98] = dict(pos_list=rng.normal(size=(2, 2)), cov_list=np.tile(np.array([[0.5, 0.1], [0.1, 0.4]]), (2, 1, 1)),
+                     orientation_list=np.zeros(2), shape=dict(length=4, width=2))
+    preds[97] = dict(pos_list=np.zeros((0, 2)), cov_list=np.zeros((0, 2, 2)), orientation_list=np.zeros(0), shape=dict(length=4, width=2))
+    preds[96] = dict(pos_list=rng.normal(size=(9, 2)).tolist(), cov_list=[[[0.2, 0.05], [0.05, 0.3]]] * 9,
+                     orientation_list=list(np.linspace(0, 1, 9)), shape=dict(length=4.5, width=1.8))   # plain lists
+    for n_samples in (31, 8):
+        a = pack_predictions(preds, n_samples, build_obstacle_hulls)          # library: one call
+        b = pack_predictions(preds, n_samples, oracle.build_obstacle_hulls)   # Python loop + oracle hulls
+        assert a["K"] == b["K"] == 9 and a["P"] == b["P"]
+        for k in ("pos", "cov_inv", "npred", "hull", "nhull"):
+            assert np.array_equal(a[k], b[k]), (n_samples, k)
+            assert a[k].flags["C_CONTIGUOUS"]
+    with pytest.raises(np.linalg.LinAlgError):
+        pack_predictions({1: dict(pos_list=np.zeros((3, 2)), cov_list=np.zeros((3, 2, 2)))}, 31, build_obstacle_hulls)
