@@ -449,10 +449,19 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     if (lane < FX_CNT_BEST_IDX) cnt = atomicExch(&P.counters[lane], 0ULL);
     bc = INFINITY;
     bi = 0x7fffffffffffffffLL;
-    for (int b = lane; b < P.n_blocks; b += 64) {
-        const double c = __hip_atomic_load(as_global(P.part_cost) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long ix = __hip_atomic_load(as_global(P.part_idx) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c < bc || (c == bc && ix < bi)) { bc = c; bi = ix; }
+    // device-coherent loads cross the fabric (~1 us each): eight per lane in flight before the first comparison
+    for (int b0 = lane; b0 < P.n_blocks; b0 += 8 * 64) {
+        double c[8];
+        long long ix[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int b = min(b0 + u * 64, P.n_blocks - 1);   // a repeated entry does not change the minimum
+            c[u] = __hip_atomic_load(as_global(P.part_cost) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ix[u] = __hip_atomic_load(as_global(P.part_idx) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (c[u] < bc || (c[u] == bc && ix[u] < bi)) { bc = c[u]; bi = ix[u]; }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
