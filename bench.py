@@ -546,7 +546,8 @@ def _timed(args, world, dist, torch, step, est_step_s=1e-4):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    preheat(step, args.preheat, world, est_step_s)
+    if est_step_s:   # a closed-loop simulation is not preheated: every step advances its state
+        preheat(step, args.preheat, world, est_step_s)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -707,7 +708,7 @@ def bench_multiagent(args, world, rank, local_rank, torch, dist):
         if sim.batch.launches > before:
             counts["batch_ms"].append(sim.batch.last_batch_ms)
 
-    elapsed, lat = _timed(args, world, dist, torch, step, 5e-4)
+    elapsed, lat = _timed(args, world, dist, torch, step, None)
     if rank == 0:
         n_agents = len(sim.agent_ids)
         per_agent = sim.batch.agents[0].planner.last_step.n_candidates if sim.batch.agents[0].planner.last_step else 0
