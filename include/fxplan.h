@@ -239,8 +239,8 @@ int32_t fx_step(FxContext *ctx, FxResult *res);
 
 /* ---- per-step update of a planner that keeps its reference path, grid shape and cost function: the new ego state,
  *      desired velocity, sampling values and predictions of planner.py:172-217 (update_externals) / reactive_planner_cpp.py:
- *      56-86 (set_predictions) rewritten in place in the context's pinned staging block, ONE host-to-device copy of what
- *      changed in front of the next evaluation.  NULL pointers, NaN doubles and a negative low_vel_mode keep the uploaded
+ *      56-86 (set_predictions) rewritten in place in the context's pinned staging block; the range that
+ *      changed is staged in front of the next evaluation (a copy kernel reading the mapped block; the DMA engine above 1 MiB).  NULL pointers, NaN doubles and a negative low_vel_mode keep the uploaded
  *      value; array lengths (nT, nV, nD, K, P) are those of the upload.  fx_update_step = fx_update_state(agent 0) + fx_step. */
 typedef struct FxStateUpdate {
     const double *x0_lon, *x0_lat;             /* [3] each */
