@@ -76,7 +76,8 @@ struct FxAgentSlot {
     size_t off_t = (size_t)-1, off_v = (size_t)-1, off_d = (size_t)-1, off_ref = (size_t)-1;
     size_t off_pos = (size_t)-1, off_cov = (size_t)-1, off_npred = (size_t)-1, off_hull = (size_t)-1, off_nhull = (size_t)-1;
     size_t off_rec = (size_t)-1, off_pm = (size_t)-1, off_hm = (size_t)-1, off_hot = (size_t)-1;
-    size_t dyn_end = 0;   // end of this agent's step-dependent inputs that the kernels read
+    size_t dyn_end = 0;   // end of this agent's step-dependent inputs that the walk reads every step
+    size_t raw_end = 0;   // end of the raw predictions behind them
     int32_t nT = 0, nV = 0, nD = 0, K = 0, P = 0, M = 0;
     bool have_hull = false, want_collision = false;
 };
@@ -748,12 +749,10 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         unsigned long long *pm = nullptr, *hm = nullptr;
         const bool have_hull = p->K > 0 && p->obs_hull && p->obs_nhull;
         if (p->K > 0) {
-            sl.off_pos = ar.off; d.obs_pos = ar.put(p->obs_pos, (size_t)2 * p->K * p->P, &ok);
-            sl.off_cov = ar.off; d.obs_cov_inv = ar.put(p->obs_cov_inv, (size_t)4 * p->K * p->P, &ok);
-            sl.off_npred = ar.off; d.obs_npred = ar.put(p->obs_npred, p->K, &ok);
             sl.have_hull = have_hull;
             if (!have_hull) d.mode &= ~FX_MODE_COLLISION;
-            // step-major packed records + per-step obstacle masks + hot table (filled below, once the knots are staged)
+            // step-major packed records + per-step obstacle masks + hot table (filled below, once the knots are staged): what the
+            // walk reads every step comes first, so that a state update stages this range only
             const double *dev = nullptr, *dhot = nullptr;
             const unsigned long long *dpm = nullptr, *dhm = nullptr;
             sl.off_rec = ar.off; rec = ar.host_slot<double>((size_t)S * p->K * 12, &dev, &ok);
@@ -762,6 +761,11 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             sl.off_hot = ar.off; hot = ar.host_slot<double>((size_t)S * p->K * FX_HOT_STRIDE, &dhot, &ok);
             d.obs_rec = dev; d.obs_pmask = dpm; d.obs_hmask = dhm; d.obs_hot = dhot;
             sl.dyn_end = ar.off;
+            // the raw predictions: read on the device only by the generic kernel's windowed costs, kept for re-packing
+            sl.off_pos = ar.off; d.obs_pos = ar.put(p->obs_pos, (size_t)2 * p->K * p->P, &ok);
+            sl.off_cov = ar.off; d.obs_cov_inv = ar.put(p->obs_cov_inv, (size_t)4 * p->K * p->P, &ok);
+            sl.off_npred = ar.off; d.obs_npred = ar.put(p->obs_npred, p->K, &ok);
+            sl.raw_end = ar.off;
             if (have_hull) {  // kept in the staging block for re-packing; the kernels read the hulls from `rec`
                 sl.off_hull = ar.off; d.obs_hull = ar.put(p->obs_hull, (size_t)6 * p->K * (p->P - 1), &ok);
                 sl.off_nhull = ar.off; d.obs_nhull = ar.put(p->obs_nhull, p->K, &ok);
@@ -1036,7 +1040,8 @@ int32_t fx_update_state(FxContext *c, int32_t agent, const FxStateUpdate *u) {
                                                 reinterpret_cast<unsigned long long *>(c->h_in + sl.off_pm),
                                                 reinterpret_cast<unsigned long long *>(c->h_in + sl.off_hm),
                                                 reinterpret_cast<double *>(c->h_in + sl.off_hot));
-        touch(sl.off_pos, sl.dyn_end - sl.off_pos);
+        // the generic kernel also reads the raw predictions (windowed costs); the grid kernel only the packed tables
+        touch(sl.off_rec, (c->use_grid ? sl.dyn_end : sl.raw_end) - sl.off_rec);
     }
     c->probs_dirty = true;
     return FX_OK;
