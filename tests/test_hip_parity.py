@@ -40,7 +40,7 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
       * candidates whose decisions the reference takes by the last ulp (oracle margin < FRAGILE) against every outcome those
         decisions admit: the device result must equal ONE of them."""
     from oracle import oracle
-    from tests.admissible import FRAGILE_STATE_TOL, conditioning_many, matches_one_outcome
+    from tests.admissible import FRAGILE_STATE_TOL, KINEMATIC_PLANES, conditioning_many, kinematic_conditioning_many, matches_one_outcome
     robust = out["margin"] >= FRAGILE
     n_frag = int((~robust).sum())
     cost, flags = eng.costs(agent)
@@ -62,15 +62,17 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
     assert res["n_candidates"] == ref["n_candidates"]
     # per-candidate conditioning of the reference's own arithmetic (1 for ordinary candidates)
     cond = conditioning_many(out["planes"]) if out.get("planes") is not None else np.ones(len(flags))
+    # the same without the cap, for what divides by cos(theta_cl): v, a, kappa, kappa_dot and the costs built on them
+    cond_kin = kinematic_conditioning_many(out["planes"]) if out.get("planes") is not None else np.ones(len(flags))
     # costs
     c = out["costed"] & robust & ((flags & _abi.FX_FLAG_COSTED) != 0)
     cm = eng.costmap(agent) if inp.write_costmap and len(inp.cost_names) else None
     if c.any():
         rel = np.abs(cost[c] - out["cost"][c]) / np.maximum(np.abs(out["cost"][c]), 1e-12)
-        assert (rel < COST_RTOL + 4e-14 * cond[c]).all(), f"cost rel err {rel.max()}"
+        assert (rel < COST_RTOL + 4e-14 * cond_kin[c]).all(), f"cost rel err {rel.max()}"
         if cm is not None:
             relm = np.abs(cm[c] - out["costmap"][c]) / np.maximum(np.abs(out["costmap"][c]), 1e-9)
-            assert (relm < 1e-8 + 4e-14 * cond[c][:, None]).all(), f"costmap rel err {relm.max()}"
+            assert (relm < 1e-8 + 4e-14 * cond_kin[c][:, None]).all(), f"costmap rel err {relm.max()}"
     # winner: identical unless a fragile candidate or a sub-tolerance cost gap is involved
     if res["best_index"] != ref["best_index"]:
         a, b = res["best_index"], ref["best_index"]
@@ -87,10 +89,13 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
         stored = out["returned"] & robust & (out["costed"] | (inp.draw_traj_set))
         got = eng.bundle(agent)
         refp = out["planes"]
-        err = (np.abs(got - refp) / (1.0 + np.abs(refp).max(axis=2, keepdims=True))).max(axis=(1, 2))
+        err = (np.abs(got - refp) / (1.0 + np.abs(refp).max(axis=2, keepdims=True))).max(axis=2)   # [C, 14]
         err[~stored] = 0
-        tol = STATE_TOL + 2e-14 * cond
-        assert (err < tol).all(), f"plane err {err.max()} (tolerance {tol[err.argmax()]}) at candidate {err.argmax()}"
+        tol = np.repeat((STATE_TOL + 2e-14 * cond)[:, None], err.shape[1], axis=1)
+        tol[:, KINEMATIC_PLANES] = (STATE_TOL + 2e-14 * cond_kin)[:, None]
+        bad = err >= tol
+        assert not bad.any(), (f"plane err {err[bad].max()} at (candidate, plane) {np.argwhere(bad)[0]} "
+                               f"(tolerance {tol[bad][0]})")
         # coefficients / traj_len of a few candidates
         for g in np.linspace(0, inp.n_candidates - 1, 5).astype(int):
             lon, lat, tl = eng.coeffs(int(g), agent)
