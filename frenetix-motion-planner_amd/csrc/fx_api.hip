@@ -849,7 +849,14 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     c->n_agents = n_agents;
     c->in_used = ar.off;
     c->dirty_lo = (size_t)-1; c->dirty_hi = 0; c->probs_dirty = false;
-    HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, ar.off, hipMemcpyHostToDevice, c->stream));  // problems + inputs
+    // problems + inputs: small uploads through the staging kernel as well (the DMA engine's submission latency dominates below ~1 MiB)
+    {
+        const size_t up = (ar.off + 15) & ~(size_t)15;
+        if (c->stage_mode == 2 || (c->stage_mode == 0 && up <= FX_STAGE_KERNEL_MAX && up <= c->in_bytes))
+            HIP_TRY(fx_launch_stage(c->h_in_dev, c->d_in, up, c->stream));
+        else
+            HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, ar.off, hipMemcpyHostToDevice, c->stream));
+    }
     if (br.off) HIP_TRY(hipMemcpyAsync(c->d_bound, c->h_bound, br.off, hipMemcpyHostToDevice, c->stream));
     c->uploaded = true;
     c->in_flight = true;
