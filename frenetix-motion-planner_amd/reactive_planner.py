@@ -461,13 +461,18 @@ class ReactivePlannerHip:
             # the state objects are built when they are indexed
             b = pkg.block
             n, t0 = b.shape[1], self.x_0.time_step
-            x, y, th, v, a, kap = (b[r].tolist() for r in (0, 1, 2, 3, 4, 5))
-            yr, st, orl = (b[r].tolist() for r in (_abi.PKG_ROW_YAW_RATE, _abi.PKG_ROW_STEERING, _abi.PKG_ROW_ORIENTATION))
-            s_, d_ = b[7].tolist(), b[8].tolist()
-            cart_list = _LazyStates(n, lambda i: ReactivePlannerState(t0 + i, np.array((x[i], y[i])), orl[i], v[i], a[i], yr[i], st[i]))
-            cl_list = _LazyStates(n, lambda i: dict(time_step=t0 + i, position=np.array((s_[i], d_[i])), velocity=v[i],
-                                                    acceleration=a[i], orientation=th[i], yaw_rate=kap[i]))
-            return cart_list, cl_list, b[[7, 10, 11]].T.tolist(), b[[8, 12, 13]].T.tolist()
+            YR, ST, OR = _abi.PKG_ROW_YAW_RATE, _abi.PKG_ROW_STEERING, _abi.PKG_ROW_ORIENTATION
+
+            def cart(i):   # one column of the block -> one state (a closed-loop step reads one or two of them)
+                c = b[:, i].tolist()
+                return ReactivePlannerState(t0 + i, np.array((c[0], c[1])), c[OR], c[3], c[4], c[YR], c[ST])
+
+            def curv(i):
+                c = b[:, i].tolist()
+                return dict(time_step=t0 + i, position=np.array((c[7], c[8])), velocity=c[3], acceleration=c[4], orientation=c[2],
+                            yaw_rate=c[5])
+
+            return _LazyStates(n, cart), _LazyStates(n, curv), b[[7, 10, 11]].T.tolist(), b[[8, 12, 13]].T.tolist()
         c, k = trajectory.cartesian, trajectory.curvilinear
         n = len(c.x)
         theta = np.asarray(c.theta, dtype=np.float64)
