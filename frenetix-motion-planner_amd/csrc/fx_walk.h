@@ -678,8 +678,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
         const auto rec_i = obs_rec + (int64_t)iu * nK * 12;
         // -- prediction cost: ego step i pairs with prediction i-1 (collision_probability.py:283-292) --
         unsigned long long pm = emit ? obs_pmask[iu] : 0ULL;
-        if (USTEP) pm = __builtin_amdgcn_readfirstlane((unsigned)(pm & 0xffffffffu)) |
-                        ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(pm >> 32)) << 32);
+        if (USTEP) pm = uniform_u64(pm);   // (the builtin returns int: without the helper's casts bit 31 sign-extends into 32 ... 63)
         if (USTEP && !emit) pm = 0ULL;  // emit is wave-uniform whenever the step index is
         while (pm) {
             const int k = __builtin_ctzll(pm);
@@ -701,8 +700,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                 heading_trig(r, cosTheta, tanTheta, cu, su);
                 const double bx = fma(K.wb, cu, x_i), by = fma(K.wb, su, y_i);
                 unsigned long long hm = emit ? hm_now : 0ULL;
-                if (USTEP) hm = __builtin_amdgcn_readfirstlane((unsigned)(hm & 0xffffffffu)) |
-                                ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(hm >> 32)) << 32);
+                if (USTEP) hm = uniform_u64(hm);
                 if (hm) {
                     // OBB-sum hull of ego boxes (i-1, i) lives at time index i-1 and meets obstacle hull i-2
                     const Obb hull = obb_hull(C.bx_prev, C.by_prev, C.ux_prev, C.uy_prev, bx, by, cu, su, K.half_len, K.half_wid);

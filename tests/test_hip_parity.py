@@ -720,3 +720,22 @@ def test_long_reference_runs_on_the_grid_kernel():
         res = eng.plan_step(inp)
     ref = oracle.plan_step(inp, want_planes=False)["result"]
     assert res["best_index"] == ref["best_index"] and res["n_feasible"] == ref["n_feasible"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [31, 32, 33, 48, 64])
+@pytest.mark.parametrize("tuning", [(0, 0, 0, 0, 0), (1, 2, 1, 0, 0), (8, 2, 2, 128, 1), (2, 2, 2, 0, 1), (2, 2, 2, 0, 2)])
+def test_thirty_two_and_more_obstacles_on_every_kernel_variant(K, tuning):
+    """Obstacle 31 and beyond: the per-step masks are 64-bit words assembled from two 32-bit scalar reads -- a sign extension of
+    the low half made obstacles 32 ... 63 appear on the generic kernel and the lane-split variants (found by the crowded soak:
+    prediction cost inf).  Every kernel variant against the oracle, automatic decomposition included."""
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    from oracle import oracle
+    kw = dict(ref_kind="arc", v0=9.0, grid=(3, 5, 7), n_obstacles=K, seed=K)
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
+    with FrenetEngine(max_candidates=256, max_steps=inp.N, max_obstacles=64) as e:
+        e.set_tuning(*tuning)
+        res = e.plan_step(inp)
+        compare(e, inp, out, res)
+        assert res["n_collisions"] == out["result"]["n_collisions"]
