@@ -73,6 +73,26 @@ def planes_within(got, ref, base=1e-9):
     return bool((err <= tol).all())
 
 
+def signed_integral_slack(planes, dt, base=1e-9):
+    """Absolute tolerance, per candidate, of path_length = Simpson(v) dt -- the one cost that is a SIGNED sum of a kinematic plane.
+    Every other cost sums squares or magnitudes, so a relative tolerance on the sum follows from the one on the plane; a signed sum
+    cancels (LOW_VEL_MODE candidates whose v alternates between +-1e6 m/s integrate to a few metres), and what the plane tolerance
+    allows per sample, tol * (1 + max|v|), is allowed (S - 1) dt times in the integral: the plane's tolerance times the norm of
+    the linear functional, nothing more."""
+    planes = np.asarray(planes)
+    vmax = np.nan_to_num(np.abs(planes[:, 3, :]), nan=np.inf).max(axis=1)
+    return (planes.shape[2] - 1) * dt * (base + 2e-14 * kinematic_conditioning_many(planes)) * (1.0 + vmax)
+
+
+def path_length_weight(inp):
+    """weight of the path_length term in inp's cost function (0 if absent), and its column in the cost map (or None)"""
+    names = list(inp.cost_names)
+    if "path_length" not in names:
+        return 0.0, None
+    j = names.index("path_length")
+    return float(inp.cost_weights["path_length"]), j
+
+
 def cost_tolerance(ref_planes, base=1e-9):
     """relative cost tolerance: the costs are sums of (squares of) the kinematic planes"""
     return base + 4e-14 * float(kinematic_conditioning_many(ref_planes[None])[0])
@@ -86,13 +106,16 @@ def same_decisions(flags_a, flags_b):
     return (int(flags_a) & mask) == (int(flags_b) & mask)
 
 
-def matches_one_outcome(outcomes, flags, cost=None, planes=None, *, cost_rtol=1e-9, state_tol=1e-9, planes_stored=True):
-    """True iff (flags, cost, planes) equals one of the admissible outcomes: decisions exactly, cost and planes to tolerance"""
+def matches_one_outcome(outcomes, flags, cost=None, planes=None, *, cost_rtol=1e-9, state_tol=1e-9, planes_stored=True,
+                        path_length=(0.0, 0.0)):
+    """True iff (flags, cost, planes) equals one of the admissible outcomes: decisions exactly, cost and planes to tolerance.
+    path_length = (weight of that term, dt): adds signed_integral_slack to the cost tolerance"""
     for o in outcomes:
         if not same_decisions(o["flags"], flags):
             continue
         if cost is not None and (o["flags"] & _abi.FX_FLAG_COSTED):
-            if abs(cost - o["cost"]) > cost_tolerance(o["planes"], cost_rtol) * max(abs(o["cost"]), 1e-12):
+            slack = path_length[0] * float(signed_integral_slack(o["planes"][None], path_length[1], state_tol)[0]) if path_length[0] else 0.0
+            if abs(cost - o["cost"]) > cost_tolerance(o["planes"], cost_rtol) * max(abs(o["cost"]), 1e-12) + slack:
                 continue
         if planes is not None and planes_stored and (o["flags"] & _abi.FX_FLAG_RETURNED):
             if not planes_within(planes, o["planes"], state_tol):

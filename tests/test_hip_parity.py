@@ -40,7 +40,8 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
       * candidates whose decisions the reference takes by the last ulp (oracle margin < FRAGILE) against every outcome those
         decisions admit: the device result must equal ONE of them."""
     from oracle import oracle
-    from tests.admissible import FRAGILE_STATE_TOL, KINEMATIC_PLANES, conditioning_many, kinematic_conditioning_many, matches_one_outcome
+    from tests.admissible import (FRAGILE_STATE_TOL, KINEMATIC_PLANES, conditioning_many, kinematic_conditioning_many, matches_one_outcome,
+                                  path_length_weight, signed_integral_slack)
     robust = out["margin"] >= FRAGILE
     n_frag = int((~robust).sum())
     cost, flags = eng.costs(agent)
@@ -67,12 +68,19 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
     # costs
     c = out["costed"] & robust & ((flags & _abi.FX_FLAG_COSTED) != 0)
     cm = eng.costmap(agent) if inp.write_costmap and len(inp.cost_names) else None
+    # path_length is a signed sum of v: an absolute slack where it cancels (tests/admissible.py::signed_integral_slack)
+    w_pl, j_pl = path_length_weight(inp)
+    slack = signed_integral_slack(out["planes"], inp.dt, STATE_TOL) if w_pl and out.get("planes") is not None else np.zeros(len(flags))
     if c.any():
-        rel = np.abs(cost[c] - out["cost"][c]) / np.maximum(np.abs(out["cost"][c]), 1e-12)
-        assert (rel < COST_RTOL + 4e-14 * cond_kin[c]).all(), f"cost rel err {rel.max()}"
+        err = np.abs(cost[c] - out["cost"][c])
+        lim = (COST_RTOL + 4e-14 * cond_kin[c]) * np.maximum(np.abs(out["cost"][c]), 1e-12) + abs(w_pl) * slack[c]
+        assert (err < lim).all(), f"cost rel err {(err / np.maximum(np.abs(out['cost'][c]), 1e-12)).max()}"
         if cm is not None:
-            relm = np.abs(cm[c] - out["costmap"][c]) / np.maximum(np.abs(out["costmap"][c]), 1e-9)
-            assert (relm < 1e-8 + 4e-14 * cond_kin[c][:, None]).all(), f"costmap rel err {relm.max()}"
+            errm = np.abs(cm[c] - out["costmap"][c])
+            limm = (1e-8 + 4e-14 * cond_kin[c][:, None]) * np.maximum(np.abs(out["costmap"][c]), 1e-9)
+            if j_pl is not None:
+                limm[:, j_pl] += slack[c]
+            assert (errm < limm).all(), f"costmap rel err {(errm / np.maximum(np.abs(out['costmap'][c]), 1e-9)).max()}"
     # winner: identical unless a fragile candidate or a sub-tolerance cost gap is involved
     if res["best_index"] != ref["best_index"]:
         a, b = res["best_index"], ref["best_index"]
@@ -110,7 +118,7 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
         stored = bool(flags[g] & _abi.FX_FLAG_RETURNED) and (bool(flags[g] & _abi.FX_FLAG_COSTED) or inp.draw_traj_set)
         ok = matches_one_outcome(outs, flags[g], cost[g] if flags[g] & _abi.FX_FLAG_COSTED else None,
                                  got[g] if got is not None else None, cost_rtol=COST_RTOL, state_tol=FRAGILE_STATE_TOL,
-                                 planes_stored=stored)
+                                 planes_stored=stored, path_length=(abs(w_pl), inp.dt))
         assert ok, (f"fragile candidate {g} (sites {[oracle.SITES[k] for k in range(len(oracle.SITES)) if (out['frag_sites'][g] >> k) & 1]}): "
                     f"device flags {hex(int(flags[g]))} match none of {[hex(o['flags']) for o in outs]}")
 
@@ -739,3 +747,26 @@ def test_thirty_two_and_more_obstacles_on_every_kernel_variant(K, tuning):
         res = e.plan_step(inp)
         compare(e, inp, out, res)
         assert res["n_collisions"] == out["result"]["n_collisions"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [100211, 100666, 100833, 101349] + list(range(100000, 100012)))
+def test_random_cost_functions_vs_oracle(case):
+    """Random subsets of all ten cost terms with random weights over the random scenarios (the windowed terms run on the generic
+    kernel).  The first four are the ones a 1 500-case soak flagged: standstill starts in LOW_VEL_MODE whose v alternates between
+    +-1e6 m/s -- path_length, a signed sum, cancels to a few metres and agrees to what the v plane's tolerance allows
+    (tests/admissible.py::signed_integral_slack), not to 1e-9 of the sum."""
+    from frenetix_motion_planner_amd._abi import COST_NAMES
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    from oracle import oracle
+    rng = np.random.default_rng([20241008, case])
+    kw = _random_case(rng)
+    w = {n: float(rng.uniform(0.1, 5.0)) for n in COST_NAMES if rng.uniform() < 0.5}
+    kw["cost_weights"] = w or {"lateral_jerk": 1.0}
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
+    with FrenetEngine(max_candidates=max(inp.n_candidates, 64), max_steps=inp.N, max_pred_steps=max(64, inp.N + 2)) as e:
+        res = e.plan_step(inp)
+        compare(e, inp, out, res)
+        if np.all(out["margin"] >= FRAGILE):
+            assert res["best_index"] == out["result"]["best_index"] and res["n_collisions"] == out["result"]["n_collisions"]

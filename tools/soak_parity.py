@@ -20,6 +20,12 @@ for case in range(first, first + n):
         kw["n_obstacles"] = int(rng.integers(9, 49))
         if "grid" in kw:
             kw["grid"] = (min(kw["grid"][0], 4), kw["grid"][1], kw["grid"][2])
+    if os.environ.get("FX_SOAK_COSTS"):  # random cost functions over all ten terms (windowed costs -> generic kernel)
+        from frenetix_motion_planner_amd._abi import COST_NAMES
+        w = {n: float(rng.uniform(0.1, 5.0)) for n in COST_NAMES if rng.uniform() < 0.5}
+        kw["cost_weights"] = w or {"lateral_jerk": 1.0}
+    if os.environ.get("FX_SOAK_MATRIX") and "stop_point_s" not in kw:   # the adapter's C x 13 sampling matrix
+        kw["as_matrix"] = True
     try:
         inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
         out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
