@@ -403,7 +403,7 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     const int S = max_steps + 1;
     // every agent's leading dimension is rounded up to 64 candidates
     c->total_ld = (int64_t)align_up((size_t)max_candidates_total, 64) + 64 * (int64_t)max_agents;
-    c->max_blocks_total = c->total_ld / 8 + max_agents + 1;  // 64-lane workgroups at G = 8: 8 candidates each
+    c->max_blocks_total = c->total_ld / 2 + max_agents + 1;  // 64-lane workgroups at G = 32: 2 candidates each
     c->in_bytes = (size_t)max_agents * input_bytes_for(0, S, max_ref_knots, max_obstacles, c->max_pred, false) +
                   align_up(sizeof(double) * 13 * (size_t)max_candidates_total, 256) + 4096;
     c->probs_bytes = align_up(sizeof(DevProblem) * (size_t)max_agents, 256);
@@ -538,8 +538,8 @@ int32_t fx_set_block_size(FxContext *c, int32_t block_size) {
 int32_t fx_set_tuning(FxContext *c, int32_t lanes_per_candidate, int32_t waves_per_simd, int32_t kernel_variant) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     if (lanes_per_candidate != 0 && lanes_per_candidate != 1 && lanes_per_candidate != 2 && lanes_per_candidate != 4 &&
-        lanes_per_candidate != 8)
-        return set_err(FX_ERR_INVALID_ARGUMENT, "lanes_per_candidate must be 0 (auto), 1, 2, 4 or 8");
+        lanes_per_candidate != 8 && lanes_per_candidate != 16 && lanes_per_candidate != 32)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "lanes_per_candidate must be 0 (auto), 1, 2, 4, 8, 16 or 32");
     if (waves_per_simd != 0 && (waves_per_simd < 2 || waves_per_simd > 4))
         return set_err(FX_ERR_INVALID_ARGUMENT, "waves_per_simd must be 0 (auto), 2, 3 or 4");
     if (kernel_variant < 0 || kernel_variant > 2) return set_err(FX_ERR_INVALID_ARGUMENT, "kernel_variant must be 0 (auto), 1 (generic) or 2 (grid)");
@@ -608,7 +608,11 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         int G = 1;
         if (waves1 < 3072) G = 2;
         if (waves1 < 200) G = 4;
-        if (waves1 < 64) G = 8;   // planner-sized grids (<= ~4 000 candidates): 8 lanes x 4 steps, 128-lane workgroups (32 vs 41 us)
+        // planner-sized grids are one dependent chain per lane on a mostly idle chip: spread the horizon until every lane walks
+        // one or two steps (plus its carry-in step) -- tools/sweep_small.py, 5 obstacles, kernel time at 4 / 8 / 16 / 32 lanes:
+        // 630 candidates 45 / 31 / 21 / 19 us; 1 260 x 51 samples 69 / 47 / 33 / 27; 3 060: 44 / 31 / 25 / 28; 4 200: 46 / 34 / 27 / 45
+        if (waves1 < 100) G = 16;
+        if (waves1 < 32) G = 32;
         if (c->G_force) G = c->G_force;
         if (extra_any) G = 1;
         c->G_step = G;
@@ -658,7 +662,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                 // two parts on two waves (G = 2, wave split) with the obstacle stage: 128-lane workgroups -- one wave per part --
                 // finish 3 - 8 % earlier than 256-lane ones (config 3: 88 - 95 vs 96 us); without obstacles they are slower
                 // (config 2: 48.6 vs 42.1 us, select-only 38.4 vs 29.1) -- tools/sweep_tuning.py, tools/c3.py
-                const int blk = (G == 8 || (G == 2 && obst_any) ? order_small : order_big)[bi];
+                const int blk = (G >= 8 || (G == 2 && obst_any) ? order_small : order_big)[bi];
                 const size_t need = lds_for(blk);
                 const int by_lds = (int)((160 * 1024) / (need + lds_static));
                 const int waves = by_lds * (blk / 64);
@@ -672,6 +676,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             if (lds_need > lds_cap) grid_ok = false;   // at least two workgroups per CU
         }
         if (c->variant_force == 1) grid_ok = false;
+        if (!grid_ok && G > 8) c->G_step = G = 8;   // 16 / 32 lanes per candidate exist on the grid kernel only
         if (c->variant_force == 2 && !grid_ok) return set_err(FX_ERR_INVALID_ARGUMENT, "grid kernel forced but not applicable (G=%d block=%d rows+tables need %zu B of LDS per workgroup)", G, block, lds_need);
         c->use_grid = grid_ok;
         if (const char *pad = getenv("FX_LDS_PAD")) lds_need = std::max(lds_need, (size_t)atol(pad));  // experiments: occupancy cap through LDS
@@ -811,6 +816,9 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         d.traj_len = c->d_trajlen + cand_off;
         d.bound_step = c->d_bstep + cand_off;
         d.n_blocks = (int)((C + CPB - 1) / CPB);
+        if (block_off + d.n_blocks > c->max_blocks_total)
+            return set_err(FX_ERR_CAPACITY, "agent %d: %lld workgroups exceed the partial-result capacity %lld", a,
+                           (long long)(block_off + d.n_blocks), (long long)c->max_blocks_total);
         d.part_cost = c->d_part_cost + block_off;
         d.part_idx = c->d_part_idx + block_off;
         d.counters = c->d_counters + (size_t)a * FX_CNT_COUNT;

@@ -416,6 +416,8 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
         }
     }
     switch (G) {
+    case 32: FX_BO(32, 2, false);   // planner-sized grids: one or two steps per lane, one occupancy target
+    case 16: FX_BO(16, 2, false);
     case 8: FX_W(8, false);
     case 4: FX_W(4, false);
     case 2: FX_W(2, false);

@@ -236,6 +236,25 @@ def test_work_decomposition_does_not_change_results(eng, name, lanes, wpe, varia
         eng.set_tuning(0, 0, 0)
 
 
+@pytest.mark.parametrize("lanes", [16, 32])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_one_or_two_steps_per_lane(eng, name, lanes):
+    """16 / 32 lanes per candidate (planner-sized grids: every lane walks one or two steps plus its carry-in step; horizons
+    shorter than the lane count leave parts without a step) against the oracle, on every synthetic case the grid kernel takes."""
+    from oracle import oracle
+    kw = CASES[name]
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
+    eng.set_tuning(lanes, 2, 0)
+    try:
+        res = eng.plan_step(inp)
+        info = eng.step_info()
+        assert info["lanes_per_candidate"] == lanes or not info["grid_kernel"]
+        compare(eng, inp, out, res)
+    finally:
+        eng.set_tuning(0, 0, 0)
+
+
 @pytest.mark.parametrize("lanes", [2, 4])
 @pytest.mark.parametrize("wpe", [2, 4])
 @pytest.mark.parametrize("name", ["dense_debug_obs", "dense_prod_obs", "dense_lowvel", "dense_horizon5", "ragged_tail",
@@ -332,12 +351,16 @@ def test_sampling_matrix_mode_matches_ranges(eng):
     kw = dict(ref_kind="arc", v0=10.0, grid=(5, 9, 11), n_obstacles=4)
     a = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
     b = synthetic.make_inputs(hull_builder=hip_hulls(), as_matrix=True, **kw)
-    ra = eng.plan_step(a)
-    ca, fa = eng.costs()
-    pa = eng.bundle()
-    rb = eng.plan_step(b)
-    cb, fb = eng.costs()
-    pb = eng.bundle()
+    eng.set_tuning(8, 0, 0)   # the same horizon split on both kernels: the cost sums associate identically -> bitwise
+    try:
+        ra = eng.plan_step(a)
+        ca, fa = eng.costs()
+        pa = eng.bundle()
+        rb = eng.plan_step(b)
+        cb, fb = eng.costs()
+        pb = eng.bundle()
+    finally:
+        eng.set_tuning(0, 0, 0)
     assert np.array_equal(fa, fb) and np.array_equal(ca, cb) and np.array_equal(pa, pb)
     for k in ("best_index", "best_cost", "n_returned", "n_feasible", "n_collisions", "reason_hist"):
         assert ra[k] == rb[k]

@@ -23,7 +23,7 @@ def test_soak_block(block):
         ref_inp = synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw)
         out = oracle.plan_step(ref_inp)
         with FrenetEngine(max_candidates=max(inp.n_candidates, 64), max_steps=inp.N, max_pred_steps=max(64, inp.N + 2)) as e:
-            tn = (int(rng.choice([0, 1, 2, 4, 8])), int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 1, 2])),
+            tn = (int(rng.choice([0, 1, 2, 4, 8, 16, 32])), int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 1, 2])),
                   int(rng.choice([0, 64, 128, 256])), int(rng.choice([0, 1, 2])))
             e.set_tuning(*tn)
             e.set_store_mode(int(rng.integers(0, 3)))

@@ -13,13 +13,13 @@ from frenetix_motion_planner_amd import synthetic, _lib
 from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
 
 SL = 16
-def run(label, G, mp, fused, wpe=2, **kw):
+def run(label, G, mp, fused, wpe=2, blk=256, **kw):
     inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, hull_builder=build_obstacle_hulls, **kw)
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
-        eng.set_timing("kernel"); eng.set_fused_selection(fused); eng.set_tuning(G, wpe, 2, 256, mp); eng.upload(inp)
+        eng.set_timing("kernel"); eng.set_fused_selection(fused); eng.set_tuning(G, wpe, 2, blk, mp); eng.upload(inp)
         for _ in range(5): eng.evaluate(); eng.finish()
         ms = eng.last_eval_kernel_ms
-        n_waves = -(-inp.n_candidates // (256 // G)) * 4
+        n_waves = -(-inp.n_candidates // (blk // G)) * (blk // 64)
         buf = np.zeros(n_waves * SL, dtype=np.uint64)
         lib = _lib.lib()
         lib.fx_probe_read.argtypes = [C.c_void_p, C.c_size_t]
@@ -47,6 +47,9 @@ RUNS = dict(
     c3B_g4=lambda: run("c3_B", 4, 2, True, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0),
     c3B_g4w3=lambda: run("c3_B", 4, 2, True, wpe=3, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0),
     c3A=lambda: run("c3_A", 2, 2, True, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0, write_bundle=False, write_costmap=False),
+    c1_g8=lambda: run("c1", 8, 0, True, blk=128, level=2, n_obstacles=5),
+    c1_g4=lambda: run("c1", 4, 2, True, blk=256, level=2, n_obstacles=5),
+    c1_g8_sel=lambda: run("c1", 8, 0, False, blk=128, level=2, n_obstacles=5),
     c2A_g4=lambda: run("50k_A", 4, 2, True, grid=(19, 51, 51), write_bundle=False, write_costmap=False),
 )
 for name in sys.argv[1:] or list(RUNS):
