@@ -676,7 +676,6 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             if (lds_need > lds_cap) grid_ok = false;   // at least two workgroups per CU
         }
         if (c->variant_force == 1) grid_ok = false;
-        if (!grid_ok && G > 8) c->G_step = G = 8;   // 16 / 32 lanes per candidate exist on the grid kernel only
         if (c->variant_force == 2 && !grid_ok) return set_err(FX_ERR_INVALID_ARGUMENT, "grid kernel forced but not applicable (G=%d block=%d rows+tables need %zu B of LDS per workgroup)", G, block, lds_need);
         c->use_grid = grid_ok;
         if (const char *pad = getenv("FX_LDS_PAD")) lds_need = std::max(lds_need, (size_t)atol(pad));  // experiments: occupancy cap through LDS

@@ -1,7 +1,7 @@
 // fx_eval_kernel.h -- the fused evaluation kernel (included by fx_kernels.hip).
 //
 // Work decomposition.  A candidate's horizon of S samples is cut into G contiguous chunks ("parts") that are
-// walked by G adjacent lanes; G = 1, 2, 4 or 8 is chosen on the host from the candidate count:
+// walked by G adjacent lanes; G = 1 ... 32 is chosen on the host from the candidate count:
 //   * G = 1 -- one lane per candidate.  Zero redundancy; right once there are enough candidates to fill the
 //     chip with waves (256 CUs x 4 SIMDs want >= 2-4 waves each, i.e. >= 130k-260k candidates).
 //   * G > 1 -- the 50k-candidate plan step of BASELINE config 2 is only 788 waves at G = 1 (< 1 per SIMD),
@@ -492,7 +492,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
 // ---------------------------------------------------------------------------------------------------
 // Generic kernel: arbitrary sampling-matrix rows (or ranges), every lane derives its own longitudinal row.
 // grid = (ceil(maxC / (256/G)), n_agents), block = 256, dynamic LDS = M*64 B + FX_TP*S*8 B.
-//   G      : lanes per candidate (1, 2, 4, 8)
+//   G      : lanes per candidate (1, 2, 4, 8; 16, 32 at WPE = 2)
 //   BUNDLE : write the 14-plane SoA TrajectoryBundle + coefficients (FX_MODE_WRITE_BUNDLE)
 //   OBST   : obstacles present (prediction cost and/or collision stage)
 //   EXTRA  : Simpson / distance_to_obstacles costs active (windowed over steps: G == 1 only)

@@ -371,6 +371,8 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
         FX_LAUNCH(1, false, false, true, 2);
     }
     switch (G) {
+    case 32: FX_BO(32, 2);   // planner-sized sampling matrices: one or two steps per lane, one occupancy target
+    case 16: FX_BO(16, 2);
     case 8: FX_W(8);
     case 4: FX_W(4);
     case 2: FX_W(2);

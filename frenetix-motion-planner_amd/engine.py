@@ -47,16 +47,30 @@ def invert_cov2(m: np.ndarray) -> np.ndarray:
 def _pack_predictions_c(entries, P: int, n_samples: int):
     """fx_pack_predictions: entries = [(pos [n,2], cov [n,2,2], yaw [n] or None, length, width)] -> packed arrays"""
     K = len(entries)
-    # inputs: counts, three pointer columns, box sizes in ONE int64 / float64 block each; outputs in one block, handed out as views
-    meta = np.array([[len(e[0]) for e in entries], [e[0].ctypes.data for e in entries], [e[1].ctypes.data for e in entries],
-                     [0 if e[2] is None else e[2].ctypes.data for e in entries]], dtype=np.int64)
-    n32 = meta[0].astype(np.int32)
-    lw = np.array([[e[3] for e in entries], [e[4] for e in entries]])
+    lens = [len(e[0]) for e in entries]
+    i64 = C.c_int64 * K
+    if all(e[2] is not None and len(e[2]) == n and len(e[1]) == n for e, n in zip(entries, lens)):
+        # the usual case (every obstacle with orientations and a shape): three concatenations, the pointer columns are
+        # base + offset -- one .ctypes access per kind instead of one per array
+        pos_all = np.concatenate([e[0] for e in entries])
+        cov_all = np.concatenate([e[1] for e in entries])
+        yaw_all = np.concatenate([e[2] for e in entries])
+        bp, bc, by = pos_all.ctypes.data, cov_all.ctypes.data, yaw_all.ctypes.data
+        pp, pc, py, off = [], [], [], 0
+        for n in lens:
+            pp.append(bp + 16 * off); pc.append(bc + 32 * off); py.append(by + 8 * off)
+            off += n
+    else:
+        pp = [e[0].ctypes.data for e in entries]
+        pc = [e[1].ctypes.data for e in entries]
+        py = [0 if e[2] is None else e[2].ctypes.data for e in entries]
+    f64 = C.c_double * K
     sizes = (2 * K * P, 4 * K * P, 6 * K * (P - 1))
-    out = np.empty(sum(sizes))
+    out = np.empty(sum(sizes))   # outputs in one block, handed out as views
     cnt = np.empty((2, K), np.int32)
-    o0, m0, l0, c0 = out.ctypes.data, meta.ctypes.data, lw.ctypes.data, cnt.ctypes.data
-    rc = lib().fx_pack_predictions(K, P, int(n_samples), n32.ctypes.data, m0 + 8 * K, m0 + 16 * K, m0 + 24 * K, l0, l0 + 8 * K,
+    o0, c0 = out.ctypes.data, cnt.ctypes.data
+    rc = lib().fx_pack_predictions(K, P, int(n_samples), (C.c_int32 * K)(*lens), i64(*pp), i64(*pc), i64(*py),
+                                   f64(*[e[3] for e in entries]), f64(*[e[4] for e in entries]),
                                    o0, o0 + 8 * sizes[0], c0, o0 + 8 * (sizes[0] + sizes[1]), c0 + 4 * K)
     if rc != 0:
         if b"singular" in lib().fx_last_error():

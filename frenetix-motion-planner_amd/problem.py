@@ -115,8 +115,10 @@ def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
             pr = predictions[k]
             pl = _f64(pr["pos_list"]).reshape(-1, 2)
             hulls = "orientation_list" in pr and "shape" in pr
-            entries.append((pl, _f64(pr["cov_list"]) if len(pl) else pl, _f64(pr["orientation_list"]) if hulls else None,
-                            float(pr["shape"]["length"]) if hulls else 0.0, float(pr["shape"]["width"]) if hulls else 0.0))
+            sh = pr["shape"] if hulls else None
+            entries.append((pl, _f64(pr["cov_list"]).reshape(-1, 2, 2) if len(pl) else pl.reshape(0, 2, 2),
+                            _f64(pr["orientation_list"]).reshape(-1) if hulls else None,
+                            float(sh["length"]) if hulls else 0.0, float(sh["width"]) if hulls else 0.0))
         return pack(entries, P, n_samples)
     pos = np.zeros((K, P, 2))
     cov_inv = np.zeros((K, P, 4))

@@ -198,7 +198,7 @@ int32_t fx_create(FxContext **out, int32_t device, int64_t max_candidates, int32
                   int32_t max_ref_knots, int32_t max_obstacles, int32_t max_pred_steps);
 int32_t fx_destroy(FxContext *ctx);
 int32_t fx_set_stream(FxContext *ctx, void *hip_stream);
-/* tuning override (0 = automatic): lanes that share one candidate's horizon (1, 2, 4, 8; 16, 32 on the grid kernel), the occupancy
+/* tuning override (0 = automatic): lanes that share one candidate's horizon (1, 2, 4, 8, 16, 32), the occupancy
  * target in waves per SIMD (2..4) of the evaluation kernel, and the kernel variant (1 = generic per-candidate
  * kernel, 2 = grid kernel with the per-(t,v) longitudinal table).  Results do not depend on any of them. */
 int32_t fx_set_tuning(FxContext *ctx, int32_t lanes_per_candidate, int32_t waves_per_simd, int32_t kernel_variant);

@@ -101,7 +101,7 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
         err[~stored] = 0
         tol = np.repeat((STATE_TOL + 2e-14 * cond)[:, None], err.shape[1], axis=1)
         tol[:, KINEMATIC_PLANES] = (STATE_TOL + 2e-14 * cond_kin)[:, None]
-        bad = err >= tol
+        bad = (err >= tol) & (tol < 1.0)   # a relative tolerance of 1 or more: the reference's own value carries no digit
         assert not bad.any(), (f"plane err {err[bad].max()} at (candidate, plane) {np.argwhere(bad)[0]} "
                                f"(tolerance {tol[bad][0]})")
         # coefficients / traj_len of a few candidates
@@ -236,20 +236,27 @@ def test_work_decomposition_does_not_change_results(eng, name, lanes, wpe, varia
         eng.set_tuning(0, 0, 0)
 
 
+@pytest.mark.parametrize("matrix", [False, True])
 @pytest.mark.parametrize("lanes", [16, 32])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_one_or_two_steps_per_lane(eng, name, lanes):
+def test_one_or_two_steps_per_lane(eng, name, lanes, matrix):
     """16 / 32 lanes per candidate (planner-sized grids: every lane walks one or two steps plus its carry-in step; horizons
-    shorter than the lane count leave parts without a step) against the oracle, on every synthetic case the grid kernel takes."""
+    shorter than the lane count leave parts without a step) against the oracle, on every synthetic case: sampling ranges (grid
+    kernel where it applies) and the same candidates as a C x 13 sampling matrix (generic kernel)."""
     from oracle import oracle
-    kw = CASES[name]
+    kw = dict(CASES[name])
+    if matrix:
+        if "stop_point_s" in kw or kw.get("as_matrix"):
+            pytest.skip("stop-point sampling has no matrix form / the case is a matrix already")
+        kw["as_matrix"] = True
     inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
     out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
     eng.set_tuning(lanes, 2, 0)
     try:
         res = eng.plan_step(inp)
         info = eng.step_info()
-        assert info["lanes_per_candidate"] == lanes or not info["grid_kernel"]
+        windowed = set(inp.cost_names) & {"acceleration", "jerk", "orientation_offset", "path_length", "distance_to_obstacles"}
+        assert info["lanes_per_candidate"] == (1 if windowed else lanes)   # windowed costs keep the horizon in one lane
         compare(eng, inp, out, res)
     finally:
         eng.set_tuning(0, 0, 0)

@@ -7,7 +7,8 @@ from frenetix_motion_planner_amd import synthetic
 from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
 
 W = dict(l2=dict(level=2, n_obstacles=5), l2_no=dict(level=2), l3=dict(level=3, n_obstacles=5), g4k=dict(grid=(7, 24, 24), n_obstacles=5),
-         l4=dict(level=4, n_obstacles=5), l2_h5=dict(level=2, n_obstacles=5, horizon=5.0, n_pred=50))
+         l4=dict(level=4, n_obstacles=5), l2_h5=dict(level=2, n_obstacles=5, horizon=5.0, n_pred=50),
+         l2m=dict(level=2, n_obstacles=5, as_matrix=True), l3m=dict(level=3, n_obstacles=5, as_matrix=True))   # ..m: C x 13 matrix -> generic kernel
 for name in sys.argv[1:] or list(W):
     inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, ref_kind="arc", v0=10.0, **W[name])
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
@@ -18,7 +19,7 @@ for name in sys.argv[1:] or list(W):
         rows = []
         for G, blk in [(0, 0)] + [(G, b) for G in (4, 8, 16, 32) for b in (64, 128, 256)]:
             try:
-                eng.set_tuning(G, 2, 2 if G else 0, blk, 1 if G else 0)
+                eng.set_tuning(G, 2, 2 if G and not W[name].get('as_matrix') else 0, blk, 1 if G else 0)
                 eng.upload(inp)
                 ts, tw = [], []
                 for _ in range(40):
