@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -186,6 +187,10 @@ int dev_alloc(FxContext *c, T **p, size_t n) {
     return FX_OK;
 }
 
+// per-step obstacle masks: one 64-bit word per 64 obstacles, word-major ([word][step]) so that the first word is the whole
+// table for K <= 64 (the only case the grid kernel's staged obstacle path handles)
+inline int mask_words(int K) { return K > 0 ? (K + 63) / 64 : 1; }
+
 size_t input_bytes_for(int64_t cand, int S, int M, int K, int Pn, bool matrix) {
     size_t b = 0;
     b += align_up(sizeof(double) * 5 * S, 256);
@@ -195,7 +200,7 @@ size_t input_bytes_for(int64_t cand, int S, int M, int K, int Pn, bool matrix) {
     b += align_up(sizeof(double) * 2 * (size_t)K * Pn, 256);
     b += align_up(sizeof(double) * 4 * (size_t)K * Pn, 256);
     b += align_up(sizeof(double) * 6 * (size_t)K * (Pn > 0 ? Pn : 1), 256);
-    b += align_up(sizeof(double) * 12 * (size_t)K * S, 256) + 2 * align_up(sizeof(unsigned long long) * S, 256);
+    b += align_up(sizeof(double) * 12 * (size_t)K * S, 256) + 2 * align_up(sizeof(unsigned long long) * S * (size_t)mask_words(K), 256);
     b += align_up(sizeof(double) * FX_HOT_STRIDE * (size_t)K * S, 256);  // hot obstacle table
     b += 2 * align_up(sizeof(int32_t) * (size_t)K, 256);
     b += align_up(sizeof(double) * 2 * (size_t)K, 256);           // dto positions (<= K)
@@ -275,7 +280,7 @@ int validate(const FxProblem *p) {
         if (p->cost_id[n] < 0 || p->cost_id[n] >= FX_NUM_COSTS) return set_err(FX_ERR_INVALID_ARGUMENT, "unknown cost id %d", p->cost_id[n]);
         if (n && p->cost_id[n] <= p->cost_id[n - 1]) return set_err(FX_ERR_INVALID_ARGUMENT, "cost ids must be strictly ascending");
     }
-    if (p->K > 64) return set_err(FX_ERR_CAPACITY, "at most 64 obstacles per agent (K=%d)", p->K);
+    if (p->K > FX_MAX_OBSTACLES) return set_err(FX_ERR_CAPACITY, "at most %d obstacles per agent (K=%d)", FX_MAX_OBSTACLES, p->K);
     if (p->K < 0 || p->P < 0 || (p->K > 0 && (p->P < 2 || !p->obs_pos || !p->obs_cov_inv || !p->obs_npred)))
         return set_err(FX_ERR_INVALID_ARGUMENT, "obstacle arrays inconsistent (K=%d, P=%d)", p->K, p->P);
     if ((p->mode & FX_MODE_COLLISION) && p->K > 0 && (!p->obs_hull || !p->obs_nhull))
@@ -304,9 +309,11 @@ double pack_obstacle_tables(int S, int K, int P, const double *obs_pos, const do
                             const double *obs_hull, const int32_t *obs_nhull, bool have_hull, double ox, double oy,
                             double *rec, unsigned long long *pm, unsigned long long *hm, double *hot) {
     double r2_max = 0.0;
+    for (int i = 0; i < S * mask_words(K); i++) pm[i] = hm[i] = 0ULL;
     for (int i = 0; i < S; i++) {
-        pm[i] = hm[i] = 0ULL;
         for (int k = 0; k < K; k++) {
+            const size_t mw = (size_t)(k >> 6) * S + i;   // word-major masks
+            const unsigned long long mbit = 1ULL << (k & 63);
             double *q = rec + ((size_t)i * K + k) * 12;
             for (int e = 0; e < 12; e++) q[e] = 0.0;
             double *h = hot + ((size_t)i * K + k) * FX_HOT_STRIDE;
@@ -315,7 +322,7 @@ double pack_obstacle_tables(int S, int K, int P, const double *obs_pos, const do
                 const double *mu = obs_pos + ((size_t)k * P + (i - 1)) * 2;
                 const double *iv = obs_cov_inv + ((size_t)k * P + (i - 1)) * 4;
                 q[0] = mu[0]; q[1] = mu[1]; q[2] = iv[0]; q[3] = iv[1]; q[4] = iv[2]; q[5] = iv[3];
-                pm[i] |= 1ULL << k;
+                pm[mw] |= mbit;
                 // Cholesky factor of the symmetric part of the inverse covariance: A = L^T L, L = [[l11, l12], [0, l22]];
                 // the quadratic form r0 e0 + r1 e1 of the reference only sees that symmetric part.  No factor (not
                 // positive definite, not finite): the entry stays zero, the form evaluates to 0 and the kernel redoes the
@@ -330,7 +337,7 @@ double pack_obstacle_tables(int S, int K, int P, const double *obs_pos, const do
             if (have_hull && i >= 2 && i - 2 < obs_nhull[k]) {
                 const double *oh = obs_hull + ((size_t)k * (P - 1) + (i - 2)) * 6;
                 for (int e = 0; e < 6; e++) q[6 + e] = oh[e];
-                hm[i] |= 1ULL << k;
+                hm[mw] |= mbit;
                 // broad phase: circle that holds the hull (radius h1 + h2, with slack) in expanded form
                 const double hx = oh[0] - ox, hy = oh[1] - oy, hr = (oh[4] + oh[5]) * 1.000001;
                 h[5] = -2.0 * hx; h[6] = -2.0 * hy; h[7] = -2.0 * hr; h[8] = hx * hx + hy * hy - hr * hr;
@@ -632,7 +639,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         // number of waves (small workgroups balance small grids at wave granularity).
         bool grid_ok = !extra_any;
         for (int a = 0; a < n_agents && grid_ok; a++)
-            if (probs[a].sampling_matrix || probs[a].nD < 1) grid_ok = false;
+            if (probs[a].sampling_matrix || probs[a].nD < 1 || probs[a].K > 64) grid_ok = false;   // > 64 obstacles: multi-word masks, generic kernel
         size_t lds_need = 0;
         int block = FX_BLOCK;
         if (grid_ok) {
@@ -760,8 +767,8 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             const double *dev = nullptr, *dhot = nullptr;
             const unsigned long long *dpm = nullptr, *dhm = nullptr;
             sl.off_rec = ar.off; rec = ar.host_slot<double>((size_t)S * p->K * 12, &dev, &ok);
-            sl.off_pm = ar.off; pm = ar.host_slot<unsigned long long>(S, &dpm, &ok);
-            sl.off_hm = ar.off; hm = ar.host_slot<unsigned long long>(S, &dhm, &ok);
+            sl.off_pm = ar.off; pm = ar.host_slot<unsigned long long>((size_t)S * mask_words(p->K), &dpm, &ok);
+            sl.off_hm = ar.off; hm = ar.host_slot<unsigned long long>((size_t)S * mask_words(p->K), &dhm, &ok);
             sl.off_hot = ar.off; hot = ar.host_slot<double>((size_t)S * p->K * FX_HOT_STRIDE, &dhot, &ok);
             d.obs_rec = dev; d.obs_pmask = dpm; d.obs_hmask = dhm; d.obs_hot = dhot;
             sl.dyn_end = ar.off;
@@ -1230,14 +1237,38 @@ int32_t fx_read_package(FxContext *c, int32_t agent, double yaw_rate0, FxPackage
 int32_t fx_plan_and_package(FxContext *c, const FxStateUpdate *upd, double yaw_rate0, FxResult *res, FxPackage *pkg, double *block) {
     if (!c || !res || !pkg) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_plan_and_package: NULL argument");
     int rc;
+#ifdef FX_HOST_PROBE   // probe builds: where the host side of a planner step goes (tools/probe_build)
+    static double acc[4]; static int n_acc;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+#endif
     if (upd && (rc = fx_update_state(c, 0, upd))) return rc;
+#ifdef FX_HOST_PROBE
+    const double t1 = now();
+#endif
     const bool was = c->package_enabled;
     c->package_enabled = true;
     rc = fx_evaluate(c);
     c->package_enabled = was;
     if (rc) return rc;
+#ifdef FX_HOST_PROBE
+    const double t2 = now();
+#endif
     if ((rc = fx_finish_batch(c, res))) return rc;
+#ifdef FX_HOST_PROBE
+    const double t3 = now();
+    rc = fx_read_package(c, 0, yaw_rate0, pkg, block);
+    const double t4 = now();
+    acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3;
+    if (++n_acc == 200) {
+        fprintf(stderr, "fx_plan_and_package: update_state %.1f us, evaluate (launches) %.1f us, finish (wait) %.1f us, read_package %.1f us\n",
+                acc[0] / n_acc, acc[1] / n_acc, acc[2] / n_acc, acc[3] / n_acc);
+        acc[0] = acc[1] = acc[2] = acc[3] = 0; n_acc = 0;
+    }
+    return rc;
+#else
     return fx_read_package(c, 0, yaw_rate0, pkg, block);
+#endif
 }
 
 // ---- host geometry of the callers either side of the path ----

@@ -674,34 +674,42 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
         }
     } else if (OBST && K.K > 0) {  // a batched launch may mix agents with and without obstacles
         const int nK = K.K;
+        // per-step masks: one 64-bit word per 64 obstacles, word-major ([word][step]); more than one word only on this path
+        // (the host sends agents with more than 64 obstacles to the generic kernel)
+        const int nW = (nK + 63) >> 6;
         const int iu = USTEP ? __builtin_amdgcn_readfirstlane(i) : i;
         const auto rec_i = obs_rec + (int64_t)iu * nK * 12;
         // -- prediction cost: ego step i pairs with prediction i-1 (collision_probability.py:283-292) --
-        unsigned long long pm = emit ? obs_pmask[iu] : 0ULL;
-        if (USTEP) pm = uniform_u64(pm);   // (the builtin returns int: without the helper's casts bit 31 sign-extends into 32 ... 63)
-        if (USTEP && !emit) pm = 0ULL;  // emit is wave-uniform whenever the step index is
-        while (pm) {
-            const int k = __builtin_ctzll(pm);
-            pm &= pm - 1;
-            const auto q = rec_i + k * 12;
-            const double e0 = x_i - q[0], e1 = y_i - q[1];
-            const double r0 = fma(e1, q[4], e0 * q[2]), r1 = fma(e1, q[5], e0 * q[3]);
-            const double m = fma(r1, e1, r0 * e0);
-            const double mm = m * m;
-            A.pred += mm > 0.0 ? rcp_pred(mm) : 1.0 / mm;
+        for (int w = 0; w < nW; w++) {
+            unsigned long long pm = emit ? obs_pmask[w * S + iu] : 0ULL;
+            if (USTEP) pm = uniform_u64(pm);   // (the builtin returns int: without the helper's casts bit 31 sign-extends into 32 ... 63)
+            if (USTEP && !emit) pm = 0ULL;  // emit is wave-uniform whenever the step index is
+            while (pm) {
+                const int k = __builtin_ctzll(pm) + 64 * w;
+                pm &= pm - 1;
+                const auto q = rec_i + k * 12;
+                const double e0 = x_i - q[0], e1 = y_i - q[1];
+                const double r0 = fma(e1, q[4], e0 * q[2]), r1 = fma(e1, q[5], e0 * q[3]);
+                const double m = fma(r1, e1, r0 * e0);
+                const double mm = m * m;
+                A.pred += mm > 0.0 ? rcp_pred(mm) : 1.0 / mm;
+            }
         }
         if (K.do_collision) {
             // ego box: centre = rear axle + wb_rear_axle along heading (state.py:30-39), heading theta_gl; it is needed
             // when this step closes a hull that meets an obstacle hull, or opens the next step's
-            const unsigned long long hm_now = obs_hmask[iu];
-            const unsigned long long hm_next = iu + 1 < S ? obs_hmask[iu + 1] : 0ULL;
-            if ((hm_now | hm_next) != 0ULL && i >= 1) {
+            unsigned long long any_now = 0ULL, any_next = 0ULL;
+            for (int w = 0; w < nW; w++) {
+                any_now |= obs_hmask[w * S + iu];
+                any_next |= iu + 1 < S ? obs_hmask[w * S + iu + 1] : 0ULL;
+            }
+            if ((any_now | any_next) != 0ULL && i >= 1) {
                 double su, cu;
                 heading_trig(r, cosTheta, tanTheta, cu, su);
                 const double bx = fma(K.wb, cu, x_i), by = fma(K.wb, su, y_i);
-                unsigned long long hm = emit ? hm_now : 0ULL;
-                if (USTEP) hm = uniform_u64(hm);
-                if (hm) {
+                if (!emit) any_now = 0ULL;
+                if (USTEP) any_now = uniform_u64(any_now);
+                if (any_now) {
                     // OBB-sum hull of ego boxes (i-1, i) lives at time index i-1 and meets obstacle hull i-2
                     const Obb hull = obb_hull(C.bx_prev, C.by_prev, C.ux_prev, C.uy_prev, bx, by, cu, su, K.half_len, K.half_wid);
                     // broad phase: a box lies inside the circle around its centre with radius h1 + h2 (>= its half
@@ -709,14 +717,18 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                     // separated and the axis test below would say so.  The 1e-6 slack keeps every pair that is
                     // anywhere near touching (and every NaN) on the exact path, so decisions are unchanged.
                     const double re = (hull.h1 + hull.h2) * 1.000001;
-                    while (hm) {
-                        const int k = __builtin_ctzll(hm);
-                        hm &= hm - 1;
-                        const auto q = rec_i + k * 12 + 6;
-                        const double tx = q[0] - hull.cx, ty = q[1] - hull.cy;
-                        const double rr = fma(q[4] + q[5], 1.000001, re);
-                        const bool near = !(fma(tx, tx, ty * ty) > rr * rr);
-                        if (USTEP ? __any(near) : near) A.collided |= obb_overlap(hull, q);
+                    for (int w = 0; w < nW; w++) {
+                        unsigned long long hm = obs_hmask[w * S + iu];
+                        if (USTEP) hm = uniform_u64(hm);
+                        while (hm) {
+                            const int k = __builtin_ctzll(hm) + 64 * w;
+                            hm &= hm - 1;
+                            const auto q = rec_i + k * 12 + 6;
+                            const double tx = q[0] - hull.cx, ty = q[1] - hull.cy;
+                            const double rr = fma(q[4] + q[5], 1.000001, re);
+                            const bool near = !(fma(tx, tx, ty * ty) > rr * rr);
+                            if (USTEP ? __any(near) : near) A.collided |= obb_overlap(hull, q);
+                        }
                     }
                 }
                 C.bx_prev = bx; C.by_prev = by; C.ux_prev = cu; C.uy_prev = su;

@@ -188,7 +188,7 @@ class TrajectoryHandler:
     def engine(self):
         if self._engine is None:
             from .engine import FrenetEngine
-            self._engine = FrenetEngine(max_candidates=65536, max_steps=127, max_ref_knots=4096, max_obstacles=64,
+            self._engine = FrenetEngine(max_candidates=65536, max_steps=127, max_ref_knots=4096, max_obstacles=256,
                                         max_pred_steps=130, device=self._device)
         return self._engine
 

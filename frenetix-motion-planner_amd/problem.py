@@ -86,7 +86,7 @@ def _dict_ptrs(d: dict, spec):
 
 
 _BOUND_UIDS = __import__("itertools").count(1)
-MAX_OBSTACLES = 64  # obstacles per agent (64-bit per-step masks of the obstacle stage)
+MAX_OBSTACLES = 256  # obstacles per agent (FX_MAX_OBSTACLES; beyond 64 the step runs on the generic kernel)
 
 
 def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
@@ -103,8 +103,8 @@ def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
     keys = list(predictions.keys())
     K = len(keys)
     if K > MAX_OBSTACLES:
-        raise ValueError(f"{K} predicted obstacles: the engine's per-step obstacle masks hold {MAX_OBSTACLES} -- cull the "
-                         "predictions on the host (e.g. by distance to the reachable set, get_obstacles_in_radius) before packing")
+        raise ValueError(f"{K} predicted obstacles: the engine takes at most {MAX_OBSTACLES} per agent -- cull the predictions on "
+                         "the host (e.g. by distance to the reachable set, get_obstacles_in_radius) before packing")
     # only the first n_samples predictions are ever read (prediction i-1 pairs with ego step i <= N, hulls use min(S, n)):
     # a 100-step predictor does not enlarge the tables
     P = max(2, min(n_samples, max(len(predictions[k]["pos_list"]) for k in keys)))

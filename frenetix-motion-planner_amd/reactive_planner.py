@@ -24,7 +24,7 @@ import numpy as np
 
 from . import _abi
 from .coordinate_system import CoordinateSystem, interpolate_angle
-from .problem import DEFAULT_COST_WEIGHTS, PlanInputs, VehicleParams, pack_predictions
+from .problem import DEFAULT_COST_WEIGHTS, MAX_OBSTACLES, PlanInputs, VehicleParams, pack_predictions
 from .sampling import SamplingHandler, v_sampling_bounds
 from .trajectories import (CartesianSample, CurviLinearSample, PlanStepResult, PolynomialView, StandstillSample,
                            TrajectorySample)
@@ -137,7 +137,7 @@ class ReactivePlannerHip:
             from .engine import FrenetEngine
             cap = self.max_candidates_per_step()
             self._engine = FrenetEngine(max_candidates=max(cap, 4096), max_steps=self.N, max_ref_knots=4096,
-                                        max_obstacles=64, max_pred_steps=max(64, self.N + 2), device=self._device)
+                                        max_obstacles=MAX_OBSTACLES, max_pred_steps=max(64, self.N + 2), device=self._device)
         return self._engine
 
     def max_candidates_per_step(self) -> int:

@@ -87,6 +87,7 @@ enum {
  * FX_LON_STOP_POINT: v_samp = sampled end POSITIONS s, quintic to (s, 0, 0) -- stop-point sampling,
  *   _create_end_point_trajectory_bundle, reactive_planner.py:628-671 (cpp: generate_stopping_trajectories,
  *   reactive_planner_cpp.py:258-290).  Ranges only (the C x 13 matrix has no end-position column). */
+#define FX_MAX_OBSTACLES 256   /* predicted obstacles per agent (FxProblem.K) */
 #define FX_LON_VELOCITY_KEEPING 0
 #define FX_LON_STOP_POINT 1
 
@@ -144,7 +145,9 @@ typedef struct FxProblem {
 
     /* predictions (prediction_helpers.py:209-261 dict -> packed): K obstacles, P steps each.
      * obs_pos[K][P][2], obs_cov_inv[K][P][4] (np.linalg.inv(cov_list), row-major 2x2),
-     * obs_npred[K] = len(pos_list) (<= P).  collision_probability.py:264-299. */
+     * obs_npred[K] = len(pos_list) (<= P).  collision_probability.py:264-299.
+     * K <= FX_MAX_OBSTACLES; up to 64 obstacles the grid kernel applies, beyond that the step runs on the generic kernel
+     * (the per-step obstacle masks take one 64-bit word per 64 obstacles). */
     int32_t K, P;
     const double *obs_pos, *obs_cov_inv;
     const int32_t *obs_npred;

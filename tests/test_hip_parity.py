@@ -800,3 +800,33 @@ def test_random_cost_functions_vs_oracle(case):
         compare(e, inp, out, res)
         if np.all(out["margin"] >= FRAGILE):
             assert res["best_index"] == out["result"]["best_index"] and res["n_collisions"] == out["result"]["n_collisions"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [65, 100, 128, 129, 200, 256])
+@pytest.mark.parametrize("tuning", [(0, 0, 0), (1, 2, 1), (2, 3, 1), (8, 2, 1), (32, 2, 1)])
+def test_more_than_sixty_four_obstacles(K, tuning):
+    """65 ... 256 predicted obstacles (FX_MAX_OBSTACLES): the per-step masks take one 64-bit word per 64 obstacles and the step
+    runs on the generic kernel -- one lane per candidate and split horizons, ranges and (K = 100) a sampling matrix -- against
+    the oracle; the reference itself has no obstacle limit."""
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    from oracle import oracle
+    kw = dict(ref_kind="arc", v0=9.0, grid=(3, 5, 7), n_obstacles=K, seed=K, as_matrix=(K == 100))
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
+    with FrenetEngine(max_candidates=256, max_steps=inp.N, max_obstacles=256) as e:
+        e.set_tuning(*tuning)
+        res = e.plan_step(inp)
+        assert not e.step_info()["grid_kernel"]
+        compare(e, inp, out, res)
+        assert res["n_collisions"] == out["result"]["n_collisions"]
+        # the in-place state update rebuilds the multi-word tables too
+        res2 = e.plan_step(inp)
+        assert res2["best_index"] == res["best_index"] and res2["best_cost"] == res["best_cost"]
+
+
+@pytest.mark.gpu
+def test_obstacle_limit_is_reported():
+    from frenetix_motion_planner_amd.problem import MAX_OBSTACLES
+    with pytest.raises(ValueError, match="at most"):
+        synthetic.make_inputs(hull_builder=hip_hulls(), ref_kind="arc", v0=9.0, grid=(1, 2, 2), n_obstacles=MAX_OBSTACLES + 1)

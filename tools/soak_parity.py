@@ -16,8 +16,8 @@ stats = dict(cands=0, winners=0, collided=0, fragile=0)
 for case in range(first, first + n):
     rng = np.random.default_rng([20241008, case])
     kw = _random_case(rng)
-    if os.environ.get("FX_SOAK_MANY"):   # crowded scenes: 9 ... 48 obstacles (the generator stops at 8)
-        kw["n_obstacles"] = int(rng.integers(9, 49))
+    if os.environ.get("FX_SOAK_MANY"):   # crowded scenes: 9 ... 48 obstacles (the generator stops at 8); =2: 49 ... 256 (multi-word masks)
+        kw["n_obstacles"] = int(rng.integers(9, 49)) if os.environ["FX_SOAK_MANY"] != "2" else int(rng.integers(49, 257))
         if "grid" in kw:
             kw["grid"] = (min(kw["grid"][0], 4), kw["grid"][1], kw["grid"][2])
     if os.environ.get("FX_SOAK_COSTS"):  # random cost functions over all ten terms (windowed costs -> generic kernel)
@@ -29,7 +29,7 @@ for case in range(first, first + n):
     try:
         inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
         out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
-        with FrenetEngine(max_candidates=max(inp.n_candidates, 64), max_steps=inp.N, max_pred_steps=max(64, inp.N + 2), max_obstacles=64) as e:
+        with FrenetEngine(max_candidates=max(inp.n_candidates, 64), max_steps=inp.N, max_pred_steps=max(64, inp.N + 2), max_obstacles=256) as e:
             if os.environ.get("FX_SOAK_TUNING"):  # also walk through the work decompositions / kernel variants
                 tn = (int(rng.choice([0, 1, 2, 4, 8, 16, 32])), int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 1, 2])),
                       int(rng.choice([0, 64, 128, 256])), int(rng.choice([0, 1, 2])))
