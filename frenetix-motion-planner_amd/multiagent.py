@@ -262,6 +262,12 @@ class MultiAgentSimulation:
             if sel is None:
                 continue
             # the part of the stored trajectory that lies ahead of the agent's new state (index 1 + counter - 1)
+            rows = getattr(sel, "rows", None)
+            if rows is not None:   # packaged trajectory: the block's columns, no state objects
+                ahead = rows[a.replanning_counter:][:self.S]
+                local[j, :len(ahead), :4] = ahead
+                local[j, :len(ahead), 4] = 1.0
+                continue
             ahead = sel[a.replanning_counter:]
             for i, st in enumerate(ahead[:self.S]):
                 local[j, i] = (st.position[0], st.position[1], st.orientation, st.velocity, 1.0)

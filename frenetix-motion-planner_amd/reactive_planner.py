@@ -472,7 +472,9 @@ class ReactivePlannerHip:
                 return dict(time_step=t0 + i, position=np.array((c[7], c[8])), velocity=c[3], acceleration=c[4], orientation=c[2],
                             yaw_rate=c[5])
 
-            return _LazyStates(n, cart), _LazyStates(n, curv), b[[7, 10, 11]].T.tolist(), b[[8, 12, 13]].T.tolist()
+            states = _LazyStates(n, cart)
+            states.rows = b[[0, 1, OR, 3]].T   # [n][x, y, orientation, velocity]: what a batch of agents shares as predictions
+            return states, _LazyStates(n, curv), b[[7, 10, 11]].T.tolist(), b[[8, 12, 13]].T.tolist()
         c, k = trajectory.cartesian, trajectory.curvilinear
         n = len(c.x)
         theta = np.asarray(c.theta, dtype=np.float64)
@@ -524,6 +526,8 @@ class ReactivePlannerHip:
 class _LazyStates:
     """Read-only sequence whose items are built on first access and then kept (the state lists of a trajectory pair: a
     closed-loop step reads one or two of the 31 states)."""
+
+    rows = None   # optional [n][4] array (x, y, orientation, velocity) of the same states
 
     def __init__(self, n: int, make):
         self._make = make
