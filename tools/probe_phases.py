@@ -26,16 +26,17 @@ def run(label, G, mp, fused, wpe=2, blk=256, **kw):
         assert lib.fx_probe_read(buf.ctypes.data, buf.size) == 0
     st = buf.reshape(n_waves, SL).astype(np.int64)
     t0 = st[:, 0].min()
-    wall = (st[:, 15].max() - t0) * 10e-3  # us (100 MHz)
-    cyc = st[:, 1:13] - st[:, 1:2]         # cycles relative to stamp 1
-    d = np.diff(st[:, 1:13], axis=1)       # per-phase cycles
     names = ["rows", "lat_setup", "walk", "combine", "flags", "costs", "hist", "argmin", "partial", "drain", "ticket"]
-    tot = (st[:, 12] - st[:, 1])
-    clk = np.median(tot) / max(1e-9, (np.median(st[:, 15] - st[:, 0]) * 10e-3))  # cycles per us, rough
+    def phase(i, q):   # only the first wave of a workgroup reaches the stamps behind the reductions, and only on fused steps
+        ok = (st[:, i + 1] > 0) & (st[:, i + 2] > 0)
+        return int(np.percentile(st[ok, i + 2] - st[ok, i + 1], q)) if ok.any() else None
+    done = st[:, 15] > 0
+    wall = (st[done, 15].max() - t0) * 10e-3 if done.any() else float("nan")  # us (100 MHz)
     print(label, f"G{G}m{mp} fused={fused} kernel {ms*1e3:.1f} us; first entry -> last end {wall:.1f} us; entry spread "
-          f"{(st[:,0].max()-t0)*10e-3:.1f} us; ~{clk:.0f} cycles/us")
-    print("   median cycles per phase:", {n: int(np.median(d[:, i])) for i, n in enumerate(names)})
-    print("   p95    cycles per phase:", {n: int(np.percentile(d[:, i], 95)) for i, n in enumerate(names)})
+          f"{(st[:,0].max()-t0)*10e-3:.1f} us")
+    print("   median cycles per phase:", {n: phase(i, 50) for i, n in enumerate(names)})
+    print("   p95    cycles per phase:", {n: phase(i, 95) for i, n in enumerate(names)})
+    print("   wave life (stamp 1 -> stamp 9, cycles): median", int(np.median(st[:, 9] - st[:, 1])), "max", int((st[:, 9] - st[:, 1]).max()))
 
 RUNS = dict(
     c2B=lambda: run("50k_B", 2, 2, True, grid=(19, 51, 51)),
@@ -48,6 +49,8 @@ RUNS = dict(
     c3B_g4w3=lambda: run("c3_B", 4, 2, True, wpe=3, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0),
     c3A=lambda: run("c3_A", 2, 2, True, grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0, write_bundle=False, write_costmap=False),
     c1_g8=lambda: run("c1", 8, 0, True, blk=128, level=2, n_obstacles=5),
+    c1_g32=lambda: run("c1", 32, 0, True, blk=128, level=2, n_obstacles=5),
+    c1_g32_64=lambda: run("c1", 32, 0, True, blk=64, level=2, n_obstacles=5),
     c1_g4=lambda: run("c1", 4, 2, True, blk=256, level=2, n_obstacles=5),
     c1_g8_sel=lambda: run("c1", 8, 0, False, blk=128, level=2, n_obstacles=5),
     c2A_g4=lambda: run("50k_A", 4, 2, True, grid=(19, 51, 51), write_bundle=False, write_costmap=False),
