@@ -19,12 +19,14 @@ for case in range(first, first + n):
     kws = [_random_case(rng) for _ in range(int(rng.integers(2, 6)))]
     for kw in kws:   # one step interval and one bundle mode per launch are not required; keep the generator's freedom
         kw.pop("stop_point_s", None) if rng.uniform() < 0.5 else None
+        if os.environ.get("FX_SOAK_MANY") and rng.uniform() < 0.5:   # some agents in crowded scenes, a few beyond 64 obstacles
+            kw["n_obstacles"] = int(rng.integers(9, 49)) if rng.uniform() < 0.7 else int(rng.integers(65, 200))
     try:
         inps = [synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw) for kw in kws]
         outs = [oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw)) for kw in kws]
         cap = sum(max(i.n_candidates, 64) + 64 for i in inps)
         with FrenetEngine(max_candidates=cap, max_steps=max(i.N for i in inps), max_pred_steps=max(64, max(i.N for i in inps) + 2),
-                          max_obstacles=64, max_agents=len(inps)) as e:
+                          max_obstacles=256, max_agents=len(inps)) as e:
             res = e.plan_batch(inps)
             for a, (inp, out) in enumerate(zip(inps, outs)):
                 compare(e, inp, out, res[a], agent=a)
