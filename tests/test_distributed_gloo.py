@@ -393,3 +393,72 @@ def test_hybrid_sharding_gloo(world, n_agents):
             assert (bi, bc) == (ref["best_index"], ref["best_cost"])
     # every rank evaluated a part: with fewer agents than ranks nobody idles
     assert all(any(p is not None for p in parts) for _, _, parts in got)
+
+
+class _CommStubEngine:
+    """Only what ShardedEvaluator._init_library_exchange touches; `fail` = which call raises on this rank."""
+
+    def __init__(self, fail=None):
+        self.fail, self.inits, self.destroys, self.uid_seen = fail, 0, 0, None
+
+    def comm_unique_id(self):
+        if self.fail == "uid":
+            raise RuntimeError("no communicator library")
+        return bytes(range(128))
+
+    def comm_init(self, uid, rank, world):
+        if self.fail == "init":
+            raise RuntimeError("communicator initialisation failed")
+        self.inits += 1
+        self.uid_seen = bytes(uid)
+
+    def comm_destroy(self):
+        self.destroys += 1
+
+
+def _exchange_agreement_worker(rank, world, port, q, scenario):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fail = {"ok": None, "uid_fails_on_rank0": "uid" if rank == 0 else None,
+                "init_fails_on_rank1": "init" if rank == 1 else None}[scenario]
+        ev = ShardedEvaluator.__new__(ShardedEvaluator)   # the agreement logic alone (the constructor needs a GPU for this path)
+        ev.torch, ev.dist, ev.group, ev.rank, ev.world = torch, dist, None, rank, world
+        ev.engine = _CommStubEngine(fail)
+        ok = ev._init_library_exchange(torch.device("cpu"))
+        q.put((rank, ok, ev.engine.inits, ev.engine.destroys, ev.engine.uid_seen == bytes(range(128))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("scenario", ["ok", "uid_fails_on_rank0", "init_fails_on_rank1"])
+def test_library_exchange_setup_is_agreed_by_all_ranks(scenario):
+    """The in-library exchange is used only if EVERY rank could set it up: rank 0 draws the id (or says it could not), the id
+    travels over the torch group, and one failing rank sends all of them to the torch.distributed path (communicators that
+    were created are destroyed) -- otherwise half the ranks would wait in an all-gather the others never enter."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_agreement_worker, args=(r, world, port, q, scenario)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    oks = [g[1] for g in got]
+    assert oks == ([True, True] if scenario == "ok" else [False, False])
+    if scenario == "ok":
+        assert all(g[2] == 1 and g[3] == 0 and g[4] for g in got)
+    elif scenario == "uid_fails_on_rank0":
+        assert all(g[2] == 0 and g[3] == 0 for g in got)            # nobody initialises without an id
+    else:
+        assert got[0][2] == 1 and got[0][3] == 1                    # rank 0 had a communicator: destroyed again
+        assert got[1][2] == 0 and got[1][3] == 0
