@@ -1,0 +1,139 @@
+"""The oracle's collision primitives against elementary geometry written independently of them.
+
+pycrcc -- what the reference calls for the collision walk -- is not in the reference tree, so the OBB-sum hull and the
+separating-axis test cannot be pinned against it.  What can be checked: the axis test decides exactly what "two convex
+quadrilaterals share a point" means (edges cross or a corner lies inside), and the hull of two boxes contains both and is
+tight in its own frame.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+
+def _pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def corners(box):
+    cx, cy, ex, ey, h1, h2 = box
+    e, f = np.array([ex, ey]), np.array([-ey, ex])
+    c = np.array([cx, cy])
+    return np.array([c + h1 * e + h2 * f, c - h1 * e + h2 * f, c - h1 * e - h2 * f, c + h1 * e - h2 * f])
+
+
+def _orient(a, b, c):
+    return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0])
+
+
+def _segments_cross(p, q, r, s):
+    """closed segments pq and rs share a point; with the smallest |orientation| met, as a margin for near-degenerate pairs"""
+    d1, d2, d3, d4 = _orient(r, s, p), _orient(r, s, q), _orient(p, q, r), _orient(p, q, s)
+    return (d1 * d2 <= 0) and (d3 * d4 <= 0), min(abs(d1), abs(d2), abs(d3), abs(d4))
+
+
+def _inside(poly, pt):
+    """pt in the closed convex polygon (counter-clockwise corners); smallest |orientation| as a margin"""
+    o = [_orient(poly[i], poly[(i + 1) % 4], pt) for i in range(4)]
+    return all(v >= 0 for v in o), min(abs(v) for v in o)
+
+
+def polygons_intersect(A, B):
+    """(shares a point, margin): edge crossings or containment -- no projections, no axes"""
+    hit, margin = False, np.inf
+    for i in range(4):
+        for j in range(4):
+            h, m = _segments_cross(A[i], A[(i + 1) % 4], B[j], B[(j + 1) % 4])
+            hit, margin = hit or h, min(margin, m)
+    for poly, pts in ((A, B), (B, A)):
+        for pt in pts:
+            h, m = _inside(poly, pt)
+            hit, margin = hit or h, min(margin, m)
+    return hit, margin
+
+
+def _random_box(rng, spread):
+    th = rng.uniform(-np.pi, np.pi)
+    return np.array([rng.uniform(-spread, spread), rng.uniform(-spread, spread), np.cos(th), np.sin(th),
+                     rng.uniform(0.3, 4.0), rng.uniform(0.3, 2.0)])
+
+
+def test_axis_test_equals_polygon_intersection():
+    rng = np.random.default_rng(42)
+    L = oracle.lib()
+    n_hit = n_checked = 0
+    for t in range(20000):
+        a, b = _random_box(rng, 4.0), _random_box(rng, 4.0)
+        if t % 7 == 0:   # aligned and nested pairs: the containment branch, parallel edges
+            b[2:4] = a[2:4] if t % 14 == 0 else (-a[3], a[2])
+        if t % 11 == 0:
+            b[:2] = a[:2] + rng.uniform(-0.1, 0.1, 2)
+        want, margin = polygons_intersect(corners(a), corners(b))
+        if margin < 1e-9:
+            continue   # touching to rounding: the two formulations may round differently
+        got = bool(L.fxo_obb_overlap(_pd(a), _pd(b)))
+        assert got == want, (a, b, margin)
+        n_checked += 1
+        n_hit += want
+    assert n_checked > 19000 and 0.2 < n_hit / n_checked < 0.8   # both outcomes well represented
+
+
+def test_touching_boxes_collide():
+    """strict `>` for separation: boxes that share exactly an edge or a corner collide"""
+    L = oracle.lib()
+    a = np.array([0.0, 0.0, 1.0, 0.0, 2.0, 1.0])
+    for b in (np.array([4.0, 0.0, 1.0, 0.0, 2.0, 1.0]),      # shared edge
+              np.array([4.0, 2.0, 1.0, 0.0, 2.0, 1.0]),      # shared corner
+              np.array([3.0, 0.0, 0.0, 1.0, 1.0, 1.0])):     # shared edge, rotated by a quarter turn
+        assert L.fxo_obb_overlap(_pd(a), _pd(b)) == 1
+        away = b.copy(); away[0] += 1e-9
+        assert L.fxo_obb_overlap(_pd(a), _pd(away)) == 0
+
+
+def test_hull_contains_both_boxes_and_is_tight():
+    rng = np.random.default_rng(7)
+    L = oracle.lib()
+    out = np.zeros(6)
+    for t in range(5000):
+        c0, c1 = rng.uniform(-30, 30, 2), None
+        th0 = rng.uniform(-np.pi, np.pi)
+        th1 = th0 + (rng.uniform(-0.4, 0.4) if t % 5 else rng.uniform(-np.pi, np.pi))
+        if t % 97 == 0:
+            th1 = th0 + np.pi   # opposite headings: the axis falls back to the first box's
+        c1 = c0 + rng.uniform(0.0, 3.0) * np.array([np.cos(th0), np.sin(th0)]) + rng.uniform(-0.3, 0.3, 2)
+        hl, hw = rng.uniform(1.0, 3.0), rng.uniform(0.5, 1.2)
+        u0, u1 = np.array([np.cos(th0), np.sin(th0)]), np.array([np.cos(th1), np.sin(th1)])
+        L.fxo_obb_hull(_pd(c0), _pd(u0), _pd(c1), _pd(u1), hl, hw, _pd(out))
+        e, f, c = out[2:4], np.array([-out[3], out[2]]), out[:2]
+        assert abs(np.hypot(*e) - 1.0) < 1e-12
+        pts = np.concatenate([corners(np.array([*c0, *u0, hl, hw])), corners(np.array([*c1, *u1, hl, hw]))])
+        p1, p2 = (pts - c) @ e, (pts - c) @ f
+        # containment, and tightness: some corner on each of the four sides
+        assert p1.max() <= out[4] + 1e-9 and p1.min() >= -out[4] - 1e-9
+        assert p2.max() <= out[5] + 1e-9 and p2.min() >= -out[5] - 1e-9
+        assert abs(p1.max() - out[4]) < 1e-9 and abs(p1.min() + out[4]) < 1e-9
+        assert abs(p2.max() - out[5]) < 1e-9 and abs(p2.min() + out[5]) < 1e-9
+        # the axis bisects the two headings (or is the first heading when they cancel)
+        s = u0 + u1
+        if np.hypot(*s) > 1e-9:
+            assert abs(e[0] * s[1] - e[1] * s[0]) < 1e-9 * max(1.0, np.hypot(*s)) and e @ s > 0
+        else:
+            assert np.allclose(e, u0, atol=1e-9)
+
+
+def test_obstacle_hulls_are_hulls_of_consecutive_predictions():
+    """fxo_build_obstacle_hulls: hull j = hull of predicted boxes (j, j+1); obstacles with <= 2 predictions are skipped"""
+    rng = np.random.default_rng(3)
+    L = oracle.lib()
+    n = 12
+    pos = np.cumsum(rng.uniform(0.2, 1.0, (n, 2)), axis=0)
+    yaw = np.cumsum(rng.uniform(-0.1, 0.1, n))
+    hulls = oracle.build_obstacle_hulls(n, pos, yaw, 4.6, 1.9)
+    assert hulls.shape == (n - 1, 6)
+    one = np.zeros(6)
+    for j in range(n - 1):
+        u0 = np.array([np.cos(yaw[j]), np.sin(yaw[j])]); u1 = np.array([np.cos(yaw[j + 1]), np.sin(yaw[j + 1])])
+        L.fxo_obb_hull(_pd(np.ascontiguousarray(pos[j])), _pd(u0), _pd(np.ascontiguousarray(pos[j + 1])), _pd(u1), 2.3, 0.95, _pd(one))
+        assert np.allclose(hulls[j], one, rtol=0, atol=1e-12)
+    assert len(oracle.build_obstacle_hulls(2, pos[:2], yaw[:2], 4.6, 1.9)) == 0
