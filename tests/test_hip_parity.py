@@ -830,3 +830,46 @@ def test_obstacle_limit_is_reported():
     from frenetix_motion_planner_amd.problem import MAX_OBSTACLES
     with pytest.raises(ValueError, match="at most"):
         synthetic.make_inputs(hull_builder=hip_hulls(), ref_kind="arc", v0=9.0, grid=(1, 2, 2), n_obstacles=MAX_OBSTACLES + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("what", ["s0", "v0", "a0", "d0", "dd0", "obstacle_pos", "cov_inv", "hull", "v_des"])
+def test_non_finite_inputs(what):
+    """NaN / inf in the ego state, the predictions or the desired velocity (an upstream fault; the reference has no test for
+    it): the step completes, the masks equal the oracle's wherever the ego state is finite, and a candidate whose cost is
+    NaN is never selected -- the reference's sort would leave such candidates in list order and take the first."""
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    from oracle import oracle
+    kw = dict(ref_kind="arc", v0=9.0, grid=(3, 5, 7), n_obstacles=3)
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    ref = synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw)
+    for x in (inp, ref):
+        if what in ("s0", "v0", "a0"):
+            x.x0_lon = np.array(x.x0_lon, dtype=np.float64)
+            x.x0_lon[("s0", "v0", "a0").index(what)] = np.inf if what == "a0" else np.nan
+        elif what in ("d0", "dd0"):
+            x.x0_lat = np.array(x.x0_lat, dtype=np.float64)
+            x.x0_lat[("d0", "dd0").index(what)] = np.inf if what == "dd0" else np.nan
+        elif what == "obstacle_pos":
+            x.obstacles["pos"] = np.array(x.obstacles["pos"]); x.obstacles["pos"][0, 3] = np.nan
+        elif what == "cov_inv":
+            x.obstacles["cov_inv"] = np.array(x.obstacles["cov_inv"]); x.obstacles["cov_inv"][1, 2] = np.inf
+        elif what == "hull":
+            x.obstacles["hull"] = np.array(x.obstacles["hull"]); x.obstacles["hull"][2, 4, 0] = np.nan
+        else:
+            x.v_des = np.nan
+    out = oracle.plan_step(ref)
+    with FrenetEngine(max_candidates=256, max_steps=inp.N) as e:
+        res = e.plan_step(inp)
+        cost, flags = e.costs()
+    if what in ("s0", "v0", "a0", "d0", "dd0"):
+        assert res["best_index"] == -1 == out["result"]["best_index"] and res["n_feasible"] == 0 == out["result"]["n_feasible"]
+    else:
+        assert np.array_equal(flags, out["flags"])
+        assert res["n_feasible"] == out["result"]["n_feasible"] and res["n_collisions"] == out["result"]["n_collisions"]
+        costed = (flags & _abi.FX_FLAG_COSTED) != 0
+        if np.isnan(cost[costed]).all():
+            assert res["best_index"] == -1
+        else:
+            assert res["best_index"] == out["result"]["best_index"]
