@@ -26,6 +26,8 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
 extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agents, int max_blocks, int block_size,
                                           size_t lds_bytes, int G, bool bundle, bool obst, int wpe, bool wsplit,
                                           hipEvent_t ev_start, hipEvent_t ev_stop, FuseArgs fuse, hipStream_t stream);
+extern "C" hipError_t fx_launch_obstacle(const DevProblem *d_probs, int n_agents, int max_items, size_t lds_bytes, int CH,
+                                         hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t stream);
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
                                        unsigned long long seq, double *dev_winner, double *host_pkg, int pkg_stride, int pkg_plane_rows,
                                        hipStream_t stream);
@@ -90,9 +92,9 @@ struct FxContext {
     // timing ring: per timed step (start, evaluation end, step end) events; elapsed times are read lazily, so a
     // timed step never waits for its own events
     struct TimeSlot {
-        hipEvent_t e0 = nullptr, e_eval = nullptr, e_end = nullptr;
-        bool eval_launched = false, fused = false, fetched = false;
-        float step_ms = 0.f, eval_ms = 0.f;
+        hipEvent_t e0 = nullptr, e_eval = nullptr, e_end = nullptr, e_obs0 = nullptr, e_obs1 = nullptr;
+        bool eval_launched = false, fused = false, fetched = false, obst_timed = false;
+        float step_ms = 0.f, eval_ms = 0.f, obst_ms = 0.f;
     };
     static constexpr int kTimeRing = 256;
     TimeSlot ring[kTimeRing];
@@ -114,6 +116,12 @@ struct FxContext {
     size_t probs_bytes = 0;
     // outputs
     double *d_cost = nullptr;
+    double *d_cost_tail = nullptr;     // [total_ld] cost terms behind the prediction term (obstacle stage as its own kernel)
+    // obstacle kernel scratch (allocated on first use): partial sums [chunks][ld], collision ballots [chunks][tiles], tile tickets
+    double *d_obs_part = nullptr;
+    unsigned long long *d_obs_colm = nullptr;
+    unsigned int *d_obs_ticket = nullptr;
+    size_t obs_part_cap = 0, obs_colm_cap = 0;
     uint32_t *d_flags = nullptr;
     double *d_costmap = nullptr;
     double *d_coeffs = nullptr;
@@ -166,6 +174,11 @@ struct FxContext {
     int variant_force = 0;                 // 0 auto, 1 generic kernel, 2 grid kernel
     int block_force = 0;                   // grid-kernel workgroup size override (0 auto)
     int wsplit_force = 0;                  // 0 auto, 1 lane split, 2 wave split
+    int obst_force = 0;                    // obstacle stage: 0 auto, 1 fused into the walk, 2 its own kernel (fx_set_obstacle_stage)
+    int obst_CH = 0;                       // steps per work item of the obstacle kernel (0 auto)
+    bool split_step = false;               // current step runs fx_obstacle_kernel behind the walk
+    int split_CH = 3, obs_blocks_step = 0;
+    size_t obs_lds_step = 0;
     int store_force = 0;                   // 0 auto, 1 write-back, 2 write-through plane stores
     bool wsplit_step = false;
     int block_step = FX_BLOCK;
@@ -238,6 +251,8 @@ int fetch_slot(FxContext *c, FxContext::TimeSlot &t) {
     HIP_TRY(hipEventElapsedTime(&t.step_ms, t.e0, end));
     if (t.eval_launched) HIP_TRY(hipEventElapsedTime(&t.eval_ms, t.e0, t.e_eval));
     else t.eval_ms = 0.f;
+    t.obst_ms = 0.f;
+    if (t.obst_timed) HIP_TRY(hipEventElapsedTime(&t.obst_ms, t.e_obs0, t.e_obs1));
     t.fetched = true;
     return FX_OK;
 }
@@ -406,6 +421,8 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
         HIP_TRY(hipEventCreate(&t.e0));
         HIP_TRY(hipEventCreate(&t.e_eval));
         HIP_TRY(hipEventCreate(&t.e_end));
+        HIP_TRY(hipEventCreate(&t.e_obs0));
+        HIP_TRY(hipEventCreate(&t.e_obs1));
     }
     const int S = max_steps + 1;
     // every agent's leading dimension is rounded up to 64 candidates
@@ -424,6 +441,7 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     c->d_probs = reinterpret_cast<DevProblem *>(c->d_in);
     int rc;
     if ((rc = dev_alloc(c, &c->d_cost, c->total_ld))) return rc;
+    if ((rc = dev_alloc(c, &c->d_cost_tail, c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_flags, c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_costmap, (size_t)FX_NUM_COSTS * c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_coeffs, (size_t)12 * c->total_ld))) return rc;
@@ -468,11 +486,14 @@ int32_t fx_destroy(FxContext *c) {
     if (!c) return FX_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_cost, c->d_flags, c->d_costmap, c->d_coeffs, c->d_trajlen, c->d_planes,
+    void *dev[] = {c->d_in, c->d_cost, c->d_cost_tail, c->d_flags, c->d_costmap, c->d_coeffs, c->d_trajlen, c->d_planes,
                    c->d_part_cost, c->d_part_idx, c->d_counters, c->d_topk_cost, c->d_topk_idx, c->d_topk_scr_cost,
                    c->d_topk_scr_idx};
     for (void *p : dev) if (p) (void)hipFree(p);
     if (c->d_bstep) (void)hipFree(c->d_bstep);
+    if (c->d_obs_part) (void)hipFree(c->d_obs_part);
+    if (c->d_obs_colm) (void)hipFree(c->d_obs_colm);
+    if (c->d_obs_ticket) (void)hipFree(c->d_obs_ticket);
     if (c->d_bound) (void)hipFree(c->d_bound);
     if (c->h_bound) (void)hipHostFree(c->h_bound);
     if (c->comm) (void)fx_comm_destroy(c);
@@ -483,6 +504,8 @@ int32_t fx_destroy(FxContext *c) {
         if (t.e0) (void)hipEventDestroy(t.e0);
         if (t.e_eval) (void)hipEventDestroy(t.e_eval);
         if (t.e_end) (void)hipEventDestroy(t.e_end);
+        if (t.e_obs0) (void)hipEventDestroy(t.e_obs0);
+        if (t.e_obs1) (void)hipEventDestroy(t.e_obs1);
     }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -629,6 +652,32 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         // trade at scale, four spill inside the obstacle loop (tools/obst_sweep.py)
         bool obst_any = false;
         for (int a = 0; a < n_agents; a++) obst_any |= probs[a].K > 0 || ((probs[a].mode & FX_MODE_ROAD_BOUNDARY) && probs[a].n_bound > 0);
+        // Obstacle stage as its own (candidate x step)-parallel kernel behind the walk (fx_obstacle_kernel.h): for grids whose
+        // walk leaves most of the chip's issue slots idle (two lanes per candidate: 200 ... 3 072 waves) the K x S visits of a
+        // candidate run at the walk's one or two waves per SIMD when fused; on their own they fill every SIMD.  Needs the
+        // materialised planes (x, y, theta are read back), at most 64 obstacles and no road-boundary stage (that one stays in
+        // the walk).  tools/c3_split.py: config 3 94.7 vs 98.6 - 105 us per step, config 5's agent with a bundle 240 vs 280 us,
+        // 10 000 candidates equal, 3 060 and 1 M candidates slower.
+        {
+            const int CH = c->obst_CH ? c->obst_CH : 3;
+            bool any_k = false, ok = !extra_any;
+            size_t lds = 0;
+            for (int a = 0; a < n_agents; a++) {
+                const FxProblem *p = &probs[a];
+                if ((p->mode & FX_MODE_ROAD_BOUNDARY) && p->n_bound > 0) ok = false;
+                if (p->K <= 0) continue;
+                any_k = true;
+                if (p->K > 64 || !(p->mode & FX_MODE_WRITE_BUNDLE)) ok = false;
+                lds = std::max(lds, sizeof(double) * 6 * (size_t)CH * (size_t)p->K);
+            }
+            if (c->obst_force == 2 && any_k && !ok)
+                return set_err(FX_ERR_INVALID_ARGUMENT, "obstacle kernel forced but not applicable (needs FX_MODE_WRITE_BUNDLE, K <= 64, no road "
+                               "boundary, no windowed cost term)");
+            // (a forced work decomposition -- fx_set_tuning -- runs as asked: the automatic choice only follows the automatic G)
+            c->split_step = any_k && ok && (c->obst_force == 2 || (c->obst_force == 0 && G == 2 && !c->G_force));
+            c->split_CH = CH; c->obs_lds_step = lds;
+            if (c->split_step) obst_any = false;   // the walk is tuned and built without the stage
+        }
         // a materialised bundle makes the walk store-bound: more resident waves only add spills (1 M candidates, Mode B:
         // 651 us at 2 waves per SIMD, 697 us at 4 -- tools/sweep_1m_modeB.py)
         bool bundle_any = false;
@@ -644,7 +693,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         int block = FX_BLOCK;
         if (grid_ok) {
             size_t hot_block = 0;
-            for (int a = 0; a < n_agents; a++)
+            for (int a = 0; a < n_agents && !c->split_step; a++)   // (no staging blocks when the obstacle stage is its own kernel)
                 hot_block = std::max(hot_block, align_up(sizeof(double) * FX_HOT_STRIDE * (size_t)std::max(probs[a].K, 0), 16));
             auto lds_for = [&](int blk) {
                 size_t need = 0;
@@ -695,10 +744,11 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     }
     const int CPB = c->block_step / c->G_step;
     int64_t cand_off = 0, block_off = 0;
-    size_t planes_need = 0;
+    size_t planes_need = 0, obs_part_need = 0, obs_colm_need = 0, obs_tick_need = 0;
     c->any_bundle = c->any_obst = c->any_extra = false;
     c->fusable_step = true;
     c->max_blocks_step = 0;
+    c->obs_blocks_step = 0;
     c->M_max_step = 0;
     c->K_max_step = 0;
     c->S_max_step = 0;
@@ -816,12 +866,27 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         }
         if (!ok) return set_err(FX_ERR_CAPACITY, "input arena too small (%zu bytes)", c->in_bytes);
         d.cost = c->d_cost + cand_off;
+        d.cost_tail = c->d_cost_tail + cand_off;
         d.flags = c->d_flags + cand_off;
         d.costmap = c->d_costmap + (size_t)FX_NUM_COSTS * cand_off;  // [n_cost][ld] inside this agent's slab
         d.coeffs = c->d_coeffs + (size_t)12 * cand_off;
         d.traj_len = c->d_trajlen + cand_off;
         d.bound_step = c->d_bstep + cand_off;
-        d.n_blocks = (int)((C + CPB - 1) / CPB);
+        const int walk_blocks = (int)((C + CPB - 1) / CPB);
+        d.n_blocks = walk_blocks;
+        const bool deferred = c->split_step && p->K > 0;
+        if (deferred) {   // the obstacle kernel writes this agent's arg-min partials: one per tile of 64 candidates
+            d.mode |= FX_MODE_INT_DEFER_OBST;
+            const int n_tiles = (int)((C + 63) / 64), NC = (S - 1 + c->split_CH - 1) / c->split_CH;
+            d.n_blocks = n_tiles;
+            c->obs_blocks_step = std::max(c->obs_blocks_step, n_tiles * NC);
+            d.obs_part = reinterpret_cast<double *>(obs_part_need);      // offsets for now, patched below
+            d.obs_colm = reinterpret_cast<unsigned long long *>(obs_colm_need);
+            d.obs_ticket = reinterpret_cast<unsigned int *>(obs_tick_need);
+            obs_part_need += (size_t)NC * (size_t)ld;
+            obs_colm_need += (size_t)NC * (size_t)n_tiles;
+            obs_tick_need += (size_t)n_tiles;
+        }
         if (block_off + d.n_blocks > c->max_blocks_total)
             return set_err(FX_ERR_CAPACITY, "agent %d: %lld workgroups exceed the partial-result capacity %lld", a,
                            (long long)(block_off + d.n_blocks), (long long)c->max_blocks_total);
@@ -835,10 +900,10 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             planes_need += sizeof(double) * FX_NUM_PLANES * (size_t)S * (size_t)ld;
             c->any_bundle = true;
         }
-        c->any_obst |= p->K > 0 || (d.mode & FX_MODE_ROAD_BOUNDARY);
-        if ((d.mode & FX_MODE_COLLISION) || d.n_blocks == 0) c->fusable_step = false;
+        c->any_obst |= (p->K > 0 && !deferred) || (d.mode & FX_MODE_ROAD_BOUNDARY);
+        if ((d.mode & FX_MODE_COLLISION) || d.n_blocks == 0 || deferred) c->fusable_step = false;
         c->any_extra |= extra;
-        c->max_blocks_step = std::max(c->max_blocks_step, d.n_blocks);
+        c->max_blocks_step = std::max(c->max_blocks_step, walk_blocks);
         c->M_max_step = std::max(c->M_max_step, p->M);
         c->K_max_step = std::max(c->K_max_step, std::max(p->K, 0));
         c->S_max_step = std::max(c->S_max_step, S);
@@ -859,6 +924,32 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             if (c->h_probs[a].mode & FX_MODE_WRITE_BUNDLE)
                 c->h_probs[a].planes = reinterpret_cast<double *>(reinterpret_cast<char *>(c->d_planes) +
                                                                   reinterpret_cast<size_t>(c->h_probs[a].planes));
+    }
+    if (obs_part_need) {   // scratch of the obstacle kernel: grown on demand, tickets start (and are left) zeroed
+        if (obs_part_need > c->obs_part_cap || obs_colm_need > c->obs_colm_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->d_obs_part) { (void)hipFree(c->d_obs_part); c->dev_bytes -= (int64_t)(sizeof(double) * c->obs_part_cap); }
+            if (c->d_obs_colm) { (void)hipFree(c->d_obs_colm); c->dev_bytes -= (int64_t)(sizeof(unsigned long long) * c->obs_colm_cap); }
+            c->d_obs_part = nullptr; c->d_obs_colm = nullptr;
+            c->obs_part_cap = c->obs_colm_cap = 0;
+            int rc;
+            if ((rc = dev_alloc(c, &c->d_obs_part, obs_part_need))) return rc;
+            if ((rc = dev_alloc(c, &c->d_obs_colm, obs_colm_need))) return rc;
+            c->obs_part_cap = obs_part_need; c->obs_colm_cap = obs_colm_need;
+        }
+        if (!c->d_obs_ticket) {
+            int rc;
+            const size_t n_tick = (size_t)(c->total_ld / 64) + (size_t)c->max_agents;
+            if ((rc = dev_alloc(c, &c->d_obs_ticket, n_tick))) return rc;
+            HIP_TRY(hipMemset(c->d_obs_ticket, 0, sizeof(unsigned int) * n_tick));
+        }
+        for (int a = 0; a < n_agents; a++) {
+            DevProblem &d = c->h_probs[a];
+            if (!(d.mode & FX_MODE_INT_DEFER_OBST)) continue;
+            d.obs_part = c->d_obs_part + reinterpret_cast<size_t>(d.obs_part);
+            d.obs_colm = c->d_obs_colm + reinterpret_cast<size_t>(d.obs_colm);
+            d.obs_ticket = c->d_obs_ticket + reinterpret_cast<size_t>(d.obs_ticket);
+        }
     }
     c->n_agents = n_agents;
     c->in_used = ar.off;
@@ -931,6 +1022,13 @@ int32_t fx_evaluate(FxContext *c) {
                                    c->G_step, c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, k0, k1, fuse, c->stream));
     }
     if (timed && !attached) HIP_TRY(hipEventRecord(ts->e_eval, c->stream));
+    if (timed) ts->obst_timed = false;
+    if (c->split_step && c->obs_blocks_step > 0) {
+        const bool t_obs = timed && c->timing == FX_TIMING_KERNEL;
+        HIP_TRY(fx_launch_obstacle(c->d_probs, c->n_agents, c->obs_blocks_step, c->obs_lds_step, c->split_CH,
+                                   t_obs ? ts->e_obs0 : nullptr, t_obs ? ts->e_obs1 : nullptr, c->stream));
+        if (timed) ts->obst_timed = t_obs;
+    }
     if (!c->fused_step) {
         // with a package the selection's publishing workgroup gathers the winner's arrays itself (no further launch)
         HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, winner, c->pkg_step ? c->h_pkg_dev : nullptr,
@@ -1695,6 +1793,44 @@ int32_t fx_step_info(const FxContext *c, int64_t *out10) {
     const int64_t v[10] = {c->use_grid, c->G_step, c->wpe_step, c->block_step, c->wsplit_step, c->fused_step, c->max_blocks_step,
                            c->n_agents, c->pkg_step, (int64_t)c->lds_step};
     memcpy(out10, v, sizeof(v));
+    return FX_OK;
+}
+
+int32_t fx_set_obstacle_stage(FxContext *c, int32_t stage, int32_t steps_per_item) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (stage < 0 || stage > 2) return set_err(FX_ERR_INVALID_ARGUMENT, "stage must be 0 (auto), 1 (fused into the walk) or 2 (own kernel)");
+    if (steps_per_item != 0 && steps_per_item != 2 && steps_per_item != 3 && steps_per_item != 5)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "steps_per_item must be 0 (auto), 2, 3 or 5");
+    c->obst_force = stage; c->obst_CH = steps_per_item;
+    return FX_OK;
+}
+double fx_last_obstacle_kernel_ms(const FxContext *cc) {
+    FxContext *c = const_cast<FxContext *>(cc);
+    if (!c || !c->evaluated || c->n_timed == 0) return 0.0;
+    FxContext::TimeSlot &t = c->ring[(c->n_timed - 1) % FxContext::kTimeRing];
+    return fetch_slot(c, t) ? 0.0 : (double)t.obst_ms;
+}
+int32_t fx_read_obstacle_kernel_times(FxContext *c, int32_t max_n, double *obst_ms, int32_t *n_out) {
+    if (!c || max_n < 0 || !n_out) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_read_obstacle_kernel_times: bad argument");
+    const long long have = std::min<long long>(c->n_timed, FxContext::kTimeRing);
+    const int n = (int)std::min<long long>(have, max_n);
+    for (int k = 0; k < n; k++) {  // oldest of the returned window first
+        FxContext::TimeSlot &t = c->ring[(c->n_timed - n + k) % FxContext::kTimeRing];
+        int rc = fetch_slot(c, t);
+        if (rc) return rc;
+        if (obst_ms) obst_ms[k] = t.obst_ms;
+    }
+    *n_out = n;
+    return FX_OK;
+}
+// fx_step_info, extended: out[0 .. 9] as fx_step_info, [10] obstacle stage as its own kernel, [11] steps per work item, [12] work
+// items (waves) per agent (max) and [13] dynamic LDS bytes of that kernel, [14 .. 15] reserved
+int32_t fx_step_info_ex(const FxContext *c, int64_t *out16) {
+    if (!c || !out16) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_step_info_ex: NULL argument");
+    int rc = fx_step_info(c, out16);
+    if (rc) return rc;
+    out16[10] = c->split_step; out16[11] = c->split_CH; out16[12] = c->obs_blocks_step; out16[13] = (int64_t)c->obs_lds_step;
+    out16[14] = out16[15] = 0;
     return FX_OK;
 }
 

@@ -10,6 +10,10 @@
 
 #define FX_BLOCK 256            // candidates per workgroup (4 wave64)
 #define FX_MODE_INT_STORE_WT (1u << 30)  // internal DevProblem.mode bit: write-through plane stores (fx_set_store_mode)
+// internal DevProblem.mode bit: the obstacle stage of this agent runs as its own (candidate x step)-parallel kernel behind the
+// walk (fx_obstacle_kernel.h): the walk leaves the cost sum up to the prediction term in cost[], the terms behind it in
+// cost_tail[], and no arg-min partial; the obstacle kernel completes cost / flags / cost map and writes the partials
+#define FX_MODE_INT_DEFER_OBST (1u << 29)
 #define FX_HOT_STRIDE 10        // doubles per (step, obstacle) entry of the hot obstacle table (80 B)
 #define FX_HOT_PRE 4            // table elements per lane prefetched one step ahead (covers K <= 25 obstacles)
 #define FX_TP 12                // doubles per step of the time table in LDS: t .. t^5, then 2t, 3t^2, 4t^3, 5t^4, 6t, 12t^2, 20t^3
@@ -68,6 +72,11 @@ struct DevProblem {
     // ---- outputs (device) ----
     int32_t *bound_step;       // [ld] first step that meets the road boundary, -1 if never (FX_MODE_ROAD_BOUNDARY)
     double *cost;              // [ld]
+    double *cost_tail;         // [ld] weighted cost terms ordered behind the prediction term (FX_MODE_INT_DEFER_OBST)
+    // obstacle kernel: partial prediction sums [chunks][ld], collision ballots [chunks][tiles], tile tickets
+    double *obs_part;
+    unsigned long long *obs_colm;
+    unsigned int *obs_ticket;
     uint32_t *flags;           // [ld]
     double *costmap;           // [n_cost][ld]      (FX_MODE_WRITE_COSTMAP)
     double *planes;            // [14][S][ld]       (FX_MODE_WRITE_BUNDLE)
@@ -119,6 +128,7 @@ struct ProblemRegs {
     double bound_d_reach;
     int32_t *bound_step;
     double *cost;
+    double *cost_tail;
     uint32_t *flags;
     double *costmap;
     double *planes;
@@ -145,7 +155,7 @@ struct ProblemRegs {
         r.hot_origin[0] = g.hot_origin[0]; r.hot_origin[1] = g.hot_origin[1]; r.hot_gap_margin = g.hot_gap_margin;
         r.n_bound = g.n_bound; r.bound_piece = g.bound_piece; r.bound_bin = g.bound_bin; r.bound_item = g.bound_item;
         r.bound_d_reach = g.bound_d_reach; r.bound_step = g.bound_step;
-        r.cost = g.cost; r.flags = g.flags; r.costmap = g.costmap; r.planes = g.planes; r.coeffs = g.coeffs;
+        r.cost = g.cost; r.cost_tail = g.cost_tail; r.flags = g.flags; r.costmap = g.costmap; r.planes = g.planes; r.coeffs = g.coeffs;
         r.traj_len = g.traj_len; r.part_cost = g.part_cost; r.part_idx = g.part_idx; r.counters = g.counters;
         r.n_blocks = g.n_blocks;
         return r;
@@ -164,8 +174,17 @@ extern __device__ unsigned long long fx_probe_stamps[FX_PROBE_WAVES * FX_PROBE_S
         if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && w_ < FX_PROBE_WAVES)                                   \
             fx_probe_stamps[(size_t)w_ * FX_PROBE_SLOTS + (k)] = (k) == 0 || (k) == 15 ? wall_clock64() : clock64(); \
     } while (0)
+// the obstacle kernel's own stamp block (it runs behind the walk and would overwrite the walk's stamps)
+extern __device__ unsigned long long fx_probe_stamps_obs[FX_PROBE_WAVES * FX_PROBE_SLOTS];
+#define FX_OSTAMP(k)                                                                                             \
+    do {                                                                                                         \
+        const unsigned w_ = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));                               \
+        if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && w_ < FX_PROBE_WAVES)                                   \
+            fx_probe_stamps_obs[(size_t)w_ * FX_PROBE_SLOTS + (k)] = (k) == 0 || (k) == 15 ? wall_clock64() : clock64(); \
+    } while (0)
 #else
 #define FX_STAMP(k) do { } while (0)
+#define FX_OSTAMP(k) do { } while (0)
 #endif
 
 // winner package tail behind the [14][S] planes (doubles): lon6 lat6 | raw[FX_NUM_COSTS] | cost | traj_len | flags | index | found

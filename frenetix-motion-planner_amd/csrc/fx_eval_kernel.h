@@ -334,6 +334,12 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
 
     FX_STAMP(6);
     // ---- weighted cost sum in name-sorted order (cost_function.py:78-91) ----
+    // Deferred obstacle stage (FX_MODE_INT_DEFER_OBST, only in kernels built without the stage): the prediction term is not
+    // known yet -- cost[] receives the running sum in front of it, cost_tail[] the weighted terms behind it (by the ids'
+    // order that is velocity_offset alone), and fx_obstacle_kernel continues the same sequence of additions.
+    const bool defer = !OBST && (P.mode & FX_MODE_INT_DEFER_OBST) != 0;
+    bool have_pre = false;
+    double pre = 0.0, tail = 0.0;
     double total = 0.0;
     {
         const double tt = dt, tt2 = tt * tt, tt3 = tt2 * tt, tt4 = tt3 * tt, tt5 = tt4 * tt;
@@ -370,13 +376,16 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
             case FX_COST_DISTANCE_TO_OBSTACLES: c = EXTRA ? dto : 0.0; break;
             default: break;
             }
+            if (defer && id == FX_COST_PREDICTION) { pre = sum; have_pre = true; continue; }
             if ((P.mode & FX_MODE_WRITE_COSTMAP) && active && leader) as_global(P.costmap)[(int64_t)n * ld + g] = costed ? c : 0.0;
+            if (have_pre) tail += w * c;
             sum += w * c;
         }
         total = 0.0 + sum;
     }
     if (active && leader) {
-        as_global(P.cost)[g] = costed ? total : 0.0;
+        if (defer) as_global(P.cost_tail)[g] = tail;
+        as_global(P.cost)[g] = costed ? (have_pre ? pre : total) : 0.0;
         as_global(P.flags)[g] = flags;
         if (OBST && (P.mode & FX_MODE_ROAD_BOUNDARY)) as_global(P.bound_step)[g] = (selectable && off_road) ? (int)bound_step : -1;
     }
@@ -420,7 +429,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     if (wave != 0) return;
     for (int w = 1; w < (int)blockDim.x / 64; w++)
         if (red_cost[w] < bc || (red_cost[w] == bc && red_idx[w] < bi)) { bc = red_cost[w]; bi = red_idx[w]; }
-    if (lane == 0) {
+    if (lane == 0 && !defer) {   // deferred obstacle stage: fx_obstacle_kernel owns this agent's partials
         // agent-scope stores: visible to whichever XCD runs the reducing workgroup without an L2 write-back
         __hip_atomic_store(as_global(P.part_cost) + blockIdx.x, bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(as_global(P.part_idx) + blockIdx.x, (int64_t)bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

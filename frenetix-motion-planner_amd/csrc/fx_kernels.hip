@@ -25,6 +25,7 @@
 
 #include "fx_eval_kernel.h"
 #include "fx_eval_grid_kernel.h"
+#include "fx_obstacle_kernel.h"
 
 using fxk::wave_count;
 
@@ -32,6 +33,10 @@ using fxk::wave_count;
 __device__ unsigned long long fx_probe_stamps[FX_PROBE_WAVES * FX_PROBE_SLOTS];
 extern "C" int fx_probe_read(unsigned long long *out, size_t n_words) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fx_probe_stamps), n_words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+__device__ unsigned long long fx_probe_stamps_obs[FX_PROBE_WAVES * FX_PROBE_SLOTS];
+extern "C" int fx_probe_read_obs(unsigned long long *out, size_t n_words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fx_probe_stamps_obs), n_words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
 }
 #endif
 
@@ -428,6 +433,23 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
 #undef FX_W
 #undef FX_BO
 #undef FX_LAUNCH
+}
+
+// The obstacle stage as its own kernel (fx_obstacle_kernel.h): grid = (max tiles x chunks, n_agents), one wave per item,
+// dynamic LDS = CH * K * 48 B.
+extern "C" hipError_t fx_launch_obstacle(const DevProblem *d_probs, int n_agents, int max_items, size_t lds_bytes, int CH,
+                                         hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t stream) {
+#define FX_LAUNCH(CHv)                                                                                                                \
+    do {                                                                                                                            \
+        hipExtLaunchKernelGGL((fxk::fx_obstacle_kernel<CHv, 4>), dim3(max_items, n_agents), dim3(64), lds_bytes, stream, ev_start, ev_stop, \
+                              0, d_probs);                                                                                          \
+        return hipGetLastError();                                                                                                   \
+    } while (0)
+    if (CH == 2) FX_LAUNCH(2);
+    if (CH == 3) FX_LAUNCH(3);
+    if (CH == 5) FX_LAUNCH(5);
+#undef FX_LAUNCH
+    return hipErrorInvalidValue;
 }
 
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,

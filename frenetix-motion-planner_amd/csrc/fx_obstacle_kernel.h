@@ -1,0 +1,330 @@
+// fx_obstacle_kernel.h -- the obstacle stage as its own (candidate x step)-parallel kernel.
+//
+// Prediction cost (collision_probability.py:264-299, called from partial_cost_functions.py:341-356) and the OBB-sum collision
+// walk (planner.py:329-392, collision_check.py:110-200) of a candidate have no step-to-step dependency once
+// (x, y, theta_gl) exist.  Inside the walk they run with the walk's occupancy -- one or two waves per SIMD, ~230 VGPRs --
+// although a visit is ten independent FP64 operations.  For grids whose walk does not fill the chip the host therefore splits
+// the step (FX_MODE_INT_DEFER_OBST): the walk kernel (built without the stage) materialises the planes and leaves the cost sum
+// open at the prediction term; this kernel reads x / y / theta back from the planes, visits every (candidate, step, obstacle),
+// closes the cost sum, sets the collision flag and writes the per-tile (cost, index) arg-min partials the selection reduces.
+//
+// Work items.  One wave = one (tile of 64 candidates, chunk of CH steps): no workgroup barrier, a wave-private operand table in
+// LDS, items small enough for the dispatcher to balance (config 3: 788 tiles x 10 chunks over 1 024 SIMDs).  The rows of
+// x / y / theta the chunk needs are requested in ONE round of global loads at entry, together with the chunk's slice of the hot
+// obstacle table.  The chunks of a tile meet through global memory: every wave stores its partial prediction sum per candidate
+// and its collision ballot (agent-scope stores), waits for them, and takes the tile's ticket; the wave that draws the last
+// ticket adds the partials in chunk order (deterministic), closes the candidates and leaves the ticket zeroed for the next
+// step.
+//
+// Operands.  The step index of a wave is uniform, so are the obstacle operands.  Of the five per (step, obstacle) -- the
+// Cholesky-whitened inverse covariance l11, l12, l22 and the transformed centre cu, cw (fx_walk.h, ObsHot) -- the three
+// multipliers come in through SCALAR loads straight from the hot table (a VALU instruction takes one scalar operand: each of
+// them has its own FMA) and only the two addends travel through LDS, 16 B per visit.
+//
+// Collision.  Per step the ego box (rear axle + wb along the heading, state.py:30-39) is rebuilt from (x, y, theta) -- one
+// sincos per (candidate, step), the box of the previous step is carried --, then exactly the walk's sequence: OBB-sum hull of
+// boxes (i-1, i), one bounding circle for the wave's 64 hulls against which lane k tests obstacle k, the expanded circle test
+// per lane for the survivors, the exact 4-axis test on the raw records for what is still near (same obb_hull / obb_overlap as
+// the walk: decisions are those of the brute-force definition).
+//
+// Measured (MI355X, tools/c3_split.py): config 3 walk 39.8 us + this kernel 41 us against 85 - 91 us fused (step 94.7 vs
+// 98.6 - 105 us); config 5's agent with a bundle 240 vs 280 us; 10 000-candidate grids equal; 3 060 candidates and 1 M
+// candidates slower (44 vs 35 us, 1.10 vs 1.07 ms) -- the host picks it where two lanes share a candidate (200 ... 3 072 waves).
+// Of its 25 us without the collision stage ~5 are launch and the first round of loads, ~6 the hand-off chain (stores ->
+// ticket -> partials -> closing stores) at the kernel's tail; the visits themselves run at the FP64 issue rate.
+#pragma once
+
+#include "fx_eval_kernel.h"
+
+namespace fxk {
+
+// Prediction operands of one (step, obstacle): l11, l12, l22 in scalar registers, (cu, cw) in vector registers
+struct ObsEntry {
+    double l11, l12, l22;
+    fx_d2 cc;
+};
+__device__ __forceinline__ ObsEntry obs_load(const FX_GLOBAL double *hot_i, const fx_d2 *cc_i, int k) {
+    const FX_GLOBAL double *q = hot_i + (size_t)k * FX_HOT_STRIDE;
+    ObsEntry e;
+    e.l11 = q[FX_HOT_L11]; e.l12 = q[FX_HOT_L12]; e.l22 = q[FX_HOT_L22];
+    e.cc = cc_i[k];
+    return e;
+}
+// m^2 of one obstacle for the ego point (xr, yr) relative to the table's origin (fx_walk.h: same expression tree)
+__device__ __forceinline__ double obs_msq(const ObsEntry &e, double xr, double yr) {
+    const double u = fma(e.l11, xr, fma(e.l12, yr, -e.cc.x));
+    const double w = fma(e.l22, yr, -e.cc.y);
+    const double m = fma(u, u, w * w);
+    return m * m;
+}
+// 1/a + 1/b + 1/c + 1/d over one reciprocal (fx_walk.h: same expression tree as the fused stage)
+__device__ __forceinline__ double obs_four(double a, double b, double c, double d) {
+    const double ab = a * b, cd = c * d;
+    const double num = fma(a + b, cd, (c + d) * ab);
+    return num * rcp_pred(ab * cd);
+}
+
+// grid = (max tiles x chunks, n_agents), block = 64, dynamic LDS = CH * K * 48 B.  CH: steps per item (compile time: the rows
+// live in registers), WPS: waves per SIMD handed to the register allocator.
+template <int CH, int WPS>
+__global__ __launch_bounds__(64, WPS) void fx_obstacle_kernel(const DevProblem *__restrict__ probs) {
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];  // (cu, cw) [CH][K][2] | hull circles [CH][K][4]
+    const DevProblem &P = probs[blockIdx.y];
+    const uint32_t mode = P.mode;
+    if (!(mode & FX_MODE_INT_DEFER_OBST)) return;
+    const int S = P.S, K = P.K;
+    const int NC = (S - 1 + CH - 1) / CH;
+    const int64_t C = P.C, ld = P.ld;
+    const int tile = blockIdx.x / NC, chunk = blockIdx.x - tile * NC;
+    const int64_t c0 = (int64_t)tile * 64;
+    if (c0 >= C) return;
+    const int lane = threadIdx.x;
+    FX_OSTAMP(0);
+    const int64_t g_raw = c0 + lane;
+    const bool act = g_raw < C;
+    const int64_t g = act ? g_raw : C - 1;
+    const uint32_t f = as_global(P.flags)[g];
+
+    const int i_a = 1 + chunk * CH, i_b = min(S, i_a + CH);
+    const int64_t ps = (int64_t)S * ld;
+    const FX_GLOBAL double *__restrict__ pl = as_global(P.planes);
+    const bool col_mode = (mode & FX_MODE_COLLISION) != 0 && K > 0;
+    // ---- everything the chunk needs, requested before the flags are looked at (nearly every tile needs it) ----
+    // rows i_a - 1 .. i_b - 1 of x, y (and theta with the collision stage)
+    double xs[CH + 1], ys[CH + 1], ts[CH + 1];
+#pragma unroll
+    for (int j = 0; j <= CH; j++) {
+        const int i = min(i_a - 1 + j, S - 1);
+        xs[j] = pl[(int64_t)FX_PL_X * ps + (int64_t)i * ld + g];
+        ys[j] = pl[(int64_t)FX_PL_Y * ps + (int64_t)i * ld + g];
+        ts[j] = col_mode ? pl[(int64_t)FX_PL_THETA * ps + (int64_t)i * ld + g] : 0.0;
+    }
+    // the chunk's slice of the hot table -> LDS: per (step, obstacle) the addends (cu, cw) as one 16-byte pair, then the hull
+    // circles (hx2, hy2, hr2, ck) as 32 bytes; entry e of the slice is handled by lane e, e + 64, ... (two entries in flight)
+    const FX_GLOBAL double *__restrict__ hot_a = as_global(P.obs_hot) + (size_t)i_a * K * FX_HOT_STRIDE;
+    fx_d2 *__restrict__ cc_tab = reinterpret_cast<fx_d2 *>(lds_dyn);   // [CH][K]
+    double *__restrict__ circ_tab = lds_dyn + 2 * (size_t)CH * K;       // [CH][K][4]
+    {
+        const int n_e = (i_b - i_a) * K;
+        for (int e0 = lane; e0 < n_e; e0 += 128) {
+            double v[2][6];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int e = min(e0 + 64 * u, n_e - 1);
+                const FX_GLOBAL double *q = hot_a + (size_t)e * FX_HOT_STRIDE;
+                v[u][0] = q[FX_HOT_CU]; v[u][1] = q[FX_HOT_CW];
+                v[u][2] = q[FX_HOT_HX2]; v[u][3] = q[FX_HOT_HY2]; v[u][4] = q[FX_HOT_HR2]; v[u][5] = q[FX_HOT_CK];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int e = e0 + 64 * u;
+                if (e < n_e) {
+                    cc_tab[e] = fx_d2{v[u][0], v[u][1]};
+                    circ_tab[4 * e + 0] = v[u][2]; circ_tab[4 * e + 1] = v[u][3]; circ_tab[4 * e + 2] = v[u][4]; circ_tab[4 * e + 3] = v[u][5];
+                }
+            }
+        }
+    }
+
+    // where the prediction term sits in the (id-sorted) cost function
+    int n_pred = -1;
+    double w_pred = 0.0;
+    bool has_tail = false;
+    for (int n = 0; n < P.n_cost; n++)
+        if (P.cost_id[n] == FX_COST_PREDICTION) { n_pred = n; w_pred = P.cost_w[n]; has_tail = n + 1 < P.n_cost; }
+    // every chunk of a tile looks at the same 64 flag words: these are tile-uniform
+    const bool do_pred = n_pred >= 0 && K > 0 && wave_any_bit(act && (f & FX_FLAG_COSTED));
+    const bool do_col = col_mode && wave_any_bit(act && (f & FX_FLAG_SELECTABLE));
+    FX_OSTAMP(1);
+
+    double acc = 0.0;
+    bool collided = false;
+    const bool work = do_pred || do_col;
+    if (!work && chunk != 0) return;   // nothing to add: chunk 0 closes the tile on its own
+    if (work) {
+        const FX_GLOBAL double *__restrict__ rec = as_global(P.obs_rec);
+        const FX_GLOBAL unsigned long long *__restrict__ pmask = as_global(P.obs_pmask);
+        const FX_GLOBAL unsigned long long *__restrict__ hmask = as_global(P.obs_hmask);
+        const double ox = P.hot_origin[0], oy = P.hot_origin[1];
+        const double wb = P.veh.wb_rear_axle, half_len = P.veh.length / 2, half_wid = P.veh.width / 2;
+        const double gap_margin = P.hot_gap_margin;
+        const unsigned long long full = K >= 64 ? ~0ULL : ((1ULL << K) - 1ULL);
+        const int kl = min(lane, K - 1);
+        // the table writes above are this wave's own: LDS operations of one wave execute in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double bxp = 0.0, byp = 0.0, uxp = 0.0, uyp = 0.0;
+        if (do_col) {   // ego box of step i_a - 1
+            double sn, cs;
+            fxm::sincos(ts[0], &sn, &cs);
+            bxp = fma(wb, cs, xs[0]); byp = fma(wb, sn, ys[0]); uxp = cs; uyp = sn;
+        }
+        FX_OSTAMP(2);
+#pragma unroll
+        for (int j = 1; j <= CH; j++) {
+            const int i = i_a + j - 1;
+            if (i < i_b) {
+                const unsigned long long pm = do_pred ? uniform_u64(pmask[i]) : 0ULL;
+                const unsigned long long hm = (do_col && i >= 2) ? uniform_u64(hmask[i]) : 0ULL;
+                const FX_GLOBAL double *__restrict__ hot_i = hot_a + (size_t)(j - 1) * K * FX_HOT_STRIDE;
+                const fx_d2 *__restrict__ cc_i = cc_tab + (size_t)(j - 1) * K;
+                const double *__restrict__ circ_i = circ_tab + 4 * (size_t)(j - 1) * K;
+                // ---- prediction cost: sum over the obstacles of 1 / m^2 (collision_probability.py:283-292) ----
+                if (pm) {
+                    const double xr = xs[j] - ox, yr = ys[j] - oy;
+                    double ssum = 0.0;
+                    auto ld_ = [&](int k) { return obs_load(hot_i, cc_i, k); };
+                    if (pm == full) {
+                        // four obstacles per iteration in two alternating register sets: the loads of one pair are in flight
+                        // while the other pair is consumed
+                        ObsEntry a = ld_(0), b = ld_(K > 1 ? 1 : 0), c, d;
+                        int k = 0;
+                        for (; k + 5 < K; k += 4) {
+                            c = ld_(k + 2); d = ld_(k + 3);
+                            const double qa = obs_msq(a, xr, yr), qb = obs_msq(b, xr, yr);
+                            a = ld_(k + 4); b = ld_(k + 5);
+                            ssum += obs_four(qa, qb, obs_msq(c, xr, yr), obs_msq(d, xr, yr));
+                        }
+                        // entries k (a) and k + 1 (b) are loaded; up to five remain
+                        for (; k + 3 < K; k += 2) {
+                            c = ld_(k + 2); d = ld_(k + 3);
+                            ssum += rcp_pred(obs_msq(a, xr, yr)) + rcp_pred(obs_msq(b, xr, yr));
+                            a = c; b = d;
+                        }
+                        ssum += rcp_pred(obs_msq(a, xr, yr));
+                        if (k + 1 < K) ssum += rcp_pred(obs_msq(b, xr, yr));
+                        if (k + 2 < K) ssum += rcp_pred(obs_msq(ld_(k + 2), xr, yr));
+                    } else {
+                        unsigned long long m = pm;
+                        while (m) {
+                            const int k = __builtin_ctzll(m);
+                            m &= m - 1;
+                            ssum += rcp_pred(obs_msq(ld_(k), xr, yr));
+                        }
+                    }
+                    // anything not finite (an obstacle centre hit to the last bit, a covariance without a Cholesky factor: the
+                    // host leaves a zero entry) sends the step to the reference form on the raw records -- rare
+                    if (wave_any_bit(!(ssum < 1e300))) {
+                        const auto rec_i = rec + (int64_t)i * K * 12;
+                        double a = 0.0;
+                        unsigned long long m = pm;
+                        while (m) {
+                            const int k = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const auto q = rec_i + k * 12;
+                            const double e0 = xs[j] - q[0], e1 = ys[j] - q[1];
+                            const double r0 = fma(e1, q[4], e0 * q[2]), r1 = fma(e1, q[5], e0 * q[3]);
+                            const double mq = fma(r1, e1, r0 * e0);
+                            const double mm = mq * mq;
+                            a += mm > 0.0 ? rcp_pred(mm) : 1.0 / mm;
+                        }
+                        ssum = !(ssum < 1e300) ? a : ssum;
+                    }
+                    acc += ssum;
+                }
+                // ---- collision: OBB-sum hull of ego boxes (i-1, i) against the obstacle hulls of this step ----
+                if (do_col) {
+                    double sn, cs;
+                    fxm::sincos(ts[j], &sn, &cs);
+                    const double bx = fma(wb, cs, xs[j]), by = fma(wb, sn, ys[j]);
+                    if (hm) {
+                        const auto rec_i = rec + (int64_t)i * K * 12;
+                        const Obb hull = obb_hull(bxp, byp, uxp, uyp, bx, by, cs, sn, half_len, half_wid);
+                        // the walk's broad phase (fx_walk.h): circles around the hulls, one bound for the wave, lane k tests obstacle k
+                        const double re = (hull.h1 + hull.h2) * 1.000001;
+                        const double cxr = hull.cx - ox, cyr = hull.cy - oy;
+                        const double wq = fma(cxr, cxr, fma(cyr, cyr, -re * re));
+                        unsigned long long cand;
+                        {
+                            const double *qo = circ_i + 4 * (size_t)kl;
+                            const double c0x = uniform_f64(cxr), c0y = uniform_f64(cyr);
+                            const double dx = cxr - c0x, dy = cyr - c0y;
+                            const double q = fma(dx, dx, dy * dy);
+                            const bool bad = !(q + re < 1e300);   // a hull that is not finite keeps every obstacle on the exact path
+                            const float reach = fmaf(__builtin_amdgcn_sqrtf((float)q), 1.00001f, (float)re * 1.00001f);
+                            const unsigned rb = wave_max_u32(bad ? 0u : __float_as_uint(reach));  // reach >= 0: bit patterns order like values
+                            const double Rw = (double)__uint_as_float(rb);
+                            const double ex = fma(-0.5, qo[0], -c0x), ey = fma(-0.5, qo[1], -c0y);   // h - c0
+                            const double rr = fma(-0.5, qo[2], Rw) * 1.00001;                        // r_o + R
+                            cand = __builtin_amdgcn_ballot_w64(!(fma(ex, ex, ey * ey) > rr * rr)) & hm;
+                            if (wave_any_bit(bad)) cand = hm;
+                        }
+                        while (cand) {
+                            const int k = __builtin_ctzll(cand);
+                            cand &= cand - 1;
+                            const double *q = circ_i + 4 * (size_t)k;
+                            const double gq = fma(q[0], cxr, fma(q[1], cyr, fma(q[2], re, q[3] + wq)));
+                            if (wave_any_bit(!(gq > gap_margin))) collided |= obb_overlap(hull, rec_i + k * 12 + 6);
+                        }
+                    }
+                    bxp = bx; byp = by; uxp = cs; uyp = sn;
+                }
+            }
+        }
+    }
+    FX_OSTAMP(4);
+    FX_GLOBAL double *__restrict__ part = as_global(P.obs_part);
+    FX_GLOBAL unsigned long long *__restrict__ colm = as_global(P.obs_colm);
+    FX_GLOBAL unsigned int *__restrict__ ticket = as_global(P.obs_ticket);
+    const int64_t n_tiles = (C + 63) / 64;
+    if (work) {
+        // hand-off: agent-scope stores, acknowledged (vmcnt 0) before the ticket is taken -- whoever draws the last ticket
+        // sees every chunk's partial
+        __hip_atomic_store(part + (int64_t)chunk * ld + g_raw, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // g_raw < ld
+        const unsigned long long cm = __builtin_amdgcn_ballot_w64(collided);
+        if (lane == 0) __hip_atomic_store(colm + (int64_t)chunk * n_tiles + tile, cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(ticket + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = __builtin_amdgcn_readfirstlane(t);
+        FX_OSTAMP(5);
+        if (t != (unsigned)(NC - 1)) return;
+        if (lane == 0) __hip_atomic_store(ticket + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- close the tile: partials in chunk order ----
+    double pred = 0.0;
+    unsigned long long cmask = 0ULL;
+    if (work) {
+        for (int q = 0; q < NC; q++) {
+            pred += __hip_atomic_load(part + (int64_t)q * ld + g_raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cmask |= __hip_atomic_load(colm + (int64_t)q * n_tiles + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    uint32_t fl = f;
+    const bool costed = (fl & FX_FLAG_COSTED) != 0, selectable = (fl & FX_FLAG_SELECTABLE) != 0;
+    double total = as_global(P.cost)[g];
+    if (n_pred >= 0) {
+        // the walk left the running sum in front of the prediction term: continue the same sequence of additions
+        double sum = total;
+        sum += w_pred * pred;
+        if (has_tail) sum += as_global(P.cost_tail)[g];
+        total = 0.0 + sum;
+        if (act) {
+            as_global(P.cost)[g] = costed ? total : 0.0;
+            if (mode & FX_MODE_WRITE_COSTMAP) as_global(P.costmap)[(int64_t)n_pred * ld + g] = costed ? pred : 0.0;
+        }
+    }
+    if (selectable && (mode & FX_MODE_COLLISION) && ((cmask >> lane) & 1ULL)) {
+        fl |= FX_FLAG_COLLISION;
+        if (act) as_global(P.flags)[g] = fl;
+    }
+    // (cost, index) arg-min of the tile as finish_candidate forms it: candidate indices grow with the lane, so the minimum is the
+    // lowest lane that holds the minimum cost
+    const bool eligible = act && selectable && !(fl & (FX_FLAG_COLLISION | FX_FLAG_BOUNDARY)) && total == total;
+    const double bc = eligible ? total : INFINITY;
+    long long bi = eligible ? (long long)(g_raw + P.g_base) : 0x7fffffffffffffffLL;
+    double m = bc;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off));
+    const unsigned long long hit = __ballot(eligible && bc == m);
+    const int src = hit ? __ffsll((long long)hit) - 1 : 0;
+    bi = hit ? __shfl(bi, src) : 0x7fffffffffffffffLL;
+    if (lane == 0) {
+        as_global(P.part_cost)[tile] = m;
+        as_global(P.part_idx)[tile] = (int64_t)bi;
+    }
+    FX_OSTAMP(15);
+}
+
+}  // namespace fxk

@@ -223,13 +223,31 @@ class FrenetEngine:
         """Selection fused into the evaluation kernel (default on; applies when no agent runs the collision stage)."""
         check(lib().fx_set_fused_selection(self._ctx, int(bool(enabled))))
 
+    def set_obstacle_stage(self, stage: int = 0, steps_per_item: int = 0):
+        """Where the obstacle stage runs: 0 auto, 1 fused into the walk, 2 its own (candidate x step)-parallel kernel
+        (fx_set_obstacle_stage; steps_per_item 0 auto / 2 / 3 / 5); takes effect at the next upload.  Decisions are unaffected."""
+        check(lib().fx_set_obstacle_stage(self._ctx, int(stage), int(steps_per_item)))
+        self._resident_key = None   # the decomposition is chosen at upload time
+        self._resident_keys = None
+
     def step_info(self) -> dict:
-        """how the last evaluation was launched (fx_step_info)"""
-        v = np.zeros(10, np.int64)
-        check(lib().fx_step_info(self._ctx, v.ctypes.data))
+        """how the last evaluation was launched (fx_step_info_ex)"""
+        v = np.zeros(16, np.int64)
+        check(lib().fx_step_info_ex(self._ctx, v.ctypes.data))
         keys = ("grid_kernel", "lanes_per_candidate", "waves_per_simd", "block", "wave_split", "fused_selection", "blocks", "agents",
-                "package", "lds_bytes")
+                "package", "lds_bytes", "obstacle_kernel", "obstacle_steps_per_item", "obstacle_items", "obstacle_lds_bytes")
         return dict(zip(keys, (int(x) for x in v)))
+
+    def obstacle_kernel_times(self, max_n: int = 256):
+        """obstacle-kernel ms of the most recent timed steps, oldest first (0 where the stage ran fused)"""
+        ob = np.zeros(max_n, dtype=np.float64)
+        n = C.c_int32(0)
+        check(lib().fx_read_obstacle_kernel_times(self._ctx, max_n, ob.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n)))
+        return ob[:n.value]
+
+    @property
+    def last_obstacle_kernel_ms(self) -> float:
+        return float(lib().fx_last_obstacle_kernel_ms(self._ctx))
 
     TIMING = {"off": 0, "stream": 1, "kernel": 2}
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 4
+#define FX_ABI_VERSION 5
 
 /* ---- status codes (planner.py / reactive_planner_cpp.py raise Python exceptions; the shim maps
  *      <0 -> ValueError, >0 -> RuntimeError, see SURVEY 8b "Error conventions") ---- */
@@ -222,6 +222,14 @@ int32_t fx_set_block_size(FxContext *ctx, int32_t block_size);
  * whole bundle is small (measured on MI355X: 42 vs 45 us at 175 MB, 780 vs 650 us at 3.5 GB).  Results are unaffected. */
 int32_t fx_set_store_mode(FxContext *ctx, int32_t store_mode);
 
+/* where the obstacle stage (prediction cost collision_probability.py:264-299 + OBB-sum collision walk planner.py:329-392) runs:
+ * 0 auto, 1 fused into the horizon walk, 2 as its own (candidate x step)-parallel kernel behind the walk -- it reads x / y /
+ * theta back from the materialised planes, so it needs FX_MODE_WRITE_BUNDLE, at most 64 obstacles, no road-boundary stage and
+ * no windowed cost term (FX_ERR_INVALID_ARGUMENT at the next upload otherwise).  steps_per_item (0 auto, 2, 3, 5): horizon steps
+ * one wave of that kernel visits.  Decisions (flags, counters, winner) do not depend on either; the prediction cost is summed
+ * in a different order (agreement 1e-13 relative). */
+int32_t fx_set_obstacle_stage(FxContext *ctx, int32_t stage, int32_t steps_per_item);
+
 /* ---- staging: copy the shared inputs of a plan step to the device (borrowed for the call).
  *      Replaces handler.generate_trajectories(matrix, low_vel_mode) + the functor registration
  *      at reactive_planner_cpp.py:96-178,256. ---- */
@@ -384,6 +392,13 @@ int32_t fx_set_fused_selection(FxContext *ctx, int32_t enabled);
 /* how the last evaluation was launched: grid kernel, lanes per candidate, waves per SIMD, workgroup size, wave split, fused
  * selection, workgroups per agent, agents, winner package, dynamic LDS bytes */
 int32_t fx_step_info(const FxContext *ctx, int64_t *out10);
+/* the same ten values, then: [10] obstacle stage ran as its own kernel, [11] its steps per work item, [12] work items (waves) per
+ * agent (max), [13] dynamic LDS bytes, [14 .. 15] reserved */
+int32_t fx_step_info_ex(const FxContext *ctx, int64_t *out16);
+/* HIP-event time of the obstacle kernel of the latest timed step / of the most recent <= max_n timed steps (FX_TIMING_KERNEL;
+ * 0 where the stage ran fused into the walk) */
+double fx_last_obstacle_kernel_ms(const FxContext *ctx);
+int32_t fx_read_obstacle_kernel_times(FxContext *ctx, int32_t max_n, double *obst_ms, int32_t *n_out);
 /* per-step HIP-event timing (default FX_TIMING_OFF: fx_finish only polls the result block the kernel publishes
  * into pinned host memory).  FX_TIMING_STREAM -- stream events around the kernels (the evaluation figure includes
  * the dispatch gap in front of the kernel); FX_TIMING_KERNEL -- start/stop events attached to the evaluation
