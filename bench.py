@@ -61,14 +61,8 @@ NORTH_STAR_GRID = (19, 230, 229)  # 19 x 230 x 230 (d0 added) = 1 005 100 candid
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: FP64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
 LEAD_GAP = 25.0                # obstacle 0 is a slow lead vehicle 25 m ahead (the cheapest candidates collide)
 STRESS_GRID = (39, 51, 51)     # config 5: T = 1.1 .. 4.9 (39) x 51 x 51 (+ d0), 5 s horizon
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r2", "summary.json")  # rocprofv3 summaries of these commands (tools/collect_profiles_r2.sh)
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r3", "summary.json")  # rocprofv3 summaries of these commands (tools/collect_profiles_r3.sh)
 UPSTREAM_NOTE = "upstream OpenMP C++ handler (frenetix 0.4.0): not run -- not installable offline, not in the reference tree"
-
-
-def algorithmic_flops_per_candidate(n_samples, n_obstacles):
-    """SURVEY.md 8(d) planning figure: ~5.5 kflop per candidate at 31 samples without obstacles (~177 flop per step) plus
-    ~100 flop per (obstacle, step).  Only used where no executed-work count is available (config 5)."""
-    return 177.0 * n_samples + 100.0 * n_obstacles * (n_samples - 1)
 
 
 def bundle_bytes_per_candidate(n_samples):
@@ -82,11 +76,33 @@ def profile_summary():
         return {}
 
 
-def executed_fp64_flops(section):
-    """FP64 flops one launch EXECUTES, from the tracked PMC summary of the same workload: 64 lanes x (ADD + MUL + 2 FMA +
-    transcendental) wave-instructions (SQ_INSTS_VALU_*_F64; an upper bound in that partially masked instructions count
-    whole).  None when the summary has no such section."""
-    pmc = profile_summary().get(section, {}).get("pmc_per_launch_mean", {})
+def kernel_names(info, bundle, obstacles_fused, extra=False):
+    """Names (as rocprofv3 prints them) of the evaluation kernels a step launched, from fx_step_info_ex: the walk and -- when
+    the obstacle stage ran on its own -- the obstacle kernel."""
+    b = lambda v: "true" if v else "false"
+    if info["grid_kernel"]:
+        walk = (f"fx_eval_grid_kernel<{info['lanes_per_candidate']}, {b(bundle)}, {b(obstacles_fused)}, {info['waves_per_simd']}, "
+                f"{b(info['wave_split'])}>")
+    else:
+        walk = f"fx_eval_kernel<{info['lanes_per_candidate']}, {b(bundle)}, {b(obstacles_fused)}, {b(extra)}, {info['waves_per_simd']}>"
+    obst = f"fx_obstacle_kernel<{info['obstacle_steps_per_item']}, 4>" if info.get("obstacle_kernel") else None
+    return walk, obst
+
+
+def kernel_pmc(section, kernel):
+    """Per-launch PMC means of `kernel` in `section` of the tracked summary -- None unless the summary holds THIS kernel (a
+    changed tuning launches another specialisation: its counters would describe a different kernel)."""
+    for name, pmc in profile_summary().get(section, {}).get("kernels", {}).items():
+        if kernel and kernel in name:
+            return pmc
+    return None
+
+
+def executed_fp64_flops(section, kernel):
+    """FP64 flops one launch EXECUTES, from the tracked PMC summary of the same workload and kernel: 64 lanes x (ADD + MUL +
+    2 FMA + transcendental) wave-instructions (SQ_INSTS_VALU_*_F64; an upper bound in that partially masked instructions count
+    whole).  None when the summary does not hold this kernel."""
+    pmc = kernel_pmc(section, kernel) or {}
     try:
         return 64.0 * (pmc["SQ_INSTS_VALU_ADD_F64"] + pmc["SQ_INSTS_VALU_MUL_F64"] + 2.0 * pmc["SQ_INSTS_VALU_FMA_F64"] +
                        pmc["SQ_INSTS_VALU_TRANS_F64"])
@@ -94,14 +110,29 @@ def executed_fp64_flops(section):
         return None
 
 
-def pmc_traffic(section):
+def pmc_traffic(section, kernel):
     """HBM bytes per launch from the tracked PMC passes (separate --pmc runs): WRITE_SIZE [KiB] x 1024 + FETCH_SIZE [KiB] x
     1024 x 2 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half of the bytes read)."""
-    pmc = profile_summary().get(section, {}).get("pmc_per_launch_mean", {})
+    pmc = kernel_pmc(section, kernel) or {}
     try:
         return pmc["WRITE_SIZE"] * 1024.0 + 2.0 * pmc["FETCH_SIZE"] * 1024.0
     except KeyError:
         return None
+
+
+def fp64_roofline(section, kernel, kernel_ms):
+    """Executed-work view of one kernel: FP64 flops per launch from the tracked PMC summary of the SAME kernel over the live
+    HIP-event duration.  When the summary holds another specialisation (the tuning changed since the passes were taken) no
+    fraction is printed at all -- `flops_source` says "stale" -- rather than one that describes a different kernel."""
+    fl = executed_fp64_flops(section, kernel)
+    if fl is None:
+        return {"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "flops_per_launch": None, "kernel": kernel, "avg_launch_ms": kernel_ms,
+                "flops_source": f"stale: {os.path.relpath(PROFILE_SUMMARY, ROOT)} has no PMC section for {kernel} -- no executed-work figure"}
+    tf = fl / (kernel_ms * 1e-3) / 1e12
+    return {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+            "traffic": pmc_traffic(section, kernel), "flops_per_launch": fl, "kernel": kernel, "avg_launch_ms": kernel_ms,
+            "flops_source": "executed FP64 instructions of this kernel (SQ_INSTS_VALU_*_F64 x 64 lanes), " + os.path.relpath(PROFILE_SUMMARY, ROOT)}
 
 
 def make_workload(args, world, grid=GRID, n_obst=None, select_only=None):
@@ -294,23 +325,17 @@ def north_star(args, local_rank):
                "value": C / (step_ms * 1e-3), "launches_timed": int(len(evalk)),
                "winner": {"index": int(res.best_index), "cost": float(res.best_cost), "n_collisions": int(res.n_collisions)},
                "target": "< 10 ms on one MI355X"}
+        info = eng.step_info()
+        k_walk, _ = kernel_names(info, not select_only, bool(n_obst))
+        rec["launch"] = info
         if select_only:
-            fl = executed_fp64_flops("north_star_obstacles")
-            src = PROFILE_SUMMARY if fl else None
-            if fl is None:
-                fl = algorithmic_flops_per_candidate(S, n_obst) * C
-            tf = fl / (k_ms * 1e-3) / 1e12
-            rec["roofline"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_launch": fl,
-                               "flops_source": ("executed FP64 instructions of this kernel (SQ_INSTS_VALU_*_F64 x 64 lanes), "
-                                                + os.path.relpath(src, ROOT)) if src else "SURVEY.md 8(d) planning figure",
-                               "traffic": pmc_traffic("north_star_obstacles")}
+            rec["roofline"] = fp64_roofline("north_star_obstacles", k_walk, k_ms)
         else:
             alg = bundle_bytes_per_candidate(S) * C
             ach = alg / (k_ms * 1e-3) / 1e9
             rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "algorithmic_bytes_per_launch": alg, "traffic": pmc_traffic("north_star_bundle"),
-                               "note": "3.49 GB per launch: past the 256 MiB Infinity Cache"}
+                               "algorithmic_bytes_per_launch": alg, "traffic": pmc_traffic("north_star_bundle", k_walk),
+                               "kernel": k_walk, "note": "3.49 GB per launch: past the 256 MiB Infinity Cache"}
         out[key] = rec
         eng.close()
     return out
@@ -412,6 +437,8 @@ def main():
         step()
     barrier()
     evalk, kern = eng.kernel_times(n_timed)
+    obstk = eng.obstacle_kernel_times(n_timed)
+    info = eng.step_info()
     winner = {"index": int(res.get("global_best_index", res["best_index"])),
               "cost": float(res.get("global_best_cost", res["best_cost"])), "n_feasible_local": int(res["n_feasible"]),
               "n_collisions": int(res["n_collisions"])}
@@ -455,34 +482,37 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = C_global * args.steps / elapsed
-        eval_ms = float(np.mean(evalk))
+        walk_ms = float(np.mean(evalk))
+        obst_ms = float(np.mean(obstk)) if info["obstacle_kernel"] else 0.0
+        eval_ms = walk_ms + obst_ms
         per_cand = BYTES_PER_CAND_MODE_A if args.select_only else bundle_bytes_per_candidate(S)
         alg_bytes = per_cand * C_local
-        achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
+        achieved = alg_bytes / (walk_ms * 1e-3) / 1e9
         section = f"{args.workload}_{'modeA' if args.select_only else 'modeB'}"
-        traffic = pmc_traffic(section) if world == 1 else None
+        k_walk, k_obst = kernel_names(info, not args.select_only, bool(n_obst) and not info["obstacle_kernel"])
+        timing_note = ("HIP events attached to every evaluation launch (hipExtLaunchKernel start/stop) of an instrumented "
+                       "repeat of the timed steps, same process and inputs; the timed region itself carries no events"
+                       if args.timing == "kernel" else "stream events around every launch of an instrumented repeat of the timed steps")
+        traffic = pmc_traffic(section, k_walk) if world == 1 else None
         hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                "traffic": traffic, "traffic_source": os.path.relpath(PROFILE_SUMMARY, ROOT) if traffic else None,
-               "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_candidate": per_cand}
-        common = {"kernel": "fx_eval_grid_kernel" + ("" if n_obst else " (evaluation + fused selection)"),
-                  "avg_launch_ms": eval_ms, "launches_timed": int(len(evalk)),
-                  "timing": ("HIP events attached to every evaluation launch (hipExtLaunchKernel start/stop) of an instrumented "
-                             "repeat of the timed steps, same process and inputs; the timed region itself carries no events")
-                  if args.timing == "kernel" else "stream events around every launch of an instrumented repeat of the timed steps"}
-        if n_obst:
-            # the obstacle stage is FP64-issue-bound: executed work of this kernel against the FP64 vector peak
-            fl = executed_fp64_flops(section) if world == 1 else None
-            fsrc = os.path.relpath(PROFILE_SUMMARY, ROOT) if fl else None
-            if fl is None:
-                fl = algorithmic_flops_per_candidate(S, n_obst) * C_local
-            tf = fl / (eval_ms * 1e-3) / 1e12
-            roofline = dict({"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic, "flops_per_launch": fl,
-                             "flops_source": ("executed FP64 instructions of this kernel (SQ_INSTS_VALU_*_F64 x 64 lanes), " + fsrc)
-                             if fsrc else "SURVEY.md 8(d) planning figure (no tracked PMC summary for this command)"}, **common)
-            hbm.update(common)
+               "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_candidate": per_cand,
+               "kernel": k_walk + ("" if n_obst else " (evaluation + fused selection)"), "avg_launch_ms": walk_ms,
+               "launches_timed": int(len(evalk)), "timing": timing_note}
+        kernels = [hbm]
+        if n_obst and info["obstacle_kernel"]:
+            # the step's obstacle stage ran as its own kernel: the walk is the store stream (bytes), the obstacle kernel FP64 issue
+            ob = fp64_roofline(section, k_obst, obst_ms)
+            ob.update({"launches_timed": int(len(obstk)), "timing": timing_note})
+            kernels.append(ob)
+            roofline = ob if obst_ms > walk_ms else hbm   # the dominant kernel of the step
+        elif n_obst:
+            # fused obstacle stage: FP64-issue-bound, executed work of this kernel against the FP64 vector peak
+            roofline = fp64_roofline(section, k_walk, walk_ms)
+            roofline.update({"launches_timed": int(len(evalk)), "timing": timing_note})
+            kernels = [roofline]
         else:
-            roofline = dict(hbm, **common)
+            roofline = hbm
         out = {
             "metric": "candidate trajectories/sec (30-step horizon)",
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -502,10 +532,12 @@ def main():
                               "(fx_update_step: re-packed tables, one host-to-device copy, evaluation, result on the host); "
                               "resident_step_* and value = inputs resident in HBM",
             "with_upload_ms_per_step": elapsed_u / args.steps * 1e3, "value_with_upload": C_global * args.steps / elapsed_u,
-            "device_ms_per_step": float(np.mean(kern)), "eval_kernel_ms": eval_ms,
+            "device_ms_per_step": float(np.mean(kern)), "eval_kernel_ms": eval_ms, "walk_kernel_ms": walk_ms,
+            "obstacle_kernel_ms": obst_ms, "launch": info,
             "pipelined_value": C_global * args.steps / pipelined,
             "winner": winner,
             "roofline": roofline,
+            "kernels": kernels,
         }
         if n_obst:
             out["roofline_hbm"] = hbm
@@ -590,13 +622,17 @@ def bench_stress(args, world, rank, local_rank, torch, dist):
     elapsed, lat = _timed(args, world, dist, torch, step, 5e-3)
     n_timed = min(256, (args.steps + args.timing_every - 1) // args.timing_every)
     evalk, kern = eng.kernel_times(n_timed)
+    obstk = eng.obstacle_kernel_times(n_timed)
+    info = eng.step_info()
     if rank == 0:
         C_global = C_local * world  # every rank carries the same number of candidates (same grid per agent)
         eval_ms = float(np.mean(evalk))
         alg_bytes = BYTES_PER_CAND_MODE_A * C_local
         achieved = alg_bytes / (eval_ms * 1e-3) / 1e9
-        flops = algorithmic_flops_per_candidate(S, K) * C_local
-        tf = flops / (eval_ms * 1e-3) / 1e12
+        k_walk, _ = kernel_names(info, False, True)
+        # executed FP64 work of THIS kernel from the tracked PMC pass (the planning figure of SURVEY 8(d) prices a full
+        # axis test per (obstacle, step) although the broad phase skips nearly all of them: it is not used here)
+        compute = fp64_roofline("config5_modeA", k_walk, eval_ms)
         res = last["res"]
         out = {
             "metric": "candidate trajectories/sec (50-step horizon, 20 obstacles per agent)",
@@ -613,12 +649,11 @@ def bench_stress(args, world, rank, local_rank, torch, dist):
             "device_ms_per_step": float(np.mean(kern)), "eval_kernel_ms": eval_ms,
             "agents_with_winner": int(sum(r["best_index"] >= 0 for r in res)),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "fx_eval_grid_kernel (batched over agents)",
+                         "traffic": None, "kernel": k_walk + " (batched over agents)",
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_candidate": BYTES_PER_CAND_MODE_A,
                          "avg_launch_ms": eval_ms, "launches_timed": int(len(evalk)),
                          "note": "select-only writes 12 B per candidate: this workload is FP64-issue-bound, see `compute`"},
-            "compute": {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_candidate": algorithmic_flops_per_candidate(S, K)},
+            "compute": compute, "launch": info,
         }
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle
@@ -653,6 +688,8 @@ def bench_scenario_step(args, world, rank, local_rank, torch, dist):
     elapsed, lat = _timed(args, world, dist, torch, step, 5e-5)
     n_timed = min(256, (args.steps + args.timing_every - 1) // args.timing_every)
     evalk, kern = eng.kernel_times(n_timed)
+    obstk = eng.obstacle_kernel_times(n_timed)
+    info = eng.step_info()
     if rank == 0:
         C, S = inp.n_candidates, inp.n_samples
         eval_ms = float(np.mean(evalk))

@@ -16,9 +16,17 @@ from .sampling import dense_ranges as _dense_ranges
 SEED = 20241008
 
 
-def reference_polyline(kind: str = "arc", n_knots: int = 400, spacing: float = 0.5, kappa: float = 0.01):
-    """straight | arc (constant curvature) | scurve (curvature sign change) polyline."""
+def reference_polyline(kind: str = "arc", n_knots: int = 400, spacing: float = 0.5, kappa: float = 0.01, knot_jitter: float = 0.0,
+                       seed: int = SEED):
+    """straight | arc (constant curvature) | scurve (curvature sign change) polyline.  knot_jitter > 0 (straight / arc): the
+    knots sit at deliberately NON-uniform arc lengths -- segment lengths spacing * (1 +- knot_jitter), seeded -- as a route
+    polyline does after spline smoothing (the segment lookup and every interpolation weight then differ from knot to knot)."""
     s = np.arange(n_knots) * spacing
+    if knot_jitter > 0.0:
+        if kind == "scurve":
+            raise ValueError("knot_jitter is for the straight / arc references")
+        w = np.random.default_rng([seed, 77]).uniform(1.0 - knot_jitter, 1.0 + knot_jitter, n_knots - 1)
+        s = np.concatenate([[0.0], np.cumsum(spacing * w)])
     if kind == "straight":
         return np.stack([s, np.zeros_like(s)], axis=1)
     if kind == "arc":
@@ -87,7 +95,7 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
                 n_obstacles=0, n_pred=30, cost_weights=None, draw_traj_set=False, kinematic_debug=False,
                 write_bundle=True, write_costmap=True, collision=True, low_vel_threshold=2.0, hull_builder=None,
                 seed=SEED, vehicle=None, x0_orientation=None, as_matrix=False, stop_point_s=None, road_half_width=None,
-                obstacle_min_gap=0.0, lead_gap=0.0):
+                obstacle_min_gap=0.0, lead_gap=0.0, knot_jitter=0.0):
     """One agent's PlanInputs on a synthetic reference.
 
     level: reference sampling level (set-ordered ranges, SamplingHandler) -- or
@@ -96,7 +104,7 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
     stop_point_s: distance ahead of s0 of a stop point -> stop-point sampling (end positions in
     [(s0 + s_stop) / 2, s_stop], reactive_planner.py:637) instead of end velocities."""
     veh = vehicle or VehicleParams()
-    cs = CoordinateSystem(reference_polyline(ref_kind, n_knots, spacing, kappa))
+    cs = CoordinateSystem(reference_polyline(ref_kind, n_knots, spacing, kappa, knot_jitter, seed))
     N = int(horizon / dt)
     s0 = float(cs.ref_pos[s_knot] + s_off)
     low_vel = v0 < low_vel_threshold

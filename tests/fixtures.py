@@ -50,6 +50,28 @@ def inputs_from_fixture(fx, hull_builder, **override):
     return inp
 
 
+def scenario_inputs(kw):
+    """PlanInputs of the first plan step of a scenario's planning problem, built by this package's own host side: stdlib XML
+    reader fixture -> route polyline -> prepare_reference_path -> initial Frenet state -> velocity planner -> sampling ranges ->
+    ground-truth predictions (frenet_interface.py:33-205).  No GPU involved (the hull builder and the projection are host C).
+    kw: scenario (fixture name under tests/golden), planning_problem, level, draw_traj_set, kinematic_debug."""
+    from frenetix_motion_planner_amd import commonroad_xml as crx
+    from frenetix_motion_planner_amd.frenet_interface import FrenetPlannerInterfaceHip
+    from frenetix_motion_planner_amd.reactive_planner import PlannerConfig
+    sc = crx.read_scenario_json(os.path.join(GOLDEN_DIR, kw["scenario"] + ".scenario.json"))
+    cfg = PlannerConfig()
+    cfg.draw_traj_set = bool(kw.get("draw_traj_set", False))
+    cfg.kinematic_debug = bool(kw.get("kinematic_debug", False))
+    cfg.sampling_min, cfg.sampling_max = kw["level"], kw["level"] + 1
+    itf = FrenetPlannerInterfaceHip(kw["planning_problem"], sc, sc.planning_problems[kw["planning_problem"]], config=cfg)
+    preds = sc.ground_truth_predictions(0, itf.planner.N)
+    itf.update_planner(None, preds)
+    inp = itf.begin_step()
+    inp.predictions = preds
+    inp.x0_velocity = float(itf.x_0.velocity)   # the v-range is built from the Cartesian speed (planner.py:304-306)
+    return inp
+
+
 import textwrap  # noqa: E402
 
 
