@@ -726,7 +726,8 @@ def bench_scenario_step(args, world, rank, local_rank, torch, dist):
 
 
 def bench_multiagent(args, world, rank, local_rank, torch, dist):
-    """BASELINE config 4: closed-loop multi-agent ZAM_Tjunction, agents round-robin over the GPUs."""
+    """BASELINE config 4: closed-loop multi-agent ZAM_Tjunction; agents dealt to the GPUs by distributed.hybrid_assignment (whole
+    agents round-robin, or -- fewer agents than GPUs -- every GPU one part of an agent's candidates)."""
     from frenetix_motion_planner_amd import commonroad_xml as crx
     from frenetix_motion_planner_amd.multiagent import MultiAgentSimulation
     from frenetix_motion_planner_amd.reactive_planner import PlannerConfig
@@ -748,7 +749,8 @@ def bench_multiagent(args, world, rank, local_rank, torch, dist):
     elapsed, lat = _timed(args, world, dist, torch, step, None)
     if rank == 0:
         n_agents = len(sim.agent_ids)
-        per_agent = sim.batch.agents[0].planner.last_step.n_candidates if sim.batch.agents[0].planner.last_step else 0
+        ls = sim.batch.agents[0].planner.last_step
+        per_agent = ls.inputs.n_candidates_global if ls else 0
         plan_steps = len(counts["batch_ms"])
         out = {
             "metric": "candidate trajectories/sec (30-step horizon), closed-loop multi-agent simulation",
@@ -759,7 +761,12 @@ def bench_multiagent(args, world, rank, local_rank, torch, dist):
                                    f"({'sampling level ' + str(lvl) if lvl >= 0 else 'dense 19 x 23 x 23(+1) grid'}), bundle materialised, collision stage; a step = one simulation step "
                                    "(replanning every 3rd step)",
                        "agents": n_agents, "candidates_per_agent": per_agent, "plan_steps_timed": plan_steps,
-                       "parallelism": f"agent round-robin x{world}, one all-gather of the plans per step" if world > 1 else "single GPU"},
+                       "parallelism": ("single GPU" if world == 1 else
+                                       (f"{n_agents} agents over {world} GPUs: every GPU one contiguous part of an agent's candidates "
+                                        f"({[len([1 for it in sim.items for k, _, _ in it if k == a]) for a in range(n_agents)]} parts), "
+                                        "winners merged in one all-gather, one all-gather of the plans per step") if sim.split else
+                                       f"agent round-robin x{world}, one all-gather of the plans per step"),
+                       "items_per_gpu": [len(it) for it in sim.items]},
             "sim_step_p50_ms": float(np.percentile(lat, 50) * 1e3), "sim_step_p95_ms": float(np.percentile(lat, 95) * 1e3),
             "batched_plan_launch_ms": float(np.median(counts["batch_ms"])) if plan_steps else None,
             "escalations": sim.batch.escalations,

@@ -13,9 +13,13 @@ are independent given the predictions frozen at the start of a step, so here
     * `MultiAgentSimulation` -- closed loop over a scenario: agent selection as simulation.py:168-211, predictions =
                                 recorded futures of non-agent obstacles + the planned trajectories of the other agents
                                 (what the reference obtains by writing the plans back into the scenario), agents
-                                round-robin over ranks (`distributed.agents_of_rank`), and ONE all-gather per
-                                simulation step of the planned trajectories [agents_per_rank][S][5] so every rank
-                                builds the same predictions for the next step.
+                                dealt to the ranks by `distributed.hybrid_assignment` -- round-robin when there are at
+                                least as many agents as ranks (the reference's agent batches), otherwise (BASELINE
+                                config 4: 5 agents on 8 GPUs) every rank still gets one item: the ranks of an agent
+                                split its candidates into contiguous parts, their winners meet in one small
+                                all-gather and every replica re-evaluates the one winning candidate, so no GPU idles
+                                --, and ONE all-gather per simulation step of the planned trajectories
+                                [items_per_rank][S][5] so every rank builds the same predictions for the next step.
 
 Out of scope: goal/collision status bookkeeping of `Agent`, visualisation, evaluation, the prediction
 network -- only the stepping that feeds the hot path.
@@ -26,7 +30,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from .commonroad_xml import GoalState, PlanningProblem, Scenario, State
-from .distributed import agents_of_rank
+from .distributed import hybrid_assignment, merge_agent_parts, shard_range
 from .frenet_interface import FrenetPlannerInterfaceHip
 from .problem import VehicleParams
 from .reactive_planner import PlannerConfig
@@ -85,11 +89,19 @@ def trajectory_as_prediction(states: Sequence, shape: dict, wb_rear_axle: float,
 
 
 class AgentBatchHip:
-    """The agents of one rank stepped together: one batched launch for every agent that plans in this step."""
+    """The agents of one rank stepped together: one batched launch for every agent that plans in this step.
+
+    parts: per agent (part, n_parts) -- n_parts > 1: this rank holds one of n_parts replicas of the agent and evaluates the
+    contiguous part `part` of its candidates (distributed.hybrid_assignment); slots: the agent's index in the simulation;
+    winner_exchange: collective callable([(slot, cost, global index), ...]) -> per-slot global (cost, index) -- called
+    once per step by every rank when any agent of the simulation is split."""
 
     def __init__(self, agents: List[FrenetPlannerInterfaceHip], max_candidates: int, device: int = 0, max_ref_knots: int = 4096,
-                 max_obstacles: int = 64, engine=None):
+                 max_obstacles: int = 64, engine=None, parts=None, slots=None, winner_exchange=None):
         self.agents = list(agents)
+        self.parts = list(parts) if parts is not None else [(0, 1)] * len(self.agents)
+        self.slots = list(slots) if slots is not None else list(range(len(self.agents)))
+        self.winner_exchange = winner_exchange
         N = max(a.planner.N for a in self.agents) if self.agents else 30
         if engine is None:
             from .engine import FrenetEngine
@@ -108,29 +120,58 @@ class AgentBatchHip:
         """agent_batch.py:140-189: update every agent with its predictions, plan (batched), finish the step.
         predictions: {agent id: predictions dict of that agent}.  Returns {agent id: selected Cartesian state list
         (None: no trajectory found)}."""
+        import copy
         planning, passive = [], []
-        for a in self.agents:
+        for k, a in enumerate(self.agents):
             if a.id in predictions or a.needs_plan():
                 a.update_planner(None, predictions.get(a.id, {}))
             inp = a.begin_step()
-            (planning if inp is not None else passive).append((a, inp))
+            if inp is not None and self.parts[k][1] > 1:   # this replica's contiguous part of the agent's candidates
+                inp.shard = shard_range(inp.n_candidates_global, *self.parts[k])
+            (planning if inp is not None else passive).append((a, inp, k))
         out: Dict[int, Optional[list]] = {}
+        t0 = time.time()
+        results = []
         if planning:
-            t0 = time.time()
-            results = self.engine.plan_batch([inp for _, inp in planning])
+            results = self.engine.plan_batch([inp for _, inp, _ in planning])
             self.launches += 1
             self.last_batch_ms = (time.time() - t0) * 1e3
-            for j, (a, inp) in enumerate(planning):
-                p = a.planner
-                best = p.plan_consume(inp, results[j], self.engine, j)
-                if best is None and p._sampling_min + 1 < p._sampling_max:
-                    self.escalations += 1
-                    pair = p.plan_escalate(t0)
+
+        def conclude(a, inp, res, j):
+            p = a.planner
+            best = p.plan_consume(inp, res, self.engine, j) if res is not None else None
+            if best is None and p._sampling_min + 1 < p._sampling_max:
+                self.escalations += 1
+                pair = p.plan_escalate(t0)   # the whole next level on the planner's own engine (identical on every replica)
+            else:
+                pair = p.plan_finish(best, t0)
+            sel, _ = a.finish_step(pair, global_timestep)
+            out[a.id] = sel
+
+        split = [(j, a, inp, k) for j, (a, inp, k) in enumerate(planning) if self.parts[k][1] > 1]
+        for j, (a, inp, k) in enumerate(planning):
+            if self.parts[k][1] == 1:
+                conclude(a, inp, results[j], j)
+        if self.winner_exchange is not None:
+            # the parts of a split agent meet: ONE all-gather of (slot, cost, global index) per rank item, every rank takes
+            # the same lexicographic minimum; then every replica evaluates the one winning candidate (the same launch on
+            # every replica, so their states stay bit-identical)
+            winners = self.winner_exchange([(self.slots[k], results[j]["best_cost"], results[j]["best_index"]) for j, a, inp, k in split])
+            again = []
+            for j, a, inp, k in split:
+                c, g = winners[self.slots[k]]
+                if g >= 0:
+                    one = copy.copy(inp)
+                    one.shard = (int(g), 1)
+                    again.append((a, one))
                 else:
-                    pair = p.plan_finish(best, t0)
-                sel, _ = a.finish_step(pair, global_timestep)
-                out[a.id] = sel
-        for a, _ in passive:
+                    conclude(a, inp, None, j)
+            if again:
+                res1 = self.engine.plan_batch([one for _, one in again])
+                self.launches += 1
+                for j1, (a, one) in enumerate(again):
+                    conclude(a, one, res1[j1], j1)
+        for a, _, _ in passive:
             sel, _ = a.finish_step(None, global_timestep)
             out[a.id] = sel[0] if sel is not None else None
         return out
@@ -169,7 +210,11 @@ class MultiAgentSimulation:
         self.shapes = {i: (dict(length=scenario.obstacles[i].length, width=scenario.obstacles[i].width)
                            if i in scenario.obstacles else dict(length=self.vehicle.length, width=self.vehicle.width))
                        for i in self.agent_ids}
-        self.my_slots = agents_of_rank(len(self.agent_ids), self.rank, self.world)
+        # work items of every rank: whole agents round-robin, or -- fewer agents than ranks -- one part of an agent's candidates
+        self.items = hybrid_assignment(len(self.agent_ids), self.world)
+        my_items = self.items[self.rank]
+        self.my_slots = [k for k, _, _ in my_items]
+        self.split = any(n_parts > 1 for it in self.items for _, _, n_parts in it)
         mine = [FrenetPlannerInterfaceHip(self.agent_ids[k], scenario, self.problems[self.agent_ids[k]], config=self._cfg(),
                                           vehicle=self.vehicle, device=device, use_road_boundary=use_road_boundary,
                                           engine=engine_factory() if engine_factory else None)
@@ -177,7 +222,9 @@ class MultiAgentSimulation:
         # per-agent capacity from the sampling sets the planners can really reach (the time set is not bounded by 16 values)
         cap = max_candidates or max([4096] + [a.planner.max_candidates_per_step() for a in mine])
         self.batch = AgentBatchHip(mine, max_candidates=cap, device=device,
-                                   engine=engine_factory() if engine_factory else None)
+                                   engine=engine_factory() if engine_factory else None,
+                                   parts=[(part, n_parts) for _, part, n_parts in my_items], slots=self.my_slots,
+                                   winner_exchange=self._exchange_winners if self.split else None)
         self.S = self.batch.agents[0].planner.N + 1 if mine else int(self.config.planning_horizon / self.config.dt) + 1
         self.time_step = 0
         # planned trajectories of ALL agents, identical on every rank after the exchange: [agents][S][FIELDS]
@@ -225,30 +272,42 @@ class MultiAgentSimulation:
                 preds[aid] = own[aid]
         return preds
 
+    def _all_gather(self, buf: np.ndarray) -> np.ndarray:
+        """[world] + buf.shape: every rank's buffer (one collective; nccl = RCCL on device tensors, gloo on the host)."""
+        if self.world == 1:
+            return buf[None]
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(buf))
+        if self.dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+            g = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            self.dist.all_gather_into_tensor(g, t, group=self.group)
+            return g.cpu().numpy()
+        gl = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(gl, t, group=self.group)
+        return torch.stack(gl).numpy()
+
+    def _exchange_winners(self, rows) -> list:
+        """Winners of the parts of split agents: ONE all-gather of (slot, cost, global index) per rank item; every rank takes
+        the same lexicographic (cost, index) minimum per agent (distributed.merge_agent_parts)."""
+        per = max(len(it) for it in self.items)
+        buf = np.full((per, 3), -1.0)
+        for j, row in enumerate(rows):
+            buf[j] = row
+        return merge_agent_parts(len(self.agent_ids), self._all_gather(buf).reshape(-1, 3))
+
     def _exchange(self, local_rows: np.ndarray) -> np.ndarray:
-        """ONE all-gather per simulation step: [per_rank][S][FIELDS] from every rank -> plans of all agents."""
-        per = (len(self.agent_ids) + self.world - 1) // self.world
+        """ONE all-gather per simulation step: [items_per_rank][S][FIELDS] from every rank -> plans of all agents (the replicas
+        of a split agent hold the same plan: part 0's is taken)."""
+        per = max(len(it) for it in self.items)
         buf = np.zeros((per, self.S, self.FIELDS))
         buf[:len(local_rows)] = local_rows
-        if self.world == 1:
-            gathered = buf[None]
-        else:
-            import torch
-            t = torch.from_numpy(buf)
-            cuda = self.dist.get_backend(self.group) == "nccl"
-            if cuda:
-                t = t.cuda()
-                g = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-                self.dist.all_gather_into_tensor(g, t, group=self.group)
-                gathered = g.cpu().numpy()
-            else:
-                gl = [torch.empty_like(t) for _ in range(self.world)]
-                self.dist.all_gather(gl, t, group=self.group)
-                gathered = torch.stack(gl).numpy()
+        gathered = self._all_gather(buf)
         plans = np.zeros_like(self.plans)
         for r in range(self.world):
-            for j, k in enumerate(agents_of_rank(len(self.agent_ids), r, self.world)):
-                plans[k] = gathered[r, j]
+            for j, (k, part, _) in enumerate(self.items[r]):
+                if part == 0:
+                    plans[k] = gathered[r, j]
         return plans
 
     def step(self) -> Dict[int, Optional[list]]:

@@ -73,7 +73,8 @@ class PolynomialView:
 class TrajectorySample:
     def __init__(self, step: "PlanStepResult", index: int):
         self._step = step
-        self.uniqueId = int(index)
+        self.uniqueId = int(index)           # index within the evaluated shard (== creation order when nothing is sharded)
+        self.global_id = int(index) + step.inputs.shard_begin   # creation order in the whole grid (reactive_planner.py:172)
         self._planes = None
         self._costmap = None
         self._coeffs = None

@@ -100,7 +100,8 @@ def _run_sim(sc, steps, **kw):
     winners = []
     for _ in range(steps):
         sim.step()
-        winners.append([a.optimal_trajectory.uniqueId if a.optimal_trajectory is not None else -1 for a in sim.batch.agents])
+        winners.append([getattr(a.optimal_trajectory, "global_id", a.optimal_trajectory.uniqueId) if a.optimal_trajectory is not None else -1
+                        for a in sim.batch.agents])
     return sim, winners
 
 
@@ -163,6 +164,51 @@ def test_agent_sharding_world2_gloo(scenario):
     single, _ = _run_sim(scenario, 4, engine_factory=OracleEngine)
     assert got[0][1] == [60000, 4, 7] and got[1][1] == [1, 5]
     assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][2], single.plans)
+
+
+def _worker_split(rank, world, port, q, n_agents):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = crx.read_scenario_json(FIXTURE)
+        sim, winners = _run_sim(sc, 4, engine_factory=OracleEngine, number_of_agents=n_agents - 1)
+        q.put((rank, [a.id for a in sim.batch.agents], sim.batch.parts, sim.plans.copy(), winners, sim.batch.launches))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,n_agents", [(2, 1), (3, 2)])
+def test_fewer_agents_than_ranks_split_their_candidates_gloo(scenario, world, n_agents):
+    """BASELINE config 4's shape (5 agents on 8 GPUs) in small: ONE agent over two ranks, two agents over three -- every rank
+    carries a part of an agent's candidates in the closed loop (distributed.hybrid_assignment), the parts' winners meet in one
+    all-gather, every replica re-evaluates the winning candidate: winners and plans are those of a single process, on every
+    rank, and nobody idles."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_split, args=(r, world, port, q, n_agents)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=500) for _ in range(world)], key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single, w_single = _run_sim(scenario, 4, engine_factory=OracleEngine, number_of_agents=n_agents - 1)
+    ids = single.agent_ids
+    assert len(ids) == n_agents
+    for r, agents, parts, plans, winners, launches in got:
+        assert len(agents) == 1 and np.array_equal(plans, single.plans)     # every rank has exactly one item, same plans
+        k = ids.index(agents[0])
+        assert [w[0] for w in winners] == [w[k] for w in w_single]            # the replica chose the global winner every step
+    split = [g for g in got if g[2][0][1] > 1]
+    assert len(split) >= 2 and all(g[5] == 4 for g in split)                 # two plan steps: part launch + winner launch each
+    assert sorted(g[2][0] for g in got if g[1][0] == ids[0]) == [(p, len([1 for h in got if h[1][0] == ids[0]])) for p in
+                                                                 range(len([1 for h in got if h[1][0] == ids[0]]))]
 
 
 # ------------------------------------------------------------------------------------------------------------ GPU
