@@ -14,6 +14,7 @@ FX_ERR_NOT_READY = -2
 FX_ERR_CAPACITY = -3
 FX_ERR_HIP = 1
 FX_ERR_NO_DEVICE = 2
+FX_ERR_TIMEOUT = 3
 
 PLANE_NAMES = ("x", "y", "theta", "v", "a", "kappa", "kappa_dot",
                "s", "d", "theta_cl", "s_dot", "s_ddot", "d_dot", "d_ddot")

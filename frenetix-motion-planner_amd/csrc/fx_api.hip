@@ -140,7 +140,11 @@ struct FxContext {
     // survivor exchange inside the library (fx_comm_init): an RCCL communicator of this context's own, the gathered winners
     void *comm = nullptr;                  // ncclComm_t
     int comm_rank = 0, comm_world = 0;
-    double *d_gather = nullptr;            // [world][max_agents][2]
+    double *d_gather = nullptr;            // [world][max_agents][2] (grown to [world][max_agents][2 k] by the top-k exchange)
+    size_t gather_cap = 0;                 // doubles
+    double *d_xsend = nullptr;             // [max_agents][2][64]: a rank's survivors, [cost n k | index n k], the all-gather's send buffer
+    int timeout_ms = 20000;                // bound of every host wait on device work (fx_set_timeout_ms)
+    bool timed_out = false;                // a wait ran out: the stream may never drain, the context refuses further steps
     double *h_pub = nullptr, *h_pub_dev = nullptr;   // pinned + mapped [FX_PUB_MAX + 1]: published buffer, last word = sequence
     unsigned long long pub_seq = 0;
     int pub_n = 0;
@@ -191,7 +195,32 @@ struct FxContext {
     int64_t dev_bytes = 0;
 };
 
+// Time-bounded wait for a sequence word the device publishes into pinned host memory.  The reference bounds every hand-off
+// between its processes with TIMEOUT = 20 s (cr_scenario_handler/simulation/simulation.py:637,655, agent_batch.py:98): a
+// peer that never joins a collective, or a faulted kernel, must surface as an error, not as a hang.  Pure host code.
+extern "C" int32_t fx_wait_word(const volatile unsigned long long *word, unsigned long long expected, int32_t timeout_ms) {
+    if (!word) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_wait_word: NULL argument");
+    for (int spin = 0; spin < 4096; spin++)
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == expected) return FX_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto limit = std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms);
+    for (;;) {
+        for (int spin = 0; spin < 1024; spin++)
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == expected) return FX_OK;
+        if (std::chrono::steady_clock::now() - t0 >= limit)
+            return set_err(FX_ERR_TIMEOUT, "no answer from the device within %d ms (a peer that never joined the collective, or a "
+                           "faulted kernel)", timeout_ms);
+    }
+}
+
 namespace {
+
+// wait for a word of this context's pinned blocks; a timeout poisons the context (its stream may never drain)
+int wait_seq(FxContext *c, const volatile unsigned long long *word, unsigned long long expected) {
+    const int rc = fx_wait_word(word, expected, c->timeout_ms);
+    if (rc == FX_ERR_TIMEOUT) c->timed_out = true;
+    return rc;
+}
 
 template <typename T>
 int dev_alloc(FxContext *c, T **p, size_t n) {
@@ -485,7 +514,7 @@ int32_t fx_create(FxContext **out, int32_t device, int64_t max_candidates, int32
 int32_t fx_destroy(FxContext *c) {
     if (!c) return FX_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream && !c->timed_out) (void)hipStreamSynchronize(c->stream);   // (a timed-out stream may never drain)
     void *dev[] = {c->d_in, c->d_cost, c->d_cost_tail, c->d_flags, c->d_costmap, c->d_coeffs, c->d_trajlen, c->d_planes,
                    c->d_part_cost, c->d_part_idx, c->d_counters, c->d_topk_cost, c->d_topk_idx, c->d_topk_scr_cost,
                    c->d_topk_scr_idx};
@@ -498,6 +527,7 @@ int32_t fx_destroy(FxContext *c) {
     if (c->h_bound) (void)hipHostFree(c->h_bound);
     if (c->comm) (void)fx_comm_destroy(c);
     if (c->d_winner_own) (void)hipFree(c->d_winner_own);
+    if (c->d_xsend) (void)hipFree(c->d_xsend);
     void *host[] = {c->h_in, c->h_counters, c->h_topk_cost, c->h_topk_idx, c->h_pub, c->h_cand, c->h_pkg};
     for (void *p : host) if (p) (void)hipHostFree(p);
     for (auto &t : c->ring) {
@@ -529,11 +559,16 @@ int32_t fx_publish(FxContext *c, const void *d_src, int32_t n) {
 int32_t fx_wait_published(FxContext *c, double *out) {
     if (!c || !out) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_wait_published: NULL argument");
     if (c->pub_n < 1) return set_err(FX_ERR_NOT_READY, "nothing published");
-    const volatile unsigned long long *sq = reinterpret_cast<const unsigned long long *>(c->h_pub + FX_PUB_MAX);
-    bool done = false;
-    for (long spin = 0; spin < 20000000L && !done; spin++) done = __atomic_load_n(sq, __ATOMIC_ACQUIRE) == c->pub_seq;
-    if (!done) HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = wait_seq(c, reinterpret_cast<const unsigned long long *>(c->h_pub + FX_PUB_MAX), c->pub_seq);
+    if (rc) return rc;
     memcpy(out, c->h_pub, sizeof(double) * c->pub_n);
+    return FX_OK;
+}
+
+int32_t fx_set_timeout_ms(FxContext *c, int32_t timeout_ms) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (timeout_ms < 1) return set_err(FX_ERR_INVALID_ARGUMENT, "timeout must be at least 1 ms");
+    c->timeout_ms = timeout_ms;
     return FX_OK;
 }
 
@@ -973,6 +1008,7 @@ int32_t fx_upload(FxContext *c, const FxProblem *prob) { return fx_upload_batch(
 int32_t fx_evaluate(FxContext *c) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     if (!c->uploaded) return set_err(FX_ERR_NOT_READY, "fx_evaluate before fx_upload");
+    if (c->timed_out) return set_err(FX_ERR_TIMEOUT, "an earlier wait on this context timed out: destroy it (its stream may never drain)");
     HIP_TRY(hipSetDevice(c->device));
     if (c->probs_dirty || c->dirty_hi > c->dirty_lo) {
         // inputs rewritten by fx_update_state since the last evaluation: ONE copy of the front of the staging block (the
@@ -1049,22 +1085,16 @@ int32_t fx_evaluate(FxContext *c) {
 int32_t fx_finish_batch(FxContext *c, FxResult *res) {
     if (!c || !res) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_finish: NULL argument");
     if (!c->evaluated) return set_err(FX_ERR_NOT_READY, "fx_finish before fx_evaluate");
-    {   // poll the sequence words the selection kernel publishes; fall back to a stream sync (which also surfaces
-        // a faulted kernel) if they do not arrive
-        bool done = false;
-        for (long spin = 0; spin < 20000000L && !done; spin++) {
-            done = true;
-            for (int a = 0; a < c->n_agents; a++) {
-                // with a winner package the last word to arrive is the package's (its kernel runs behind the selection)
-                const volatile unsigned long long *sq = c->pkg_step
-                    ? reinterpret_cast<const unsigned long long *>(c->h_pkg + (size_t)a * c->pkg_stride + c->pkg_stride - 1)
-                    : c->h_counters + (size_t)a * (FX_CNT_COUNT + 1) + FX_CNT_COUNT;
-                if (__atomic_load_n(sq, __ATOMIC_ACQUIRE) != c->seq) { done = false; break; }
-            }
-        }
-        if (!done) HIP_TRY(hipStreamSynchronize(c->stream));
-        c->in_flight = false;
+    // wait for the sequence words the selection kernel publishes (bounded in TIME: fx_set_timeout_ms)
+    for (int a = 0; a < c->n_agents; a++) {
+        // with a winner package the last word to arrive is the package's (its kernel runs behind the selection)
+        const volatile unsigned long long *sq = c->pkg_step
+            ? reinterpret_cast<const unsigned long long *>(c->h_pkg + (size_t)a * c->pkg_stride + c->pkg_stride - 1)
+            : c->h_counters + (size_t)a * (FX_CNT_COUNT + 1) + FX_CNT_COUNT;
+        int rc = wait_seq(c, sq, c->seq);
+        if (rc) return rc;
     }
+    c->in_flight = false;
     // device time of this step: only if its events have already completed (a timed step never waits for them here;
     // fx_last_kernel_ms / fx_read_kernel_times do)
     double step_ms = -1.0;
@@ -1220,59 +1250,134 @@ int32_t fx_comm_unique_id(uint8_t *id128) {
     return FX_OK;
 }
 
-int32_t fx_comm_init(FxContext *c, const uint8_t *id128, int32_t rank, int32_t world) {
-    if (!c || !id128) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_comm_init: NULL argument");
-    if (world < 1 || rank < 0 || rank >= world) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_comm_init: rank %d of %d", rank, world);
+// Local preconditions of fx_comm_init, WITHOUT entering anything collective: every rank calls this first and the ranks agree
+// (e.g. an all-reduce MIN over the host program's own group) before any of them calls fx_comm_init -- a rank that would fail
+// there never reaches ncclCommInitRank, and its peers would wait for it forever.
+int32_t fx_comm_check(const FxContext *c, int32_t world) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_comm_check: NULL argument");
+    if (world < 1) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_comm_check: world %d", world);
     if ((size_t)world * c->max_agents * 2 > FX_PUB_MAX) return set_err(FX_ERR_CAPACITY, "%d ranks x %d agents exceed the publication block", world, c->max_agents);
     if (!rccl()->ok) return set_err(FX_ERR_NOT_READY, "librccl.so.1 not available");
     if (c->comm) return set_err(FX_ERR_INVALID_ARGUMENT, "this context already has a communicator");
+    return FX_OK;
+}
+
+int32_t fx_comm_init(FxContext *c, const uint8_t *id128, int32_t rank, int32_t world) {
+    if (!c || !id128) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_comm_init: NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_comm_init: rank %d of %d", rank, world);
+    int rc = fx_comm_check(c, world);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    // everything that can fail locally comes BEFORE the collective call
+    const size_t need = (size_t)world * c->max_agents * 2;
+    if ((rc = dev_alloc(c, &c->d_gather, need))) return rc;
+    c->gather_cap = need;
+    if (!c->d_winner_own && (rc = dev_alloc(c, &c->d_winner_own, (size_t)c->max_agents * 2))) return rc;
+    if (!c->d_xsend && (rc = dev_alloc(c, &c->d_xsend, (size_t)c->max_agents * 2 * 64))) return rc;
     Rccl::UniqueId id;
     memcpy(id.internal, id128, 128);
     RCCL_TRY(rccl()->CommInitRank(&c->comm, world, id, rank));
     c->comm_rank = rank; c->comm_world = world;
-    int rc = dev_alloc(c, &c->d_gather, (size_t)world * c->max_agents * 2);
-    if (rc) return rc;
-    if (!c->d_winner_own && (rc = dev_alloc(c, &c->d_winner_own, (size_t)c->max_agents * 2))) return rc;
     return FX_OK;
 }
 
 int32_t fx_comm_destroy(FxContext *c) {
     if (!c || !c->comm) return FX_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream && !c->timed_out) (void)hipStreamSynchronize(c->stream);   // (a timed-out stream may never drain)
     (void)rccl()->CommDestroy(c->comm);
     c->comm = nullptr;
-    if (c->d_gather) { (void)hipFree(c->d_gather); c->d_gather = nullptr; }
+    if (c->d_gather) { (void)hipFree(c->d_gather); c->d_gather = nullptr; c->gather_cap = 0; }
     return FX_OK;
 }
 
 // One plan step of every rank: evaluation (+ selection), ONE all-gather of the ranks' winners (cost f64, global index i64 per
 // agent; 16 B per rank and agent) on the context's stream, publication to pinned host memory -- enqueued back to back, then the
-// host takes the local result block while the collective runs and polls for the gathered winners.
+// host takes the local result block while the collective runs and waits (bounded in time) for the gathered winners.
+// A rank whose own evaluation fails STILL enters the all-gather -- with (inf, -1) for every agent -- and returns its error
+// afterwards: its peers are not left waiting for it.
 int32_t fx_step_exchange(FxContext *c, FxResult *res, double *cost, int64_t *index) {
     if (!c || !res || !cost || !index) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_step_exchange: NULL argument");
     if (!c->comm) return set_err(FX_ERR_NOT_READY, "fx_step_exchange before fx_comm_init");
+    if (c->timed_out) return set_err(FX_ERR_TIMEOUT, "an earlier wait on this context timed out: destroy it");
     double *saved = c->dev_winner;
     if (!saved) c->dev_winner = c->d_winner_own;   // the selection leaves (cost, index) of every agent here
-    int rc = fx_evaluate(c);
+    int rc_eval = fx_evaluate(c);
     const double *send = c->dev_winner;
     c->dev_winner = saved;
-    if (rc) return rc;
-    const int n = c->n_agents * 2, total = n * c->comm_world;
+    const int n_agents = c->n_agents > 0 ? c->n_agents : 1;
+    char err_eval[sizeof(g_err)];
+    if (rc_eval) {
+        memcpy(err_eval, g_err, sizeof(err_eval));
+        // nothing was selected on this rank: send "no survivor" for every agent
+        double none[2 * 64];
+        double *h = c->h_topk_cost;   // pinned
+        (void)none;
+        for (int a = 0; a < n_agents; a++) { h[2 * a] = INFINITY; const long long m1 = -1; memcpy(&h[2 * a + 1], &m1, sizeof(m1)); }
+        HIP_TRY(hipMemcpyAsync(c->d_winner_own, h, sizeof(double) * 2 * n_agents, hipMemcpyHostToDevice, c->stream));
+        send = c->d_winner_own;
+    }
+    const int n = n_agents * 2, total = n * c->comm_world;
     RCCL_TRY(rccl()->AllGather(send, c->d_gather, (size_t)n, /*ncclDouble*/ 8, c->comm, c->stream));
+    int rc;
     if ((rc = fx_publish(c, c->d_gather, total))) return rc;
-    if ((rc = fx_finish_batch(c, res))) return rc;
-    const volatile unsigned long long *sq = reinterpret_cast<const unsigned long long *>(c->h_pub + FX_PUB_MAX);
-    bool done = false;
-    for (long spin = 0; spin < 20000000L && !done; spin++) done = __atomic_load_n(sq, __ATOMIC_ACQUIRE) == c->pub_seq;
-    if (!done) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!rc_eval && (rc = fx_finish_batch(c, res))) return rc;
+    if ((rc = wait_seq(c, reinterpret_cast<const unsigned long long *>(c->h_pub + FX_PUB_MAX), c->pub_seq))) return rc;
     for (int r = 0; r < c->comm_world; r++)
-        for (int a = 0; a < c->n_agents; a++) {
+        for (int a = 0; a < n_agents; a++) {
             const double *q = c->h_pub + (size_t)r * n + 2 * a;
-            cost[(size_t)r * c->n_agents + a] = q[0];
-            memcpy(&index[(size_t)r * c->n_agents + a], &q[1], sizeof(int64_t));
+            cost[(size_t)r * n_agents + a] = q[0];
+            memcpy(&index[(size_t)r * n_agents + a], &q[1], sizeof(int64_t));
         }
+    if (rc_eval) { memcpy(g_err, err_eval, sizeof(err_eval)); return rc_eval; }
+    return FX_OK;
+}
+
+// The same for the k best survivors per agent (BASELINE config 5: per-agent top-32 over 8 GPUs): evaluation, selection, the two
+// top-k launches writing [cost n k | index n k] into the send buffer, ONE all-gather of 16 k bytes per rank and agent,
+// publication, results -- no host code between the launches.  cost / index: [world][n_agents][k], index -1 where a rank has
+// fewer than k survivors.
+int32_t fx_step_exchange_topk(FxContext *c, int32_t k, FxResult *res, double *cost, int64_t *index) {
+    if (!c || !res || !cost || !index) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_step_exchange_topk: NULL argument");
+    if (k < 1 || k > 64) return set_err(FX_ERR_INVALID_ARGUMENT, "k=%d outside [1,64]", k);
+    if (!c->comm) return set_err(FX_ERR_NOT_READY, "fx_step_exchange_topk before fx_comm_init");
+    if (c->timed_out) return set_err(FX_ERR_TIMEOUT, "an earlier wait on this context timed out: destroy it");
+    const int n_agents = c->n_agents > 0 ? c->n_agents : 1;
+    const size_t n = (size_t)n_agents * 2 * k, total = n * c->comm_world;
+    if (total > FX_PUB_MAX) return set_err(FX_ERR_CAPACITY, "%d ranks x %d agents x %d survivors exceed the publication block", c->comm_world, n_agents, k);
+    HIP_TRY(hipSetDevice(c->device));
+    if (total > c->gather_cap) {   // (before anything is enqueued: a failure here leaves the peers un-entered as well)
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_gather) { (void)hipFree(c->d_gather); c->d_gather = nullptr; c->gather_cap = 0; }
+        int rc = dev_alloc(c, &c->d_gather, (size_t)FX_PUB_MAX);
+        if (rc) return rc;
+        c->gather_cap = FX_PUB_MAX;
+    }
+    int rc_eval = fx_evaluate(c);
+    char err_eval[sizeof(g_err)];
+    long long *send_idx = reinterpret_cast<long long *>(c->d_xsend + (size_t)n_agents * k);
+    if (!rc_eval) {
+        HIP_TRY(fx_launch_topk(c->d_probs, c->n_agents, k, c->d_topk_scr_cost, c->d_topk_scr_idx, c->d_xsend, send_idx, c->stream));
+    } else {
+        memcpy(err_eval, g_err, sizeof(err_eval));
+        double *h = c->h_topk_cost;   // pinned [max_agents][64]
+        long long *hi = c->h_topk_idx;
+        for (size_t e = 0; e < (size_t)n_agents * k; e++) { h[e] = INFINITY; hi[e] = -1; }
+        HIP_TRY(hipMemcpyAsync(c->d_xsend, h, sizeof(double) * n_agents * k, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(send_idx, hi, sizeof(long long) * n_agents * k, hipMemcpyHostToDevice, c->stream));
+    }
+    RCCL_TRY(rccl()->AllGather(c->d_xsend, c->d_gather, n, /*ncclDouble*/ 8, c->comm, c->stream));
+    int rc;
+    if ((rc = fx_publish(c, c->d_gather, (int32_t)total))) return rc;
+    if (!rc_eval && (rc = fx_finish_batch(c, res))) return rc;
+    if ((rc = wait_seq(c, reinterpret_cast<const unsigned long long *>(c->h_pub + FX_PUB_MAX), c->pub_seq))) return rc;
+    const size_t nk = (size_t)n_agents * k;
+    for (int r = 0; r < c->comm_world; r++) {
+        const double *q = c->h_pub + (size_t)r * n;
+        memcpy(cost + (size_t)r * nk, q, sizeof(double) * nk);
+        memcpy(index + (size_t)r * nk, q + nk, sizeof(int64_t) * nk);
+    }
+    if (rc_eval) { memcpy(g_err, err_eval, sizeof(err_eval)); return rc_eval; }
     return FX_OK;
 }
 
@@ -1289,11 +1394,8 @@ int32_t fx_read_package(FxContext *c, int32_t agent, double yaw_rate0, FxPackage
     if (!pkg) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_read_package: NULL argument");
     if (!c->pkg_step) return set_err(FX_ERR_NOT_READY, "the last step ran without a winner package (fx_set_package, FX_MODE_WRITE_BUNDLE)");
     if (c->in_flight) {  // fx_finish has not been called for this step: wait for the package word here
-        const volatile unsigned long long *sq =
-            reinterpret_cast<const unsigned long long *>(c->h_pkg + (size_t)agent * c->pkg_stride + c->pkg_stride - 1);
-        bool done = false;
-        for (long spin = 0; spin < 20000000L && !done; spin++) done = __atomic_load_n(sq, __ATOMIC_ACQUIRE) == c->seq;
-        if (!done) HIP_TRY(hipStreamSynchronize(c->stream));
+        rc = wait_seq(c, reinterpret_cast<const unsigned long long *>(c->h_pkg + (size_t)agent * c->pkg_stride + c->pkg_stride - 1), c->seq);
+        if (rc) return rc;
     }
     const FxAgentSlot &sl = c->slots[agent];
     const DevProblem &d = c->h_probs[agent];

@@ -21,6 +21,26 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 
+def exit_on_timeout(fn, *args, code: int = 3, **kwargs):
+    """Run one collective step; a time-out of the exchange (FxTimeoutError from the library's bounded waits, or the process
+    group's own time-out on the torch.distributed path) ends THIS PROCESS with a non-zero code after saying why -- the
+    reference's processes give up after TIMEOUT = 20 s the same way (simulation.py:637,655, agent_batch.py:98).  The stuck
+    stream cannot be recovered in-process; a supervisor may start a fresh child (never re-exec a process that touched the GPU)."""
+    import os
+    import sys
+    from ._lib import FxTimeoutError
+    try:
+        return fn(*args, **kwargs)
+    except FxTimeoutError as e:
+        print(f"[fxplan] collective step timed out: {e}", file=sys.stderr, flush=True)
+        os._exit(code)
+    except RuntimeError as e:
+        if "imed out" in str(e) or "timeout" in str(e).lower():
+            print(f"[fxplan] collective step timed out: {e}", file=sys.stderr, flush=True)
+            os._exit(code)
+        raise
+
+
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """(begin, count) of rank's contiguous share of n items; the first n % world ranks get one more."""
     if world < 1 or not 0 <= rank < world:
@@ -157,15 +177,30 @@ class ShardedEvaluator:
         # all-gather, publication and result in ONE call, no Python between the launches); FX_EXCHANGE=torch keeps the
         # torch.distributed path
         self.lib_exchange = False
+        self.lib_exchange_agents = False
         import os
         if self.on_device and self.k == 1 and hasattr(engine, "comm_init") and (self.world > 1 or self.force_exchange) \
                 and os.environ.get("FX_EXCHANGE", "lib") != "torch":
             self.lib_exchange = self._init_library_exchange(dev)
 
     def _init_library_exchange(self, dev) -> bool:
-        """Every rank ends with the same answer: rank 0 draws the id (a flag byte says whether it could), it is broadcast over
-        the torch group, every rank initialises its communicator and the ranks agree (MIN) on whether all of them succeeded."""
+        """Every rank ends with the same answer.  Nothing collective of the LIBRARY is entered before the ranks have agreed, over
+        the torch group, that every one of them can: (1) local preconditions (RCCL present, capacity -- fx_comm_check) MIN-reduced;
+        (2) rank 0 draws the id (a flag byte says whether it could) and broadcasts it; (3) only then every rank calls
+        ncclCommInitRank -- a rank that would have failed before it would leave its peers inside that call forever;
+        (4) the outcome is MIN-reduced once more (a rank whose initialisation failed AFTER the rendezvous)."""
         torch, dist = self.torch, self.dist
+
+        def all_agree(ok: bool) -> bool:
+            if self.world == 1:
+                return ok
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return bool(flag.item())
+
+        ok = hasattr(self.engine, "comm_check") and bool(self.engine.comm_check(self.world))
+        if not all_agree(ok):
+            return False
         uid = torch.zeros(129, dtype=torch.uint8, device=dev)
         if self.rank == 0:
             try:
@@ -177,20 +212,17 @@ class ShardedEvaluator:
             src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
             dist.broadcast(uid, src=src, group=self.group)
         host = uid.cpu().numpy()
-        ok = bool(host[128])
-        if ok:
-            try:
-                self.engine.comm_init(bytes(host[:128]), self.rank, self.world)
-            except Exception:
-                ok = False
-        if self.world > 1:
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-            all_ok = bool(flag.item())
-            if ok and not all_ok:
-                self.engine.comm_destroy()
-            ok = all_ok
-        return ok
+        if not bool(host[128]):   # the same byte on every rank
+            return False
+        try:
+            self.engine.comm_init(bytes(host[:128]), self.rank, self.world)
+            ok = True
+        except Exception:
+            ok = False
+        all_ok = all_agree(ok)
+        if ok and not all_ok:
+            self.engine.comm_destroy()
+        return all_ok
 
     def shard(self, inputs):
         begin, count = shard_range(inputs.n_candidates_global, self.rank, self.world)
@@ -278,11 +310,21 @@ class ShardedEvaluator:
             self._asurv = self.torch.empty(2 * n, dtype=self.torch.float64, device=dev)
             self._agath = self.torch.empty(self.world * 2 * n, dtype=self.torch.float64, device=dev)
             self.engine.set_winner_buffer(0)
+            # the per-agent top-k exchange inside the library (fx_step_exchange_topk) on a communicator of the engine's own;
+            # FX_EXCHANGE=torch keeps the torch.distributed path
+            import os
+            if hasattr(self.engine, "step_exchange_topk_raw") and (self.world > 1 or self.force_exchange) \
+                    and os.environ.get("FX_EXCHANGE", "lib") != "torch" and self.world * self.n_local * 2 * self.k <= 16384:
+                self.lib_exchange_agents = self.lib_exchange or self._init_library_exchange(dev)
 
     def step_agents_enqueued(self, exchange: bool = True):
         """One batched launch over this rank's (already uploaded) agents, per-agent top-k on the device, ONE all-gather
         of every rank's survivors, published to the host.  Returns (results of the local agents, survivors
         (cost [W, n_local, k], index [W, n_local, k]) or None)."""
+        if exchange and self.lib_exchange_agents:
+            # evaluation, per-agent top-k, ONE all-gather and the publication enqueued by the library back to back
+            res, gc, gi = self.engine.step_exchange_topk_raw(self.k)
+            return [r.as_dict() for r in res] if hasattr(res[0], "as_dict") else res, (gc, gi)
         self.engine.evaluate()
         surv = None
         if exchange:

@@ -395,6 +395,28 @@ class FrenetEngine:
         check(lib().fx_comm_init(self._ctx, C.addressof(buf), int(rank), int(world)))
         self._comm_world = int(world)
 
+    def comm_check(self, world: int) -> bool:
+        """Local preconditions of comm_init (RCCL present, capacity), nothing collective: the ranks agree on the answer
+        BEFORE any of them calls comm_init (fx_comm_check)."""
+        return lib().fx_comm_check(self._ctx, int(world)) == 0
+
+    def set_timeout_ms(self, timeout_ms: int):
+        """Bound of every host wait on device work (default 20 000 ms, the reference's TIMEOUT); FxTimeoutError beyond it."""
+        check(lib().fx_set_timeout_ms(self._ctx, int(timeout_ms)))
+
+    def step_exchange_topk_raw(self, k: int):
+        """evaluate + per-agent top-k + ONE all-gather + finish in one call (fx_step_exchange_topk):
+        (FxResult array, cost [W, n, k], index [W, n, k])"""
+        n = len(self._inputs)
+        res = getattr(self, "_res_buf", None)
+        if res is None or len(res) != n:
+            res = self._res_buf = (_abi.FxResult * n)()
+        x = getattr(self, "_xchg_topk", None)
+        if x is None or x[0].shape != (self._comm_world, n, k):
+            x = self._xchg_topk = (np.empty((self._comm_world, n, k)), np.empty((self._comm_world, n, k), np.int64))
+        check(lib().fx_step_exchange_topk(self._ctx, int(k), res, x[0].ctypes.data, x[1].ctypes.data))
+        return res, x[0], x[1]
+
     def comm_destroy(self):
         check(lib().fx_comm_destroy(self._ctx))
         self._comm_world = 0

@@ -34,6 +34,11 @@ extern "C" {
 #define FX_ERR_CAPACITY (-3)      /* problem larger than the context was created for */
 #define FX_ERR_HIP 1              /* a HIP runtime call failed; text in fx_last_error() */
 #define FX_ERR_NO_DEVICE 2
+#define FX_ERR_TIMEOUT 3          /* no answer from the device within the context's time bound (fx_set_timeout_ms): a peer that never
+                                   * joined a collective or a faulted kernel.  The context refuses further steps; destroy it (and, in a
+                                   * multi-rank job, end the process: a fresh child may be started, a process that touched the GPU is
+                                   * never re-exec'ed).  The reference bounds its inter-process hand-offs the same way, TIMEOUT = 20 s:
+                                   * cr_scenario_handler/simulation/simulation.py:637,655, agent_batch.py:98 */
 
 /* ---- trajectory planes of the structure-of-arrays TrajectoryBundle.
  *      trajectories.py:56-197 (CartesianSample) and :200-334 (CurviLinearSample).
@@ -274,9 +279,24 @@ int32_t fx_update_step(FxContext *ctx, const FxStateUpdate *upd, FxResult *res);
  *      fx_finish_batch: cost / index [world][n_agents], index -1 where a rank found nothing.  RCCL is bound at run time
  *      (librccl.so.1); without it these return FX_ERR_NOT_READY and everything else works. */
 int32_t fx_comm_unique_id(uint8_t *id128);
+/* local preconditions of fx_comm_init (RCCL present, capacity) WITHOUT entering anything collective: every rank calls it and the
+ * ranks agree (all-reduce MIN over the host program's own group) before any of them calls fx_comm_init -- a rank that would fail
+ * there never reaches ncclCommInitRank and its peers would wait for it forever */
+int32_t fx_comm_check(const FxContext *ctx, int32_t world);
 int32_t fx_comm_init(FxContext *ctx, const uint8_t *id128, int32_t rank, int32_t world);
 int32_t fx_comm_destroy(FxContext *ctx);
+/* a rank whose own evaluation fails still enters the all-gather (with cost inf / index -1 for every agent) and returns its
+ * error afterwards: the peers are never left waiting */
 int32_t fx_step_exchange(FxContext *ctx, FxResult *res, double *cost /*[world][n_agents]*/, int64_t *index /*[world][n_agents]*/);
+/* the same for the k <= 64 best survivors per agent (agent sharding with a top-k gather, BASELINE config 5): evaluation,
+ * selection, top-k, ONE all-gather of 16 k bytes per rank and agent, publication -- no host code between the launches */
+int32_t fx_step_exchange_topk(FxContext *ctx, int32_t k, FxResult *res, double *cost /*[world][n_agents][k]*/,
+                              int64_t *index /*[world][n_agents][k]*/);
+/* every host wait on device work (fx_finish, fx_wait_published, the exchanges, fx_read_package) is bounded in TIME: default
+ * 20 000 ms, the reference's TIMEOUT (simulation.py:637); FX_ERR_TIMEOUT when it runs out.  fx_wait_word is the wait itself
+ * (pure host code): returns FX_OK once *word == expected, FX_ERR_TIMEOUT after timeout_ms. */
+int32_t fx_set_timeout_ms(FxContext *ctx, int32_t timeout_ms);
+int32_t fx_wait_word(const volatile unsigned long long *word, unsigned long long expected, int32_t timeout_ms);
 
 /* ---- the chosen trajectory, packaged (planner.py:394-447 _compute_trajectory_pair; reactive_planner_cpp.py:355-357 reads the
  *      optimal trajectory's arrays; frenet_interface.py:243-277 consumes the pair) ----

@@ -302,6 +302,107 @@ def test_agent_sharded_topk_gather_single_rank():
         dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+def test_library_side_topk_exchange_equals_the_torch_path():
+    """fx_step_exchange_topk (evaluation, selection, top-k, all-gather, publication enqueued by the library) against the
+    torch.distributed path (FX_EXCHANGE=torch) on a one-rank nccl group: same survivors, same results."""
+    import torch
+    import torch.distributed as dist
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator
+    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        agents = synthetic.stress_agents(4, grid=(7, 9, 9), n_obstacles=6, hull_builder=build_obstacle_hulls)
+        got = {}
+        for mode in ("lib", "torch"):
+            os.environ["FX_EXCHANGE"] = mode
+            with FrenetEngine(max_candidates=sum(a.n_candidates for a in agents) + 4 * 64, max_steps=50, max_agents=4, device=0) as eng:
+                ev = ShardedEvaluator(eng, k=16, force_exchange=True)
+                ev.setup_agents(4)
+                assert ev.lib_exchange_agents == (mode == "lib")
+                eng.upload(agents)
+                for _ in range(3):
+                    res, (sc, si) = ev.step_agents_enqueued()
+                got[mode] = ([dict(r) if isinstance(r, dict) else r.as_dict() for r in res], sc.copy(), si.copy())
+        a, b = got["lib"], got["torch"]
+        assert a[1].shape == (1, 4, 16) and np.array_equal(a[2], b[2]) and np.array_equal(a[1][a[2] >= 0], b[1][b[2] >= 0])
+        for ra, rb in zip(a[0], b[0]):
+            for k in ("best_index", "best_cost", "n_feasible", "n_collisions", "n_returned"):
+                assert ra[k] == rb[k], k
+    finally:
+        os.environ.pop("FX_EXCHANGE", None)
+        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Watchdog: every wait on a hand-off is bounded in time (the reference: TIMEOUT = 20 s, simulation.py:637,655)
+# ---------------------------------------------------------------------------------------------------------
+def test_wait_word_times_out_and_returns_when_the_word_arrives():
+    """fx_wait_word is the wait behind fx_finish / the exchanges (pure host code): FX_ERR_TIMEOUT after the bound when nothing
+    arrives, FX_OK as soon as the word does."""
+    import ctypes as C
+    import threading
+    import time
+    from frenetix_motion_planner_amd import _abi, _lib
+    L = _lib.lib()
+    word = C.c_uint64(0)
+    t0 = time.perf_counter()
+    rc = L.fx_wait_word(C.addressof(word), 7, 150)
+    dt = time.perf_counter() - t0
+    assert rc == _abi.FX_ERR_TIMEOUT and 0.14 < dt < 1.5
+    assert b"no answer from the device within 150 ms" in L.fx_last_error()
+    with pytest.raises(_lib.FxTimeoutError):
+        _lib.check(rc)
+    threading.Timer(0.05, lambda: setattr(word, "value", 7)).start()
+    t0 = time.perf_counter()
+    assert L.fx_wait_word(C.addressof(word), 7, 5000) == 0 and time.perf_counter() - t0 < 2.0
+
+
+def _absent_peer_worker(rank, port, q):
+    """rank 0 runs a sharded plan step; rank 1 joins the group and then never enters the exchange"""
+    sys.path.insert(0, ROOT)
+    import datetime
+    import time
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2, timeout=datetime.timedelta(seconds=3))
+    if rank == 1:
+        time.sleep(12)      # alive, but not in the collective
+        os._exit(0)
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator, exit_on_timeout
+    from tests.oracle_engine import OracleEngine
+    from oracle import oracle
+    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, level=1, hull_builder=oracle.build_obstacle_hulls)
+    ev = ShardedEvaluator(OracleEngine(), k=4)
+    q.put("started")
+    exit_on_timeout(ev.plan_step, inp, code=7)
+    q.put("returned")      # not reached: the exchange times out and the process ends with code 7
+
+
+@pytest.mark.timeout(120)
+def test_a_rank_that_never_joins_ends_its_peer_with_an_error_not_a_hang():
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_absent_peer_worker, args=(r, port, q)) for r in range(2)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    assert q.get(timeout=60) == "started"
+    procs[0].join(timeout=60)
+    assert procs[0].exitcode == 7, procs[0].exitcode        # gave up after the group's 3 s bound, non-zero exit
+    assert time.time() - t0 < 60 and q.empty()
+    procs[1].join(timeout=30)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Hybrid agent x candidate sharding (fewer agents than ranks: BASELINE config 4 has 5 agents on 8 GPUs)
 # ---------------------------------------------------------------------------------------------------------
@@ -401,6 +502,9 @@ class _CommStubEngine:
     def __init__(self, fail=None):
         self.fail, self.inits, self.destroys, self.uid_seen = fail, 0, 0, None
 
+    def comm_check(self, world):
+        return self.fail != "check"     # local preconditions (RCCL present, capacity): nothing collective
+
     def comm_unique_id(self):
         if self.fail == "uid":
             raise RuntimeError("no communicator library")
@@ -426,7 +530,8 @@ def _exchange_agreement_worker(rank, world, port, q, scenario):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         fail = {"ok": None, "uid_fails_on_rank0": "uid" if rank == 0 else None,
-                "init_fails_on_rank1": "init" if rank == 1 else None}[scenario]
+                "init_fails_on_rank1": "init" if rank == 1 else None,
+                "precondition_fails_on_rank1": "check" if rank == 1 else None}[scenario]
         ev = ShardedEvaluator.__new__(ShardedEvaluator)   # the agreement logic alone (the constructor needs a GPU for this path)
         ev.torch, ev.dist, ev.group, ev.rank, ev.world = torch, dist, None, rank, world
         ev.engine = _CommStubEngine(fail)
@@ -437,7 +542,7 @@ def _exchange_agreement_worker(rank, world, port, q, scenario):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("scenario", ["ok", "uid_fails_on_rank0", "init_fails_on_rank1"])
+@pytest.mark.parametrize("scenario", ["ok", "uid_fails_on_rank0", "init_fails_on_rank1", "precondition_fails_on_rank1"])
 def test_library_exchange_setup_is_agreed_by_all_ranks(scenario):
     """The in-library exchange is used only if EVERY rank could set it up: rank 0 draws the id (or says it could not), the id
     travels over the torch group, and one failing rank sends all of them to the torch.distributed path (communicators that
@@ -457,8 +562,10 @@ def test_library_exchange_setup_is_agreed_by_all_ranks(scenario):
     assert oks == ([True, True] if scenario == "ok" else [False, False])
     if scenario == "ok":
         assert all(g[2] == 1 and g[3] == 0 and g[4] for g in got)
-    elif scenario == "uid_fails_on_rank0":
-        assert all(g[2] == 0 and g[3] == 0 for g in got)            # nobody initialises without an id
+    elif scenario in ("uid_fails_on_rank0", "precondition_fails_on_rank1"):
+        # nobody initialises without an id -- and nobody enters the (blocking, collective) initialisation when one rank's
+        # local preconditions fail: its peers would wait inside ncclCommInitRank for a rank that never comes
+        assert all(g[2] == 0 and g[3] == 0 for g in got)
     else:
         assert got[0][2] == 1 and got[0][3] == 1                    # rank 0 had a communicator: destroyed again
         assert got[1][2] == 0 and got[1][3] == 0
