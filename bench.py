@@ -412,9 +412,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from frenetix_motion_planner_amd.distributed import exit_on_timeout
+
     def step():
-        # inputs are resident: upload happened once; a step re-runs evaluation + selection (+ survivor exchange)
-        return ev.step_enqueued()
+        # inputs are resident: upload happened once; a step re-runs evaluation + selection (+ survivor exchange); with several
+        # ranks a peer that never joins ends this process with an error after the time bound instead of hanging the job
+        return ev.step_enqueued() if world == 1 else exit_on_timeout(ev.step_enqueued)
 
     eng.upload(inp)
     preheat(step, args.preheat, world, 1.2e-4)
@@ -616,8 +619,10 @@ def bench_stress(args, world, rank, local_rank, torch, dist):
     eng.upload(agents)
     last = {}
 
+    from frenetix_motion_planner_amd.distributed import exit_on_timeout
+
     def step():
-        last["res"], last["surv"] = ev.step_agents_enqueued()
+        last["res"], last["surv"] = ev.step_agents_enqueued() if world == 1 else exit_on_timeout(ev.step_agents_enqueued)
 
     elapsed, lat = _timed(args, world, dist, torch, step, 5e-3)
     n_timed = min(256, (args.steps + args.timing_every - 1) // args.timing_every)
@@ -740,9 +745,11 @@ def bench_multiagent(args, world, rank, local_rank, torch, dist):
     sim = MultiAgentSimulation(sc, config=cfg, device=local_rank)
     counts = {"cands": 0, "batch_ms": []}
 
+    from frenetix_motion_planner_amd.distributed import exit_on_timeout
+
     def step():
         before = sim.batch.launches
-        sim.step()
+        sim.step() if world == 1 else exit_on_timeout(sim.step)
         if sim.batch.launches > before:
             counts["batch_ms"].append(sim.batch.last_batch_ms)
 

@@ -211,6 +211,48 @@ def test_fewer_agents_than_ranks_split_their_candidates_gloo(scenario, world, n_
                                                                  range(len([1 for h in got if h[1][0] == ids[0]]))]
 
 
+def _worker_split_gpu(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # (RCCL refuses two ranks on one device)
+    try:
+        sc = crx.read_scenario_json(FIXTURE)
+        sim, winners = _run_sim(sc, 6, number_of_agents=0)
+        q.put((rank, sim.batch.parts, sim.plans.copy(), winners, sim.batch.launches))
+        sim.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_one_agent_split_over_two_processes_on_the_engine(scenario):
+    """The closed loop with ONE agent whose candidates are split over two ranks, on the real engine (two processes on cuda:0,
+    exchange over gloo): the replicas stay bit-identical and equal a single process, plan step after plan step."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_split_gpu, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=500) for _ in range(2)], key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single, w_single = _run_sim(scenario, 6, number_of_agents=0)
+    try:
+        assert [g[1] for g in got] == [[(0, 2)], [(1, 2)]]
+        assert np.array_equal(got[0][2], got[1][2])                       # replicas bit-identical
+        assert np.abs(got[0][2] - single.plans).max() < 1e-9              # and equal to the unsplit run
+        assert got[0][3] == got[1][3] == w_single
+        assert got[0][4] == got[1][4] == 4                                # two plan steps x (part launch + winner launch)
+    finally:
+        single.close()
+
+
 # ------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_closed_loop_on_the_engine_matches_the_oracle_engine(scenario):
