@@ -120,11 +120,15 @@ def pmc_traffic(section, kernel):
         return None
 
 
-def fp64_roofline(section, kernel, kernel_ms):
+def fp64_roofline(section, kernel, kernel_ms, units=None):
     """Executed-work view of one kernel: FP64 flops per launch from the tracked PMC summary of the SAME kernel over the live
     HIP-event duration.  When the summary holds another specialisation (the tuning changed since the passes were taken) no
     fraction is printed at all -- `flops_source` says "stale" -- rather than one that describes a different kernel."""
     fl = executed_fp64_flops(section, kernel)
+    if fl is not None and units is not None:
+        # the tracked passes ran `units_per_launch` units (agents) per launch; this run launches `units`
+        per = profile_summary().get(section, {}).get("units_per_launch")
+        fl = fl * units / per if per else None
     if fl is None:
         return {"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "flops_per_launch": None, "kernel": kernel, "avg_launch_ms": kernel_ms,
@@ -637,7 +641,7 @@ def bench_stress(args, world, rank, local_rank, torch, dist):
         k_walk, _ = kernel_names(info, False, True)
         # executed FP64 work of THIS kernel from the tracked PMC pass (the planning figure of SURVEY 8(d) prices a full
         # axis test per (obstacle, step) although the broad phase skips nearly all of them: it is not used here)
-        compute = fp64_roofline("config5_modeA", k_walk, eval_ms)
+        compute = fp64_roofline("config5_modeA", k_walk, eval_ms, units=n_local)
         res = last["res"]
         out = {
             "metric": "candidate trajectories/sec (50-step horizon, 20 obstacles per agent)",

@@ -28,7 +28,7 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
                                           hipEvent_t ev_start, hipEvent_t ev_stop, FuseArgs fuse, hipStream_t stream);
 extern "C" hipError_t fx_launch_obstacle(const DevProblem *d_probs, int n_agents, int max_items, size_t lds_bytes, int CH,
                                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t stream);
-extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
+extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, int64_t max_candidates, unsigned long long *host_result,
                                        unsigned long long seq, double *dev_winner, double *host_pkg, int pkg_stride, int pkg_plane_rows,
                                        hipStream_t stream);
 extern "C" hipError_t fx_launch_math_test(int n, const double *x, double *at, double *sn, double *cs, hipStream_t stream);
@@ -1067,7 +1067,9 @@ int32_t fx_evaluate(FxContext *c) {
     }
     if (!c->fused_step) {
         // with a package the selection's publishing workgroup gathers the winner's arrays itself (no further launch)
-        HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c->h_counters_dev, c->seq, winner, c->pkg_step ? c->h_pkg_dev : nullptr,
+        int64_t c_max = 0;
+        for (int a = 0; a < c->n_agents; a++) c_max = std::max(c_max, c->slots[a].C);
+        HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c_max, c->h_counters_dev, c->seq, winner, c->pkg_step ? c->h_pkg_dev : nullptr,
                                  c->pkg_stride, c->pkg_plane_rows, c->stream));
     } else if (c->pkg_step) {
         // fused selection publishes while other waves' plane stores may still be in flight: the gather runs as its own small
@@ -1145,6 +1147,13 @@ int32_t fx_update_state(FxContext *c, int32_t agent, const FxStateUpdate *u) {
     }
     FxAgentSlot &sl = c->slots[agent];
     DevProblem &d = c->h_probs[agent];
+    // every argument is checked BEFORE anything is rewritten: an update that is refused leaves the context as it was
+    if ((u->t_samp || u->v_samp || u->d_samp) && sl.off_t == (size_t)-1)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d was uploaded with a sampling matrix: upload again", agent);
+    if ((u->obs_pos || u->obs_cov_inv || u->obs_npred || u->obs_hull || u->obs_nhull) && sl.K <= 0)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d was uploaded without obstacles: upload again", agent);
+    if ((u->obs_hull || u->obs_nhull) && !sl.have_hull)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d was uploaded without obstacle hulls: upload again", agent);
     auto touch = [&](size_t off, size_t bytes) {
         c->dirty_lo = std::min(c->dirty_lo, off);
         c->dirty_hi = std::max(c->dirty_hi, off + bytes);
@@ -1159,13 +1168,11 @@ int32_t fx_update_state(FxContext *c, int32_t agent, const FxStateUpdate *u) {
     if (u->v_des == u->v_des) d.v_des = u->v_des;
     if (u->low_vel_mode >= 0) d.low_vel_mode = u->low_vel_mode;
     if (u->t_samp || u->v_samp || u->d_samp) {
-        if (sl.off_t == (size_t)-1) return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d was uploaded with a sampling matrix: upload again", agent);
         if (u->t_samp) { memcpy(c->h_in + sl.off_t, u->t_samp, sizeof(double) * sl.nT); touch(sl.off_t, sizeof(double) * sl.nT); }
         if (u->v_samp) { memcpy(c->h_in + sl.off_v, u->v_samp, sizeof(double) * sl.nV); touch(sl.off_v, sizeof(double) * sl.nV); }
         if (u->d_samp) { memcpy(c->h_in + sl.off_d, u->d_samp, sizeof(double) * sl.nD); touch(sl.off_d, sizeof(double) * sl.nD); }
     }
     const bool new_obs = u->obs_pos || u->obs_cov_inv || u->obs_npred || u->obs_hull || u->obs_nhull;
-    if (new_obs && sl.K <= 0) return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d was uploaded without obstacles: upload again", agent);
     if (new_obs || (origin_moved && sl.K > 0)) {
         const int K = sl.K, P = sl.P, S = sl.S;
         double *pos = reinterpret_cast<double *>(c->h_in + sl.off_pos), *cov = reinterpret_cast<double *>(c->h_in + sl.off_cov);
@@ -1180,8 +1187,6 @@ int32_t fx_update_state(FxContext *c, int32_t agent, const FxStateUpdate *u) {
             nhull = reinterpret_cast<int32_t *>(c->h_in + sl.off_nhull);
             if (u->obs_hull) memcpy(hull, u->obs_hull, sizeof(double) * 6 * K * (P - 1));
             if (u->obs_nhull) memcpy(nhull, u->obs_nhull, sizeof(int32_t) * K);
-        } else if (u->obs_hull || u->obs_nhull) {
-            return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d was uploaded without obstacle hulls: upload again", agent);
         }
         hot_origin_of(reinterpret_cast<const double *>(c->h_in + sl.off_ref), sl.M, d.x0_lon[0], d.hot_origin);
         d.hot_gap_margin = pack_obstacle_tables(S, K, P, pos, cov, npred, hull, nhull, sl.have_hull, d.hot_origin[0], d.hot_origin[1],

@@ -229,7 +229,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
                 pred = 0.0;
                 for (int i = max(i_begin, 1); i < i_end; i++)
                     for (int k = 0; k < K; k++)
-                        if (i < obs_npred[k]) {
+                        if (i < obs_npred[k] && i - 1 < Pn) {   // npred is the real length of the prediction, Pn what is stored
                             const FX_GLOBAL double *__restrict__ mu = obs_pos + ((int64_t)k * Pn + (i - 1)) * 2;
                             const FX_GLOBAL double *__restrict__ iv = obs_cov_inv + ((int64_t)k * Pn + (i - 1)) * 4;
                             const double e0 = 0.0 - mu[0], e1 = 0.0 - mu[1];

@@ -91,11 +91,14 @@ extern "C" hipError_t fx_launch_package(const DevProblem *d_probs, int n_agents,
 // counts the colliding candidates that the reference's cost-ordered walk would have visited before it
 // (planner.py:336-357 `_collision_counter`).
 // ---------------------------------------------------------------------------------------------------
-// grid = (FX_SELECT_SLICES, n_agents): every workgroup reduces the (few hundred) partials to the winner on its own, counts
+// grid = (slices, n_agents): every workgroup reduces the (few hundred) partials to the winner on its own, counts
 // the colliding candidates ordered before the winner in its slice of the candidates (loads of four iterations in
 // flight), adds its count to the agent's device counter and takes a ticket; the workgroup that draws the last ticket
 // publishes the result block.  One workgroup scanning 50 000 candidates took ~30 us; the slices take ~5.
-#define FX_SELECT_SLICES 32
+// The number of slices grows with the candidate count (host: fx_launch_select): 32 for planner-sized and 50 000-candidate steps,
+// 256 at a million candidates -- with a fixed 32 every workgroup scanned 31 000 cost / flag pairs there while 224 CUs idled.
+#define FX_SELECT_SLICES_MIN 32
+#define FX_SELECT_SLICES_MAX 512
 __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__restrict__ probs, unsigned long long *host_result,
                                                         unsigned long long seq, double *dev_winner, double *host_pkg, int pkg_stride,
                                                         int pkg_plane_rows) {
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__rest
     const bool none = bi == 0x7fffffffffffffffLL;
     // colliding selectable candidates ordered before the winner (all of them when nothing is collision-free)
     if (P.mode & FX_MODE_COLLISION) {
-        const int64_t per = (P.C + FX_SELECT_SLICES - 1) / FX_SELECT_SLICES;
+        const int64_t per = (P.C + gridDim.x - 1) / gridDim.x;
         const int64_t g0 = (int64_t)blockIdx.x * per, g1 = min(P.C, g0 + per);
         const FX_GLOBAL uint32_t *__restrict__ fl = as_global(P.flags);
         const FX_GLOBAL double *__restrict__ co = as_global(P.cost);
@@ -166,13 +169,13 @@ __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__rest
         __syncthreads();
     }
     // The workgroup that draws the last ticket of this agent publishes.  ONE device-scope atomic per workgroup carries both
-    // the ticket (low byte) and the slice's count (upper bits): no second atomic, no fence between them -- the chain of
+    // the ticket (low 16 bits) and the slice's count (upper bits): no second atomic, no fence between them -- the chain of
     // device-coherent round trips is what this kernel's 8 us are made of.
-    static_assert(FX_SELECT_SLICES < 256, "the ticket lives in the low byte");
-    if (tid == 0) s_ticket = atomicAdd(&P.counters[FX_DCNT_TICKET], ((unsigned long long)scnt << 8) | 1ULL);
+    static_assert(FX_SELECT_SLICES_MAX < 65536, "the ticket lives in the low 16 bits");
+    if (tid == 0) s_ticket = atomicAdd(&P.counters[FX_DCNT_TICKET], ((unsigned long long)scnt << 16) | 1ULL);
     __syncthreads();
-    if ((s_ticket & 0xffULL) != (unsigned long long)(FX_SELECT_SLICES - 1)) return;
-    const unsigned long long collisions = (s_ticket >> 8) + scnt;
+    if ((s_ticket & 0xffffULL) != (unsigned long long)(gridDim.x - 1)) return;
+    const unsigned long long collisions = (s_ticket >> 16) + scnt;
     // Publish the step's result straight into pinned host memory (the host polls the sequence word instead of
     // paying for a D2H copy and a stream synchronisation) and leave the device counters zeroed for the next step.  The
     // counters were accumulated by the evaluation kernel, which is complete: plain loads and stores.
@@ -452,10 +455,15 @@ extern "C" hipError_t fx_launch_obstacle(const DevProblem *d_probs, int n_agents
     return hipErrorInvalidValue;
 }
 
-extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, unsigned long long *host_result,
+extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, int64_t max_candidates, unsigned long long *host_result,
                                        unsigned long long seq, double *dev_winner, double *host_pkg, int pkg_stride, int pkg_plane_rows,
                                        hipStream_t stream) {
-    hipLaunchKernelGGL(fx_select_kernel, dim3(FX_SELECT_SLICES, n_agents), dim3(256), 0, stream, d_probs, host_result, seq, dev_winner,
+    // one slice per ~4 096 candidates of the largest agent, at least 32 (the small-step tuning), a power of two, at most 512
+    int slices = FX_SELECT_SLICES_MIN;
+    while (slices < FX_SELECT_SLICES_MAX && (int64_t)slices * 4096 < max_candidates) slices *= 2;
+    // batched launches: keep the grid around a thousand workgroups (every workgroup reduces all of an agent's partials)
+    while (slices > FX_SELECT_SLICES_MIN && (int64_t)slices * n_agents > 2048) slices /= 2;
+    hipLaunchKernelGGL(fx_select_kernel, dim3(slices, n_agents), dim3(256), 0, stream, d_probs, host_result, seq, dev_winner,
                        host_pkg, pkg_stride, pkg_plane_rows);
     return hipGetLastError();
 }

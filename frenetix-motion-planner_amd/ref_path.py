@@ -4,7 +4,8 @@ Behaviour contract (checked against vectors the reference's own functions produc
 
     cr_scenario_handler/utils/utils_coordinate_system.py
         extend_path_linearly :21-51     extend_ref_path_both_ends :54-58     extend_points :61-77
-        extend_ref_path      :102-108   smooth_ref_path           :110-134
+        extend_points_end    :80-99     extend_ref_path           :102-108   smooth_ref_path :110-134
+        extrapolate_ref_path :158-170   preprocess_ref_path       :173-184
 
 `FrenetPlannerInterface` feeds `smooth_ref_path(extend_ref_path_both_ends(route.reference_path))` to the planner's
 coordinate system (`frenet_interface.py:110-114`); `prepare_reference_path` is that composition.
@@ -118,6 +119,52 @@ def extend_ref_path(ref_path, init_pos):
     gap2 = (ref_path[:, 0] - init_pos[0]) ** 2 + (ref_path[:, 1] - init_pos[1]) ** 2
     nearest = ref_path[int(np.argmin(gap2))]
     return extend_points(ref_path) if (nearest == ref_path[0]).all() else ref_path
+
+
+def extend_points_end(points, extension_length=30):
+    """`extension_length` metres of extra vertices behind the path, spaced like its last segment (:80-99).  Coincident end
+    vertices: the input is handed back untouched."""
+    last = np.array([points[-1][0] - points[-2][0], points[-1][1] - points[-2][1]], dtype=np.float64)
+    spacing = float(np.sqrt(last[0] ** 2 + last[1] ** 2))
+    if spacing == 0:
+        return points
+    return prolong(points, int(extension_length / spacing), last, front=False)
+
+
+def extrapolate_ref_path(reference_path: np.ndarray, resample_step: float = 0.25) -> np.ndarray:
+    """One vertex on the straight line through the last two vertices, 1.3 x their x-distance further on, then resampled
+    (:158-170: a reference shorter than the planning horizon would leave the projection domain)."""
+    ref = _as_polyline(reference_path)
+    line = np.poly1d(np.polyfit(ref[-2:, 0], ref[-2:, 1], 1))
+    x = 2.3 * ref[-1, 0] - ref[-2, 0]
+    return resample_polyline(np.concatenate([ref, np.array([[x, line(x)]])]), step=resample_step)
+
+
+def chaikins_corner_cutting(polyline, refinements: int = 1) -> np.ndarray:
+    """Chaikin's corner cutting: every refinement replaces each segment (p, q) by the points 3/4 p + 1/4 q and 1/4 p + 3/4 q
+    and keeps the two end vertices.  Stands in for `commonroad_dc.geometry.util.chaikins_corner_cutting` (not in the reference
+    tree): restated from the published algorithm, parity unpinned."""
+    pts = _as_polyline(polyline)
+    for _ in range(int(refinements)):
+        if len(pts) < 2:
+            break
+        p, q = pts[:-1], pts[1:]
+        cut = np.empty((2 * len(p), 2))
+        cut[0::2] = 0.75 * p + 0.25 * q
+        cut[1::2] = 0.25 * p + 0.75 * q
+        pts = np.concatenate([pts[:1], cut, pts[-1:]])
+    return pts
+
+
+def preprocess_ref_path(ref_path: np.ndarray, resample_step: float = 0.1, max_curv_desired: float = 0.1):
+    """Corner cutting + resampling until the largest curvature of the path is at most `max_curv_desired` (:173-184)."""
+    from .coordinate_system import compute_curvature_from_polyline
+    out = _as_polyline(ref_path).copy()
+    max_curv = max_curv_desired + 0.2
+    while max_curv > max_curv_desired:
+        out = resample_polyline(chaikins_corner_cutting(out), resample_step)
+        max_curv = max(compute_curvature_from_polyline(out))
+    return out
 
 
 ROUTE_SPACING = 0.125  # vertex spacing the route planner delivers; smooth_ref_path is written for it (:117)

@@ -150,7 +150,9 @@ typedef struct FxProblem {
 
     /* predictions (prediction_helpers.py:209-261 dict -> packed): K obstacles, P steps each.
      * obs_pos[K][P][2], obs_cov_inv[K][P][4] (np.linalg.inv(cov_list), row-major 2x2),
-     * obs_npred[K] = len(pos_list) (<= P).  collision_probability.py:264-299.
+     * obs_npred[K] = len(pos_list): the REAL length of the prediction -- it decides which ego steps see the obstacle
+ * (collision_probability.py:287) and may exceed the stride P, which only bounds what is stored and read (a predictor with a longer
+ * horizon than the planner's does not enlarge the tables; fx_pack_predictions).  collision_probability.py:264-299.
      * K <= FX_MAX_OBSTACLES; up to 64 obstacles the grid kernel applies, beyond that the step runs on the generic kernel
      * (the per-step obstacle masks take one 64-bit word per 64 obstacles). */
     int32_t K, P;

@@ -48,6 +48,11 @@ def main():
     from frenetix_motion_planner_amd import ref_path as mine
     import cr_scenario_handler.utils.utils_coordinate_system as ucs
     ucs.resample_polyline = mine.resample_polyline
+    # the two other commonroad_dc helpers preprocess_ref_path calls: the build's restatements (unpinned), so that the vectors pin
+    # the reference's own loop
+    from frenetix_motion_planner_amd.coordinate_system import compute_curvature_from_polyline
+    ucs.chaikins_corner_cutting = mine.chaikins_corner_cutting
+    ucs.compute_curvature_from_polyline = compute_curvature_from_polyline
     fx = {}
     for name, pl in polylines().items():
         fx[f"{name}/in"] = pl
@@ -56,6 +61,12 @@ def main():
         fx[f"{name}/extend_points"] = np.asarray(ucs.extend_points(pl))
         fx[f"{name}/extend_ref_path_first"] = np.asarray(ucs.extend_ref_path(pl, pl[0] + np.array([-0.3, 0.1])))
         fx[f"{name}/extend_ref_path_mid"] = np.asarray(ucs.extend_ref_path(pl, pl[len(pl) // 2]))
+        fx[f"{name}/extend_points_end_30"] = np.asarray(ucs.extend_points_end(pl))
+        fx[f"{name}/extrapolate"] = np.asarray(ucs.extrapolate_ref_path(pl))
+        if name == "coarse_diag":
+            bent = np.vstack([pl[:12], pl[12:] + np.array([0.0, 1.0]) * np.arange(len(pl) - 12)[:, None] * 0.8])
+            fx[f"{name}/bent_in"] = bent
+            fx[f"{name}/preprocessed"] = np.asarray(ucs.preprocess_ref_path(bent))
         if name != "coarse_diag":
             fx[f"{name}/smooth"] = np.asarray(ucs.smooth_ref_path(pl))
             fx[f"{name}/smooth_8"] = np.asarray(ucs.smooth_ref_path(pl, 8))

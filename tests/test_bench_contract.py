@@ -45,11 +45,12 @@ def test_default_line_is_config3_with_north_star():
     assert d["launch"]["obstacle_kernel"] == 1 and len(d["kernels"]) == 2
     hb, ob = d["kernels"]
     assert d["roofline"] in (hb, ob) and d["roofline"]["avg_launch_ms"] == max(hb["avg_launch_ms"], ob["avg_launch_ms"])
-    assert ob["bound"] == "fp64_valu" and ob["peak"] == 78.6 and ob["unit"] == "TFLOP/s" and 0.02 < ob["frac"] < 1.0
-    assert ob["achieved"] == pytest.approx(ob["flops_per_launch"] / (ob["avg_launch_ms"] * 1e-3) / 1e12)
+    assert ob["bound"] == "fp64_valu" and ob["peak"] == 78.6 and ob["unit"] == "TFLOP/s"
     assert ob["launches_timed"] == 24 and "fx_obstacle_kernel" in ob["kernel"]  # every launch is timed below 64 steps
-    # a figure taken from the tracked PMC summary names the kernel it was measured on; anything else says "stale"
-    assert ob["kernel"] in ob["flops_source"] or ob["flops_source"].startswith("executed FP64 instructions of this kernel")
+    # the executed-work figure comes from the tracked PMC summary of THIS kernel (profiles/r3); the tracked summary must hold
+    # the specialisation the automatic tuning launches -- a "stale" line (no fraction at all) means the profiles need re-collecting
+    assert ob["flops_source"].startswith("executed FP64 instructions of this kernel"), ob["flops_source"]
+    assert 0.02 < ob["frac"] < 1.0 and ob["achieved"] == pytest.approx(ob["flops_per_launch"] / (ob["avg_launch_ms"] * 1e-3) / 1e12)
     assert hb == d["roofline_hbm"]
     assert hb["bound"] == "hbm" and hb["peak"] == 8000.0 and hb["algorithmic_bytes_per_launch"] == 50388 * 3472 and 0.2 < hb["frac"] < 1.0
     assert hb["achieved"] == pytest.approx(hb["algorithmic_bytes_per_launch"] / (hb["avg_launch_ms"] * 1e-3) / 1e9)
@@ -62,7 +63,8 @@ def test_default_line_is_config3_with_north_star():
     ns = d["north_star"]
     a, b = ns["obstacles_select_only"], ns["bundle_no_obstacles"]
     assert a["candidates"] == 1005100 and a["obstacles"] == 20 and a["samples"] == 31 and a["eval_kernel_ms"] < 10.0 and a["step_ms"] < 10.0
-    assert a["roofline"]["bound"] == "fp64_valu" and 0 < a["roofline"]["frac"] < 1 and a["launch"]["obstacle_kernel"] == 0
+    assert a["roofline"]["bound"] == "fp64_valu" and a["launch"]["obstacle_kernel"] == 0
+    assert a["roofline"]["flops_source"].startswith("executed FP64") and 0 < a["roofline"]["frac"] < 1
     assert b["candidates"] == 1005100 and b["roofline"]["bound"] == "hbm" and b["roofline"]["algorithmic_bytes_per_launch"] == 1005100 * 3472
     assert 0.2 < b["roofline"]["frac"] < 1.0
 

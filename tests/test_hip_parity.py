@@ -17,6 +17,15 @@ pytestmark = pytest.mark.gpu
 STATE_TOL = 1e-9
 COST_RTOL = 1e-9
 FRAGILE = 1e-9
+# How the candidates of every compare() were checked (tests/admissible.py): the tolerances grow with the conditioning of the
+# reference's own arithmetic, and a tolerance of 1 or more is not asserted at all -- so the suite counts what went through
+# each door and fails when more than a sliver did: a regression in the arithmetic cannot hide behind the scaling.
+#   checked      candidates compared                      fixed    well-conditioned (cond <= 1e3): asserted at 1e-9 (+ 2 %)
+#   scaled       cond > 1e3: conditioning-scaled tolerance  escaped  some plane's tolerance >= 1: that plane not asserted
+#   fragile      decided by the last ulp: compared with every admissible outcome
+PARITY_STATS = dict(checked=0, fixed=0, scaled=0, escaped=0, fragile=0)
+WELL_CONDITIONED = 1e3
+MAX_ESCAPED_FRACTION = 2e-3     # per compare(): at most this share of the stored candidates (or 2 of them) without an assertion
 
 
 @pytest.fixture(scope="module")
@@ -75,6 +84,10 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
         err = np.abs(cost[c] - out["cost"][c])
         lim = (COST_RTOL + 4e-14 * cond_kin[c]) * np.maximum(np.abs(out["cost"][c]), 1e-12) + abs(w_pl) * slack[c]
         assert (err < lim).all(), f"cost rel err {(err / np.maximum(np.abs(out['cost'][c]), 1e-12)).max()}"
+        # well-conditioned candidates without a signed-integral term: the FIXED relative bound
+        wellc = (cond_kin[c] <= WELL_CONDITIONED) & (abs(w_pl) * slack[c] == 0)
+        assert (err[wellc] < 1.05 * COST_RTOL * np.maximum(np.abs(out["cost"][c][wellc]), 1e-12)).all(), \
+            "cost of a well-conditioned candidate beyond 1e-9 relative"
         if cm is not None:
             errm = np.abs(cm[c] - out["costmap"][c])
             limm = (1e-8 + 4e-14 * cond_kin[c][:, None]) * np.maximum(np.abs(out["costmap"][c]), 1e-9)
@@ -104,6 +117,16 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
         bad = (err >= tol) & (tol < 1.0)   # a relative tolerance of 1 or more: the reference's own value carries no digit
         assert not bad.any(), (f"plane err {err[bad].max()} at (candidate, plane) {np.argwhere(bad)[0]} "
                                f"(tolerance {tol[bad][0]})")
+        # well-conditioned candidates: the FIXED bound, whatever the scaling machinery says
+        well = stored & (cond_kin <= WELL_CONDITIONED)
+        assert not (err[well] >= 1.02 * STATE_TOL).any(), f"plane err {err[well].max()} on a well-conditioned candidate"
+        escaped = stored & (tol >= 1.0).any(axis=1)
+        PARITY_STATS["checked"] += int(stored.sum())
+        PARITY_STATS["fixed"] += int(well.sum())
+        PARITY_STATS["scaled"] += int((stored & ~well).sum())
+        PARITY_STATS["escaped"] += int(escaped.sum())
+        assert escaped.sum() <= max(2, MAX_ESCAPED_FRACTION * stored.sum()), \
+            f"{int(escaped.sum())} of {int(stored.sum())} candidates have a plane whose tolerance reached 1 (not asserted)"
         # coefficients / traj_len of a few candidates
         for g in np.linspace(0, inp.n_candidates - 1, 5).astype(int):
             lon, lat, tl = eng.coeffs(int(g), agent)
@@ -112,6 +135,7 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
             assert tl == out["traj_len"][g]
             assert np.array_equal(eng.sample(int(g), agent), got[g])
     # fragile candidates: one of the admissible outcomes, nothing skipped
+    PARITY_STATS["fragile"] += n_frag
     src = ref_inp if ref_inp is not None else inp
     for g in np.nonzero(~robust)[0]:
         outs = oracle.admissible_outcomes(src, int(g), out["frag_sites"][g])

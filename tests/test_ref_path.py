@@ -26,6 +26,43 @@ def test_extensions_match_reference(name):
     close(ref_path.extend_ref_path(pl, pl[len(pl) // 2]), GOLD[f"{name}/extend_ref_path_mid"], 0.0)
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_end_extension_extrapolation_and_preprocessing_match_reference(name):
+    """extend_points_end (:80-99), extrapolate_ref_path (:158-170), preprocess_ref_path (:173-184)"""
+    pl = GOLD[f"{name}/in"]
+    close(np.asarray(ref_path.extend_points_end(pl)), GOLD[f"{name}/extend_points_end_30"], 1e-12)
+    close(ref_path.extrapolate_ref_path(pl), GOLD[f"{name}/extrapolate"], 1e-9)
+    if f"{name}/preprocessed" in GOLD.files:
+        out = ref_path.preprocess_ref_path(GOLD[f"{name}/bent_in"])
+        close(out, GOLD[f"{name}/preprocessed"], 1e-9)
+        from frenetix_motion_planner_amd.coordinate_system import compute_curvature_from_polyline
+        assert max(compute_curvature_from_polyline(out)) <= 0.1
+
+
+def test_resample_against_hand_computed_vectors():
+    """resample_polyline stands in for commonroad_dc's helper (unpinned): vectors worked out by hand, independent of the
+    implementation -- walk the path, drop a vertex every `step` metres of arc length, close with the last vertex."""
+    # 3 m east, then 4 m north (7 m): samples at arc length 0, 2, 4, 6 and the end
+    L = np.array([[0.0, 0.0], [3.0, 0.0], [3.0, 4.0]])
+    assert np.allclose(ref_path.resample_polyline(L, 2.0), [[0, 0], [2, 0], [3, 1], [3, 3], [3, 4]], atol=1e-12)
+    # 2.5 m straight, step 1: 0, 1, 2 and the end vertex at 2.5
+    assert np.allclose(ref_path.resample_polyline(np.array([[0.0, 0.0], [2.5, 0.0]]), 1.0), [[0, 0], [1, 0], [2, 0], [2.5, 0]], atol=1e-12)
+    # the last sample lands exactly on the end: no duplicate
+    assert np.allclose(ref_path.resample_polyline(np.array([[0.0, 0.0], [4.0, 0.0]]), 2.0), [[0, 0], [2, 0], [4, 0]], atol=1e-12)
+    # a 3-4-5 diagonal followed by a short leg: arc 0 .. 5 on the diagonal (unit vector (0.6, 0.8)), 5 .. 6.5 east
+    D = np.array([[0.0, 0.0], [3.0, 4.0], [4.5, 4.0]])
+    want = [[0, 0], [1.2, 1.6], [2.4, 3.2], [4.0, 4.0], [4.5, 4.0]]       # arc 0, 2, 4, 6 (= 1 m past the corner), end
+    assert np.allclose(ref_path.resample_polyline(D, 2.0), want, atol=1e-12)
+    # step longer than the path: just the two ends
+    assert np.allclose(ref_path.resample_polyline(np.array([[1.0, 1.0], [1.0, 2.0]]), 5.0), [[1, 1], [1, 2]], atol=1e-12)
+
+
+def test_chaikin_keeps_the_ends_and_cuts_the_corner():
+    sq = np.array([[0.0, 0.0], [4.0, 0.0], [4.0, 4.0]])
+    assert np.allclose(ref_path.chaikins_corner_cutting(sq), [[0, 0], [1, 0], [3, 0], [4, 1], [4, 3], [4, 4]])
+    assert len(ref_path.chaikins_corner_cutting(sq, 3)) == 24   # n vertices -> 2 n per refinement
+
+
 @pytest.mark.parametrize("name", [n for n in NAMES if f"{n}/smooth" in GOLD.files])
 def test_smoothing_matches_reference(name):
     pl = GOLD[f"{name}/in"]

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from frenetix_motion_planner_amd import synthetic
-from tests.test_hip_parity import FRAGILE, _random_case, compare, hip_hulls
+from tests.test_hip_parity import FRAGILE, PARITY_STATS, _random_case, compare, hip_hulls
 
 pytestmark = pytest.mark.gpu
 
@@ -16,6 +16,7 @@ def test_soak_block(block):
     from frenetix_motion_planner_amd.engine import FrenetEngine
     from oracle import oracle
     n_fragile = n_cands = 0
+    before = dict(PARITY_STATS)
     for case in range(5000 + 30 * block, 5000 + 30 * (block + 1)):
         rng = np.random.default_rng([20241008, case])
         kw = _random_case(rng)
@@ -27,10 +28,12 @@ def test_soak_block(block):
                   int(rng.choice([0, 64, 128, 256])), int(rng.choice([0, 1, 2])))
             e.set_tuning(*tn)
             e.set_store_mode(int(rng.integers(0, 3)))
+            e.set_obstacle_stage(int(rng.choice([0, 1, 2])), int(rng.choice([0, 2, 3, 5])))   # fused / its own kernel
             try:
                 res = e.plan_step(inp)
             except ValueError:  # a forced variant that does not apply to this case
                 e.set_tuning(0, 0, 0, 0, 0)
+                e.set_obstacle_stage(0)
                 res = e.plan_step(inp)
             try:
                 compare(e, inp, out, res, ref_inp=ref_inp)
@@ -41,3 +44,9 @@ def test_soak_block(block):
         n_fragile += int((out["margin"] < FRAGILE).sum())
         n_cands += inp.n_candidates
     assert n_cands > 0
+    # how the block's candidates were checked: nearly all of them at the fixed 1e-9, a sliver with a conditioning-scaled
+    # tolerance, (almost) none without an assertion, the fragile ones against their admissible outcomes
+    d = {k: PARITY_STATS[k] - before[k] for k in PARITY_STATS}
+    assert d["checked"] > 0 and d["fixed"] >= 0.97 * d["checked"], d
+    assert d["escaped"] <= max(2, 5e-4 * d["checked"]), d
+    assert n_fragile <= 0.12 * n_cands, (n_fragile, n_cands)

@@ -48,6 +48,7 @@ for sec, cmd in cmds.items():
     out[sec] = {"command": "rocprofv3 --pmc <group> -- " + cmd + "  (one pass per counter group)",
                 "kernels": {k: {c: sum(v) / len(v) for c, v in sorted(d.items())} for k, d in agg.items()},
                 "launches": {k: {c: len(v) for c, v in sorted(d.items())} for k, d in agg.items()}}
+out["config5_modeA"]["units_per_launch"] = 32   # agents per launch of that command (bench.py scales the counts to its own)
 json.dump(out, open(O + "/summary.json", "w"), indent=1)
 print(json.dumps({k: (v if k == "kernel_stats" else list(v.get("kernels", {})) if isinstance(v, dict) else v) for k, v in out.items()}, indent=1)[:4000])
 PY

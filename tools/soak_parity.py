@@ -7,7 +7,7 @@ import numpy as np
 from frenetix_motion_planner_amd import synthetic
 from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
 from oracle import oracle
-from tests.test_hip_parity import _random_case, compare, FRAGILE
+from tests.test_hip_parity import _random_case, compare, FRAGILE, PARITY_STATS
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
@@ -35,10 +35,12 @@ for case in range(first, first + n):
                       int(rng.choice([0, 64, 128, 256])), int(rng.choice([0, 1, 2])))
                 e.set_tuning(*tn)
                 e.set_store_mode(int(rng.integers(0, 3)))
+                e.set_obstacle_stage(int(rng.choice([0, 1, 2])), int(rng.choice([0, 2, 3, 5])))   # fused / its own kernel
                 try:
                     res = e.plan_step(inp)
                 except ValueError:  # a forced variant that does not apply to this case
                     e.set_tuning(0, 0, 0, 0, 0)
+                    e.set_obstacle_stage(0)
                     res = e.plan_step(inp)
             else:
                 res = e.plan_step(inp)
@@ -54,4 +56,11 @@ for case in range(first, first + n):
     except Exception as ex:
         bad += 1
         print("CASE", case, "FAILED:", repr(ex)[:300], kw, flush=True)
-print(f"soak: {n} cases from {first}: {bad} failures; {stats}", flush=True)
+print(f"soak: {n} cases from {first}: {bad} failures; {stats}; how they were checked: {PARITY_STATS}", flush=True)
+ck = max(PARITY_STATS["checked"], 1)
+print(f"   fixed 1e-9: {PARITY_STATS['fixed'] / ck:.4%}  conditioning-scaled: {PARITY_STATS['scaled'] / ck:.4%}  not asserted (tolerance >= 1): "
+      f"{PARITY_STATS['escaped'] / ck:.5%}  fragile (admissible outcomes): {stats['fragile'] / max(stats['cands'], 1):.3%} of all candidates", flush=True)
+if PARITY_STATS["escaped"] > max(3, 5e-4 * ck) or PARITY_STATS["fixed"] < 0.97 * ck:
+    print("soak: TOO MANY candidates went through the scaled / unasserted doors", flush=True)
+    bad += 1
+sys.exit(1 if bad else 0)
