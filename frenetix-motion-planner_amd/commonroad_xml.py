@@ -53,17 +53,24 @@ class Lanelet:
         return 0.5 * (self.left_vertices + self.right_vertices)
 
     def contains(self, p) -> bool:
-        """Point-in-polygon (ray casting) on the lanelet's outline."""
-        poly = np.vstack([self.left_vertices, self.right_vertices[::-1]])
+        """Point-in-polygon (ray casting) on the lanelet's outline; the outline (and its bounding box, which settles most
+        queries) is built once per lanelet."""
+        c = self.__dict__.get("_outline")
+        if c is None:
+            poly = np.vstack([self.left_vertices, self.right_vertices[::-1]])
+            xi, yi = poly[:, 0], poly[:, 1]
+            c = self.__dict__["_outline"] = (xi, yi, np.roll(xi, 1), np.roll(yi, 1), float(xi.min()), float(xi.max()),
+                                             float(yi.min()), float(yi.max()))
+        xi, yi, xj, yj, x0, x1, y0, y1 = c
         x, y = float(p[0]), float(p[1])
-        inside = False
-        j = len(poly) - 1
-        for i in range(len(poly)):
-            xi, yi, xj, yj = poly[i, 0], poly[i, 1], poly[j, 0], poly[j, 1]
-            if (yi > y) != (yj > y) and x < (xj - xi) * (y - yi) / (yj - yi) + xi:
-                inside = not inside
-            j = i
-        return inside
+        if x < x0 or x > x1 or y < y0 or y > y1:
+            return False
+        cross = (yi > y) != (yj > y)
+        if not cross.any():
+            return False
+        with np.errstate(divide="ignore", invalid="ignore"):
+            hit = cross & (x < (xj - xi) * (y - yi) / (yj - yi) + xi)
+        return bool(np.count_nonzero(hit) & 1)
 
 
 @dataclass

@@ -80,7 +80,45 @@ def _pack_predictions_c(entries, P: int, n_samples: int):
                 npred=cnt[0], hull=out[sizes[0] + sizes[1]:].reshape(K, P - 1, 6), nhull=cnt[1])
 
 
+_FXHOST = None
+
+
+def _fxhost():
+    """the CPython extension `_fxhost` (csrc/fx_host_ext.c, built next to the package by `make`); False when it is not there"""
+    global _FXHOST
+    if _FXHOST is None:
+        try:
+            from . import _fxhost as m
+            _FXHOST = (m, C.cast(lib().fx_pack_predictions, C.c_void_p).value)
+        except ImportError:
+            _FXHOST = False
+    return _FXHOST
+
+
+def _pack_predictions_dict(predictions: dict, n_samples: int, max_obstacles: int):
+    """The whole predictions dict in one call: walked in C (buffer protocol), packed by fx_pack_predictions.  None when some
+    entry is not a contiguous float64 array (the caller converts and takes the general path)."""
+    h = _fxhost()
+    if not h:
+        return None
+    try:
+        r = h[0].pack_predictions(h[1], predictions, int(n_samples), int(max_obstacles))
+    except ValueError as e:
+        if b"singular" in lib().fx_last_error():
+            raise np.linalg.LinAlgError("Singular matrix") from e
+        raise
+    if r is None:
+        return None
+    K, P, out, cnt = r
+    o = np.frombuffer(out, dtype=np.float64)
+    c = np.frombuffer(cnt, dtype=np.int32)
+    n_pos, n_cov = 2 * K * P, 4 * K * P
+    return dict(K=K, P=P, pos=o[:n_pos].reshape(K, P, 2), cov_inv=o[n_pos:n_pos + n_cov].reshape(K, P, 4), npred=c[:K],
+                hull=o[n_pos + n_cov:].reshape(K, P - 1, 6), nhull=c[K:])
+
+
 build_obstacle_hulls.pack = _pack_predictions_c
+build_obstacle_hulls.pack_dict = _pack_predictions_dict
 build_obstacle_hulls.batch = _build_obstacle_hulls_batch
 build_obstacle_hulls.invert_cov2 = invert_cov2
 

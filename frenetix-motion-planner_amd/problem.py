@@ -100,6 +100,11 @@ def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
     if not predictions:
         z = np.zeros(0)
         return dict(K=0, P=0, pos=z, cov_inv=z, npred=np.zeros(0, np.int32), hull=z, nhull=np.zeros(0, np.int32))
+    pack_dict = getattr(build_hulls, "pack_dict", None)
+    if pack_dict is not None:   # the dict walked in C (csrc/fx_host_ext.c); None: something needs converting first
+        packed = pack_dict(predictions, n_samples, MAX_OBSTACLES)
+        if packed is not None:
+            return packed
     keys = list(predictions.keys())
     K = len(keys)
     if K > MAX_OBSTACLES:

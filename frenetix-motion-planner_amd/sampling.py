@@ -141,13 +141,19 @@ def dense_ranges(n_t: int, n_v: int, n_d: int, v_lo: float, v_hi: float, horizon
                  t_min: float = 1.1, d_min: float = -3.0, d_max: float = 3.0):
     """Dense grid in natural (ascending) order: T = t_min .. horizon step dt (first n_t), V = linspace(v_lo, v_hi, n_v),
     D = linspace(d_min, d_max, n_d) plus d0 appended if absent (BASELINE configs 2 - 5)."""
-    t = np.round(t_min + dt * np.arange(n_t), 2)
-    t = t[t <= horizon + 1e-9]
+    key = (n_t, n_d, horizon, dt, t_min, d_min, d_max)
+    c = _DENSE_CACHE.get(key)
+    if c is None:   # the time and lateral sets of a planner never change: built once
+        t = np.round(t_min + dt * np.arange(n_t), 2)
+        c = _DENSE_CACHE[key] = (t[t <= horizon + 1e-9], np.linspace(d_min, d_max, n_d))
+    t, d = c
     v = np.linspace(v_lo, v_hi, n_v)
-    d = np.linspace(d_min, d_max, n_d)
     if d0 not in d:
         d = np.append(d, d0)
     return t, v, d
+
+
+_DENSE_CACHE: dict = {}
 
 
 def generate_sampling_matrix(*, t0_range, t1_range, s0_range, ss0_range, sss0_range, ss1_range, sss1_range,
