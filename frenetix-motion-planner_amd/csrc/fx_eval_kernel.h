@@ -79,27 +79,37 @@ struct Obb {
     double cx, cy, ex, ey, h1, h2;
 };
 
+// Arithmetic diet (the hull is built once per (candidate, step) of the collision stage -- as many instructions as the twenty
+// prediction visits of the step when it used the IEEE sqrt and two IEEE divisions): the unit axis comes from v_rsq_f64 + two
+// coupled Newton steps (1 / |m| to an ulp, sqrt_rsqrt in fx_walk.h), and the two boxes' extents along the hull axes are formed
+// from the same two products each (|u . e| and |u x e| serve both axes: u . f = -(u x e), u x f = u . e for f = e rotated by
+// 90 degrees).  Differs from the oracle's libm form by an ulp or two in (ex, ey); decisions are unaffected (tests).
+__device__ __forceinline__ void sqrt_rsqrt(double x, double &sq, double &rsq);
 __device__ __forceinline__ Obb obb_hull(double c0x, double c0y, double u0x, double u0y, double c1x, double c1y,
                                         double u1x, double u1y, double hl, double hw) {
-    double mx = u0x + u1x, my = u0y + u1y;
-    double mn = sqrt(mx * mx + my * my);
-    double ex, ey;
-    if (mn < 1e-12) { ex = u0x; ey = u0y; } else { ex = mx / mn; ey = my / mn; }
-    double fx = -ey, fy = ex;
-    double p1 = c0x * ex + c0y * ey, p2 = c0x * fx + c0y * fy;
-    double r1 = hl * fabs(u0x * ex + u0y * ey) + hw * fabs(-u0y * ex + u0x * ey);
-    double r2 = hl * fabs(u0x * fx + u0y * fy) + hw * fabs(-u0y * fx + u0x * fy);
+    const double mx = u0x + u1x, my = u0y + u1y;
+    double mn, r_mn;
+    sqrt_rsqrt(fma(mx, mx, my * my), mn, r_mn);
+    const bool flat = !(mn >= 1e-12);   // opposite headings (or a non-finite one): the first box's axis
+    const double ex = flat ? u0x : mx * r_mn, ey = flat ? u0y : my * r_mn;
+    // box 0
+    double p1 = fma(c0x, ex, c0y * ey), p2 = fma(c0y, ex, -(c0x * ey));
+    double a = fabs(fma(u0x, ex, u0y * ey)), b = fabs(fma(u0x, ey, -(u0y * ex)));
+    double r1 = fma(hl, a, hw * b), r2 = fma(hl, b, hw * a);
     double lo1 = p1 - r1, hi1 = p1 + r1, lo2 = p2 - r2, hi2 = p2 + r2;
-    p1 = c1x * ex + c1y * ey;
-    p2 = c1x * fx + c1y * fy;
-    r1 = hl * fabs(u1x * ex + u1y * ey) + hw * fabs(-u1y * ex + u1x * ey);
-    r2 = hl * fabs(u1x * fx + u1y * fy) + hw * fabs(-u1y * fx + u1x * fy);
+    // box 1
+    p1 = fma(c1x, ex, c1y * ey);
+    p2 = fma(c1y, ex, -(c1x * ey));
+    a = fabs(fma(u1x, ex, u1y * ey));
+    b = fabs(fma(u1x, ey, -(u1y * ex)));
+    r1 = fma(hl, a, hw * b);
+    r2 = fma(hl, b, hw * a);
     lo1 = fmin(lo1, p1 - r1); hi1 = fmax(hi1, p1 + r1);
     lo2 = fmin(lo2, p2 - r2); hi2 = fmax(hi2, p2 + r2);
-    double m1 = 0.5 * (lo1 + hi1), m2 = 0.5 * (lo2 + hi2);
+    const double m1 = 0.5 * (lo1 + hi1), m2 = 0.5 * (lo2 + hi2);
     Obb o;
-    o.cx = m1 * ex + m2 * fx;
-    o.cy = m1 * ey + m2 * fy;
+    o.cx = fma(m1, ex, -(m2 * ey));   // m1 e + m2 f, f = (-ey, ex)
+    o.cy = fma(m1, ey, m2 * ex);
     o.ex = ex;
     o.ey = ey;
     o.h1 = 0.5 * (hi1 - lo1);

@@ -348,10 +348,12 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
     dim3 grid(max_blocks, n_agents), block(FX_BLOCK);
 #define FX_LAUNCH(Gv, B, O, E, W)                                                                                \
     do {                                                                                                        \
-        if (lds_bytes > 48 * 1024) {                                                                            \
+        static size_t lds_set_ = 48 * 1024;   /* largest dynamic LDS size this specialisation has been enabled for */ \
+        if (lds_bytes > lds_set_) {           /* (the attribute call costs microseconds: once per size, not per launch) */ \
             hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fx_eval_kernel<Gv, B, O, E, W>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);    \
             if (e_ != hipSuccess) return e_;                                                                    \
+            lds_set_ = lds_bytes;                                                                               \
         }                                                                                                       \
         hipExtLaunchKernelGGL((fx_eval_kernel<Gv, B, O, E, W>), grid, block, lds_bytes, stream, ev_start, ev_stop, 0, d_probs, fuse); \
         return hipGetLastError();                                                                               \
@@ -398,10 +400,12 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
     dim3 grid(max_blocks, n_agents), block(block_size);
 #define FX_LAUNCH(Gv, B, O, W, WS)                                                                                 \
     do {                                                                                                          \
-        if (lds_bytes > 48 * 1024) {                                                                              \
+        static size_t lds_set_ = 48 * 1024;   /* largest dynamic LDS size this specialisation has been enabled for */   \
+        if (lds_bytes > lds_set_) {           /* (the attribute call costs microseconds: once per size, not per launch) */ \
             hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fx_eval_grid_kernel<Gv, B, O, W, WS>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);      \
             if (e_ != hipSuccess) return e_;                                                                      \
+            lds_set_ = lds_bytes;                                                                                 \
         }                                                                                                         \
         hipExtLaunchKernelGGL((fx_eval_grid_kernel<Gv, B, O, W, WS>), grid, block, lds_bytes, stream, ev_start, ev_stop, 0, d_probs, fuse); \
         return hipGetLastError();                                                                                 \
