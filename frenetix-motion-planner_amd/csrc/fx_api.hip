@@ -483,7 +483,10 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
                           hipHostMallocMapped | hipHostMallocCoherent));
     memset(c->h_counters, 0, sizeof(unsigned long long) * max_agents * (FX_CNT_COUNT + 1));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_counters_dev), c->h_counters, 0));
-    HIP_TRY(hipMemset(c->d_counters, 0, sizeof(unsigned long long) * max_agents * FX_CNT_COUNT));
+    // ON THE CONTEXT'S STREAM: hipMemset on device memory runs on the null stream and may return before it has executed, and
+    // a non-blocking stream does not wait for the null stream -- on a busy GPU (a second process) the zeroing landed behind the
+    // first step's counter atomics and the step published zeros (tests/test_soak_parity.py, once in a few hundred contexts)
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * max_agents * FX_CNT_COUNT, c->stream));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_pub), sizeof(double) * (FX_PUB_MAX + 1), hipHostMallocMapped | hipHostMallocCoherent));
     memset(c->h_pub, 0, sizeof(double) * (FX_PUB_MAX + 1));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_pub_dev), c->h_pub, 0));
@@ -976,7 +979,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             int rc;
             const size_t n_tick = (size_t)(c->total_ld / 64) + (size_t)c->max_agents;
             if ((rc = dev_alloc(c, &c->d_obs_ticket, n_tick))) return rc;
-            HIP_TRY(hipMemset(c->d_obs_ticket, 0, sizeof(unsigned int) * n_tick));
+            HIP_TRY(hipMemsetAsync(c->d_obs_ticket, 0, sizeof(unsigned int) * n_tick, c->stream));   // (in order with the step's kernels)
         }
         for (int a = 0; a < n_agents; a++) {
             DevProblem &d = c->h_probs[a];
