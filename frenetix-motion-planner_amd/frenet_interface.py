@@ -221,9 +221,10 @@ class FrenetPlannerInterfaceHip:
             self.x_cl = (self.replanning_traj[2][k], self.replanning_traj[3][k])
             self.planner.plan_postprocessing(self.planner.optimal_trajectory, 0.0, replanning_counter=self.replanning_counter)
             selected = self.replanning_traj
-        self.msg_logger.info(f"current time step: {current_timestep}")
-        self.msg_logger.info(f"current velocity: {self.x_0.velocity}")
-        self.msg_logger.info(f"current target velocity: {self.desired_velocity}")
+        if self.msg_logger.isEnabledFor(logging.INFO):   # (three formatted strings per agent and step otherwise)
+            self.msg_logger.info("current time step: %s", current_timestep)
+            self.msg_logger.info("current velocity: %s", self.x_0.velocity)
+            self.msg_logger.info("current target velocity: %s", self.desired_velocity)
         self.replanning_counter += 1
         return selected, self.replanning_counter - 1
 

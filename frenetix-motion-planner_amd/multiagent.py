@@ -231,6 +231,7 @@ class MultiAgentSimulation:
         self.plans = np.zeros((len(self.agent_ids), self.S, self.FIELDS))
         self.history: Dict[int, list] = {i: [] for i in self.agent_ids}
         self._shared = None
+        self._cov_tiles: Dict[int, np.ndarray] = {}
 
     def _cfg(self) -> PlannerConfig:
         import copy
@@ -247,16 +248,22 @@ class MultiAgentSimulation:
         others = [o for o in self.scenario.obstacles if o not in self.problems]
         base = {k: v for k, v in self.scenario.ground_truth_predictions(t, horizon, obstacle_ids=others).items() if len(v["pos_list"])}
         own = {}
-        cov = np.eye(2) * 0.1
+        wb = self.vehicle.wb_rear_axle
         for k, aid in enumerate(self.agent_ids):
             rows = self.plans[k]
             valid = rows[:, 4] > 0
-            if valid.any():
-                r = rows[valid]
-                th = r[:, 2]
-                pos = r[:, :2] + self.vehicle.wb_rear_axle * np.stack([np.cos(th), np.sin(th)], axis=1)
-                own[aid] = dict(pos_list=pos, cov_list=np.tile(cov, (len(r), 1, 1)), orientation_list=th.copy(),
-                                v_list=r[:, 3].copy(), shape=dict(self.shapes[aid]))
+            n = int(np.count_nonzero(valid))
+            if n:
+                r = rows[:n] if valid[n - 1] else rows[valid]   # (the valid rows are a prefix: what lies ahead of the agent)
+                th = r[:, 2].copy()
+                pos = np.empty((n, 2))
+                pos[:, 0] = r[:, 0] + wb * np.cos(th)
+                pos[:, 1] = r[:, 1] + wb * np.sin(th)
+                cov = self._cov_tiles.get(n)
+                if cov is None:   # covariance 0.1 I per step (prediction_helpers.py:245): one read-only block per length
+                    cov = self._cov_tiles[n] = np.tile(np.eye(2) * 0.1, (n, 1, 1))
+                    cov.setflags(write=False)
+                own[aid] = dict(pos_list=pos, cov_list=cov, orientation_list=th, v_list=r[:, 3].copy(), shape=dict(self.shapes[aid]))
             elif aid in self.scenario.obstacles:  # no plan yet: the recorded future (first step)
                 gt = self.scenario.ground_truth_predictions(t, horizon, obstacle_ids=[aid])[aid]
                 if len(gt["pos_list"]):

@@ -141,15 +141,25 @@ def dense_ranges(n_t: int, n_v: int, n_d: int, v_lo: float, v_hi: float, horizon
                  t_min: float = 1.1, d_min: float = -3.0, d_max: float = 3.0):
     """Dense grid in natural (ascending) order: T = t_min .. horizon step dt (first n_t), V = linspace(v_lo, v_hi, n_v),
     D = linspace(d_min, d_max, n_d) plus d0 appended if absent (BASELINE configs 2 - 5)."""
-    key = (n_t, n_d, horizon, dt, t_min, d_min, d_max)
+    key = (n_t, n_v, n_d, horizon, dt, t_min, d_min, d_max)
     c = _DENSE_CACHE.get(key)
     if c is None:   # the time and lateral sets of a planner never change: built once
         t = np.round(t_min + dt * np.arange(n_t), 2)
-        c = _DENSE_CACHE[key] = (t[t <= horizon + 1e-9], np.linspace(d_min, d_max, n_d))
-    t, d = c
-    v = np.linspace(v_lo, v_hi, n_v)
-    if d0 not in d:
-        d = np.append(d, d0)
+        d = np.linspace(d_min, d_max, n_d)
+        c = _DENSE_CACHE[key] = (t[t <= horizon + 1e-9], d, frozenset(d.tolist()), np.arange(0, n_v, dtype=np.float64))
+    t, d, d_set, ramp = c
+    # np.linspace(v_lo, v_hi, n_v) with its arithmetic (function_base.py: arange * step + start, the end point set exactly)
+    # on the cached ramp -- a third of the time of the call
+    if n_v > 1 and v_hi != v_lo:
+        v = ramp * ((v_hi - v_lo) / (n_v - 1)) + v_lo
+        v[-1] = v_hi
+    else:
+        v = np.linspace(v_lo, v_hi, n_v)
+    if d0 not in d_set:
+        d1 = np.empty(len(d) + 1)
+        d1[:-1] = d
+        d1[-1] = d0
+        d = d1
     return t, v, d
 
 

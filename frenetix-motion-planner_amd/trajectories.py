@@ -79,6 +79,8 @@ class TrajectorySample:
         self._costmap = None
         self._coeffs = None
         self._pkg = None
+        self._sp = None
+        self._materialised = False
         pkg = step.package
         if pkg is not None and pkg.index == int(index) + step.inputs.shard_begin:
             # the winner: the library has already delivered everything (fx_read_package), nothing is fetched
@@ -156,7 +158,9 @@ class TrajectorySample:
 
     @property
     def sampling_parameters(self) -> np.ndarray:
-        return self._step.inputs.candidate_params(self.uniqueId + self._step.inputs.shard_begin)
+        if self._sp is None:
+            self._sp = self._step.inputs.candidate_params(self.uniqueId + self._step.inputs.shard_begin)
+        return self._sp
 
     # ---- lazily gathered from the device bundle ----
     def _need_planes(self):
@@ -166,6 +170,9 @@ class TrajectorySample:
 
     def materialise(self):
         """Pull everything this sample can ever need off the device (call before the next plan step)."""
+        if self._materialised:
+            return self
+        self._materialised = True
         self._need_planes()
         _ = self.costMap
         _ = self.trajectory_long

@@ -30,7 +30,7 @@ for lvl in (2, 4):
         tu.append(t1 - t0); tp.append(t2 - t1)
     print(f"level {lvl}: {p.last_step.n_candidates} candidates  update_externals p50 {np.median(tu)*1e6:.1f} us  plan() p50 {np.median(tp)*1e6:.1f} us "
           f"p95 {np.percentile(tp, 95)*1e6:.1f} us", flush=True)
-    if lvl == 2:
+    if lvl == 2 and '--profile' in sys.argv:
         pr = cProfile.Profile(); pr.enable()
         for _ in range(200):
             p.update_externals(x_0=x0, predictions=preds); p.plan()
