@@ -18,6 +18,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "../../include/fxplan.h"
+
 #define FXH_MAX_OBSTACLES 256
 
 typedef int32_t (*fx_pack_fn)(int32_t K, int32_t P, int32_t n_samples, const int32_t *n, const double *const *pos, const double *const *cov,
@@ -117,7 +119,63 @@ static PyObject *pack_predictions(PyObject *self, PyObject *args) {
     Py_RETURN_NONE;
 }
 
+/* address of a C-contiguous buffer of the given item format ('d' or 'i'), NULL for None; -1 on anything else */
+static int buf_addr(PyObject *obj, char fmt, Py_ssize_t itemsize, const void **out) {
+    *out = NULL;
+    if (obj == Py_None) return 0;
+    Py_buffer view;
+    if (PyObject_GetBuffer(obj, &view, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) return -1;
+    const char *f = view.format ? view.format : "B";
+    if (*f == '=' || *f == '<' || *f == '@') f++;
+    const int ok = view.itemsize == itemsize && (f[0] == fmt || (fmt == 'i' && f[0] == 'l' && itemsize == 4)) && f[1] == 0;
+    *out = view.buf;
+    PyBuffer_Release(&view);   /* (the caller keeps the arrays alive; the address stays valid) */
+    if (!ok) {
+        PyErr_SetString(PyExc_TypeError, "expected a C-contiguous float64 / int32 array");
+        return -1;
+    }
+    return 0;
+}
+
+static PyObject *state_update(PyObject *self, PyObject *args) {
+    unsigned long long addr;
+    PyObject *x0_lon, *x0_lat, *t, *v, *d, *pos, *cov, *npred, *hull, *nhull;
+    double orient, v_des;
+    int low_vel;
+    if (!PyArg_ParseTuple(args, "KOOddiOOOOOOOO", &addr, &x0_lon, &x0_lat, &orient, &v_des, &low_vel, &t, &v, &d, &pos, &cov, &npred,
+                          &hull, &nhull))
+        return NULL;
+    if (addr == 0) {
+        PyErr_SetString(PyExc_ValueError, "state_update: NULL struct address");
+        return NULL;
+    }
+    FxStateUpdate u;
+    memset(&u, 0, sizeof(u));
+    const void *p;
+#define FXH_PTR(field, obj, fmt, size, type)                 \
+    if (buf_addr(obj, fmt, size, &p) != 0) return NULL; \
+    u.field = (const type *)p
+    FXH_PTR(x0_lon, x0_lon, 'd', 8, double);
+    FXH_PTR(x0_lat, x0_lat, 'd', 8, double);
+    FXH_PTR(t_samp, t, 'd', 8, double);
+    FXH_PTR(v_samp, v, 'd', 8, double);
+    FXH_PTR(d_samp, d, 'd', 8, double);
+    FXH_PTR(obs_pos, pos, 'd', 8, double);
+    FXH_PTR(obs_cov_inv, cov, 'd', 8, double);
+    FXH_PTR(obs_npred, npred, 'i', 4, int32_t);
+    FXH_PTR(obs_hull, hull, 'd', 8, double);
+    FXH_PTR(obs_nhull, nhull, 'i', 4, int32_t);
+#undef FXH_PTR
+    u.x0_orientation = orient;
+    u.v_des = v_des;
+    u.low_vel_mode = low_vel;
+    memcpy((void *)(uintptr_t)addr, &u, sizeof(u));
+    Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
+    {"state_update", state_update, METH_VARARGS,
+     "state_update(struct_addr, x0_lon, x0_lat, x0_orientation, v_des, low_vel_mode, t, v, d, pos, cov_inv, npred, hull, nhull): fill an FxStateUpdate"},
     {"pack_predictions", pack_predictions, METH_VARARGS,
      "pack_predictions(fn_addr, predictions, n_samples, max_obstacles) -> (K, P, out, counts) or None (general path)"},
     {NULL, NULL, 0, NULL}};

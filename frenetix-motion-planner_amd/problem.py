@@ -86,6 +86,7 @@ def _dict_ptrs(d: dict, spec):
 
 
 _BOUND_UIDS = __import__("itertools").count(1)
+_COST_MEMO: dict = {}   # id(weights dict) -> (the dict, (len, sum of values), (names, ids, weights))
 MAX_OBSTACLES = 256  # obstacles per agent (FX_MAX_OBSTACLES; beyond 64 the step runs on the generic kernel)
 
 
@@ -255,13 +256,23 @@ class PlanInputs:
             if self.t_samp is None or self.v_samp is None or self.d_samp is None:
                 raise ValueError("either sampling_matrix or t_samp/v_samp/d_samp are required")
             self.t_samp, self.v_samp, self.d_samp = _f64(self.t_samp), _f64(self.v_samp), _f64(self.d_samp)
-        bad = [n for n, w in self.cost_weights.items() if w != 0 and n not in _abi.COST_ID]
-        if bad:
-            raise NotImplementedError(f"cost terms outside the hot-path scope: {bad}")
-        names = sorted(n for n, w in self.cost_weights.items() if w != 0)  # cost_function.py:52-60
-        self.cost_names = names
-        self._cost_id = np.array([_abi.COST_ID[n] for n in names], dtype=np.int32)
-        self._cost_w = _f64([self.cost_weights[n] for n in names])
+        # a planner hands over the same weights dict step after step: names / ids / weights are derived once per dict object
+        # (guarded by its length and the sum of its values against in-place edits)
+        cw = self.cost_weights
+        memo = _COST_MEMO.get(id(cw))
+        if memo is not None and memo[0] is cw and memo[1] == (len(cw), sum(cw.values())):
+            self.cost_names, self._cost_id, self._cost_w = memo[2]
+        else:
+            bad = [n for n, w in cw.items() if w != 0 and n not in _abi.COST_ID]
+            if bad:
+                raise NotImplementedError(f"cost terms outside the hot-path scope: {bad}")
+            names = sorted(n for n, w in cw.items() if w != 0)  # cost_function.py:52-60
+            self.cost_names = names
+            self._cost_id = np.array([_abi.COST_ID[n] for n in names], dtype=np.int32)
+            self._cost_w = _f64([cw[n] for n in names])
+            if len(_COST_MEMO) > 256:
+                _COST_MEMO.clear()
+            _COST_MEMO[id(cw)] = (cw, (len(cw), sum(cw.values())), (self.cost_names, self._cost_id, self._cost_w))
         if self.obstacles is None:
             self.obstacles = pack_predictions(None, S, None)
         self._dto = _f64(self.dto_pos).reshape(-1, 2) if self.dto_pos is not None else np.zeros((0, 2))

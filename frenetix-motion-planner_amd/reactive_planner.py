@@ -106,6 +106,7 @@ class ReactivePlannerHip:
         self.use_prediction = False
         self.desired_velocity = None
         self.cost_weights = dict(self.config.cost_weights)
+        self._weights_nz = self._weights_src = self._weights_sig = None
         self._sampling_min, self._sampling_max = self.config.sampling_min, self.config.sampling_max
         self.sampling_handler = SamplingHandler(dt=self.dT, max_sampling_number=self.config.sampling_max,
                                                 t_min=self.config.t_min, horizon=self.horizon,
@@ -188,6 +189,7 @@ class ReactivePlannerHip:
 
     def set_cost_function(self, cost_weights):
         self.cost_weights = dict(cost_weights)
+        self._weights_nz = None
 
     def set_road_boundary(self, segments):
         """Road boundary as straight segments [n][4] = (ax, ay, bx, by) (planner.py:550-565 builds it once per
@@ -251,7 +253,11 @@ class ReactivePlannerHip:
                 pb = self._packed_boundary = pack_road_boundary(self.road_boundary, self.coordinate_system,
                                                                 self.vehicle_params, d_reach)
             boundary = pb
-        weights = {k: w for k, w in self.cost_weights.items() if w != 0}
+        weights, cw = self._weights_nz, self.cost_weights
+        sig = (len(cw), sum(cw.values()))
+        if weights is None or self._weights_src is not cw or self._weights_sig != sig:   # replaced, or edited in place
+            weights = self._weights_nz = {k: w for k, w in cw.items() if w != 0}
+            self._weights_src, self._weights_sig = cw, sig
         if not self._packed_predictions["K"]:
             # prediction_costs over an empty predictions dict is 0 for every candidate
             pass
@@ -473,8 +479,10 @@ class ReactivePlannerHip:
                             yaw_rate=c[5])
 
             states = _LazyStates(n, cart)
-            states.rows = b[[0, 1, OR, 3]].T   # [n][x, y, orientation, velocity]: what a batch of agents shares as predictions
-            return states, _LazyStates(n, curv), b[[7, 10, 11]].T.tolist(), b[[8, 12, 13]].T.tolist()
+            states._rows_src = (b, [0, 1, OR, 3])   # [n][x, y, orientation, velocity]: what a batch of agents shares as predictions
+            # (s, s', s'') and (d, d', d'') per step: x_cl of the next cycle is entry 1 (+ replanning counter) -- built on access
+            return (states, _LazyStates(n, curv), _LazyStates(n, lambda i: b[_LON_ROWS, i].tolist()),
+                    _LazyStates(n, lambda i: b[_LAT_ROWS, i].tolist()))
         c, k = trajectory.cartesian, trajectory.curvilinear
         n = len(c.x)
         theta = np.asarray(c.theta, dtype=np.float64)
@@ -523,15 +531,30 @@ class ReactivePlannerHip:
             self._engine = None
 
 
+_LON_ROWS, _LAT_ROWS = np.array([7, 10, 11]), np.array([8, 12, 13])   # planes s, s', s'' / d, d', d'' of the package block
+
+
 class _LazyStates:
     """Read-only sequence whose items are built on first access and then kept (the state lists of a trajectory pair: a
     closed-loop step reads one or two of the 31 states)."""
 
-    rows = None   # optional [n][4] array (x, y, orientation, velocity) of the same states
+    _rows_src = None   # optional (block, row indices): the same states as an [n][4] array (x, y, orientation, velocity)
+    _rows = None
 
     def __init__(self, n: int, make):
         self._make = make
         self._items = [None] * n
+
+    @property
+    def rows(self):
+        if self._rows is None and self._rows_src is not None:
+            self._rows = self._rows_src[0][self._rows_src[1]].T
+        return self._rows
+
+    def __eq__(self, other):
+        if isinstance(other, (list, tuple, _LazyStates)):
+            return len(other) == len(self) and all(a == b for a, b in zip(self, other))
+        return NotImplemented
 
     def __len__(self):
         return len(self._items)

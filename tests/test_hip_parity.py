@@ -18,14 +18,18 @@ STATE_TOL = 1e-9
 COST_RTOL = 1e-9
 FRAGILE = 1e-9
 # How the candidates of every compare() were checked (tests/admissible.py): the tolerances grow with the conditioning of the
-# reference's own arithmetic, and a tolerance of 1 or more is not asserted at all -- so the suite counts what went through
+# reference's own arithmetic, and a tolerance of 1 or more leaves only the order of magnitude to assert -- so the suite counts what went through
 # each door and fails when more than a sliver did: a regression in the arithmetic cannot hide behind the scaling.
 #   checked      candidates compared                      fixed    well-conditioned (cond <= 1e3): asserted at 1e-9 (+ 2 %)
-#   scaled       cond > 1e3: conditioning-scaled tolerance  escaped  some plane's tolerance >= 1: that plane not asserted
-#   fragile      decided by the last ulp: compared with every admissible outcome
+#   scaled       cond > 1e3: conditioning-scaled tolerance  escaped  some plane's tolerance >= 1: that plane carries no digit in the
+#   fragile      decided by the last ulp: compared with every     reference either (theta_cl = pi/2 to the last bit: v = x / cos with
+#                admissible outcome                                cos = rounding noise) -- asserted to its ORDER OF MAGNITUDE only
 PARITY_STATS = dict(checked=0, fixed=0, scaled=0, escaped=0, fragile=0)
 WELL_CONDITIONED = 1e3
-MAX_ESCAPED_FRACTION = 2e-3     # per compare(): at most this share of the stored candidates (or 2 of them) without an assertion
+MAX_ESCAPED_FRACTION = 1e-2     # per compare(): at most this share of the stored candidates (or 2 of them) asserted to magnitude only
+#                                 (a (t, v) pair that drives backwards from standstill in LOW_VEL_MODE takes its ~10 lateral siblings along:
+#                                 tools/dbg_escaped.py on soak case 920156: 9 of 1 260, d' = 1e16, v = 1e29); the soak bounds the total at 5e-4
+MAGNITUDE_DECADES = 4.0         # what "order of magnitude" means for those planes: peak |value| within 10^+-4 of the oracle's, finite alike
 
 
 @pytest.fixture(scope="module")
@@ -120,13 +124,20 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
         # well-conditioned candidates: the FIXED bound, whatever the scaling machinery says
         well = stored & (cond_kin <= WELL_CONDITIONED)
         assert not (err[well] >= 1.02 * STATE_TOL).any(), f"plane err {err[well].max()} on a well-conditioned candidate"
-        escaped = stored & (tol >= 1.0).any(axis=1)
+        esc_planes = stored[:, None] & (tol >= 1.0)
+        if esc_planes.any():   # no digit to compare: both sides at least agree on finiteness and on the order of magnitude
+            pk_ref, pk_dev = np.abs(refp).max(axis=2)[esc_planes], np.abs(got).max(axis=2)[esc_planes]
+            fin = np.isfinite(pk_ref)
+            assert np.array_equal(np.isfinite(pk_dev), fin), "a plane without digits is finite on one side only"
+            dec = np.abs(np.log10(np.maximum(pk_dev[fin], 1e-300) / np.maximum(pk_ref[fin], 1e-300)))
+            assert (dec < MAGNITUDE_DECADES).all(), f"a plane without digits differs by {dec.max():.1f} decades"
+        escaped = esc_planes.any(axis=1)
         PARITY_STATS["checked"] += int(stored.sum())
         PARITY_STATS["fixed"] += int(well.sum())
         PARITY_STATS["scaled"] += int((stored & ~well).sum())
         PARITY_STATS["escaped"] += int(escaped.sum())
         assert escaped.sum() <= max(2, MAX_ESCAPED_FRACTION * stored.sum()), \
-            f"{int(escaped.sum())} of {int(stored.sum())} candidates have a plane whose tolerance reached 1 (not asserted)"
+            f"{int(escaped.sum())} of {int(stored.sum())} candidates have a plane whose tolerance reached 1 (magnitude only)"
         # coefficients / traj_len of a few candidates
         for g in np.linspace(0, inp.n_candidates - 1, 5).astype(int):
             lon, lat, tl = eng.coeffs(int(g), agent)

@@ -2,6 +2,7 @@
 from itertools import product
 
 import numpy as np
+import pytest
 
 from frenetix_motion_planner_amd import VehicleParams, _abi, synthetic
 from frenetix_motion_planner_amd.reactive_planner import PlannerConfig, ReactivePlannerHip, ReactivePlannerState
@@ -148,3 +149,32 @@ def test_prediction_dict_walked_in_c_equals_the_general_path():
     assert h.pack_predictions(addr, base, 31, 256) is not None and h.pack_predictions(addr, lists, 31, 256) is None
     assert h.pack_predictions(addr, f32, 31, 256) is None and h.pack_predictions(addr, strided, 31, 256) is None
     assert h.pack_predictions(addr, base, 31, 3) is None      # more obstacles than allowed: the Python path words the error
+
+
+def test_state_update_struct_filled_in_c_equals_the_python_path():
+    """_fxhost.state_update writes the same FxStateUpdate the ctypes assignments do; anything that is not a plain contiguous
+    float64 / int32 array sends the caller to the long way (engine.FrenetEngine._state_update_of)."""
+    import ctypes as C
+    from frenetix_motion_planner_amd import _abi, engine, synthetic
+    h = engine._fxhost()
+    if not h:
+        pytest.skip("_fxhost extension not built")
+    for kw in (dict(n_obstacles=0), dict(n_obstacles=3), dict(n_obstacles=2, n_pred=2)):
+        inp = synthetic.make_inputs(ref_kind="arc", v0=8.0, grid=(3, 5, 5), **kw)
+        fast = engine.FrenetEngine._state_update_of(inp)
+        saved, engine._FXHOST = engine._FXHOST, False
+        try:
+            slow = engine.FrenetEngine._state_update_of(inp)
+        finally:
+            engine._FXHOST = saved
+        for name, _ in _abi.FxStateUpdate._fields_:
+            a, b = getattr(fast, name), getattr(slow, name)
+            assert (a or 0) == (b or 0), name
+    a, b = np.arange(3.0), np.arange(4.0)
+    u = _abi.FxStateUpdate()
+    with pytest.raises((TypeError, ValueError, BufferError)):
+        h[0].state_update(C.addressof(u), a, a, 0.0, 1.0, 0, b, b, b[::2], None, None, None, None, None)   # not contiguous
+    with pytest.raises(TypeError):
+        h[0].state_update(C.addressof(u), a, a, 0.0, 1.0, 0, b, b, np.arange(4, dtype=np.int32), None, None, None, None, None)
+    with pytest.raises(ValueError):
+        h[0].state_update(0, a, a, 0.0, 1.0, 0, b, b, b, None, None, None, None, None)

@@ -58,7 +58,7 @@ for case in range(first, first + n):
         print("CASE", case, "FAILED:", repr(ex)[:300], kw, flush=True)
 print(f"soak: {n} cases from {first}: {bad} failures; {stats}; how they were checked: {PARITY_STATS}", flush=True)
 ck = max(PARITY_STATS["checked"], 1)
-print(f"   fixed 1e-9: {PARITY_STATS['fixed'] / ck:.4%}  conditioning-scaled: {PARITY_STATS['scaled'] / ck:.4%}  not asserted (tolerance >= 1): "
+print(f"   fixed 1e-9: {PARITY_STATS['fixed'] / ck:.4%}  conditioning-scaled: {PARITY_STATS['scaled'] / ck:.4%}  magnitude only (tolerance >= 1): "
       f"{PARITY_STATS['escaped'] / ck:.5%}  fragile (admissible outcomes): {stats['fragile'] / max(stats['cands'], 1):.3%} of all candidates", flush=True)
 if PARITY_STATS["escaped"] > max(3, 5e-4 * ck) or PARITY_STATS["fixed"] < 0.97 * ck:
     print("soak: TOO MANY candidates went through the scaled / unasserted doors", flush=True)
