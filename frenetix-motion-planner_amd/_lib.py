@@ -102,7 +102,7 @@ def lib():
         "fx_step_exchange": ([vp, PR, vp, vp], C.c_int32),
         "fx_set_package": ([vp, C.c_int32], C.c_int32),
         "fx_read_package": ([vp, C.c_int32, C.c_double, C.POINTER(_abi.FxPackage), pd], C.c_int32),
-        "fx_plan_and_package": ([vp, C.POINTER(_abi.FxStateUpdate), C.c_double, PR, C.POINTER(_abi.FxPackage), pd], C.c_int32),
+        "fx_plan_and_package": ([vp, C.POINTER(_abi.FxStateUpdate), C.c_double, PR, C.POINTER(_abi.FxPackage), vp], C.c_int32),   # (block: a plain address)
         # host geometry called once per plan step: addresses as integers (array.ctypes.data), no pointer objects on the way
         "fx_cs_to_curvilinear": ([C.c_int32, vp, vp, vp, C.c_double, C.c_double, vp], C.c_int32),
         "fx_invert_cov2": ([C.c_int32, vp, vp], C.c_int32),

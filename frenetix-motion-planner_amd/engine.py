@@ -435,7 +435,7 @@ class FrenetEngine:
         pkg = _abi.FxPackage()
         block = np.empty((_abi.FX_PKG_ROWS, inputs.n_samples))
         check(lib().fx_plan_and_package(self._ctx, C.byref(upd) if upd is not None else None, float(yaw_rate0), res,
-                                        C.byref(pkg), block.ctypes.data_as(C.POINTER(C.c_double))))
+                                        C.byref(pkg), block.ctypes.data))
         return res[0].as_dict(), (WinnerPackage(pkg, block, inputs) if pkg.found else None)
 
     # -- survivor exchange inside the library (fx_comm_*) --

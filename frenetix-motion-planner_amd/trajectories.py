@@ -87,11 +87,7 @@ class TrajectorySample:
             flags, self._cost = pkg.flags, pkg.cost
             self._planes = pkg.planes
             self._coeffs = (pkg.lon, pkg.lat, pkg.traj_len)
-            self._pkg = pkg
-            raw = pkg.raw_cost_list()
-            if raw is not None:
-                names, w = step.inputs.cost_names, step.inputs.cost_weights
-                self._costmap = {n: (raw[k], float(w[n] * raw[k])) for k, n in enumerate(names)}
+            self._pkg = pkg   # (the cost map is built from the package's raw costs when it is asked for)
         elif step.have_arrays:
             flags = int(step.flags[index])
             self._cost = float(step.cost[index])
@@ -173,6 +169,10 @@ class TrajectorySample:
         if self._materialised:
             return self
         self._materialised = True
+        if self._pkg is not None:   # the library's package is host memory already: nothing on the device this sample still needs
+            if self.leaves_road:
+                self._boundary_harm = self.boundary_harm
+            return self
         self._need_planes()
         _ = self.costMap
         _ = self.trajectory_long
@@ -193,6 +193,11 @@ class TrajectorySample:
 
     @property
     def costMap(self) -> dict:
+        if self._costmap is None and self._pkg is not None:
+            raw = self._pkg.raw_cost_list()
+            if raw is not None:
+                names, w = self._step.inputs.cost_names, self._step.inputs.cost_weights
+                self._costmap = {n: (raw[k], float(w[n] * raw[k])) for k, n in enumerate(names)}
         if self._costmap is None:
             raw = self._step.fetch_costmap_row(self.uniqueId)
             names = self._step.inputs.cost_names
