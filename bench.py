@@ -403,10 +403,17 @@ def main():
 
     inp = make_workload(args, world)
     C_global = inp.n_candidates_global
-    eng = FrenetEngine(max_candidates=C_global // world + 64, max_steps=inp.N, max_ref_knots=1024, max_obstacles=32,
-                       max_pred_steps=64, device=local_rank)
-    ev = ShardedEvaluator(eng, k=args.topk)
-    ev.shard(inp)
+    from frenetix_motion_planner_amd.distributed import exit_on_timeout, verified_evaluator
+
+    def prepare(eng_, ev_):
+        ev_.shard(inp)
+        eng_.upload(inp)
+
+    # several ranks: the library-side survivor exchange is cross-checked once against the torch.distributed exchange of the same
+    # step (untimed) and switched off everywhere if the two differ; `exchange` in the line says which one the timed steps used
+    eng, ev, exchange_note = exit_on_timeout(verified_evaluator, lambda: FrenetEngine(
+        max_candidates=C_global // world + 64, max_steps=inp.N, max_ref_knots=1024, max_obstacles=32, max_pred_steps=64,
+        device=local_rank), args.topk, prepare)
     C_local = inp.n_candidates
     S = inp.n_samples
     n_obst = int(inp.obstacles["K"])
@@ -416,14 +423,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from frenetix_motion_planner_amd.distributed import exit_on_timeout
-
     def step():
         # inputs are resident: upload happened once; a step re-runs evaluation + selection (+ survivor exchange); with several
         # ranks a peer that never joins ends this process with an error after the time bound instead of hanging the job
         return ev.step_enqueued() if world == 1 else exit_on_timeout(ev.step_enqueued)
 
-    eng.upload(inp)
     preheat(step, args.preheat, world, 1.2e-4)
     for _ in range(args.warmup):
         res = step()
@@ -532,7 +536,8 @@ def main():
                                    f"{'select-only (Mode A)' if args.select_only else 'SoA TrajectoryBundle materialised (Mode B)'}",
                        "candidates_global": C_global, "candidates_per_gpu": C_local, "samples": S,
                        "reference_knots": int(inp.coordinate_system.ref_pos.shape[0]), "obstacles": n_obst,
-                       "parallelism": f"candidate-shard x{world}, all-gather top-{args.topk}" if world > 1 else "single GPU"},
+                       "parallelism": f"candidate-shard x{world}, all-gather top-{args.topk}" if world > 1 else "single GPU",
+                       "exchange": exchange_note},
             "resident_step_p50_ms": float(np.percentile(lat, 50) * 1e3), "resident_step_p95_ms": float(np.percentile(lat, 95) * 1e3),
             "plan_step_p50_ms": float(np.percentile(lat_u, 50) * 1e3), "plan_step_p95_ms": float(np.percentile(lat_u, 95) * 1e3),
             "plan_step_note": "plan_step_* = the step fed a new ego state and new predictions from host buffers every time "
@@ -615,15 +620,17 @@ def bench_stress(args, world, rank, local_rank, torch, dist):
     agents = synthetic.stress_agents(n_local, grid=STRESS_GRID, first_agent=rank * n_local, hull_builder=build_obstacle_hulls)
     C_local = sum(a.n_candidates for a in agents)
     S, K = agents[0].n_samples, int(agents[0].obstacles["K"])
-    eng = FrenetEngine(max_candidates=C_local + 64 * n_local, max_steps=agents[0].N, max_ref_knots=1024, max_obstacles=32,
-                       max_pred_steps=64, device=local_rank, max_agents=n_local)
-    ev = ShardedEvaluator(eng, k=k)
-    ev.setup_agents(n_local)
-    eng.set_timing(args.timing, every=args.timing_every)
-    eng.upload(agents)
-    last = {}
+    from frenetix_motion_planner_amd.distributed import exit_on_timeout, verified_evaluator
 
-    from frenetix_motion_planner_amd.distributed import exit_on_timeout
+    def prepare(eng_, ev_):
+        ev_.setup_agents(n_local)
+        eng_.upload(agents)
+
+    eng, ev, exchange_note = exit_on_timeout(verified_evaluator, lambda: FrenetEngine(
+        max_candidates=C_local + 64 * n_local, max_steps=agents[0].N, max_ref_knots=1024, max_obstacles=32, max_pred_steps=64,
+        device=local_rank, max_agents=n_local), k, prepare)
+    eng.set_timing(args.timing, every=args.timing_every)
+    last = {}
 
     def step():
         last["res"], last["surv"] = ev.step_agents_enqueued() if world == 1 else exit_on_timeout(ev.step_agents_enqueued)
@@ -653,7 +660,8 @@ def bench_stress(args, world, rank, local_rank, torch, dist):
                                    f"(Mode A), one batched launch per step, top-{k} survivors per agent",
                        "agents_global": n_local * world, "agents_per_gpu": n_local, "candidates_global": C_global,
                        "candidates_per_gpu": C_local, "samples": S, "obstacles": K,
-                       "parallelism": f"agent-shard x{world}, all-gather of per-agent top-{k}" if world > 1 else "single GPU"},
+                       "parallelism": f"agent-shard x{world}, all-gather of per-agent top-{k}" if world > 1 else "single GPU",
+                       "exchange": exchange_note},
             "plan_step_p50_ms": float(np.percentile(lat, 50) * 1e3), "plan_step_p95_ms": float(np.percentile(lat, 95) * 1e3),
             "device_ms_per_step": float(np.mean(kern)), "eval_kernel_ms": eval_ms,
             "agents_with_winner": int(sum(r["best_index"] >= 0 for r in res)),

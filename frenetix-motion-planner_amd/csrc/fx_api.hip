@@ -13,8 +13,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 #include <dlfcn.h>
 
@@ -1282,9 +1285,34 @@ int32_t fx_comm_init(FxContext *c, const uint8_t *id128, int32_t rank, int32_t w
     c->gather_cap = need;
     if (!c->d_winner_own && (rc = dev_alloc(c, &c->d_winner_own, (size_t)c->max_agents * 2))) return rc;
     if (!c->d_xsend && (rc = dev_alloc(c, &c->d_xsend, (size_t)c->max_agents * 2 * 64))) return rc;
-    Rccl::UniqueId id;
-    memcpy(id.internal, id128, 128);
-    RCCL_TRY(rccl()->CommInitRank(&c->comm, world, id, rank));
+    // ncclCommInitRank is a blocking collective without a time bound of its own: a peer that never arrives (or a fabric that
+    // never answers) would hold this thread forever.  It runs on a helper thread; this one waits for it with the context's time
+    // bound and, past it, gives the communicator up (the helper is left behind, detached, with its state) -- the caller falls
+    // back to another exchange instead of hanging the job.
+    struct InitState {
+        std::atomic<int> done{0};
+        int rc = 0;
+        void *comm = nullptr;
+        Rccl::UniqueId id;
+    };
+    auto st = std::make_shared<InitState>();
+    memcpy(st->id.internal, id128, 128);
+    const int device = c->device;
+    std::thread([st, world, rank, device] {
+        (void)hipSetDevice(device);
+        st->rc = rccl()->CommInitRank(&st->comm, world, st->id, rank);
+        st->done.store(1, std::memory_order_release);
+    }).detach();
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto limit = std::chrono::milliseconds(c->timeout_ms > 0 ? c->timeout_ms : 20000);
+    while (!st->done.load(std::memory_order_acquire)) {
+        if (std::chrono::steady_clock::now() - t0 >= limit)
+            return set_err(FX_ERR_TIMEOUT, "fx_comm_init: ncclCommInitRank did not return within %d ms (rank %d of %d)",
+                           (int)limit.count(), rank, world);
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    if (st->rc != 0) return set_err(FX_ERR_HIP, "ncclCommInitRank failed: %s (rank %d of %d)", rccl()->GetErrorString(st->rc), rank, world);
+    c->comm = st->comm;
     c->comm_rank = rank; c->comm_world = world;
     return FX_OK;
 }
@@ -1318,9 +1346,7 @@ int32_t fx_step_exchange(FxContext *c, FxResult *res, double *cost, int64_t *ind
     if (rc_eval) {
         memcpy(err_eval, g_err, sizeof(err_eval));
         // nothing was selected on this rank: send "no survivor" for every agent
-        double none[2 * 64];
         double *h = c->h_topk_cost;   // pinned
-        (void)none;
         for (int a = 0; a < n_agents; a++) { h[2 * a] = INFINITY; const long long m1 = -1; memcpy(&h[2 * a + 1], &m1, sizeof(m1)); }
         HIP_TRY(hipMemcpyAsync(c->d_winner_own, h, sizeof(double) * 2 * n_agents, hipMemcpyHostToDevice, c->stream));
         send = c->d_winner_own;

@@ -299,6 +299,57 @@ class ShardedEvaluator:
         res["global_best_cost"], res["global_best_index"], res["survivors"] = best_c, best_i, order
         return res
 
+
+    # ---- the library exchange is trusted only after it has agreed with the torch.distributed exchange once ----
+    def uses_library_exchange(self) -> bool:
+        return bool(self.lib_exchange or self.lib_exchange_agents)
+
+    def _agree_min(self, value: int) -> int:
+        """MIN of an integer over the ranks (torch group; a device tensor under nccl)."""
+        if self.dist is None or self.world == 1:
+            return int(value)
+        dev = self.torch.device("cuda", self.torch.cuda.current_device()) if self.on_device else self.torch.device("cpu")
+        t = self.torch.tensor([int(value)], dtype=self.torch.int32, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return int(t.item())
+
+    def crosscheck_exchange(self) -> int:
+        """One step exchanged through the library and once more through torch.distributed, on the resident inputs: 1 = both
+        agree on every rank, 0 = they differ somewhere (the library exchange is switched off on every rank), -1 = the library
+        exchange did not come back within the time bound on this rank (the context is lost).  Collective: every rank calls it."""
+        from ._lib import FxTimeoutError
+        if not self.uses_library_exchange():
+            return 1
+        state = 1
+        try:
+            if self.lib_exchange_agents and getattr(self, "n_local", 0):
+                _, a = self.step_agents_enqueued()
+                self.lib_exchange_agents, keep = False, self.lib_exchange_agents
+                try:
+                    _, b = self.step_agents_enqueued()
+                finally:
+                    self.lib_exchange_agents = keep
+                same = a is not None and b is not None and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            else:
+                a = self.step_enqueued()
+                self.lib_exchange, keep = False, self.lib_exchange
+                try:
+                    b = self.step_enqueued()
+                finally:
+                    self.lib_exchange = keep
+                same = a["global_best_index"] == b["global_best_index"] and a["global_best_cost"] == b["global_best_cost"]
+            state = 1 if same else 0
+        except FxTimeoutError:
+            return -1   # (every rank waits on the same collective: they all end here)
+        state = self._agree_min(state)
+        if state == 0:   # wrong answers somewhere: nobody uses it
+            self.lib_exchange = self.lib_exchange_agents = False
+            try:
+                self.engine.comm_destroy()
+            except Exception:
+                pass
+        return state
+
     # ---- agent sharding with a top-k survivor gather (BASELINE config 5) ----
     def setup_agents(self, n_local_agents: int):
         """Exchange buffers for `n_local_agents` agents per rank: [cost k | index k] per agent, one all-gather of
@@ -389,3 +440,24 @@ class ShardedEvaluator:
             if n_parts == 1:
                 out[a] = dict(local[j], **out[a])
         return out
+
+
+def verified_evaluator(make_engine, k: int, prepare):
+    """(engine, evaluator, note) with an exchange that has been SEEN to agree: `make_engine()` -> engine, `prepare(engine,
+    evaluator)` uploads the inputs (and calls setup_agents where needed).  With several ranks the library-side exchange
+    (fx_step_exchange / fx_step_exchange_topk on the engine's own RCCL communicator) is cross-checked once against the
+    torch.distributed exchange of the same step before anything is timed; if the two differ on any rank the library exchange
+    is switched off on every rank.  A library exchange that never comes back raises FxTimeoutError after the context's time
+    bound (a collective stuck on the device cannot be recovered from inside the process: callers leave through
+    exit_on_timeout).  Collective: every rank calls it."""
+    eng = make_engine()
+    ev = ShardedEvaluator(eng, k=k)
+    prepare(eng, ev)
+    if not ev.uses_library_exchange():
+        return eng, ev, ("torch.distributed" if ev.world > 1 else "none (one rank)")
+    state = ev.crosscheck_exchange()
+    if state < 0:
+        from ._lib import FxTimeoutError
+        raise FxTimeoutError("the library-side exchange did not come back in the cross-check")
+    return eng, ev, ("library (RCCL communicator of the engine), cross-checked against torch.distributed" if state == 1 else
+                     "torch.distributed (the library exchange disagreed in the cross-check)")

@@ -256,6 +256,9 @@ def test_library_side_exchange_single_rank():
                 for _ in range(3):
                     r2 = ev.step_enqueued()
                 assert r2["global_best_index"] == ref["best_index"] and r2["best_index"] == ref["best_index"]
+                # what bench.py does before it times anything: library exchange against the torch.distributed exchange
+                assert ev.crosscheck_exchange() == 1 and ev.lib_exchange
+                assert ev.step_enqueued()["global_best_index"] == ref["best_index"]
                 eng.set_winner_buffer(0)
         os.environ["FX_EXCHANGE"] = "torch"
         try:
@@ -569,3 +572,49 @@ def test_library_exchange_setup_is_agreed_by_all_ranks(scenario):
     else:
         assert got[0][2] == 1 and got[0][3] == 1                    # rank 0 had a communicator: destroyed again
         assert got[1][2] == 0 and got[1][3] == 0
+
+
+def _crosscheck_worker(rank, world, port, q, scenario):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        class Ev(ShardedEvaluator):
+            def step_enqueued(self):   # what the two exchanges report as the global winner
+                wrong = scenario == "library_wrong_on_rank1" and self.lib_exchange and self.rank == 1
+                return {"global_best_index": 41 if wrong else 42, "global_best_cost": 1.5}
+
+        ev = Ev.__new__(Ev)
+        ev.torch, ev.dist, ev.group, ev.rank, ev.world, ev.on_device = torch, dist, None, rank, world, False
+        ev.engine = _CommStubEngine()
+        ev.lib_exchange, ev.lib_exchange_agents = True, False
+        state = ev.crosscheck_exchange()
+        q.put((rank, state, ev.lib_exchange, ev.engine.destroys))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("scenario", ["agree", "library_wrong_on_rank1"])
+def test_library_exchange_is_cross_checked_against_the_torch_exchange(scenario):
+    """Before anything is timed the library-side exchange has to report the winner the torch.distributed exchange reports; one
+    rank that sees a difference switches it off on every rank (bench.py: `exchange` in the line says which one ran)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_crosscheck_worker, args=(r, world, port, q, scenario)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if scenario == "agree":
+        assert [g[1:] for g in got] == [(1, True, 0), (1, True, 0)]
+    else:
+        assert [g[1:] for g in got] == [(0, False, 1), (0, False, 1)]
