@@ -519,8 +519,11 @@ int32_t fx_create(FxContext **out, int32_t device, int64_t max_candidates, int32
 
 int32_t fx_destroy(FxContext *c) {
     if (!c) return FX_OK;
+    // a context whose wait timed out may hold work that never finishes (a collective a peer never joined): freeing its buffers
+    // or its communicator would wait for that work.  It is abandoned as it is; the process is expected to end.
+    if (c->timed_out) return FX_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream && !c->timed_out) (void)hipStreamSynchronize(c->stream);   // (a timed-out stream may never drain)
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_in, c->d_cost, c->d_cost_tail, c->d_flags, c->d_costmap, c->d_coeffs, c->d_trajlen, c->d_planes,
                    c->d_part_cost, c->d_part_idx, c->d_counters, c->d_topk_cost, c->d_topk_idx, c->d_topk_scr_cost,
                    c->d_topk_scr_idx};
@@ -1319,8 +1322,9 @@ int32_t fx_comm_init(FxContext *c, const uint8_t *id128, int32_t rank, int32_t w
 
 int32_t fx_comm_destroy(FxContext *c) {
     if (!c || !c->comm) return FX_OK;
+    if (c->timed_out) { c->comm = nullptr; return FX_OK; }   // (ncclCommDestroy would wait for the collective that never finishes)
     (void)hipSetDevice(c->device);
-    if (c->stream && !c->timed_out) (void)hipStreamSynchronize(c->stream);   // (a timed-out stream may never drain)
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)rccl()->CommDestroy(c->comm);
     c->comm = nullptr;
     if (c->d_gather) { (void)hipFree(c->d_gather); c->d_gather = nullptr; c->gather_cap = 0; }
