@@ -707,6 +707,28 @@ def bench_scenario_step(args, world, rank, local_rank, torch, dist):
     evalk, kern = eng.kernel_times(n_timed)
     obstk = eng.obstacle_kernel_times(n_timed)
     info = eng.step_info()
+    # "630 candidates Python-style (800 with the C++-style unions {3.0}, {s'0}, {d0} -- report both)": the same
+    # step in the form the reference's C++ adapter hands over, a C x 13 sampling matrix (reactive_planner_cpp.py:228-253)
+    cpp_style = None
+    res630 = dict(last["res"])
+    if world == 1:
+        import copy
+        from frenetix_motion_planner_amd.sampling import generate_sampling_matrix
+        t = np.union1d(inp.t_samp, [inp.N * inp.dt]); v = np.union1d(inp.v_samp, [inp.x0_lon[1]]); d = np.union1d(inp.d_samp, [inp.x0_lat[0]])
+        inp800 = copy.copy(inp)
+        inp800.t_samp = inp800.v_samp = inp800.d_samp = None
+        inp800.sampling_matrix = generate_sampling_matrix(
+            t0_range=0.0, t1_range=t, s0_range=inp.x0_lon[0], ss0_range=inp.x0_lon[1], sss0_range=inp.x0_lon[2], ss1_range=v,
+            sss1_range=0.0, d0_range=inp.x0_lat[0], dd0_range=inp.x0_lat[1], ddd0_range=inp.x0_lat[2], d1_range=d, dd1_range=0.0,
+            ddd1_range=0.0)
+        inp800.__post_init__()
+        eng.upload(inp800)
+        e800, lat800 = _timed(args, world, dist, torch, step, 5e-5)
+        ev800, _ = eng.kernel_times(n_timed)
+        cpp_style = {"candidates": int(inp800.n_candidates), "form": "C x 13 sampling matrix (generic kernel)",
+                     "ms_per_step": e800 / args.steps * 1e3, "value": inp800.n_candidates * args.steps / e800,
+                     "plan_step_p50_ms": float(np.percentile(lat800, 50) * 1e3), "eval_kernel_ms": float(np.mean(ev800)),
+                     "winner": {"index": int(last["res"]["best_index"]), "cost": float(last["res"]["best_cost"])}}
     if rank == 0:
         C, S = inp.n_candidates, inp.n_samples
         eval_ms = float(np.mean(evalk))
@@ -721,14 +743,15 @@ def bench_scenario_step(args, world, rank, local_rank, torch, dist):
                        "candidates": C, "samples": S, "obstacles": int(inp.obstacles["K"]), "parallelism": "single GPU"},
             "plan_step_p50_ms": float(np.percentile(lat, 50) * 1e3), "plan_step_p95_ms": float(np.percentile(lat, 95) * 1e3),
             "device_ms_per_step": float(np.mean(kern)), "eval_kernel_ms": eval_ms,
-            "winner": {"index": int(last["res"]["best_index"]), "cost": float(last["res"]["best_cost"]),
-                       "n_feasible": int(last["res"]["n_feasible"]), "n_collisions": int(last["res"]["n_collisions"])},
+            "winner": {"index": int(res630["best_index"]), "cost": float(res630["best_cost"]),
+                       "n_feasible": int(res630["n_feasible"]), "n_collisions": int(res630["n_collisions"])},
             "roofline": {"bound": "hbm", "achieved": alg / (eval_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
                          "avg_launch_ms": eval_ms, "launches_timed": int(len(evalk)),
                          "note": "630 candidates = 10 waves: the step is launch-latency-bound, not bandwidth-bound"},
             "reference_python_path": "about 1.2e3 trajectories/s on one core (measured in the build container, BASELINE.md section 3)",
         }
+        out["cpp_style_800"] = cpp_style
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle
             from frenetix_motion_planner_amd.problem import pack_predictions
