@@ -169,7 +169,40 @@ class CalculateVelocityOffsetCost(_Cost):
 
 
 # ---------------------------------------------------------------- handler
+def product_grid_of(m: np.ndarray):
+    """(t1 values, end-velocity values, d1 values) when the C x 13 sampling matrix is exactly their Cartesian product in row-major
+    order with every other column constant and at the values the range form assumes (t0 = 0, end accelerations and lateral end
+    rates 0) -- what generate_sampling_matrix (sampling_matrix.py:85-121) produces; None otherwise."""
+    C = len(m)
+    if C == 0:
+        return None
+    d_col, v_col, t_col = m[:, 10], m[:, 5], m[:, 1]
+    ch = np.nonzero((v_col[1:] != v_col[:-1]) | (t_col[1:] != t_col[:-1]))[0]
+    nD = int(ch[0]) + 1 if len(ch) else C
+    if C % nD:
+        return None
+    tv = t_col[::nD]
+    ch = np.nonzero(tv[1:] != tv[:-1])[0]
+    nV = int(ch[0]) + 1 if len(ch) else len(tv)
+    if (C // nD) % nV:
+        return None
+    nT = C // (nD * nV)
+    t, v, d = t_col[::nD * nV].copy(), v_col[:nD * nV:nD].copy(), d_col[:nD].copy()
+    if len(set(t.tolist())) != nT or len(set(v.tolist())) != nV or len(set(d.tolist())) != nD:
+        return None
+    want = np.empty((nT, nV, nD, 3))
+    want[..., 0], want[..., 1], want[..., 2] = t[:, None, None], v[None, :, None], d[None, None, :]
+    if not np.array_equal(want.reshape(C, 3), m[:, [1, 5, 10]]):
+        return None
+    const = m[:, [0, 2, 3, 4, 6, 7, 8, 9, 11, 12]]
+    if not (const == const[0]).all() or m[0, 0] != 0.0 or m[0, 6] != 0.0 or m[0, 11] != 0.0 or m[0, 12] != 0.0:
+        return None
+    return t, v, d
+
+
 class TrajectoryHandler:
+    detect_grid = True   # evaluate a sampling matrix that is a Cartesian product as ranges (grid kernel; identical results)
+
     def __init__(self, dt: float, engine=None, device: int = 0):
         self.dt = float(dt)
         self._engine = engine
@@ -292,7 +325,13 @@ class TrajectoryHandler:
             sampling = dict(x0_lon=st["x0_lon"], x0_lat=st["x0_lat"], t_samp=st["t"], v_samp=st["s"], d_samp=st["d"],
                             stop_point=True)
         else:
-            sampling = dict(x0_lon=self._matrix[0, 2:5], x0_lat=self._matrix[0, 7:10], sampling_matrix=self._matrix)
+            grid = product_grid_of(self._matrix) if self.detect_grid else None
+            if grid is not None:
+                # the adapter's matrix is itertools.product over three sets (reactive_planner_cpp.py:228-253): evaluated as
+                # ranges -- the grid kernel with its shared longitudinal table, same results bit for bit
+                sampling = dict(x0_lon=self._matrix[0, 2:5], x0_lat=self._matrix[0, 7:10], t_samp=grid[0], v_samp=grid[1], d_samp=grid[2])
+            else:
+                sampling = dict(x0_lon=self._matrix[0, 2:5], x0_lat=self._matrix[0, 7:10], sampling_matrix=self._matrix)
         inputs = PlanInputs(
             N=N, dt=self.dt, low_vel_mode=self._low_vel,
             x0_orientation=self._fill.initialOrientation, v_des=vo.desired_velocity if vo is not None else 0.0,

@@ -254,3 +254,28 @@ def test_library_prediction_packing_equals_the_python_path():
             assert a[k].flags["C_CONTIGUOUS"]
     with pytest.raises(np.linalg.LinAlgError):
         pack_predictions({1: dict(pos_list=np.zeros((3, 2)), cov_list=np.zeros((3, 2, 2)))}, 31, build_obstacle_hulls)
+
+
+def test_adapter_recognises_a_product_sampling_matrix():
+    """frenetix_compat.product_grid_of: the C x 13 matrix the reference's C++ adapter builds (itertools.product over three sets,
+    sampling_matrix.py:85-121) is evaluated as ranges; anything that is not exactly that product stays a matrix."""
+    from frenetix_motion_planner_amd.frenetix_compat import product_grid_of
+    from frenetix_motion_planner_amd.sampling import generate_sampling_matrix
+    t, v, d = np.array([1.1, 1.4, 2.0, 3.0]), np.array([0.001, 3.0, 5.6]), np.array([-3.0, 0.2, 3.0, 1.0, 0.4])   # (set order: unsorted)
+    kw = dict(t0_range=0.0, s0_range=5.0, ss0_range=5.6, sss0_range=0.1, sss1_range=0.0, d0_range=0.4, dd0_range=0.0, ddd0_range=0.0,
+              dd1_range=0.0, ddd1_range=0.0)
+    m = generate_sampling_matrix(t1_range=t, ss1_range=v, d1_range=d, **kw)
+    got = product_grid_of(m)
+    assert got is not None and all(np.array_equal(a, b) for a, b in zip(got, (t, v, d)))
+    one = product_grid_of(m[:1])
+    assert one is not None and [len(x) for x in one] == [1, 1, 1]
+    bad = m.copy(); bad[7, 10] += 1e-9
+    assert product_grid_of(bad) is None                      # one entry off the product
+    assert product_grid_of(m[:-1]) is None                   # a row missing
+    assert product_grid_of(m[np.random.default_rng(0).permutation(len(m))]) is None   # another order
+    acc = m.copy(); acc[:, 6] = 0.5
+    assert product_grid_of(acc) is None                      # an end acceleration the range form does not carry
+    var = m.copy(); var[3, 3] += 0.1
+    assert product_grid_of(var) is None                      # a start state that differs between rows
+    dup = generate_sampling_matrix(t1_range=t, ss1_range=np.array([1.0, 1.0]), d1_range=d, **kw)
+    assert product_grid_of(dup) is None                      # repeated values: not a set product
