@@ -48,7 +48,7 @@ class PoseWithCovariance:
     @property
     def yaw(self) -> float:
         q = self.orientation
-        return float(2.0 * np.arctan2(q[2], q[3]))
+        return float(2.0 * np.arctan2(q[2], q[3]))   # (NumPy's arctan2: math.atan2 differs in the last bit for some inputs)
 
 
 class PredictedObject:
@@ -341,7 +341,12 @@ class TrajectoryHandler:
             dto_pos=dto.obstacle_positions if dto is not None else None)
         if self._step is not None:
             self._step.invalidate()
-        res = self.engine.plan_step(inputs)
+        if inputs.sampling_matrix is None and hasattr(self.engine, "plan_batch"):
+            # same structure as the resident upload (the usual case from the second cycle on): only state, sampling values and
+            # predictions are rewritten in place (fx_update_state) instead of a full upload
+            res = self.engine.plan_batch([inputs])[0]
+        else:
+            res = self.engine.plan_step(inputs)
         self._step = PlanStepResult(self.engine, inputs, res)
         return res
 

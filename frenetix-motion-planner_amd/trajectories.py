@@ -71,16 +71,47 @@ class PolynomialView:
 
 
 class TrajectorySample:
+    # what a fresh sample has not got yet lives on the class: the reference's C++ adapter asks for EVERY evaluated trajectory as
+    # an object each plan step (reactive_planner_cpp.py:353-358), so a sample is a handful of instance attributes
+    _planes = _costmap = _coeffs = _pkg = _sp = None
+    _materialised = False
+    # writable from Python (planner.py:325-326,381-382)
+    _ego_risk = _obst_risk = _boundary_harm = None
+    harm_occ_module = None
+
+    @classmethod
+    def bulk(cls, step: "PlanStepResult", ids) -> list:
+        """the samples of `ids` (indices within the shard) from the step's cost / flag arrays, without per-sample array look-ups"""
+        ids = [int(g) for g in ids]
+        base = step.inputs.shard_begin
+        fl, co = step.flags[ids].tolist(), step.cost[ids].tolist()
+        FEAS, VALID, COLL, SEL = _abi.FX_FLAG_FEASIBLE, _abi.FX_FLAG_VALID, _abi.FX_FLAG_COLLISION, _abi.FX_FLAG_SELECTABLE
+        pkg_index = step.package.index if step.package is not None else None
+        out = []
+        new = object.__new__
+        for g, f, c in zip(ids, fl, co):
+            if pkg_index is not None and g + base == pkg_index:   # the packaged winner takes the long way (it carries its arrays)
+                out.append(cls(step, g))
+                continue
+            t = new(cls)
+            t._step, t.uniqueId, t.global_id, t._flags, t._cost = step, g, g + base, f, c
+            t.feasible, t.valid = bool(f & FEAS), bool(f & VALID)
+            t._coll_detected = bool(f & COLL) if (f & SEL) else None
+            out.append(t)
+        return out
+
+    @property
+    def dt(self) -> float:
+        return self._step.inputs.dt
+
+    @property
+    def horizon(self) -> float:
+        return self._step.inputs.N * self._step.inputs.dt
+
     def __init__(self, step: "PlanStepResult", index: int):
         self._step = step
         self.uniqueId = int(index)           # index within the evaluated shard (== creation order when nothing is sharded)
         self.global_id = int(index) + step.inputs.shard_begin   # creation order in the whole grid (reactive_planner.py:172)
-        self._planes = None
-        self._costmap = None
-        self._coeffs = None
-        self._pkg = None
-        self._sp = None
-        self._materialised = False
         pkg = step.package
         if pkg is not None and pkg.index == int(index) + step.inputs.shard_begin:
             # the winner: the library has already delivered everything (fx_read_package), nothing is fetched
@@ -105,14 +136,7 @@ class TrajectorySample:
         self._flags = flags
         self.feasible = bool(flags & _abi.FX_FLAG_FEASIBLE)
         self.valid = bool(flags & _abi.FX_FLAG_VALID)
-        self.dt = step.inputs.dt
-        self.horizon = step.inputs.N * step.inputs.dt
-        # writable from Python (planner.py:325-326,381-382)
-        self._ego_risk = None
-        self._obst_risk = None
-        self._boundary_harm = None
         self._coll_detected = bool(flags & _abi.FX_FLAG_COLLISION) if (flags & _abi.FX_FLAG_SELECTABLE) else None
-        self.harm_occ_module = None
 
     # ---- cheap attributes ----
     @property
@@ -336,6 +360,10 @@ class PlanStepResult:
         ids = self.sorted_ids(pool_bit)
         if limit is not None:
             ids = ids[:limit]
+        todo = [int(g) for g in ids if int(g) not in self._samples]
+        if len(todo) > 8:   # many new samples at once (the adapter's sorted list): built from the arrays in one go
+            for t in TrajectorySample.bulk(self, todo):
+                self._samples[t.uniqueId] = t
         return [self.sample(int(g)) for g in ids]
 
     @property
