@@ -110,6 +110,26 @@ __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double bc = INFINITY;
     long long bi = 0x7fffffffffffffffLL;
+    // Everything that does not depend on the winner is requested NOW, together with the partials -- the first eight (flag, cost)
+    // pairs per thread of this workgroup's slice (the whole slice up to 2 048 candidates: planner-sized steps, config 3) and the
+    // step's counters: the kernel is a chain of memory round trips, and these two used to be links of their own.
+    const bool count_mode = (P.mode & FX_MODE_COLLISION) != 0;
+    const int64_t per = (P.C + gridDim.x - 1) / gridDim.x;
+    const int64_t g0 = (int64_t)blockIdx.x * per, g1 = min(P.C, g0 + per);
+    uint32_t f_pre[8];
+    double c_pre[8];
+    if (count_mode) {
+        const FX_GLOBAL uint32_t *__restrict__ fl = as_global(P.flags);
+        const FX_GLOBAL double *__restrict__ co = as_global(P.cost);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int64_t gu = g0 + tid + u * 256;
+            f_pre[u] = gu < g1 ? fl[gu] : 0u;
+            c_pre[u] = gu < g1 ? co[gu] : 0.0;
+        }
+    }
+    unsigned long long cnt_pre = 0ULL;
+    if (tid < FX_CNT_BEST_IDX) cnt_pre = as_global(P.counters)[tid];   // (accumulated by the evaluation kernel, which is complete)
     {
         // the partials were written by the evaluation kernel, which is complete: plain loads, four per thread in flight
         // (device-coherent atomic loads, as the in-kernel selection needs them, serialise at ~1 us each)
@@ -143,13 +163,17 @@ __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__rest
         if (sc[w] < bc || (sc[w] == bc && si[w] < bi)) { bc = sc[w]; bi = si[w]; }
     const bool none = bi == 0x7fffffffffffffffLL;
     // colliding selectable candidates ordered before the winner (all of them when nothing is collision-free)
-    if (P.mode & FX_MODE_COLLISION) {
-        const int64_t per = (P.C + gridDim.x - 1) / gridDim.x;
-        const int64_t g0 = (int64_t)blockIdx.x * per, g1 = min(P.C, g0 + per);
+    if (count_mode) {
         const FX_GLOBAL uint32_t *__restrict__ fl = as_global(P.flags);
         const FX_GLOBAL double *__restrict__ co = as_global(P.cost);
         unsigned int cnt = 0;
-        for (int64_t g = g0 + tid; g < g1; g += 4 * 256) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {   // the pairs requested at entry
+            const int64_t gu = g0 + tid + u * 256;
+            if ((f_pre[u] & FX_FLAG_SELECTABLE) && (f_pre[u] & FX_FLAG_COLLISION) &&
+                (none || c_pre[u] < bc || (c_pre[u] == bc && gu + P.g_base < bi))) cnt++;
+        }
+        for (int64_t g = g0 + tid + 8 * 256; g < g1; g += 4 * 256) {
             uint32_t f[4];
             double c[4];
 #pragma unroll
@@ -181,9 +205,8 @@ __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__rest
     // counters were accumulated by the evaluation kernel, which is complete: plain loads and stores.
     unsigned long long *out = host_result + (size_t)blockIdx.y * (FX_CNT_COUNT + 1);
     if (tid < FX_CNT_BEST_IDX) {
-        FX_GLOBAL unsigned long long *cn = as_global(P.counters);
-        out[tid] = cn[tid];
-        cn[tid] = 0ULL;
+        out[tid] = cnt_pre;
+        as_global(P.counters)[tid] = 0ULL;
     }
     if (tid == 0 && dev_winner) {  // (cost, index bits) of the winner, device-resident for the multi-GPU exchange
         dev_winner[2 * blockIdx.y] = none ? INFINITY : bc;
