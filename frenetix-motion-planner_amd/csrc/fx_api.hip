@@ -40,7 +40,7 @@ extern "C" hipError_t fx_launch_publish(const double *src, int n, double *host_d
 extern "C" hipError_t fx_launch_stage(const void *src_mapped, void *dst, size_t bytes, hipStream_t stream);
 extern "C" hipError_t fx_launch_package(const DevProblem *d_probs, int n_agents, const double *winner, double *host_pkg, int stride,
                                         int plane_rows, unsigned long long seq, hipStream_t stream);
-extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int k, double *scr_cost, long long *scr_idx,
+extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int64_t max_candidates, int k, double *scr_cost, long long *scr_idx,
                                      double *out_cost, long long *out_idx, hipStream_t stream);
 
 namespace {
@@ -572,6 +572,12 @@ int32_t fx_wait_published(FxContext *c, double *out) {
     if (rc) return rc;
     memcpy(out, c->h_pub, sizeof(double) * c->pub_n);
     return FX_OK;
+}
+
+static int64_t max_candidates_of(const FxContext *c) {
+    int64_t m = 0;
+    for (int a = 0; a < c->n_agents; a++) m = std::max(m, c->slots[a].C);
+    return m;
 }
 
 int32_t fx_set_timeout_ms(FxContext *c, int32_t timeout_ms) {
@@ -1395,7 +1401,7 @@ int32_t fx_step_exchange_topk(FxContext *c, int32_t k, FxResult *res, double *co
     char err_eval[sizeof(g_err)];
     long long *send_idx = reinterpret_cast<long long *>(c->d_xsend + (size_t)n_agents * k);
     if (!rc_eval) {
-        HIP_TRY(fx_launch_topk(c->d_probs, c->n_agents, k, c->d_topk_scr_cost, c->d_topk_scr_idx, c->d_xsend, send_idx, c->stream));
+        HIP_TRY(fx_launch_topk(c->d_probs, c->n_agents, max_candidates_of(c), k, c->d_topk_scr_cost, c->d_topk_scr_idx, c->d_xsend, send_idx, c->stream));
     } else {
         memcpy(err_eval, g_err, sizeof(err_eval));
         double *h = c->h_topk_cost;   // pinned [max_agents][64]
@@ -1769,7 +1775,7 @@ int32_t fx_topk_to_device(FxContext *c, int32_t k, void *d_cost, void *d_index) 
     if (!c->evaluated) return set_err(FX_ERR_NOT_READY, "no evaluated plan step");
     if (k < 1 || k > 64) return set_err(FX_ERR_INVALID_ARGUMENT, "k=%d outside [1,64]", k);
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(fx_launch_topk(c->d_probs, c->n_agents, k, c->d_topk_scr_cost, c->d_topk_scr_idx, reinterpret_cast<double *>(d_cost),
+    HIP_TRY(fx_launch_topk(c->d_probs, c->n_agents, max_candidates_of(c), k, c->d_topk_scr_cost, c->d_topk_scr_idx, reinterpret_cast<double *>(d_cost),
                            reinterpret_cast<long long *>(d_index), c->stream));
     c->in_flight = true;
     return FX_OK;

@@ -316,6 +316,166 @@ __global__ __launch_bounds__(256) void fx_topk_merge_kernel(int k, const double 
     }
 }
 
+// One-wave variants (slices / survivor sets of at most 64 x FX_TOPK_R entries: grids up to 131 072 candidates per agent, k <= 32):
+// ONE pass over memory into registers, then k rounds of a wave-level arg-min -- no workgroup barrier anywhere; every lane keeps
+// the minimum of its own entries and only the owner of a round's winner retires it and looks again.  The k block-wide
+// reductions of the general kernels above (two barriers each, eight workgroups per CU contending) cost 135 + 112 us per step for
+// config 5's 32 agents x k = 32; the (cost, index) order is the same.
+#define FX_TOPK_R 32   // entries per lane
+// order-preserving key of a (non-NaN, no negative zero) double
+__device__ __forceinline__ unsigned long long f64_key(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+
+// min over the wave of a 64-bit key, wave-uniform result: row shifts and row broadcasts of the vector unit's data-parallel
+// primitives on the two halves (no LDS crossbar: a __shfl_xor chain on 64-bit values costs ~3 000 cycles per reduction)
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+#define FX_DPP_MIN64(ctrl, rows)                                                                              \
+    {                                                                                                          \
+        const unsigned oh = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, ctrl, rows, 0xf, false);   \
+        const unsigned ol = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, ctrl, rows, 0xf, false);   \
+        const bool lt = oh < hi || (oh == hi && ol < lo);                                                      \
+        hi = lt ? oh : hi; lo = lt ? ol : lo;                                                                  \
+    }
+    FX_DPP_MIN64(0x111, 0xf);  // row_shr:1
+    FX_DPP_MIN64(0x112, 0xf);  // row_shr:2
+    FX_DPP_MIN64(0x114, 0xf);  // row_shr:4
+    FX_DPP_MIN64(0x118, 0xf);  // row_shr:8   -> lane 15 of every row holds the row's minimum
+    FX_DPP_MIN64(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    FX_DPP_MIN64(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef FX_DPP_MIN64
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+}
+
+__device__ __forceinline__ long long readlane_i64(long long v, int lane) {
+    return (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), lane) << 32) |
+                       (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane));
+}
+
+// One round's winner over the wave: minimum cost over the lanes' own minima, the lowest `id` among the lanes that hold it.
+// Returns the owner lane (wave-uniform), -1 when no lane has anything left.
+__device__ __forceinline__ int wave_round_owner(const double mc, const bool have, const long long id) {
+    const unsigned long long key = have ? f64_key(mc) : ~0ULL;
+    const unsigned long long kmin = wave_min_u64(key);
+    unsigned long long tie = __builtin_amdgcn_ballot_w64(have && key == kmin);
+    if (tie == 0ULL) return -1;
+    int owner = __builtin_ctzll(tie);
+    tie &= tie - 1;
+    if (tie) {   // equal costs on several lanes (rare): the lowest index
+        long long bi = readlane_i64(id, owner);
+        while (tie) {
+            const int l = __builtin_ctzll(tie);
+            tie &= tie - 1;
+            const long long oi = readlane_i64(id, l);
+            if (oi < bi) { bi = oi; owner = l; }
+        }
+    }
+    return owner;
+}
+
+__global__ __launch_bounds__(64) void fx_topk_slice_wave_kernel(const DevProblem *__restrict__ probs, int k, double *scr_cost,
+                                                                long long *scr_idx) {
+    const DevProblem &P = probs[blockIdx.y];
+    const int lane = threadIdx.x;
+    const int64_t per = (P.C + FX_TOPK_SLICES - 1) / FX_TOPK_SLICES;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = min(P.C, lo + per);
+    const FX_GLOBAL uint32_t *__restrict__ flags = as_global(P.flags);
+    const FX_GLOBAL double *__restrict__ cost = as_global(P.cost);
+    // slot u of lane l holds candidate lo + l + 64 u: its cost, or NaN when it is not eligible (a NaN cost is never selected:
+    // the comparisons of the general kernel drop it the same way)
+    double c[FX_TOPK_R];
+#pragma unroll
+    for (int u = 0; u < FX_TOPK_R; u++) {
+        const int64_t g = lo + lane + (int64_t)u * 64;
+        c[u] = __builtin_nan("");
+        if (g < hi) {
+            const uint32_t f = flags[g];
+            const double cg = cost[g];
+            if ((f & FX_FLAG_SELECTABLE) && !(f & (FX_FLAG_COLLISION | FX_FLAG_BOUNDARY))) c[u] = cg + 0.0;   // (+ 0.0: no negative zero in the keys)
+        }
+    }
+    const size_t out = ((size_t)blockIdx.y * FX_TOPK_SLICES + blockIdx.x) * k;
+    // the lane's minimum is kept per group of eight slots: retiring an entry re-scans its group only (the rounds are bound by
+    // the instructions of that re-scan: 2 048 waves x k rounds)
+    double gm[FX_TOPK_R / 8];
+    int gu[FX_TOPK_R / 8];
+    auto scan_group = [&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        double m = INFINITY;
+        int mu_ = -1;
+#pragma unroll
+        for (int u = 8 * q; u < 8 * q + 8; u++)
+            if (c[u] < m || (mu_ < 0 && c[u] == c[u])) { m = c[u]; mu_ = u; }   // (an infinite cost is still a candidate)
+        gm[q] = m; gu[q] = mu_;
+    };
+    auto retire_in_group = [&](auto Q, int slot) {
+        constexpr int q = decltype(Q)::value;
+#pragma unroll
+        for (int u = 8 * q; u < 8 * q + 8; u++)
+            if (u == slot) c[u] = __builtin_nan("");
+        scan_group(Q);
+    };
+    static_assert(FX_TOPK_R == 32, "four groups of eight slots below");
+    scan_group(std::integral_constant<int, 0>{}); scan_group(std::integral_constant<int, 1>{});
+    scan_group(std::integral_constant<int, 2>{}); scan_group(std::integral_constant<int, 3>{});
+    for (int r = 0; r < k; r++) {
+        // first group that holds the smallest cost: slots grow with the group, so this is the lane's (cost, index) minimum
+        double mc = gm[0];
+        int mu = gu[0];
+#pragma unroll
+        for (int q = 1; q < FX_TOPK_R / 8; q++)
+            if (gu[q] >= 0 && (mu < 0 || gm[q] < mc)) { mc = gm[q]; mu = gu[q]; }
+        const long long id = (long long)(lo + lane + (int64_t)mu * 64 + P.g_base);
+        const int owner = wave_round_owner(mc, mu >= 0, id);
+        if (owner < 0) {
+            if (lane == 0) { scr_cost[out + r] = INFINITY; scr_idx[out + r] = -1; }
+            continue;
+        }
+        if (lane == owner) {   // publish, retire the entry, look again in its group (only this lane does anything here)
+            scr_cost[out + r] = mc; scr_idx[out + r] = id;
+            switch (mu >> 3) {
+            case 0: retire_in_group(std::integral_constant<int, 0>{}, mu); break;
+            case 1: retire_in_group(std::integral_constant<int, 1>{}, mu); break;
+            case 2: retire_in_group(std::integral_constant<int, 2>{}, mu); break;
+            default: retire_in_group(std::integral_constant<int, 3>{}, mu); break;
+            }
+        }
+    }
+}
+
+// Merge of the 64 slices' sorted lists: lane l walks slice l's list through a head pointer (the lists sit in LDS), one round per
+// output -- no rescans at all.
+__global__ __launch_bounds__(64) void fx_topk_merge_wave_kernel(int k, const double *__restrict__ scr_cost, const long long *__restrict__ scr_idx,
+                                                                double *out_cost, long long *out_idx) {
+    __shared__ double l_cost[FX_TOPK_SLICES * FX_TOPK_R];
+    __shared__ long long l_idx[FX_TOPK_SLICES * FX_TOPK_R];
+    const int lane = threadIdx.x;
+    const int n = FX_TOPK_SLICES * k;   // host: k <= FX_TOPK_R
+    const size_t base = (size_t)blockIdx.x * n;
+    for (int e = lane; e < n; e += 64) { l_cost[e] = scr_cost[base + e] + 0.0; l_idx[e] = scr_idx[base + e]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int head = 0;
+    double mc = l_cost[lane * k];
+    long long mi = l_idx[lane * k];   // -1: the slice's list has ended
+    for (int r = 0; r < k; r++) {
+        const int owner = wave_round_owner(mc, mi >= 0, mi);
+        if (owner < 0) {
+            if (lane == 0) { out_cost[(size_t)blockIdx.x * k + r] = INFINITY; out_idx[(size_t)blockIdx.x * k + r] = -1; }
+            continue;
+        }
+        if (lane == owner) {
+            out_cost[(size_t)blockIdx.x * k + r] = mc; out_idx[(size_t)blockIdx.x * k + r] = mi;
+            head++;
+            mi = head < k ? l_idx[lane * k + head] : -1;
+            mc = head < k ? l_cost[lane * k + head] : INFINITY;
+        }
+    }
+}
+
 // Copy a small device buffer (the all-gathered survivors) into pinned host memory and publish a sequence word:
 // the host polls instead of paying for a D2H copy + stream synchronisation.
 __global__ __launch_bounds__(256) void fx_publish_kernel(const double *__restrict__ src, int n, double *host_dst,
@@ -495,9 +655,17 @@ extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, 
     return hipGetLastError();
 }
 
-extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int k, double *scr_cost, long long *scr_idx,
-                                     double *out_cost, long long *out_idx, hipStream_t stream) {
-    hipLaunchKernelGGL(fx_topk_slice_kernel, dim3(FX_TOPK_SLICES, n_agents), dim3(256), 0, stream, d_probs, k, scr_cost, scr_idx);
-    hipLaunchKernelGGL(fx_topk_merge_kernel, dim3(n_agents), dim3(256), 0, stream, k, scr_cost, scr_idx, out_cost, out_idx);
+extern "C" hipError_t fx_launch_topk(const DevProblem *d_probs, int n_agents, int64_t max_candidates, int k, double *scr_cost,
+                                     long long *scr_idx, double *out_cost, long long *out_idx, hipStream_t stream) {
+    // one wave per slice / per agent where the entries fit its registers (fx_topk_*_wave_kernel), the general kernels beyond
+    const int64_t per = (max_candidates + FX_TOPK_SLICES - 1) / FX_TOPK_SLICES;
+    if (per <= 64 * FX_TOPK_R)
+        hipLaunchKernelGGL(fx_topk_slice_wave_kernel, dim3(FX_TOPK_SLICES, n_agents), dim3(64), 0, stream, d_probs, k, scr_cost, scr_idx);
+    else
+        hipLaunchKernelGGL(fx_topk_slice_kernel, dim3(FX_TOPK_SLICES, n_agents), dim3(256), 0, stream, d_probs, k, scr_cost, scr_idx);
+    if (FX_TOPK_SLICES * k <= 64 * FX_TOPK_R)
+        hipLaunchKernelGGL(fx_topk_merge_wave_kernel, dim3(n_agents), dim3(64), 0, stream, k, scr_cost, scr_idx, out_cost, out_idx);
+    else
+        hipLaunchKernelGGL(fx_topk_merge_kernel, dim3(n_agents), dim3(256), 0, stream, k, scr_cost, scr_idx, out_cost, out_idx);
     return hipGetLastError();
 }

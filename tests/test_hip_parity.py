@@ -908,3 +908,26 @@ def test_non_finite_inputs(what):
             assert res["best_index"] == -1
         else:
             assert res["best_index"] == out["result"]["best_index"]
+
+
+def test_topk_random_sizes_against_numpy():
+    """Top-k survivors (one-wave slice kernel with register-resident entries, head-pointer merge; the general kernels beyond
+    their sizes) against a NumPy lexicographic sort of the eligible candidates: ragged sizes, ties, k = 1 ... 64."""
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    rng = np.random.default_rng(7)
+    for case in range(24):
+        grid = (int(rng.integers(1, 12)), int(rng.integers(1, 30)), int(rng.integers(1, 30)))
+        inp = synthetic.make_inputs(hull_builder=hip_hulls(), ref_kind="arc", v0=float(rng.uniform(1, 15)), grid=grid,
+                                    n_obstacles=int(rng.integers(0, 6)), seed=case,
+                                    cost_weights=({"velocity_offset": 1.0} if case % 3 == 0 else None))   # few distinct costs: ties
+        with FrenetEngine(max_candidates=inp.n_candidates + 64) as e:
+            e.plan_step(inp)
+            cost, flags = e.costs()
+            el = np.nonzero(((flags & _abi.FX_FLAG_SELECTABLE) != 0) & ((flags & (_abi.FX_FLAG_COLLISION | _abi.FX_FLAG_BOUNDARY)) == 0)
+                            & ~np.isnan(cost))[0]
+            order = el[np.lexsort((el, cost[el]))]
+            for k in (1, 5, 32, 64):
+                c, i = e.topk(k)
+                want = list(order[:k]) + [-1] * (k - min(k, len(order)))
+                assert list(i[0]) == want, (case, k, grid)
+                assert np.array_equal(c[0][:len(order[:k])], cost[order[:k]])
