@@ -751,12 +751,13 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                     const FxProblem *p = &probs[a];
                     const size_t n_pairs = (size_t)(blk / G + p->nD - 2) / p->nD + 1;
                     const size_t S = (size_t)p->N + 1;
-                    need = std::max(need, sizeof(double) * (FX_TP * S + (((size_t)p->M + 1) & ~(size_t)1)) +
-                                              128 * n_pairs * S +
-                                              (G > 1 ? (size_t)64 * blk : 0));  // + wave-split exchange block (5 f64 + 5 u32 per slot)
+                    // time table + rows + wave-split exchange block (5 f64 + 5 u32 per slot) + tail: the knots' arc lengths
+                    // during the prologue, one staging block of the step's hot obstacle table per wave during the walk
+                    // (fx_eval_grid_kernel.h: the two share the bytes)
+                    need = std::max(need, sizeof(double) * FX_TP * S + 128 * n_pairs * S + (G > 1 ? (size_t)64 * blk : 0) +
+                                              std::max(sizeof(double) * (((size_t)p->M + 1) & ~(size_t)1), (size_t)(blk / 64) * hot_block));
                 }
-                // + one staging block of the step's hot obstacle table per wave
-                return need + (size_t)(blk / 64) * hot_block;
+                return need;
             };
             const int want_waves = 4 * c->wpe_step;
             const size_t lds_static = 256;  // static LDS of the kernels (reductions)
@@ -769,6 +770,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                 // finish 3 - 8 % earlier than 256-lane ones (config 3: 88 - 95 vs 96 us); without obstacles they are slower
                 // (config 2: 48.6 vs 42.1 us, select-only 38.4 vs 29.1) -- tools/sweep_tuning.py, tools/c3.py
                 const int blk = (G >= 8 || (G == 2 && obst_any) ? order_small : order_big)[bi];
+                if (c->wsplit_force == 2 && (G == 2 || G == 4) && (blk / G) % 64 != 0) continue;   // a forced wave split needs whole waves per part
                 const size_t need = lds_for(blk);
                 const int by_lds = (int)((160 * 1024) / (need + lds_static));
                 const int waves = by_lds * (blk / 64);

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
 
     __shared__ int32_t sh_cost_id[FX_NUM_COSTS];
     __shared__ double sh_cost_w[FX_NUM_COSTS];
+    __shared__ __attribute__((aligned(16))) double sh_atan_k[FX_ATAN_K];   // atan's polynomial coefficients (walk_step with KTAB)
 
     // every field is fetched by scalar loads issued together at kernel entry (one latency) instead of one
     // dependent s_load wherever a field is first used
@@ -76,9 +77,14 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     const int it = (int)(pair / nV), iv = (int)(pair - (int64_t)it * nV);
     const double T = as_global(P.t_samp)[it], v1 = as_global(P.v_samp)[iv], d1 = as_global(P.d_samp)[id];
     // ---- phase 1: one round of global loads -- time powers, knot arc lengths, cost ids / weights -> LDS ----
+    // dynamic LDS: time table | rows | exchange block (G > 1) | tail.  The tail holds the knots' arc lengths during the
+    // prologue (binary search of make_lon_row) and the waves' hot obstacle blocks during the walk -- the two never live at the
+    // same time (a barrier separates them), and sharing the bytes is what lets a CU hold three 256-lane workgroups of config 5
+    // (51 samples, 52 lateral offsets: 54.5 KB apart, 50.5 KB shared)
     double *__restrict__ tpw = lds_dyn;                                // [S][FX_TP] time table
-    double *__restrict__ rpos = lds_dyn + FX_TP * S;                   // [M] arc length of the knots (binary search)
-    LonRow *__restrict__ rows = reinterpret_cast<LonRow *>(rpos + ((M + 1) & ~1));  // 16-byte aligned
+    LonRow *__restrict__ rows = reinterpret_cast<LonRow *>(tpw + FX_TP * S);   // FX_TP * S * 8 is a multiple of 16
+    char *__restrict__ lds_tail = reinterpret_cast<char *>(rows + (size_t)n_pairs_max * S) + (G > 1 ? (size_t)64 * BLK : 0);
+    double *__restrict__ rpos = reinterpret_cast<double *>(lds_tail);  // [M] arc length of the knots (binary search)
     // the knots themselves are only touched once per (pair, step) item: read them through L1/L2
     const FX_GLOBAL double *__restrict__ kn = as_global(P.ref);
     {
@@ -86,6 +92,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
         for (int i = tid; i < S; i += BLK) fill_time_row(tpw + i * FX_TP, tsrc[i], tsrc[S + i], tsrc[2 * S + i], tsrc[3 * S + i], tsrc[4 * S + i]);
         for (int i = tid; i < M; i += BLK) rpos[i] = kn[(int64_t)i * FX_REF_FIELDS];
         if (tid < P.n_cost) { sh_cost_id[tid] = Pg.cost_id[tid]; sh_cost_w[tid] = Pg.cost_w[tid]; }
+        if (WPE >= 3 && OBST && tid < FX_ATAN_K) sh_atan_k[tid] = fxm::fx_ktab[FX_ATAN_K0 + tid];
     }
     if (tid < 2 + FX_NUM_REASONS) red_cnt[tid] = 0;
     __syncthreads();
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
 
     // The walk's wave-uniform doubles live in VGPRs (KV): the loop keeps ~50 lane masks and pointers in scalar registers and
     // the allocator otherwise parks these constants in VGPR lanes and reads them back (v_readlane) every step.
-    auto KV = [](double x) { return WPE <= 2 ? fxk::uniform_to_vgpr(x) : x; };  // 256 VGPRs to spend only at two waves per SIMD
+    auto KV = [](double x) { return WPE <= 3 ? fxk::uniform_to_vgpr(x) : x; };  // 256 VGPRs to spend only at two waves per SIMD
     StepConst K;
     K.dt = KV(dt); K.r_dt = KV(1.0 / dt); K.kappa_max = KV(P.veh.kappa_max); K.a_max = KV(a_max); K.v_switch = KV(P.veh.v_switch);
     K.av_switch = KV(a_max * P.veh.v_switch); K.v_des = KV(P.v_des); K.wb = KV(P.veh.wb_rear_axle); K.half_len = KV(P.veh.length / 2);
@@ -191,6 +198,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     K.do_collision = do_collision; K.store_wt = (P.mode & FX_MODE_INT_STORE_WT) != 0;
     K.n_bound = (OBST && (P.mode & FX_MODE_ROAD_BOUNDARY)) ? P.n_bound : 0; K.bound_d_reach = P.bound_d_reach;
     K.ox = KV(P.hot_origin[0]); K.oy = KV(P.hot_origin[1]); K.gap_margin = KV(P.hot_gap_margin);
+    K.cull_r0 = (float)(1.41423 * sqrt(P.veh.length * P.veh.length + P.veh.width * P.veh.width) * 0.5);
+    K.atan_k = (fxm::lds_cptr)sh_atan_k;
     const BoundView Bv{as_global(P.bound_piece), as_global(P.bound_bin), as_global(P.bound_item)};
     const FX_GLOBAL double *__restrict__ obs_rec = as_global(P.obs_rec);
     const FX_GLOBAL unsigned long long *__restrict__ obs_pmask = as_global(P.obs_pmask);
@@ -222,12 +231,31 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     ObsHot Hs;
     Hs.lds = nullptr; Hs.tab = as_global(P.obs_hot); Hs.n_el = P.K * FX_HOT_STRIDE; Hs.lane = tid & 63;
     if (HOT && P.K > 0) {
-        char *hot_base = reinterpret_cast<char *>(rows + (size_t)n_pairs_max * S) + (G > 1 ? (size_t)64 * BLK : 0);
+        char *hot_base = lds_tail;   // over the knots' arc lengths, which only the prologue reads
         const size_t hot_block = (sizeof(double) * FX_HOT_STRIDE * (size_t)fuse.k_max + 15) & ~(size_t)15;
         Hs.lds = reinterpret_cast<double *>(hot_base + (size_t)(tid >> 6) * hot_block);
         if (i_first < i_end) Hs.prefetch(i_first);
     }
 
+#ifdef FX_CULL_STATS
+    double cs_base = 0.0, cs_wd = 0.0, cs_wv = 0.0, cs_wp = 0.0;
+    {
+        const double tt = dt, tt2 = tt * tt, tt3 = tt2 * tt, tt4 = tt3 * tt, tt5 = tt4 * tt;
+        for (int n = 0; n < P.n_cost; n++) {
+            const int id = P.cost_id[n];
+            const double w = P.cost_w[n];
+            if (id == FX_COST_DISTANCE_TO_REFERENCE_PATH) cs_wd = w / S;
+            if (id == FX_COST_VELOCITY_OFFSET) cs_wv = w;
+            if (id == FX_COST_PREDICTION) cs_wp = w;
+            if (id == FX_COST_LATERAL_JERK)
+                cs_base += w * (36 * L.c3 * L.c3 * tt + 144 * L.c3 * L.c4 * tt2 + 240 * L.c3 * L.c5 * tt3 + 192 * L.c4 * L.c4 * tt3 +
+                                720 * L.c4 * L.c5 * tt4 + 720 * L.c5 * L.c5 * tt5);
+            if (id == FX_COST_LONGITUDINAL_JERK)
+                cs_base += w * (36 * cl3 * cl3 * tt + 144 * cl3 * cl4 * tt2 + 240 * cl3 * cl5 * tt3 + 192 * cl4 * cl4 * tt3 +
+                                720 * cl4 * cl5 * tt4 + 720 * cl5 * cl5 * tt5);
+        }
+    }
+#endif
     // wave-uniform step index: scalar row base + the lane's 32-bit byte offset for the plane stores (the host refuses bundles
     // whose rows exceed 4 GiB)
     constexpr bool USTEP32 = (G == 1 || WSPLIT);
@@ -236,10 +264,20 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     for (int i = i_first; i < i_end; i++) {
         const bool emit = i >= i_begin;
         const LonRow r = my[i];
-        walk_step<OBST, (G == 1 || WSPLIT), HOT>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit,
+        walk_step<OBST, (G == 1 || WSPLIT), HOT, (WPE >= 3 && OBST)>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit,
                                                  USTEP32 ? planes + (int64_t)i * ld : planes + (int64_t)i * ld + g,
                                                  USTEP32 ? (uint32_t)g * 8u : 0u, ps, Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv,
                                                  &Hs, i + 1 < i_end ? i + 1 : -1);
+#ifdef FX_CULL_STATS
+        {   // how many (wave, step) pairs lie behind the point where every lane of the wave is decided (production flag set), and
+            // behind the point where every lane is decided or its cost so far already exceeds a bound (the winner's cost)
+            const bool dead = !active || A.first_key != 0xffffffffu || A.neg || A.acc_viol;
+            const double lb = cs_base + cs_wd * A.sum_abs_d + cs_wv * A.sum_voff + cs_wp * A.pred;
+            const bool out = dead || lb > fx_probe_bound * 1.000001;
+            const unsigned long long md = __ballot(dead), mo = __ballot(out);
+            FX_CSTAT(6, 1); FX_CSTAT(5, md == ~0ULL); FX_CSTAT(7, __popcll(md)); FX_CSTAT(8, mo == ~0ULL); FX_CSTAT(9, __popcll(mo));
+        }
+#endif
     }
 
     FX_STAMP(4);

@@ -79,11 +79,14 @@ struct Obb {
     double cx, cy, ex, ey, h1, h2;
 };
 
-// Arithmetic diet (the hull is built once per (candidate, step) of the collision stage -- as many instructions as the twenty
-// prediction visits of the step when it used the IEEE sqrt and two IEEE divisions): the unit axis comes from v_rsq_f64 + two
-// coupled Newton steps (1 / |m| to an ulp, sqrt_rsqrt in fx_walk.h), and the two boxes' extents along the hull axes are formed
-// from the same two products each (|u . e| and |u x e| serve both axes: u . f = -(u x e), u x f = u . e for f = e rotated by
-// 90 degrees).  Differs from the oracle's libm form by an ulp or two in (ex, ey); decisions are unaffected (tests).
+// OBB-sum hull of two boxes with UNIT headings u0, u1, equal half extents (hl, hw) and centres c0, c1: axis
+// e = normalize(u0 + u1), extents = tight range of both boxes on (e, f).  Because e bisects the two headings, both boxes have the
+// same extent along either hull axis: |u_j . e| = |u0 + u1| / 2 and |u_j x e| = |u0 x u1| / |u0 + u1| for j = 0 and 1.  The tight
+// range on e is therefore [min_j c_j . e - r1, max_j c_j . e + r1], i.e. the hull's centre is the midpoint of the two centres
+// and its half extent |(c1 - c0) . e| / 2 + r1 (likewise on f) -- ~35 operations where forming both boxes' ranges and merging
+// them took ~70 (as many as the twenty prediction visits of the step).  The unit axis comes from v_rsq_f64 + two coupled Newton
+// steps (sqrt_rsqrt in fx_walk.h).  Differs from the oracle's box-by-box form by an ulp or two; decisions are unaffected
+// (the oracle reports every collision decision closer than 1e-9 to its threshold as fragile, tests/admissible.py).
 __device__ __forceinline__ void sqrt_rsqrt(double x, double &sq, double &rsq);
 __device__ __forceinline__ Obb obb_hull(double c0x, double c0y, double u0x, double u0y, double c1x, double c1y,
                                         double u1x, double u1y, double hl, double hw) {
@@ -91,29 +94,16 @@ __device__ __forceinline__ Obb obb_hull(double c0x, double c0y, double u0x, doub
     double mn, r_mn;
     sqrt_rsqrt(fma(mx, mx, my * my), mn, r_mn);
     const bool flat = !(mn >= 1e-12);   // opposite headings (or a non-finite one): the first box's axis
-    const double ex = flat ? u0x : mx * r_mn, ey = flat ? u0y : my * r_mn;
-    // box 0
-    double p1 = fma(c0x, ex, c0y * ey), p2 = fma(c0y, ex, -(c0x * ey));
-    double a = fabs(fma(u0x, ex, u0y * ey)), b = fabs(fma(u0x, ey, -(u0y * ex)));
-    double r1 = fma(hl, a, hw * b), r2 = fma(hl, b, hw * a);
-    double lo1 = p1 - r1, hi1 = p1 + r1, lo2 = p2 - r2, hi2 = p2 + r2;
-    // box 1
-    p1 = fma(c1x, ex, c1y * ey);
-    p2 = fma(c1y, ex, -(c1x * ey));
-    a = fabs(fma(u1x, ex, u1y * ey));
-    b = fabs(fma(u1x, ey, -(u1y * ex)));
-    r1 = fma(hl, a, hw * b);
-    r2 = fma(hl, b, hw * a);
-    lo1 = fmin(lo1, p1 - r1); hi1 = fmax(hi1, p1 + r1);
-    lo2 = fmin(lo2, p2 - r2); hi2 = fmax(hi2, p2 + r2);
-    const double m1 = 0.5 * (lo1 + hi1), m2 = 0.5 * (lo2 + hi2);
     Obb o;
-    o.cx = fma(m1, ex, -(m2 * ey));   // m1 e + m2 f, f = (-ey, ex)
-    o.cy = fma(m1, ey, m2 * ex);
-    o.ex = ex;
-    o.ey = ey;
-    o.h1 = 0.5 * (hi1 - lo1);
-    o.h2 = 0.5 * (hi2 - lo2);
+    o.ex = flat ? u0x : mx * r_mn;
+    o.ey = flat ? u0y : my * r_mn;
+    const double a = flat ? 1.0 : 0.5 * mn;                                    // |u_j . e|
+    const double b = flat ? 0.0 : fabs(fma(u0x, u1y, -(u0y * u1x))) * r_mn;    // |u_j x e|
+    const double tx = c1x - c0x, ty = c1y - c0y;
+    o.cx = fma(0.5, tx, c0x);
+    o.cy = fma(0.5, ty, c0y);
+    o.h1 = fma(0.5, fabs(fma(tx, o.ex, ty * o.ey)), fma(hl, a, hw * b));
+    o.h2 = fma(0.5, fabs(fma(ty, o.ex, -(tx * o.ey))), fma(hl, b, hw * a));
     return o;
 }
 
@@ -651,6 +641,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     K.do_collision = do_collision; K.store_wt = (P.mode & FX_MODE_INT_STORE_WT) != 0;
     K.n_bound = (OBST && (P.mode & FX_MODE_ROAD_BOUNDARY)) ? P.n_bound : 0; K.bound_d_reach = P.bound_d_reach;
     K.ox = P.hot_origin[0]; K.oy = P.hot_origin[1]; K.gap_margin = P.hot_gap_margin;
+    K.cull_r0 = (float)(1.41423 * sqrt(P.veh.length * P.veh.length + P.veh.width * P.veh.width) * 0.5);
+    K.atan_k = nullptr;
     const BoundView Bv{as_global(P.bound_piece), as_global(P.bound_bin), as_global(P.bound_item)};
     const FX_GLOBAL double *__restrict__ obs_rec = as_global(P.obs_rec);
     const FX_GLOBAL unsigned long long *__restrict__ obs_pmask = as_global(P.obs_pmask);

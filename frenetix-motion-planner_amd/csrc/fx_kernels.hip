@@ -29,6 +29,19 @@
 
 using fxk::wave_count;
 
+#ifdef FX_CULL_STATS
+__device__ unsigned long long fx_cull_stats[16];
+__device__ double fx_probe_bound = 1e300;
+extern "C" int fx_probe_bound_set(double v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(fx_probe_bound), &v, sizeof(v), 0, hipMemcpyHostToDevice); }
+extern "C" int fx_cull_stats_read(unsigned long long *out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fx_cull_stats), sizeof(fx_cull_stats), 0, hipMemcpyDeviceToHost);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(fx_cull_stats), z, sizeof(z), 0, hipMemcpyHostToDevice);
+    }
+    return rc;
+}
+#endif
 #ifdef FX_PROBE
 __device__ unsigned long long fx_probe_stamps[FX_PROBE_WAVES * FX_PROBE_SLOTS];
 extern "C" int fx_probe_read(unsigned long long *out, size_t n_words) {

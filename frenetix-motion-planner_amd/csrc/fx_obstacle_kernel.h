@@ -148,18 +148,16 @@ __global__ __launch_bounds__(64, WPS) void fx_obstacle_kernel(const DevProblem *
         const double ox = P.hot_origin[0], oy = P.hot_origin[1];
         const double wb = P.veh.wb_rear_axle, half_len = P.veh.length / 2, half_wid = P.veh.width / 2;
         const double gap_margin = P.hot_gap_margin;
+        // constant part of a hull's bounding radius for the wave-level cull: |wb| + sqrt(2) (|wb| + hd), rounded up
+        const float cull_r0 = (float)((fabs(wb) * 2.41422 + 1.41423 * sqrt(half_len * half_len + half_wid * half_wid)) * 1.00001);
         const unsigned long long full = K >= 64 ? ~0ULL : ((1ULL << K) - 1ULL);
         const int kl = min(lane, K - 1);
         // the table writes above are this wave's own: LDS operations of one wave execute in order
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        double bxp = 0.0, byp = 0.0, uxp = 0.0, uyp = 0.0;
-        if (do_col) {   // ego box of step i_a - 1
-            double sn, cs;
-            fxm::sincos(ts[0], &sn, &cs);
-            bxp = fma(wb, cs, xs[0]); byp = fma(wb, sn, ys[0]); uxp = cs; uyp = sn;
-        }
+        double sn_prev = 0.0, cs_prev = 1.0;
+        bool have_prev = false;   // wave-uniform: (sn_prev, cs_prev) = sin / cos of theta at step i - 1
         FX_OSTAMP(2);
 #pragma unroll
         for (int j = 1; j <= CH; j++) {
@@ -177,24 +175,23 @@ __global__ __launch_bounds__(64, WPS) void fx_obstacle_kernel(const DevProblem *
                     auto ld_ = [&](int k) { return obs_load(hot_i, cc_i, k); };
                     if (pm == full) {
                         // four obstacles per iteration in two alternating register sets: the loads of one pair are in flight
-                        // while the other pair is consumed
-                        ObsEntry a = ld_(0), b = ld_(K > 1 ? 1 : 0), c, d;
+                        // while the other pair is consumed; every complete group of four shares one reciprocal (fx_walk.h: same
+                        // grouping, same expression tree)
+                        const int kz = K - 1;
+                        ObsEntry a = ld_(0), b = ld_(min(1, kz)), c, d;
                         int k = 0;
-                        for (; k + 5 < K; k += 4) {
+                        for (; k + 3 < K; k += 4) {
                             c = ld_(k + 2); d = ld_(k + 3);
                             const double qa = obs_msq(a, xr, yr), qb = obs_msq(b, xr, yr);
-                            a = ld_(k + 4); b = ld_(k + 5);
+                            a = ld_(min(k + 4, kz)); b = ld_(min(k + 5, kz));
                             ssum += obs_four(qa, qb, obs_msq(c, xr, yr), obs_msq(d, xr, yr));
                         }
-                        // entries k (a) and k + 1 (b) are loaded; up to five remain
-                        for (; k + 3 < K; k += 2) {
-                            c = ld_(k + 2); d = ld_(k + 3);
-                            ssum += rcp_pred(obs_msq(a, xr, yr)) + rcp_pred(obs_msq(b, xr, yr));
-                            a = c; b = d;
-                        }
-                        ssum += rcp_pred(obs_msq(a, xr, yr));
-                        if (k + 1 < K) ssum += rcp_pred(obs_msq(b, xr, yr));
+                        // entries k (a) and k + 1 (b) are loaded where they exist; up to three remain
+                        double s1 = 0.0;
+                        if (k < K) ssum += rcp_pred(obs_msq(a, xr, yr));
+                        if (k + 1 < K) s1 += rcp_pred(obs_msq(b, xr, yr));
                         if (k + 2 < K) ssum += rcp_pred(obs_msq(ld_(k + 2), xr, yr));
+                        ssum += s1;
                     } else {
                         unsigned long long m = pm;
                         while (m) {
@@ -224,41 +221,60 @@ __global__ __launch_bounds__(64, WPS) void fx_obstacle_kernel(const DevProblem *
                     acc += ssum;
                 }
                 // ---- collision: OBB-sum hull of ego boxes (i-1, i) against the obstacle hulls of this step ----
-                if (do_col) {
-                    double sn, cs;
-                    fxm::sincos(ts[j], &sn, &cs);
-                    const double bx = fma(wb, cs, xs[j]), by = fma(wb, sn, ys[j]);
-                    if (hm) {
+                if (hm) {
+                    // Wave-level cull before anything of the boxes is built (fx_walk.h has the same cull on the box centres; here
+                    // not even the headings exist yet).  Box centre c = p + wb (cos, sin) theta of the rear-axle point p = (x, y):
+                    // the midpoint of the two centres lies within |wb| of the midpoint m of the two rear-axle points and
+                    // |c1 - c0| <= |p1 - p0| + 2 |wb|, so the hull lies inside the disc around m with radius
+                    // |wb| + sqrt(2) (|p1 - p0| / 2 + |wb| + hd), hd = |(L/2, W/2)|.  One bounding disc for the wave's 64 hulls
+                    // (around the first lane's m), lane k tests obstacle k's circle against it; for most (tile, step) pairs
+                    // nothing survives and neither the two sincos nor the hull are evaluated.
+                    unsigned long long cand;
+                    {
+                        const double mxr = fma(0.5, xs[j - 1] + xs[j], -ox), myr = fma(0.5, ys[j - 1] + ys[j], -oy);
+                        const double tx = xs[j] - xs[j - 1], ty = ys[j] - ys[j - 1];
+                        const double qd = fma(tx, tx, ty * ty);
+                        const double m0x = uniform_f64(mxr), m0y = uniform_f64(myr);
+                        const double dx = mxr - m0x, dy = myr - m0y;
+                        const double qe = fma(dx, dx, dy * dy);
+                        const bool bad = !(qd + qe < 1e300);   // a point that is not finite keeps every obstacle on the exact path
+                        const float reach = fmaf(__builtin_amdgcn_sqrtf((float)qe), 1.00001f,
+                                                 fmaf(__builtin_amdgcn_sqrtf((float)qd), 0.707115f, cull_r0));
+                        const unsigned rb = wave_max_u32(bad ? 0u : __float_as_uint(reach));  // reach >= 0: bit patterns order like values
+                        const double Rw = (double)__uint_as_float(rb);
+                        const double *qo = circ_i + 4 * (size_t)kl;
+                        const double ex = fma(-0.5, qo[0], -m0x), ey = fma(-0.5, qo[1], -m0y);   // h - m0
+                        const double rr = fma(-0.5, qo[2], Rw) * 1.00001;                        // r_o + R
+                        cand = __builtin_amdgcn_ballot_w64(!(fma(ex, ex, ey * ey) > rr * rr)) & hm;
+                        if (wave_any_bit(bad)) cand = hm;
+                    }
+                    have_prev = have_prev && cand != 0ULL;
+                    if (cand) {
+                        // the two ego boxes (rear axle + wb along the heading, state.py:30-39) and their OBB-sum hull; the heading
+                        // of step i - 1 is carried when that step built a hull too
+                        double s0 = sn_prev, c0 = cs_prev, s1, c1;
+                        if (!have_prev) fxm::sincos(ts[j - 1], &s0, &c0);   // (wave-uniform: the previous step went the same way)
+                        fxm::sincos(ts[j], &s1, &c1);
+                        sn_prev = s1; cs_prev = c1;
+                        const Obb hull = obb_hull(fma(wb, c0, xs[j - 1]), fma(wb, s0, ys[j - 1]), c0, s0, fma(wb, c1, xs[j]), fma(wb, s1, ys[j]),
+                                                  c1, s1, half_len, half_wid);
                         const auto rec_i = rec + (int64_t)i * K * 12;
-                        const Obb hull = obb_hull(bxp, byp, uxp, uyp, bx, by, cs, sn, half_len, half_wid);
-                        // the walk's broad phase (fx_walk.h): circles around the hulls, one bound for the wave, lane k tests obstacle k
+                        // per-lane circle test in the expanded form of the table for the survivors, the exact 4-axis test for
+                        // what is still near (the walk's sequence: decisions are those of the brute-force definition)
                         const double re = (hull.h1 + hull.h2) * 1.000001;
                         const double cxr = hull.cx - ox, cyr = hull.cy - oy;
                         const double wq = fma(cxr, cxr, fma(cyr, cyr, -re * re));
-                        unsigned long long cand;
-                        {
-                            const double *qo = circ_i + 4 * (size_t)kl;
-                            const double c0x = uniform_f64(cxr), c0y = uniform_f64(cyr);
-                            const double dx = cxr - c0x, dy = cyr - c0y;
-                            const double q = fma(dx, dx, dy * dy);
-                            const bool bad = !(q + re < 1e300);   // a hull that is not finite keeps every obstacle on the exact path
-                            const float reach = fmaf(__builtin_amdgcn_sqrtf((float)q), 1.00001f, (float)re * 1.00001f);
-                            const unsigned rb = wave_max_u32(bad ? 0u : __float_as_uint(reach));  // reach >= 0: bit patterns order like values
-                            const double Rw = (double)__uint_as_float(rb);
-                            const double ex = fma(-0.5, qo[0], -c0x), ey = fma(-0.5, qo[1], -c0y);   // h - c0
-                            const double rr = fma(-0.5, qo[2], Rw) * 1.00001;                        // r_o + R
-                            cand = __builtin_amdgcn_ballot_w64(!(fma(ex, ex, ey * ey) > rr * rr)) & hm;
-                            if (wave_any_bit(bad)) cand = hm;
-                        }
-                        while (cand) {
+                        do {
                             const int k = __builtin_ctzll(cand);
                             cand &= cand - 1;
                             const double *q = circ_i + 4 * (size_t)k;
                             const double gq = fma(q[0], cxr, fma(q[1], cyr, fma(q[2], re, q[3] + wq)));
                             if (wave_any_bit(!(gq > gap_margin))) collided |= obb_overlap(hull, rec_i + k * 12 + 6);
-                        }
+                        } while (cand);
+                        have_prev = true;
                     }
-                    bxp = bx; byp = by; uxp = cs; uyp = sn;
+                } else {
+                    have_prev = false;
                 }
             }
         }

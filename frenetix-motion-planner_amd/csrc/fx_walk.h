@@ -25,6 +25,15 @@
 // offset, one address register for all 14 stores instead of a 64-bit add per plane)
 #define FX_PLANE_AT(p) reinterpret_cast<FX_GLOBAL double *>(reinterpret_cast<FX_GLOBAL char *>(planes_i + (p) * ps) + lane_off)
 
+// Developer statistics of the collision broad phase (-DFX_CULL_STATS, tools/cull_stats.py): compiles to nothing in the product
+#ifdef FX_CULL_STATS
+extern __device__ unsigned long long fx_cull_stats[16];
+extern __device__ double fx_probe_bound;
+#define FX_CSTAT(slot, val) do { if ((threadIdx.x & 63) == 0) atomicAdd(&fx_cull_stats[slot], (unsigned long long)(val)); } while (0)
+#else
+#define FX_CSTAT(slot, val) do { } while (0)
+#endif
+
 namespace fxk {
 
 // a wave-uniform double pinned into a vector register pair (see fx_eval_grid_kernel.h, StepConst)
@@ -280,6 +289,8 @@ struct StepConst {  // wave-uniform constants of the walk
     double bound_d_reach;   // |d| beyond this counts as off the road
     double ox, oy;          // origin of the hot obstacle table's coordinates (a reference-path point near the ego)
     double gap_margin;      // broad phase: centre-gap values up to this go to the exact test (rounding of the expanded form)
+    fxm::lds_cptr atan_k;   // KTAB: LDS copy of atan's polynomial coefficients (fx_math.h, atan_small_tab)
+    float cull_r0;          // wave-level cull: sqrt(2) * |(L/2, W/2)|, rounded up (constant part of a hull's bounding radius)
 };
 
 struct StepCarry {  // per-lane state carried from step to step
@@ -389,7 +400,9 @@ __device__ __forceinline__ void heading_trig(const LonRow &r, double cosTheta, d
     su = fma(sinTheta, r.c_ref, cosTheta * r.s_ref);
 }
 
-template <bool OBST, bool USTEP, bool HOT = false, typename PlanePtr, typename ObsD, typename ObsM>
+// KTAB: the constants of the rare paths (general atan reduction, standstill sincos) come from constant memory instead of
+// loop-long registers (fx_math.h)
+template <bool OBST, bool USTEP, bool HOT = false, bool KTAB = false, typename PlanePtr, typename ObsD, typename ObsM>
 __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, const LatPoly &L, const double *tp, int i,
                                           int traj_len, double d_ext, bool emit, bool store, PlanePtr planes_i, uint32_t lane_off, int64_t ps,
                                           StepCarry &C, StepAcc &A, StepOut &O, ObsD obs_rec, ObsM obs_pmask, ObsM obs_hmask,
@@ -431,14 +444,14 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
     double secTheta, cosTheta;
     sqrt_rsqrt(fma(dp, dp, 1.0), secTheta, cosTheta);
     double tanTheta = dp;
-    double th_cl = __all(fabs(dp) < 0.4375) ? fxm::atan_small(dp) : fxm::atan(dp);
+    double th_cl = __all(fabs(dp) < 0.4375) ? (KTAB ? fxm::atan_small_tab(dp, K.atan_k) : fxm::atan_small(dp)) : fxm::atan<KTAB>(dp);
     double th_gl = th_cl + th_ref;
     const bool still = !(moving || K.low_vel);
     if (__any(still)) {  // standstill at high-speed mode keeps the previous global heading (:447-454)
         const double th_gl_s = C.th_prev;  // x_0.orientation at i == 0
         const double th_cl_s = th_gl_s - th_ref;
         double sn, cs;
-        fxm::sincos(th_cl_s, &sn, &cs);
+        fxm::sincos<KTAB>(th_cl_s, &sn, &cs);
         const double sec_s = rcp_nr(cs);
         if (still) { th_gl = th_gl_s; th_cl = th_cl_s; cosTheta = cs; secTheta = sec_s; tanTheta = sn * sec_s; }
     }
@@ -557,25 +570,23 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
             double s0 = 0.0, s1 = 0.0;
             if (pm == full) {
                 // four obstacles per iteration in two alternating register sets: the loads of one pair are in flight
-                // while the other pair is consumed, and no value is copied between the sets
+                // while the other pair is consumed, and no value is copied between the sets.  Every complete group of four
+                // shares one reciprocal (the look-ahead loads clamp their index instead of ending the loop a group early:
+                // K = 20 is five groups, not four groups and four single reciprocals)
                 fx_d2 la, ca, lb, cb, lc, cc, ld_, cd;
                 double wa, wb, wc, wd;
                 int k = 0;
+                const int kz = nK - 1;
                 ld(0, la, ca, wa);
-                if (nK > 1) ld(1, lb, cb, wb);
-                for (; k + 5 < nK; k += 4) {
+                ld(min(1, kz), lb, cb, wb);
+                for (; k + 3 < nK; k += 4) {
                     ld(k + 2, lc, cc, wc); ld(k + 3, ld_, cd, wd);
                     const double qa = msq(la, ca, wa), qb = msq(lb, cb, wb);
-                    ld(k + 4, la, ca, wa); ld(k + 5, lb, cb, wb);
+                    ld(min(k + 4, kz), la, ca, wa); ld(min(k + 5, kz), lb, cb, wb);
                     s0 += four(qa, qb, msq(lc, cc, wc), msq(ld_, cd, wd));
                 }
-                // entries k (a) and k + 1 (b) are loaded; up to five remain
-                for (; k + 3 < nK; k += 2) {
-                    ld(k + 2, lc, cc, wc); ld(k + 3, ld_, cd, wd);
-                    s0 += term(la, ca, wa); s1 += term(lb, cb, wb);
-                    la = lc; ca = cc; wa = wc; lb = ld_; cb = cd; wb = wd;
-                }
-                s0 += term(la, ca, wa);
+                // entries k (a) and k + 1 (b) are loaded where they exist; up to three remain
+                if (k < nK) s0 += term(la, ca, wa);
                 if (k + 1 < nK) s1 += term(lb, cb, wb);
                 if (k + 2 < nK) { ld(k + 2, lc, cc, wc); s0 += term(lc, cc, wc); }
             } else {
@@ -615,59 +626,63 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
             const double bx = fma(K.wb, cu, x_i), by = fma(K.wb, su, y_i);
             const unsigned long long hm = emit ? hm_now : 0ULL;
             if (hm) {
-                const Obb hull = obb_hull(C.bx_prev, C.by_prev, C.ux_prev, C.uy_prev, bx, by, cu, su, K.half_len, K.half_wid);
-                // broad phase on circles: a box lies inside the circle around its centre with radius h1 + h2, so hulls
-                // whose centres are farther apart than the sum of those radii (1e-6 relative slack on both) are separated
-                // and the axis test would say so.  g = |h - c|^2 - (r_o + r_e)^2 in the expanded form of the table; the
-                // exact test runs for the obstacles where some lane has g <= margin (the margin covers the rounding of the
-                // expanded form).
-                const double re = (hull.h1 + hull.h2) * 1.000001;
-                const double cxr = hull.cx - K.ox, cyr = hull.cy - K.oy;
-                const double wq = fma(cxr, cxr, fma(cyr, cyr, -re * re));
-                auto gap = [&](fx_d2 hxy, fx_d2 hrk) {  // (hx2, hy2), (hr2, ck)
-                    return fma(hxy.x, cxr, fma(hxy.y, cyr, fma(hrk.x, re, hrk.y + wq)));
-                };
-                auto ldh = [&](int k, fx_d2 &hxy, fx_d2 &hrk) {
-                    const double *q = hot + (size_t)k * FX_HOT_STRIDE;
-                    hxy = fx_d2{q[FX_HOT_HX2], q[FX_HOT_HY2]};
-                    hrk = fx_d2{q[FX_HOT_HR2], q[FX_HOT_CK]};
-                };
-                // Wave-level cull, all obstacles at once: the ego hulls of the wave's 64 candidates at this step lie inside the
-                // circle around the first lane's hull centre c0 with radius R = max over the lanes of (|c - c0| + r_e); lane k
-                // tests obstacle k's circle against that one (a pair of boxes that overlap has |h - c| <= r_o + r_e, hence
-                // |h - c0| <= r_o + R: nothing that the exact test would report is dropped; the slack covers the single-precision
-                // square root and conversions).  Candidates of a wave are neighbours in the sampling grid, R is a few metres, and
-                // for most steps no obstacle survives -- the per-lane test below then does not run at all.
+                // Wave-level cull BEFORE the hull is built, all obstacles at once.  Both ego boxes lie inside the discs of radius
+                // hd = |(L/2, W/2)| around their centres c0, c1, hence inside the disc around the midpoint m of the centres with
+                // radius rho = |c1 - c0| / 2 + hd; the OBB-sum hull is the bounding rectangle of the two boxes in some orthonormal
+                // frame, so it lies inside that disc's bounding square in the same frame, i.e. inside the disc (m, sqrt(2) rho).
+                // The hulls of the wave's 64 candidates at this step therefore lie inside the disc around the first lane's
+                // midpoint m0 with radius R = max over the lanes of (|m - m0| + sqrt(2) rho), and lane k tests obstacle k's circle
+                // (h_k, r_o) against that one: a pair of hulls that overlap has |h_k - m| <= r_o + sqrt(2) rho, hence
+                // |h_k - m0| <= r_o + R -- nothing the exact test would report is dropped (the slack factors cover the
+                // single-precision square roots and conversions; a box that is not finite keeps every obstacle).  Candidates of a
+                // wave are neighbours in the sampling grid, R is a few metres, and for most steps no obstacle survives: the hull
+                // (~70 FP64 operations per candidate and step) is only built where something is near.
                 unsigned long long cand;
                 {
-                    const double c0x = uniform_f64(cxr), c0y = uniform_f64(cyr);
-                    const double dx = cxr - c0x, dy = cyr - c0y;
-                    const double q = fma(dx, dx, dy * dy);
-                    const bool bad = !(q + re < 1e300);   // a hull that is not finite keeps every obstacle on the per-lane path
-                    const float reach = fmaf(__builtin_amdgcn_sqrtf((float)q), 1.00001f, (float)re * 1.00001f);
+                    const double mxr = fma(0.5, C.bx_prev + bx, -K.ox), myr = fma(0.5, C.by_prev + by, -K.oy);
+                    const double tx = bx - C.bx_prev, ty = by - C.by_prev;
+                    const double qd = fma(tx, tx, ty * ty);
+                    const double m0x = uniform_f64(mxr), m0y = uniform_f64(myr);
+                    const double dx = mxr - m0x, dy = myr - m0y;
+                    const double qe = fma(dx, dx, dy * dy);
+                    const bool bad = !(qd + qe < 1e300);
+                    // |m - m0| + sqrt(2) (|c1 - c0| / 2 + hd), each term rounded up
+                    const float reach = fmaf(__builtin_amdgcn_sqrtf((float)qe), 1.00001f,
+                                             fmaf(__builtin_amdgcn_sqrtf((float)qd), 0.707115f, K.cull_r0));
                     const unsigned rb = wave_max_u32(bad ? 0u : __float_as_uint(reach));  // reach >= 0: the bit patterns order like the values
                     const double R = (double)__uint_as_float(rb);
                     const int kl = min(H->lane, nK - 1);
                     const double *qo = hot + (size_t)kl * FX_HOT_STRIDE;
-                    const double ex = fma(-0.5, qo[FX_HOT_HX2], -c0x), ey = fma(-0.5, qo[FX_HOT_HY2], -c0y);  // h - c0
+                    const double ex = fma(-0.5, qo[FX_HOT_HX2], -m0x), ey = fma(-0.5, qo[FX_HOT_HY2], -m0y);  // h - m0
                     const double rr = fma(-0.5, qo[FX_HOT_HR2], R) * 1.00001;                                 // r_o + R
                     cand = __builtin_amdgcn_ballot_w64(!(fma(ex, ex, ey * ey) > rr * rr)) & hm;
                     if (wave_any_bit(bad)) cand = hm;
                 }
-                // obstacles some lane of the wave is near (wave-uniform mask): the circle test per lane, for the survivors
-                unsigned long long nm = 0ULL;
-                auto mark = [&](double g, int k) { nm |= (unsigned long long)wave_any_bit(!(g > K.gap_margin)) << k; };
-                while (cand) {
-                    const int k = __builtin_ctzll(cand);
-                    cand &= cand - 1;
-                    fx_d2 hxy, hrk;
-                    ldh(k, hxy, hrk);
-                    mark(gap(hxy, hrk), k);
-                }
-                while (nm) {  // exact axis test for whatever is near (rare; the hull comes in through scalar loads)
-                    const int k = __builtin_ctzll(nm);
-                    nm &= nm - 1;
-                    A.collided |= obb_overlap(hull, rec_i + k * 12 + 6);
+                FX_CSTAT(0, 1); FX_CSTAT(1, cand != 0); FX_CSTAT(2, __popcll(cand));
+                if (cand) {
+                    const Obb hull = obb_hull(C.bx_prev, C.by_prev, C.ux_prev, C.uy_prev, bx, by, cu, su, K.half_len, K.half_wid);
+                    // per-lane broad phase on circles for the survivors: a box lies inside the circle around its centre with
+                    // radius h1 + h2, so hulls whose centres are farther apart than the sum of those radii (1e-6 relative slack on
+                    // both) are separated and the axis test would say so.  g = |h - c|^2 - (r_o + r_e)^2 in the expanded form of
+                    // the table; the exact test runs for the obstacles where some lane has g <= margin (the margin covers the
+                    // rounding of the expanded form).
+                    const double re = (hull.h1 + hull.h2) * 1.000001;
+                    const double cxr = hull.cx - K.ox, cyr = hull.cy - K.oy;
+                    const double wq = fma(cxr, cxr, fma(cyr, cyr, -re * re));
+                    unsigned long long nm = 0ULL;
+                    do {
+                        const int k = __builtin_ctzll(cand);
+                        cand &= cand - 1;
+                        const double *q = hot + (size_t)k * FX_HOT_STRIDE;
+                        const double g = fma(q[FX_HOT_HX2], cxr, fma(q[FX_HOT_HY2], cyr, fma(q[FX_HOT_HR2], re, q[FX_HOT_CK] + wq)));
+                        nm |= (unsigned long long)wave_any_bit(!(g > K.gap_margin)) << k;
+                    } while (cand);
+                    FX_CSTAT(3, nm != 0); FX_CSTAT(4, __popcll(nm));
+                    while (nm) {  // exact axis test for whatever is near (rare; the obstacle hull comes in through scalar loads)
+                        const int k = __builtin_ctzll(nm);
+                        nm &= nm - 1;
+                        A.collided |= obb_overlap(hull, rec_i + k * 12 + 6);
+                    }
                 }
             }
             C.bx_prev = bx; C.by_prev = by; C.ux_prev = cu; C.uy_prev = su;
