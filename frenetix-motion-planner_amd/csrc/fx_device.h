@@ -16,7 +16,8 @@
 #define FX_MODE_INT_DEFER_OBST (1u << 29)
 #define FX_HOT_STRIDE 10        // doubles per (step, obstacle) entry of the hot obstacle table (80 B)
 #define FX_HOT_PRE 4            // table elements per lane prefetched one step ahead (covers K <= 25 obstacles)
-#define FX_TP 12                // doubles per step of the time table in LDS: t .. t^5, then 2t, 3t^2, 4t^3, 5t^4, 6t, 12t^2, 20t^3
+#define FX_TP 14                // doubles per step of the time table in LDS: t .. t^5, then 2t, 3t^2, 4t^3, 5t^4, 6t, 12t^2, 20t^3, then the
+                                // step's obstacle masks (pmask, hmask bit patterns; grid kernel with the staged obstacle stage, else 0)
 #define FX_REF_FIELDS 8         // per knot: pos, theta, curv, curv_d, x, y, nx, ny  (64 B, AoS in LDS)
 #define FX_MAX_SAMPLES 128      // N+1 <= 128
 

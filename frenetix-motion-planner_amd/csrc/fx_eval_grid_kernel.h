@@ -89,7 +89,14 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     const FX_GLOBAL double *__restrict__ kn = as_global(P.ref);
     {
         const FX_GLOBAL double *__restrict__ tsrc = as_global(P.tpow);
-        for (int i = tid; i < S; i += BLK) fill_time_row(tpw + i * FX_TP, tsrc[i], tsrc[S + i], tsrc[2 * S + i], tsrc[3 * S + i], tsrc[4 * S + i]);
+        for (int i = tid; i < S; i += BLK) {
+            fill_time_row(tpw + i * FX_TP, tsrc[i], tsrc[S + i], tsrc[2 * S + i], tsrc[3 * S + i], tsrc[4 * S + i]);
+            if (OBST && (G == 1 || WSPLIT) && P.K > 0) {   // staged obstacle stage (K <= 64: one mask word per step)
+                unsigned long long *m = reinterpret_cast<unsigned long long *>(tpw + i * FX_TP + 12);
+                m[0] = as_global(P.obs_pmask)[i];
+                m[1] = as_global(P.obs_hmask)[i];
+            }
+        }
         for (int i = tid; i < M; i += BLK) rpos[i] = kn[(int64_t)i * FX_REF_FIELDS];
         if (tid < P.n_cost) { sh_cost_id[tid] = Pg.cost_id[tid]; sh_cost_w[tid] = Pg.cost_w[tid]; }
         if (WPE >= 3 && OBST && tid < FX_ATAN_K) sh_atan_k[tid] = fxm::fx_ktab[FX_ATAN_K0 + tid];

@@ -257,6 +257,7 @@ struct LatU {
 __device__ __forceinline__ void fill_time_row(double *row, double t1, double t2, double t3, double t4, double t5) {
     row[0] = t1; row[1] = t2; row[2] = t3; row[3] = t4; row[4] = t5;
     row[5] = 2. * t1; row[6] = 3. * t2; row[7] = 4. * t3; row[8] = 5. * t4; row[9] = 6 * t1; row[10] = 12 * t2; row[11] = 20 * t3;
+    row[12] = 0.0; row[13] = 0.0;   // obstacle masks of the step (filled by the kernel that stages them)
 }
 
 // lateral quintic: position, velocity and acceleration by fused sums left to right
@@ -536,8 +537,10 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
         // ---- obstacle stage on the staged table (wave-uniform step index, every branch wave-uniform) ----
         const int iu = __builtin_amdgcn_readfirstlane(i);
         const int nK = K.K;
-        unsigned long long pm = obs_pmask[iu], hm_now = obs_hmask[iu];
-        const unsigned long long hm_next = iu + 1 < S ? obs_hmask[iu + 1] : 0ULL;
+        // the step's masks ride in the time table's row (LDS, filled in the kernel's first phase): no global load per step
+        const unsigned long long *mrow = reinterpret_cast<const unsigned long long *>(tp + iu * FX_TP + 12);
+        unsigned long long pm = mrow[0], hm_now = mrow[1];
+        const unsigned long long hm_next = iu + 1 < S ? mrow[FX_TP + 1] : 0ULL;
         pm = uniform_u64(pm); hm_now = uniform_u64(hm_now);
         if (!emit) pm = 0ULL;
         const unsigned long long full = nK >= 64 ? ~0ULL : ((1ULL << nK) - 1ULL);
