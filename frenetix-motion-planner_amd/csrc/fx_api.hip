@@ -124,6 +124,7 @@ struct FxContext {
     double *d_obs_part = nullptr;
     unsigned long long *d_obs_colm = nullptr;
     unsigned int *d_obs_ticket = nullptr;
+    int32_t *d_obs_list = nullptr;     // [total_ld] the walk's list of costed candidates per agent (obstacle stage as its own kernel)
     size_t obs_part_cap = 0, obs_colm_cap = 0;
     uint32_t *d_flags = nullptr;
     double *d_costmap = nullptr;
@@ -532,6 +533,7 @@ int32_t fx_destroy(FxContext *c) {
     if (c->d_obs_part) (void)hipFree(c->d_obs_part);
     if (c->d_obs_colm) (void)hipFree(c->d_obs_colm);
     if (c->d_obs_ticket) (void)hipFree(c->d_obs_ticket);
+    if (c->d_obs_list) (void)hipFree(c->d_obs_list);
     if (c->d_bound) (void)hipFree(c->d_bound);
     if (c->h_bound) (void)hipHostFree(c->h_bound);
     if (c->comm) (void)fx_comm_destroy(c);
@@ -995,12 +997,17 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             if ((rc = dev_alloc(c, &c->d_obs_ticket, n_tick))) return rc;
             HIP_TRY(hipMemsetAsync(c->d_obs_ticket, 0, sizeof(unsigned int) * n_tick, c->stream));   // (in order with the step's kernels)
         }
+        if (!c->d_obs_list) {
+            int rc;
+            if ((rc = dev_alloc(c, &c->d_obs_list, (size_t)c->total_ld))) return rc;
+        }
         for (int a = 0; a < n_agents; a++) {
             DevProblem &d = c->h_probs[a];
             if (!(d.mode & FX_MODE_INT_DEFER_OBST)) continue;
             d.obs_part = c->d_obs_part + reinterpret_cast<size_t>(d.obs_part);
             d.obs_colm = c->d_obs_colm + reinterpret_cast<size_t>(d.obs_colm);
             d.obs_ticket = c->d_obs_ticket + reinterpret_cast<size_t>(d.obs_ticket);
+            d.obs_list = c->d_obs_list + (d.cost - c->d_cost);   // the agent's slab of the per-candidate arrays
         }
     }
     c->n_agents = n_agents;

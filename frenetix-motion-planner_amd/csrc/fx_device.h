@@ -78,6 +78,7 @@ struct DevProblem {
     double *obs_part;
     unsigned long long *obs_colm;
     unsigned int *obs_ticket;
+    int32_t *obs_list;         // [ld] local indices of the costed candidates, appended by the walk (counters[FX_DCNT_LIVE] entries)
     uint32_t *flags;           // [ld]
     double *costmap;           // [n_cost][ld]      (FX_MODE_WRITE_COSTMAP)
     double *planes;            // [14][S][ld]       (FX_MODE_WRITE_BUNDLE)
@@ -130,6 +131,7 @@ struct ProblemRegs {
     int32_t *bound_step;
     double *cost;
     double *cost_tail;
+    int32_t *obs_list;
     uint32_t *flags;
     double *costmap;
     double *planes;
@@ -156,7 +158,7 @@ struct ProblemRegs {
         r.hot_origin[0] = g.hot_origin[0]; r.hot_origin[1] = g.hot_origin[1]; r.hot_gap_margin = g.hot_gap_margin;
         r.n_bound = g.n_bound; r.bound_piece = g.bound_piece; r.bound_bin = g.bound_bin; r.bound_item = g.bound_item;
         r.bound_d_reach = g.bound_d_reach; r.bound_step = g.bound_step;
-        r.cost = g.cost; r.cost_tail = g.cost_tail; r.flags = g.flags; r.costmap = g.costmap; r.planes = g.planes; r.coeffs = g.coeffs;
+        r.cost = g.cost; r.cost_tail = g.cost_tail; r.obs_list = g.obs_list; r.flags = g.flags; r.costmap = g.costmap; r.planes = g.planes; r.coeffs = g.coeffs;
         r.traj_len = g.traj_len; r.part_cost = g.part_cost; r.part_idx = g.part_idx; r.counters = g.counters;
         r.n_blocks = g.n_blocks;
         return r;
@@ -200,6 +202,9 @@ enum {
 // The device-side counters[] slot FX_CNT_BEST_IDX is free (the winner only exists in the published block): the
 // evaluation kernel's workgroups take completion tickets from it when the selection is fused into the kernel.
 #define FX_DCNT_TICKET FX_CNT_BEST_IDX
+// ... and FX_CNT_BEST_COST counts the entries of the obstacle kernel's candidate list (deferred obstacle stage): the walk's waves
+// append their costed candidates, the obstacle kernel reads the count, the selection's publishing workgroup zeroes it
+#define FX_DCNT_LIVE FX_CNT_BEST_COST
 // Fused selection (no agent asks for the collision stage): the LAST workgroup of an agent to finish reduces the
 // per-workgroup partials and publishes the step's result block, so the step is one launch.  host_result == nullptr:
 // a separate fx_select_kernel follows.

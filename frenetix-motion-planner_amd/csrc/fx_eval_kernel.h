@@ -333,6 +333,22 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     flags |= reasons << FX_REASON_SHIFT;
 
     FX_STAMP(6);
+    // Deferred obstacle stage: the costed candidates of this wave go on the agent's list -- the obstacle kernel visits the list,
+    // not the grid (a third of a production step's candidates is infeasible and has neither a prediction cost nor a collision
+    // check, reactive_planner.py:480-533 / cost_function.py:78-91).  One returning atomic per wave, requested here and consumed
+    // behind the cost sum; the order of the list varies from run to run, nothing that is computed from it does.
+    unsigned long long live_mask = 0ULL;
+    unsigned long long list_base = 0ULL;
+    if (!OBST && (P.mode & FX_MODE_INT_DEFER_OBST)) {
+        live_mask = __ballot(active && leader && costed);
+        if (live_mask) {
+            unsigned long long b = 0ULL;
+            if ((tid & 63) == __ffsll((long long)live_mask) - 1)
+                b = __hip_atomic_fetch_add(as_global(P.counters) + FX_DCNT_LIVE, (unsigned long long)__popcll(live_mask), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            list_base = b;   // (read back from the issuing lane below)
+        }
+    }
     // ---- weighted cost sum in name-sorted order (cost_function.py:78-91) ----
     // Deferred obstacle stage (FX_MODE_INT_DEFER_OBST, only in kernels built without the stage): the prediction term is not
     // known yet -- cost[] receives the running sum in front of it, cost_tail[] the weighted terms behind it (by the ids'
@@ -376,12 +392,23 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
             case FX_COST_DISTANCE_TO_OBSTACLES: c = EXTRA ? dto : 0.0; break;
             default: break;
             }
-            if (defer && id == FX_COST_PREDICTION) { pre = sum; have_pre = true; continue; }
+            if (defer && id == FX_COST_PREDICTION) {
+                pre = sum; have_pre = true;
+                // (the obstacle kernel fills the cost-map entry of the candidates it visits -- the costed ones)
+                if ((P.mode & FX_MODE_WRITE_COSTMAP) && active && leader && !costed) as_global(P.costmap)[(int64_t)n * ld + g] = 0.0;
+                continue;
+            }
             if ((P.mode & FX_MODE_WRITE_COSTMAP) && active && leader) as_global(P.costmap)[(int64_t)n * ld + g] = costed ? c : 0.0;
             if (have_pre) tail += w * c;
             sum += w * c;
         }
         total = 0.0 + sum;
+    }
+    if (live_mask) {
+        const int src = __ffsll((long long)live_mask) - 1;
+        const unsigned lo = (unsigned)__shfl((int)(unsigned)(list_base & 0xffffffffULL), src);   // (lists stay below 2^31 entries)
+        if (active && leader && costed)
+            as_global(P.obs_list)[lo + __popcll(live_mask & ((1ULL << (tid & 63)) - 1ULL))] = (int32_t)g;
     }
     if (active && leader) {
         if (defer) as_global(P.cost_tail)[g] = tail;

@@ -230,6 +230,8 @@ __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__rest
         out[FX_CNT_BEST_COST] = none ? 0ULL : (unsigned long long)__double_as_longlong(bc);
         out[FX_CNT_COLLISIONS] = collisions;
         __hip_atomic_store(&P.counters[FX_DCNT_TICKET], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the obstacle kernel's candidate list (deferred obstacle stage) starts the next step empty
+        if (P.mode & FX_MODE_INT_DEFER_OBST) as_global(P.counters)[FX_DCNT_LIVE] = 0ULL;
     }
     // the winner package (fx_set_package): the evaluation kernel is complete, so the publishing workgroup gathers the chosen
     // trajectory right here -- no further launch; its sequence word goes out behind the result block's

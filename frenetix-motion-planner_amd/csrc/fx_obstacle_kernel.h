@@ -80,9 +80,19 @@ __global__ __launch_bounds__(64, WPS) void fx_obstacle_kernel(const DevProblem *
     if (c0 >= C) return;
     const int lane = threadIdx.x;
     FX_OSTAMP(0);
-    const int64_t g_raw = c0 + lane;
-    const bool act = g_raw < C;
-    const int64_t g = act ? g_raw : C - 1;
+    // The tile's candidates: 64 entries of the list of costed candidates the walk has left (fx_eval_kernel.h, finish_candidate;
+    // the walk is complete, plain loads).  Tiles past the end of the list only leave a neutral arg-min partial.
+    const int64_t n_live = (int64_t)as_global(P.counters)[FX_DCNT_LIVE];
+    if (c0 >= n_live) {
+        if (chunk == 0 && lane == 0) {
+            as_global(P.part_cost)[tile] = INFINITY;
+            as_global(P.part_idx)[tile] = 0x7fffffffffffffffLL;
+        }
+        return;
+    }
+    const bool act = c0 + lane < n_live;
+    const int64_t g = as_global(P.obs_list)[act ? c0 + lane : n_live - 1];
+    const int64_t g_raw = g;   // (scratch rows are indexed by the candidate: inactive lanes repeat the list's last entry and never store)
     const uint32_t f = as_global(P.flags)[g];
 
     const int i_a = 1 + chunk * CH, i_b = min(S, i_a + CH);
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(64, WPS) void fx_obstacle_kernel(const DevProblem *
     if (work) {
         // hand-off: agent-scope stores, acknowledged (vmcnt 0) before the ticket is taken -- whoever draws the last ticket
         // sees every chunk's partial
-        __hip_atomic_store(part + (int64_t)chunk * ld + g_raw, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // g_raw < ld
+        if (act) __hip_atomic_store(part + (int64_t)chunk * ld + g_raw, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long cm = __builtin_amdgcn_ballot_w64(collided);
         if (lane == 0) __hip_atomic_store(colm + (int64_t)chunk * n_tiles + tile, cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -325,17 +335,16 @@ __global__ __launch_bounds__(64, WPS) void fx_obstacle_kernel(const DevProblem *
         fl |= FX_FLAG_COLLISION;
         if (act) as_global(P.flags)[g] = fl;
     }
-    // (cost, index) arg-min of the tile as finish_candidate forms it: candidate indices grow with the lane, so the minimum is the
-    // lowest lane that holds the minimum cost
+    // (cost, index) arg-min of the tile: the lanes hold the list's candidates in no particular order, so among the lanes with the
+    // minimum cost the smallest index is reduced as well
     const bool eligible = act && selectable && !(fl & (FX_FLAG_COLLISION | FX_FLAG_BOUNDARY)) && total == total;
     const double bc = eligible ? total : INFINITY;
-    long long bi = eligible ? (long long)(g_raw + P.g_base) : 0x7fffffffffffffffLL;
     double m = bc;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off));
-    const unsigned long long hit = __ballot(eligible && bc == m);
-    const int src = hit ? __ffsll((long long)hit) - 1 : 0;
-    bi = hit ? __shfl(bi, src) : 0x7fffffffffffffffLL;
+    long long bi = (eligible && bc == m) ? (long long)(g_raw + P.g_base) : 0x7fffffffffffffffLL;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const long long o = __shfl_xor(bi, off); bi = o < bi ? o : bi; }
     if (lane == 0) {
         as_global(P.part_cost)[tile] = m;
         as_global(P.part_idx)[tile] = (int64_t)bi;

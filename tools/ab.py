@@ -36,6 +36,8 @@ def child(which, agents):
             eng.set_timing("kernel")
             if os.environ.get("FX_AB_TUNING"):   # "G,wpe,variant,block,mapping" (0 = automatic)
                 eng.set_tuning(*[int(x) for x in os.environ["FX_AB_TUNING"].split(",")])
+            if os.environ.get("FX_AB_OBST"):     # "stage,steps_per_item" (fx_set_obstacle_stage)
+                eng.set_obstacle_stage(*[int(x) for x in os.environ["FX_AB_OBST"].split(",")])
             eng.upload(inp)
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < 0.5:   # warm clocks
