@@ -453,10 +453,19 @@ def main():
     winner = {"index": int(res.get("global_best_index", res["best_index"])),
               "cost": float(res.get("global_best_cost", res["best_cost"])), "n_feasible_local": int(res["n_feasible"]),
               "n_collisions": int(res["n_collisions"])}
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        allr = torch.empty(world, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(allr, t)
+        rank_ms = [float(x) / args.steps * 1e3 for x in allr.cpu().tolist()]
+        elapsed = float(allr.max().item())   # the contract's time: MAX over the ranks
+    comm = None
+    try:
+        if world > 1 and ev.uses_library_exchange():
+            comm = eng.comm_info()
+    except Exception:
+        comm = None
 
     # the same K steps fed from host buffers: every step a new ego state and new predictions (single-rank steps; with
     # N > 1 every rank does the same update, the exchange is the one above)
@@ -540,6 +549,11 @@ def main():
                        "reference_knots": int(inp.coordinate_system.ref_pos.shape[0]), "obstacles": n_obst,
                        "parallelism": f"candidate-shard x{world}, all-gather top-{args.topk}" if world > 1 else "single GPU",
                        "exchange": exchange_note},
+            # how stable the timed region was: K steps are a few milliseconds of wall time
+            "ms_per_step_min": float(np.min(lat) * 1e3), "ms_per_step_stdev": float(np.std(lat) * 1e3),
+            "steps_timed_wall_ms": elapsed * 1e3,
+            # the step a planner really takes (new ego state + predictions from host buffers every step), next to `value`
+            "plan_step_value": C_global * args.steps / elapsed_u, "plan_step_ms": elapsed_u / args.steps * 1e3,
             "resident_step_p50_ms": float(np.percentile(lat, 50) * 1e3), "resident_step_p95_ms": float(np.percentile(lat, 95) * 1e3),
             "plan_step_p50_ms": float(np.percentile(lat_u, 50) * 1e3), "plan_step_p95_ms": float(np.percentile(lat_u, 95) * 1e3),
             "plan_step_note": "plan_step_* = the step fed a new ego state and new predictions from host buffers every time "
@@ -549,12 +563,23 @@ def main():
             "device_ms_per_step": float(np.mean(kern)), "eval_kernel_ms": eval_ms, "walk_kernel_ms": walk_ms,
             "obstacle_kernel_ms": obst_ms, "launch": info,
             "pipelined_value": C_global * args.steps / pipelined,
+            # a scaling record checks itself: the ranks RCCL reports for the library's communicator (ncclCommCount; the torch
+            # group's size when the exchange ran through torch.distributed) and every rank's own time for the K steps
+            "rccl_ranks": (comm["rccl_ranks"] if comm and comm["rccl_ranks"] > 0 else world) if world > 1 else 1,
+            "ms_per_step_rank_min": min(rank_ms), "ms_per_step_rank_max": max(rank_ms), "ms_per_step_ranks": rank_ms,
             "winner": winner,
             "roofline": roofline,
             "kernels": kernels,
         }
         if n_obst:
             out["roofline_hbm"] = hbm
+        # the whole step against the HBM roofline: algorithmic bytes of the step over the STEP's wall time (launch gaps, obstacle
+        # kernel and selection included) -- a figure that cannot move by re-partitioning the work between kernels
+        step_gbs = alg_bytes / (ms_per_step * 1e-3) / 1e9
+        out["roofline_step"] = {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
+                                "algorithmic_bytes_per_step": alg_bytes, "ms_per_step": ms_per_step,
+                                "note": "algorithmic bytes of one step / ms_per_step (resident inputs, whole step incl. obstacle kernel, "
+                                        "selection and launch gaps)"}
         if world == 1 and not args.no_north_star:
             out["north_star"] = north_star(args, local_rank)
         if not args.no_cpu_baseline and world == 1:

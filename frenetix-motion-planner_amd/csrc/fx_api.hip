@@ -144,6 +144,10 @@ struct FxContext {
     // survivor exchange inside the library (fx_comm_init): an RCCL communicator of this context's own, the gathered winners
     void *comm = nullptr;                  // ncclComm_t
     int comm_rank = 0, comm_world = 0;
+    int comm_agents = 0;                   // agent rows EVERY rank contributes to an exchange (fx_comm_set_agents; default max_agents)
+    int comm_rows_clean = 0;               // send-buffer rows [comm_rows_clean, comm_agents) hold "no survivor"
+    int comm_k_clean = 0;                  // ... for this k (0: the winner buffer)
+    bool comm_init_failed = false;         // an fx_comm_init on this context timed out: never retried
     double *d_gather = nullptr;            // [world][max_agents][2] (grown to [world][max_agents][2 k] by the top-k exchange)
     size_t gather_cap = 0;                 // doubles
     double *d_xsend = nullptr;             // [max_agents][2][64]: a rank's survivors, [cost n k | index n k], the all-gather's send buffer
@@ -643,6 +647,7 @@ int32_t fx_set_stream(FxContext *c, void *hip_stream) {
 int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) {
     if (!c || !probs) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_upload: NULL argument");
     if (n_agents < 1 || n_agents > c->max_agents) return set_err(FX_ERR_CAPACITY, "n_agents=%d exceeds capacity %d", n_agents, c->max_agents);
+    if (c->timed_out) return set_err(FX_ERR_TIMEOUT, "an earlier wait on this context timed out (its stream may never drain): destroy it");
     HIP_TRY(hipSetDevice(c->device));
     if (c->in_flight) {  // the pinned staging block is about to be rewritten: earlier copies must have landed
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1243,6 +1248,7 @@ struct Rccl {
     int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
@@ -1258,6 +1264,7 @@ Rccl *rccl() {
             r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
             r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
             r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+            r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(h, "ncclCommCount"));   // optional
             r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
         }
     });
@@ -1288,6 +1295,9 @@ int32_t fx_comm_check(const FxContext *c, int32_t world) {
     if ((size_t)world * c->max_agents * 2 > FX_PUB_MAX) return set_err(FX_ERR_CAPACITY, "%d ranks x %d agents exceed the publication block", world, c->max_agents);
     if (!rccl()->ok) return set_err(FX_ERR_NOT_READY, "librccl.so.1 not available");
     if (c->comm) return set_err(FX_ERR_INVALID_ARGUMENT, "this context already has a communicator");
+    if (c->comm_init_failed)
+        return set_err(FX_ERR_TIMEOUT, "an earlier fx_comm_init on this context timed out (its helper thread may still be inside "
+                       "ncclCommInitRank): no second attempt -- use another exchange and leave the process through its exit path");
     return FX_OK;
 }
 
@@ -1299,8 +1309,15 @@ int32_t fx_comm_init(FxContext *c, const uint8_t *id128, int32_t rank, int32_t w
     HIP_TRY(hipSetDevice(c->device));
     // everything that can fail locally comes BEFORE the collective call
     const size_t need = (size_t)world * c->max_agents * 2;
-    if ((rc = dev_alloc(c, &c->d_gather, need))) return rc;
-    c->gather_cap = need;
+    if (c->d_gather && c->gather_cap < need) {   // (left by an earlier communicator of this context)
+        (void)hipFree(c->d_gather);
+        c->dev_bytes -= (int64_t)(sizeof(double) * c->gather_cap);
+        c->d_gather = nullptr; c->gather_cap = 0;
+    }
+    if (!c->d_gather) {
+        if ((rc = dev_alloc(c, &c->d_gather, need))) return rc;
+        c->gather_cap = need;
+    }
     if (!c->d_winner_own && (rc = dev_alloc(c, &c->d_winner_own, (size_t)c->max_agents * 2))) return rc;
     if (!c->d_xsend && (rc = dev_alloc(c, &c->d_xsend, (size_t)c->max_agents * 2 * 64))) return rc;
     // ncclCommInitRank is a blocking collective without a time bound of its own: a peer that never arrives (or a fabric that
@@ -1324,14 +1341,44 @@ int32_t fx_comm_init(FxContext *c, const uint8_t *id128, int32_t rank, int32_t w
     const auto t0 = std::chrono::steady_clock::now();
     const auto limit = std::chrono::milliseconds(c->timeout_ms > 0 ? c->timeout_ms : 20000);
     while (!st->done.load(std::memory_order_acquire)) {
-        if (std::chrono::steady_clock::now() - t0 >= limit)
+        if (std::chrono::steady_clock::now() - t0 >= limit) {
+            // the helper thread stays inside ncclCommInitRank (it may even finish later: that communicator is never used and
+            // never destroyed).  No second attempt on this context; the process should leave through distributed.exit_on_timeout
+            // / os._exit rather than a normal interpreter teardown that would wait for RCCL's threads.
+            c->comm_init_failed = true;
             return set_err(FX_ERR_TIMEOUT, "fx_comm_init: ncclCommInitRank did not return within %d ms (rank %d of %d)",
                            (int)limit.count(), rank, world);
+        }
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
     if (st->rc != 0) return set_err(FX_ERR_HIP, "ncclCommInitRank failed: %s (rank %d of %d)", rccl()->GetErrorString(st->rc), rank, world);
     c->comm = st->comm;
     c->comm_rank = rank; c->comm_world = world;
+    c->comm_agents = c->max_agents;
+    c->comm_rows_clean = c->comm_agents; c->comm_k_clean = -1;   // nothing known about the send buffers yet
+    return FX_OK;
+}
+
+// The number of agent rows every rank contributes to an exchange.  The element count of the all-gather must be the same on
+// every rank whatever a rank's own step does, so it is a property of the communicator, fixed here (default: the context's
+// max_agents) -- not of the rank's current upload.  The ranks agree on it before they call this (distributed.py).
+int32_t fx_comm_set_agents(FxContext *c, int32_t n_agents) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_comm_set_agents: NULL argument");
+    if (!c->comm) return set_err(FX_ERR_NOT_READY, "fx_comm_set_agents before fx_comm_init");
+    if (n_agents < 1 || n_agents > c->max_agents) return set_err(FX_ERR_CAPACITY, "fx_comm_set_agents: %d outside [1, %d]", n_agents, c->max_agents);
+    if ((size_t)c->comm_world * n_agents * 2 > FX_PUB_MAX) return set_err(FX_ERR_CAPACITY, "%d ranks x %d agents exceed the publication block", c->comm_world, n_agents);
+    c->comm_agents = n_agents;
+    c->comm_k_clean = -1;
+    return FX_OK;
+}
+
+// out[0] rank, [1] world, [2] ranks RCCL itself reports for the communicator (ncclCommCount; -1 if unavailable), [3] agent rows per rank
+int32_t fx_comm_info(const FxContext *c, int32_t *out4) {
+    if (!c || !out4) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_comm_info: NULL argument");
+    if (!c->comm) return set_err(FX_ERR_NOT_READY, "fx_comm_info before fx_comm_init");
+    int n = -1;
+    if (rccl()->CommCount && rccl()->CommCount(c->comm, &n) != 0) n = -1;
+    out4[0] = c->comm_rank; out4[1] = c->comm_world; out4[2] = n; out4[3] = c->comm_agents;
     return FX_OK;
 }
 
@@ -1346,91 +1393,134 @@ int32_t fx_comm_destroy(FxContext *c) {
     return FX_OK;
 }
 
+// "No survivor" -- (inf, -1) -- in rows [first, comm_agents) of the exchange's send buffer (k = 0: the winner buffer
+// [agents][2]; k > 0: [cost agents x k | index agents x k]).  Enqueued on the context's stream; returns a HIP status.
+static hipError_t fill_no_survivor(FxContext *c, int first, int k) {
+    const int A = c->comm_agents;
+    if (first >= A) return hipSuccess;
+    double *h = c->h_topk_cost;        // pinned [max_agents][64]
+    long long *hi = c->h_topk_idx;
+    if (k == 0) {
+        for (int a = first; a < A; a++) { h[2 * a] = INFINITY; const long long m1 = -1; memcpy(&h[2 * a + 1], &m1, sizeof(m1)); }
+        return hipMemcpyAsync(c->d_winner_own + 2 * first, h + 2 * first, sizeof(double) * 2 * (size_t)(A - first), hipMemcpyHostToDevice, c->stream);
+    }
+    const size_t e0 = (size_t)first * k, e1 = (size_t)A * k;
+    for (size_t e = e0; e < e1; e++) { h[e] = INFINITY; hi[e] = -1; }
+    hipError_t e = hipMemcpyAsync(c->d_xsend + e0, h + e0, sizeof(double) * (e1 - e0), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(reinterpret_cast<long long *>(c->d_xsend + e1) + e0, hi + e0, sizeof(long long) * (e1 - e0), hipMemcpyHostToDevice, c->stream);
+}
+
 // One plan step of every rank: evaluation (+ selection), ONE all-gather of the ranks' winners (cost f64, global index i64 per
-// agent; 16 B per rank and agent) on the context's stream, publication to pinned host memory -- enqueued back to back, then the
+// agent row; 16 B per rank and row) on the context's stream, publication to pinned host memory -- enqueued back to back, then the
 // host takes the local result block while the collective runs and waits (bounded in time) for the gathered winners.
-// A rank whose own evaluation fails STILL enters the all-gather -- with (inf, -1) for every agent -- and returns its error
-// afterwards: its peers are not left waiting for it.
+// The element count of the collective is the communicator's (fx_comm_set_agents), the same on every rank whatever this rank's
+// step does: a rank whose evaluation fails, or whose upload does not fit the agreed rows, STILL enters the all-gather -- with
+// (inf, -1) in its rows -- and returns its error afterwards; nothing that can fail locally returns ahead of the collective.
 int32_t fx_step_exchange(FxContext *c, FxResult *res, double *cost, int64_t *index) {
     if (!c || !res || !cost || !index) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_step_exchange: NULL argument");
     if (!c->comm) return set_err(FX_ERR_NOT_READY, "fx_step_exchange before fx_comm_init");
     if (c->timed_out) return set_err(FX_ERR_TIMEOUT, "an earlier wait on this context timed out: destroy it");
-    double *saved = c->dev_winner;
-    if (!saved) c->dev_winner = c->d_winner_own;   // the selection leaves (cost, index) of every agent here
-    int rc_eval = fx_evaluate(c);
-    const double *send = c->dev_winner;
-    c->dev_winner = saved;
-    const int n_agents = c->n_agents > 0 ? c->n_agents : 1;
-    char err_eval[sizeof(g_err)];
-    if (rc_eval) {
-        memcpy(err_eval, g_err, sizeof(err_eval));
-        // nothing was selected on this rank: send "no survivor" for every agent
-        double *h = c->h_topk_cost;   // pinned
-        for (int a = 0; a < n_agents; a++) { h[2 * a] = INFINITY; const long long m1 = -1; memcpy(&h[2 * a + 1], &m1, sizeof(m1)); }
-        HIP_TRY(hipMemcpyAsync(c->d_winner_own, h, sizeof(double) * 2 * n_agents, hipMemcpyHostToDevice, c->stream));
-        send = c->d_winner_own;
+    const int A = c->comm_agents;
+    int rc_local = FX_OK;
+    char err_local[sizeof(g_err)];
+    auto keep = [&](int rc) { if (rc && !rc_local) { rc_local = rc; memcpy(err_local, g_err, sizeof(err_local)); } };
+    auto keep_hip = [&](hipError_t e, const char *what) { if (e != hipSuccess) keep(set_err(FX_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e))); };
+    keep_hip(hipSetDevice(c->device), "hipSetDevice");
+    if (c->n_agents > A) keep(set_err(FX_ERR_CAPACITY, "%d uploaded agents but the communicator exchanges %d rows per rank (fx_comm_set_agents)", c->n_agents, A));
+    bool evaluated = false;
+    if (!rc_local) {
+        double *saved = c->dev_winner;
+        c->dev_winner = c->d_winner_own;   // the selection leaves (cost, index) of every agent here
+        const int rc = fx_evaluate(c);
+        c->dev_winner = saved;
+        keep(rc);
+        evaluated = rc == FX_OK;
+        if (evaluated && saved)   // a caller-owned winner buffer (fx_set_winner_buffer) gets its copy
+            keep_hip(hipMemcpyAsync(saved, c->d_winner_own, sizeof(double) * 2 * (size_t)c->n_agents, hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync");
     }
-    const int n = n_agents * 2, total = n * c->comm_world;
-    RCCL_TRY(rccl()->AllGather(send, c->d_gather, (size_t)n, /*ncclDouble*/ 8, c->comm, c->stream));
+    const int n_mine = evaluated ? c->n_agents : 0;   // rows this rank fills; the others say "no survivor"
+    if (c->comm_k_clean != 0 || c->comm_rows_clean > n_mine) {
+        keep_hip(fill_no_survivor(c, n_mine, 0), "hipMemcpyAsync");
+        c->comm_k_clean = 0;
+    }
+    c->comm_rows_clean = n_mine;
+    const int n = A * 2, total = n * c->comm_world;
+    RCCL_TRY(rccl()->AllGather(c->d_winner_own, c->d_gather, (size_t)n, /*ncclDouble*/ 8, c->comm, c->stream));
     int rc;
     if ((rc = fx_publish(c, c->d_gather, total))) return rc;
-    if (!rc_eval && (rc = fx_finish_batch(c, res))) return rc;
+    if (evaluated && (rc = fx_finish_batch(c, res))) keep(rc);
     if ((rc = wait_seq(c, reinterpret_cast<const unsigned long long *>(c->h_pub + FX_PUB_MAX), c->pub_seq))) return rc;
     for (int r = 0; r < c->comm_world; r++)
-        for (int a = 0; a < n_agents; a++) {
+        for (int a = 0; a < A; a++) {
             const double *q = c->h_pub + (size_t)r * n + 2 * a;
-            cost[(size_t)r * n_agents + a] = q[0];
-            memcpy(&index[(size_t)r * n_agents + a], &q[1], sizeof(int64_t));
+            cost[(size_t)r * A + a] = q[0];
+            memcpy(&index[(size_t)r * A + a], &q[1], sizeof(int64_t));
         }
-    if (rc_eval) { memcpy(g_err, err_eval, sizeof(err_eval)); return rc_eval; }
+    if (rc_local) { memcpy(g_err, err_local, sizeof(err_local)); return rc_local; }
     return FX_OK;
 }
 
 // The same for the k best survivors per agent (BASELINE config 5: per-agent top-32 over 8 GPUs): evaluation, selection, the two
-// top-k launches writing [cost n k | index n k] into the send buffer, ONE all-gather of 16 k bytes per rank and agent,
-// publication, results -- no host code between the launches.  cost / index: [world][n_agents][k], index -1 where a rank has
-// fewer than k survivors.
+// top-k launches writing [cost A x k | index A x k] into the send buffer, ONE all-gather of 16 k bytes per rank and agent row,
+// publication, results -- no host code between the launches.  cost / index: [world][A][k] (A = the communicator's agent rows),
+// index -1 where a rank has fewer than k survivors.  k must be the same on every rank (the ranks agree on it beforehand).
 int32_t fx_step_exchange_topk(FxContext *c, int32_t k, FxResult *res, double *cost, int64_t *index) {
     if (!c || !res || !cost || !index) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_step_exchange_topk: NULL argument");
     if (k < 1 || k > 64) return set_err(FX_ERR_INVALID_ARGUMENT, "k=%d outside [1,64]", k);
     if (!c->comm) return set_err(FX_ERR_NOT_READY, "fx_step_exchange_topk before fx_comm_init");
     if (c->timed_out) return set_err(FX_ERR_TIMEOUT, "an earlier wait on this context timed out: destroy it");
-    const int n_agents = c->n_agents > 0 ? c->n_agents : 1;
-    const size_t n = (size_t)n_agents * 2 * k, total = n * c->comm_world;
-    if (total > FX_PUB_MAX) return set_err(FX_ERR_CAPACITY, "%d ranks x %d agents x %d survivors exceed the publication block", c->comm_world, n_agents, k);
-    HIP_TRY(hipSetDevice(c->device));
-    if (total > c->gather_cap) {   // (before anything is enqueued: a failure here leaves the peers un-entered as well)
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->d_gather) { (void)hipFree(c->d_gather); c->d_gather = nullptr; c->gather_cap = 0; }
-        int rc = dev_alloc(c, &c->d_gather, (size_t)FX_PUB_MAX);
-        if (rc) return rc;
-        c->gather_cap = FX_PUB_MAX;
+    const int A = c->comm_agents;
+    const size_t n = (size_t)A * 2 * k, total = n * c->comm_world;
+    // what depends only on (communicator, k) is the same on every rank: these refusals happen everywhere or nowhere
+    if (total > FX_PUB_MAX) return set_err(FX_ERR_CAPACITY, "%d ranks x %d agents x %d survivors exceed the publication block", c->comm_world, A, k);
+    int rc_local = FX_OK;
+    char err_local[sizeof(g_err)];
+    auto keep = [&](int rc) { if (rc && !rc_local) { rc_local = rc; memcpy(err_local, g_err, sizeof(err_local)); } };
+    auto keep_hip = [&](hipError_t e, const char *what) { if (e != hipSuccess) keep(set_err(FX_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e))); };
+    keep_hip(hipSetDevice(c->device), "hipSetDevice");
+    if (total > c->gather_cap) {   // (a function of (communicator, k) as well; a failed allocation leaves the old buffer in place)
+        double *bigger = nullptr;
+        if (hipStreamSynchronize(c->stream) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&bigger), sizeof(double) * (size_t)FX_PUB_MAX) == hipSuccess) {
+            if (c->d_gather) { (void)hipFree(c->d_gather); c->dev_bytes -= (int64_t)(sizeof(double) * c->gather_cap); }
+            c->d_gather = bigger; c->gather_cap = FX_PUB_MAX; c->dev_bytes += (int64_t)(sizeof(double) * (size_t)FX_PUB_MAX);
+        } else {
+            (void)hipGetLastError();
+            // without a receive buffer of the agreed size this rank cannot take part: the one failure that cannot be carried
+            // through the collective (its peers run into their time bound)
+            return set_err(FX_ERR_HIP, "fx_step_exchange_topk: no memory for the %zu-element receive buffer", (size_t)FX_PUB_MAX);
+        }
     }
-    int rc_eval = fx_evaluate(c);
-    char err_eval[sizeof(g_err)];
-    long long *send_idx = reinterpret_cast<long long *>(c->d_xsend + (size_t)n_agents * k);
-    if (!rc_eval) {
-        HIP_TRY(fx_launch_topk(c->d_probs, c->n_agents, max_candidates_of(c), k, c->d_topk_scr_cost, c->d_topk_scr_idx, c->d_xsend, send_idx, c->stream));
-    } else {
-        memcpy(err_eval, g_err, sizeof(err_eval));
-        double *h = c->h_topk_cost;   // pinned [max_agents][64]
-        long long *hi = c->h_topk_idx;
-        for (size_t e = 0; e < (size_t)n_agents * k; e++) { h[e] = INFINITY; hi[e] = -1; }
-        HIP_TRY(hipMemcpyAsync(c->d_xsend, h, sizeof(double) * n_agents * k, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(send_idx, hi, sizeof(long long) * n_agents * k, hipMemcpyHostToDevice, c->stream));
+    if (c->n_agents > A) keep(set_err(FX_ERR_CAPACITY, "%d uploaded agents but the communicator exchanges %d rows per rank (fx_comm_set_agents)", c->n_agents, A));
+    long long *send_idx = reinterpret_cast<long long *>(c->d_xsend + (size_t)A * k);
+    bool evaluated = false;
+    if (!rc_local) {
+        const int rc = fx_evaluate(c);
+        keep(rc);
+        if (rc == FX_OK) {
+            const hipError_t e = fx_launch_topk(c->d_probs, c->n_agents, max_candidates_of(c), k, c->d_topk_scr_cost, c->d_topk_scr_idx, c->d_xsend, send_idx, c->stream);
+            keep_hip(e, "fx_launch_topk");
+            evaluated = e == hipSuccess;
+        }
     }
+    const int n_mine = evaluated ? c->n_agents : 0;
+    if (c->comm_k_clean != k || c->comm_rows_clean > n_mine) {
+        keep_hip(fill_no_survivor(c, n_mine, k), "hipMemcpyAsync");
+        c->comm_k_clean = k;
+    }
+    c->comm_rows_clean = n_mine;
     RCCL_TRY(rccl()->AllGather(c->d_xsend, c->d_gather, n, /*ncclDouble*/ 8, c->comm, c->stream));
     int rc;
     if ((rc = fx_publish(c, c->d_gather, (int32_t)total))) return rc;
-    if (!rc_eval && (rc = fx_finish_batch(c, res))) return rc;
+    if (evaluated && (rc = fx_finish_batch(c, res))) keep(rc);
     if ((rc = wait_seq(c, reinterpret_cast<const unsigned long long *>(c->h_pub + FX_PUB_MAX), c->pub_seq))) return rc;
-    const size_t nk = (size_t)n_agents * k;
+    const size_t nk = (size_t)A * k;
     for (int r = 0; r < c->comm_world; r++) {
         const double *q = c->h_pub + (size_t)r * n;
         memcpy(cost + (size_t)r * nk, q, sizeof(double) * nk);
         memcpy(index + (size_t)r * nk, q + nk, sizeof(int64_t) * nk);
     }
-    if (rc_eval) { memcpy(g_err, err_eval, sizeof(err_eval)); return rc_eval; }
+    if (rc_local) { memcpy(g_err, err_local, sizeof(err_local)); return rc_local; }
     return FX_OK;
 }
 

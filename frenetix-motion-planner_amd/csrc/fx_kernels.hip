@@ -23,11 +23,26 @@
 // and in the order of the long cost sums (the device accumulates in step order, NumPy pairwise).
 #include <hip/hip_ext.h>
 
+#include <atomic>
+
 #include "fx_eval_kernel.h"
 #include "fx_eval_grid_kernel.h"
 #include "fx_obstacle_kernel.h"
 
 using fxk::wave_count;
+
+// the vector unit's row_bcast data-parallel controls (fx_walk.h wave_max_u32, wave_min_u64 below) exist on the GFX9 family only
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "libfxplan's kernels are written for gfx950 (row_bcast DPP controls, wave64): build with --offload-arch=gfx950"
+#endif
+
+// slot of the calling thread's current device in the per-device tables of the launchers
+#define FX_MAX_DEVICES 64
+static inline int fx_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d % FX_MAX_DEVICES;
+}
 
 #ifdef FX_CULL_STATS
 __device__ unsigned long long fx_cull_stats[16];
@@ -546,12 +561,15 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
     dim3 grid(max_blocks, n_agents), block(FX_BLOCK);
 #define FX_LAUNCH(Gv, B, O, E, W)                                                                                \
     do {                                                                                                        \
-        static size_t lds_set_ = 48 * 1024;   /* largest dynamic LDS size this specialisation has been enabled for */ \
-        if (lds_bytes > lds_set_) {           /* (the attribute call costs microseconds: once per size, not per launch) */ \
+        /* largest dynamic LDS size this specialisation has been enabled for, PER DEVICE (the attribute is per device; the call */ \
+        /* costs microseconds: once per size, not per launch); relaxed atomics: two threads at worst both set the attribute */  \
+        static std::atomic<size_t> lds_set_[FX_MAX_DEVICES];                                                    \
+        std::atomic<size_t> &hw_ = lds_set_[fx_device_slot()];                                                  \
+        if (lds_bytes > 48 * 1024 && lds_bytes > hw_.load(std::memory_order_relaxed)) {                         \
             hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fx_eval_kernel<Gv, B, O, E, W>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);    \
             if (e_ != hipSuccess) return e_;                                                                    \
-            lds_set_ = lds_bytes;                                                                               \
+            hw_.store(lds_bytes, std::memory_order_relaxed);                                                    \
         }                                                                                                       \
         hipExtLaunchKernelGGL((fx_eval_kernel<Gv, B, O, E, W>), grid, block, lds_bytes, stream, ev_start, ev_stop, 0, d_probs, fuse); \
         return hipGetLastError();                                                                               \
@@ -598,12 +616,13 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
     dim3 grid(max_blocks, n_agents), block(block_size);
 #define FX_LAUNCH(Gv, B, O, W, WS)                                                                                 \
     do {                                                                                                          \
-        static size_t lds_set_ = 48 * 1024;   /* largest dynamic LDS size this specialisation has been enabled for */   \
-        if (lds_bytes > lds_set_) {           /* (the attribute call costs microseconds: once per size, not per launch) */ \
+        static std::atomic<size_t> lds_set_[FX_MAX_DEVICES];   /* per device, see fx_launch_eval */                 \
+        std::atomic<size_t> &hw_ = lds_set_[fx_device_slot()];                                                    \
+        if (lds_bytes > 48 * 1024 && lds_bytes > hw_.load(std::memory_order_relaxed)) {                           \
             hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fx_eval_grid_kernel<Gv, B, O, W, WS>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);      \
             if (e_ != hipSuccess) return e_;                                                                      \
-            lds_set_ = lds_bytes;                                                                                 \
+            hw_.store(lds_bytes, std::memory_order_relaxed);                                                      \
         }                                                                                                         \
         hipExtLaunchKernelGGL((fx_eval_grid_kernel<Gv, B, O, W, WS>), grid, block, lds_bytes, stream, ev_start, ev_stop, 0, d_probs, fuse); \
         return hipGetLastError();                                                                                 \

@@ -222,7 +222,28 @@ class ShardedEvaluator:
         all_ok = all_agree(ok)
         if ok and not all_ok:
             self.engine.comm_destroy()
-        return all_ok
+        # (5) the element count of the library's all-gathers is the communicator's: one agent row per rank for the candidate
+        # split; setup_agents agrees on the agents per rank
+        return all_ok and self._agree_agent_rows(1)
+
+    def _agree_agent_rows(self, n_rows: int) -> bool:
+        """Fix the agent rows every rank contributes to the library's exchanges (fx_comm_set_agents) -- only if EVERY rank asks
+        for the same number: ranks that entered an all-gather with different counts would hang or corrupt memory.  Returns
+        False (library exchange off on every rank, communicator destroyed) otherwise."""
+        lo, hi = self._agree_min(int(n_rows)), -self._agree_min(-int(n_rows))
+        ok = lo == hi == int(n_rows)
+        if ok:
+            try:
+                self.engine.comm_set_agents(int(n_rows))
+            except Exception:
+                ok = False
+        if not self._agree_min(1 if ok else 0):
+            try:
+                self.engine.comm_destroy()
+            except Exception:
+                pass
+            return False
+        return True
 
     def shard(self, inputs):
         begin, count = shard_range(inputs.n_candidates_global, self.rank, self.world)
@@ -367,6 +388,8 @@ class ShardedEvaluator:
             if hasattr(self.engine, "step_exchange_topk_raw") and (self.world > 1 or self.force_exchange) \
                     and os.environ.get("FX_EXCHANGE", "lib") != "torch" and self.world * self.n_local * 2 * self.k <= 16384:
                 self.lib_exchange_agents = self.lib_exchange or self._init_library_exchange(dev)
+                if self.lib_exchange_agents and not self._agree_agent_rows(self.n_local):
+                    self.lib_exchange = self.lib_exchange_agents = False
 
     def step_agents_enqueued(self, exchange: bool = True):
         """One batched launch over this rank's (already uploaded) agents, per-agent top-k on the device, ONE all-gather
@@ -374,6 +397,8 @@ class ShardedEvaluator:
         (cost [W, n_local, k], index [W, n_local, k]) or None)."""
         if exchange and self.lib_exchange_agents:
             # evaluation, per-agent top-k, ONE all-gather and the publication enqueued by the library back to back
+            # (a rank that uploaded more agents than the ranks agreed on still enters the collective -- with "no survivor" rows --
+            # and gets FX_ERR_CAPACITY afterwards: fx_step_exchange_topk)
             res, gc, gi = self.engine.step_exchange_topk_raw(self.k)
             return [r.as_dict() for r in res] if hasattr(res[0], "as_dict") else res, (gc, gi)
         self.engine.evaluate()

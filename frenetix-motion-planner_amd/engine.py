@@ -450,6 +450,7 @@ class FrenetEngine:
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(lib().fx_comm_init(self._ctx, C.addressof(buf), int(rank), int(world)))
         self._comm_world = int(world)
+        self._comm_agents = int(self.max_agents)   # (fx_comm_init's default; comm_set_agents changes it)
 
     def comm_check(self, world: int) -> bool:
         """Local preconditions of comm_init (RCCL present, capacity), nothing collective: the ranks agree on the answer
@@ -460,16 +461,27 @@ class FrenetEngine:
         """Bound of every host wait on device work (default 20 000 ms, the reference's TIMEOUT); FxTimeoutError beyond it."""
         check(lib().fx_set_timeout_ms(self._ctx, int(timeout_ms)))
 
+    def comm_set_agents(self, n_agents: int):
+        """The agent rows every rank contributes to an exchange (fx_comm_set_agents): the ranks agree on it beforehand."""
+        check(lib().fx_comm_set_agents(self._ctx, int(n_agents)))
+        self._comm_agents = int(n_agents)
+
+    def comm_info(self) -> dict:
+        """rank, world, the rank count RCCL itself reports (ncclCommCount; -1 if unavailable), agent rows per rank"""
+        v = (C.c_int32 * 4)()
+        check(lib().fx_comm_info(self._ctx, v))
+        return dict(rank=int(v[0]), world=int(v[1]), rccl_ranks=int(v[2]), agent_rows=int(v[3]))
+
     def step_exchange_topk_raw(self, k: int):
         """evaluate + per-agent top-k + ONE all-gather + finish in one call (fx_step_exchange_topk):
-        (FxResult array, cost [W, n, k], index [W, n, k])"""
-        n = len(self._inputs)
+        (FxResult array, cost [W, A, k], index [W, A, k]) with A = the communicator's agent rows (comm_set_agents)"""
+        n, A = len(self._inputs), self._comm_agents
         res = getattr(self, "_res_buf", None)
         if res is None or len(res) != n:
             res = self._res_buf = (_abi.FxResult * n)()
         x = getattr(self, "_xchg_topk", None)
-        if x is None or x[0].shape != (self._comm_world, n, k):
-            x = self._xchg_topk = (np.empty((self._comm_world, n, k)), np.empty((self._comm_world, n, k), np.int64))
+        if x is None or x[0].shape != (self._comm_world, A, k):
+            x = self._xchg_topk = (np.empty((self._comm_world, A, k)), np.empty((self._comm_world, A, k), np.int64))
         check(lib().fx_step_exchange_topk(self._ctx, int(k), res, x[0].ctypes.data, x[1].ctypes.data))
         return res, x[0], x[1]
 
@@ -478,14 +490,15 @@ class FrenetEngine:
         self._comm_world = 0
 
     def step_exchange_raw(self):
-        """evaluate + all-gather of every rank's winner(s) + finish in ONE call: (FxResult array, cost [W, n], index [W, n])"""
-        n = len(self._inputs)
+        """evaluate + all-gather of every rank's winner(s) + finish in ONE call: (FxResult array, cost [W, A], index [W, A]) with
+        A = the communicator's agent rows (comm_set_agents; rows a rank does not fill say cost inf / index -1)"""
+        n, A = len(self._inputs), self._comm_agents
         res = getattr(self, "_res_buf", None)
         if res is None or len(res) != n:
             res = self._res_buf = (_abi.FxResult * n)()
         x = getattr(self, "_xchg_buf", None)
-        if x is None or x[0].shape != (self._comm_world, n):
-            x = self._xchg_buf = (np.empty((self._comm_world, n)), np.empty((self._comm_world, n), np.int64))
+        if x is None or x[0].shape != (self._comm_world, A):
+            x = self._xchg_buf = (np.empty((self._comm_world, A)), np.empty((self._comm_world, A), np.int64))
         check(lib().fx_step_exchange(self._ctx, res, x[0].ctypes.data, x[1].ctypes.data))
         return res, x[0], x[1]
 

@@ -257,10 +257,12 @@ class PlanInputs:
                 raise ValueError("either sampling_matrix or t_samp/v_samp/d_samp are required")
             self.t_samp, self.v_samp, self.d_samp = _f64(self.t_samp), _f64(self.v_samp), _f64(self.d_samp)
         # a planner hands over the same weights dict step after step: names / ids / weights are derived once per dict object
-        # (guarded by its length and the sum of its values against in-place edits)
+        # (guarded by the exact (name, weight) items against in-place edits -- ten entries: swapping two weights or moving weight
+        # from one term to another keeps length and sum, and would otherwise upload the old cost function)
         cw = self.cost_weights
+        sig = tuple(cw.items())
         memo = _COST_MEMO.get(id(cw))
-        if memo is not None and memo[0] is cw and memo[1] == (len(cw), sum(cw.values())):
+        if memo is not None and memo[0] is cw and memo[1] == sig:
             self.cost_names, self._cost_id, self._cost_w = memo[2]
         else:
             bad = [n for n, w in cw.items() if w != 0 and n not in _abi.COST_ID]
@@ -272,7 +274,7 @@ class PlanInputs:
             self._cost_w = _f64([cw[n] for n in names])
             if len(_COST_MEMO) > 256:
                 _COST_MEMO.clear()
-            _COST_MEMO[id(cw)] = (cw, (len(cw), sum(cw.values())), (self.cost_names, self._cost_id, self._cost_w))
+            _COST_MEMO[id(cw)] = (cw, sig, (self.cost_names, self._cost_id, self._cost_w))
         if self.obstacles is None:
             self.obstacles = pack_predictions(None, S, None)
         self._dto = _f64(self.dto_pos).reshape(-1, 2) if self.dto_pos is not None else np.zeros((0, 2))

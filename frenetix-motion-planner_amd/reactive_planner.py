@@ -254,7 +254,7 @@ class ReactivePlannerHip:
                                                                 self.vehicle_params, d_reach)
             boundary = pb
         weights, cw = self._weights_nz, self.cost_weights
-        sig = (len(cw), sum(cw.values()))
+        sig = tuple(cw.items())   # exact: an in-place swap of two weights keeps length and sum
         if weights is None or self._weights_src is not cw or self._weights_sig != sig:   # replaced, or edited in place
             weights = self._weights_nz = {k: w for k, w in cw.items() if w != 0}
             self._weights_src, self._weights_sig = cw, sig

@@ -146,7 +146,12 @@ def dense_ranges(n_t: int, n_v: int, n_d: int, v_lo: float, v_hi: float, horizon
     if c is None:   # the time and lateral sets of a planner never change: built once
         t = np.round(t_min + dt * np.arange(n_t), 2)
         d = np.linspace(d_min, d_max, n_d)
-        c = _DENSE_CACHE[key] = (t[t <= horizon + 1e-9], d, frozenset(d.tolist()), np.arange(0, n_v, dtype=np.float64))
+        t = t[t <= horizon + 1e-9]
+        # the cached sets are handed out by reference: read-only, so that a caller that sorts or edits "its" range in place
+        # gets an error instead of silently changing the sampling sets of every planner with the same key
+        t.setflags(write=False)
+        d.setflags(write=False)
+        c = _DENSE_CACHE[key] = (t, d, frozenset(d.tolist()), np.arange(0, n_v, dtype=np.float64))
     t, d, d_set, ramp = c
     # np.linspace(v_lo, v_hi, n_v) with its arithmetic (function_base.py: arange * step + start, the end point set exactly)
     # on the cached ramp -- a third of the time of the call

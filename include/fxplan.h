@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 5
+#define FX_ABI_VERSION 6
 
 /* ---- status codes (planner.py / reactive_planner_cpp.py raise Python exceptions; the shim maps
  *      <0 -> ValueError, >0 -> RuntimeError, see SURVEY 8b "Error conventions") ---- */
@@ -278,7 +278,7 @@ int32_t fx_update_step(FxContext *ctx, const FxStateUpdate *upd, FxResult *res);
  *      The context gets an RCCL communicator of its own: rank 0 draws the 128-byte id (fx_comm_unique_id), the host program
  *      broadcasts it by whatever means it has, every rank calls fx_comm_init.  fx_step_exchange = fx_evaluate + ONE all-gather of
  *      every rank's winner (cost f64, global index i64) per agent on the context's stream + publication to pinned host memory +
- *      fx_finish_batch: cost / index [world][n_agents], index -1 where a rank found nothing.  RCCL is bound at run time
+ *      fx_finish_batch: cost / index [world][agent rows], index -1 where a rank found nothing.  RCCL is bound at run time
  *      (librccl.so.1); without it these return FX_ERR_NOT_READY and everything else works. */
 int32_t fx_comm_unique_id(uint8_t *id128);
 /* local preconditions of fx_comm_init (RCCL present, capacity) WITHOUT entering anything collective: every rank calls it and the
@@ -287,13 +287,23 @@ int32_t fx_comm_unique_id(uint8_t *id128);
 int32_t fx_comm_check(const FxContext *ctx, int32_t world);
 int32_t fx_comm_init(FxContext *ctx, const uint8_t *id128, int32_t rank, int32_t world);
 int32_t fx_comm_destroy(FxContext *ctx);
-/* a rank whose own evaluation fails still enters the all-gather (with cost inf / index -1 for every agent) and returns its
- * error afterwards: the peers are never left waiting */
-int32_t fx_step_exchange(FxContext *ctx, FxResult *res, double *cost /*[world][n_agents]*/, int64_t *index /*[world][n_agents]*/);
+/* the agent rows EVERY rank contributes to an exchange (default: the context's max_agents).  The element count of the all-gather
+ * is a property of the communicator, agreed between the ranks and fixed here -- not of a rank's current upload: a rank that
+ * uploaded fewer agents sends "no survivor" (inf, -1) in the remaining rows, a rank that uploaded more gets FX_ERR_CAPACITY
+ * from the exchange (after having entered it) */
+int32_t fx_comm_set_agents(FxContext *ctx, int32_t n_agents);
+/* out[0] rank, [1] world, [2] the ranks RCCL itself reports for the communicator (ncclCommCount, -1 if unavailable), [3] agent
+ * rows per rank */
+int32_t fx_comm_info(const FxContext *ctx, int32_t *out4);
+/* A = the communicator's agent rows (fx_comm_set_agents).  A rank whose own evaluation fails, or whose upload does not fit A
+ * rows, still enters the all-gather (with cost inf / index -1 in its rows) and returns its error afterwards: nothing that can
+ * fail locally returns ahead of the collective, the peers are never left waiting */
+int32_t fx_step_exchange(FxContext *ctx, FxResult *res, double *cost /*[world][A]*/, int64_t *index /*[world][A]*/);
 /* the same for the k <= 64 best survivors per agent (agent sharding with a top-k gather, BASELINE config 5): evaluation,
- * selection, top-k, ONE all-gather of 16 k bytes per rank and agent, publication -- no host code between the launches */
-int32_t fx_step_exchange_topk(FxContext *ctx, int32_t k, FxResult *res, double *cost /*[world][n_agents][k]*/,
-                              int64_t *index /*[world][n_agents][k]*/);
+ * selection, top-k, ONE all-gather of 16 k bytes per rank and agent row, publication -- no host code between the launches; k is
+ * the same on every rank */
+int32_t fx_step_exchange_topk(FxContext *ctx, int32_t k, FxResult *res, double *cost /*[world][A][k]*/,
+                              int64_t *index /*[world][A][k]*/);
 /* every host wait on device work (fx_finish, fx_wait_published, the exchanges, fx_read_package) is bounded in TIME: default
  * 20 000 ms, the reference's TIMEOUT (simulation.py:637); FX_ERR_TIMEOUT when it runs out.  fx_wait_word is the wait itself
  * (pure host code): returns FX_OK once *word == expected, FX_ERR_TIMEOUT after timeout_ms. */

@@ -44,7 +44,8 @@ def test_default_line_is_config3_with_north_star():
     # the obstacle kernel (FP64 issue); `roofline` is the longer of the two
     assert d["launch"]["obstacle_kernel"] == 1 and len(d["kernels"]) == 2
     hb, ob = d["kernels"]
-    assert d["roofline"] in (hb, ob) and d["roofline"]["avg_launch_ms"] == max(hb["avg_launch_ms"], ob["avg_launch_ms"])
+    # the walk (the bound BASELINE.json names) stands unless the obstacle kernel is more than 5 % longer
+    assert d["roofline"] == (ob if ob["avg_launch_ms"] > 1.05 * hb["avg_launch_ms"] else hb)
     assert ob["bound"] == "fp64_valu" and ob["peak"] == 78.6 and ob["unit"] == "TFLOP/s"
     assert ob["launches_timed"] == 24 and "fx_obstacle_kernel" in ob["kernel"]  # every launch is timed below 64 steps
     # the executed-work figure comes from the tracked PMC summary of THIS kernel (profiles/r3); the tracked summary must hold
@@ -60,6 +61,11 @@ def test_default_line_is_config3_with_north_star():
     assert d["winner"]["index"] >= 0 and d["winner"]["n_collisions"] > 0 and d["cpu_baseline"] is None
     # the step fed from host buffers is reported next to the resident one
     assert d["plan_step_p50_ms"] > 0 and d["resident_step_p50_ms"] > 0 and d["value_with_upload"] > 1e8
+    assert d["plan_step_value"] == d["value_with_upload"] and d["plan_step_ms"] == d["with_upload_ms_per_step"]
+    assert 0 < d["ms_per_step_min"] <= d["ms_per_step"] * 1.001 and d["ms_per_step_stdev"] >= 0 and d["steps_timed_wall_ms"] > 0
+    rs = d["roofline_step"]
+    assert rs["bound"] == "hbm" and rs["peak"] == 8000.0 and rs["algorithmic_bytes_per_step"] == 50388 * 3472
+    assert rs["achieved"] == pytest.approx(50388 * 3472 / (d["ms_per_step"] * 1e-3) / 1e9) and rs["frac"] == pytest.approx(rs["achieved"] / 8000.0)
     ns = d["north_star"]
     a, b = ns["obstacles_select_only"], ns["bundle_no_obstacles"]
     assert a["candidates"] == 1005100 and a["obstacles"] == 20 and a["samples"] == 31 and a["eval_kernel_ms"] < 10.0 and a["step_ms"] < 10.0

@@ -519,6 +519,11 @@ class _CommStubEngine:
         self.inits += 1
         self.uid_seen = bytes(uid)
 
+    def comm_set_agents(self, n):
+        if self.fail == "rows":
+            raise RuntimeError("agent rows refused")
+        self.rows = n
+
     def comm_destroy(self):
         self.destroys += 1
 
@@ -534,18 +539,23 @@ def _exchange_agreement_worker(rank, world, port, q, scenario):
     try:
         fail = {"ok": None, "uid_fails_on_rank0": "uid" if rank == 0 else None,
                 "init_fails_on_rank1": "init" if rank == 1 else None,
-                "precondition_fails_on_rank1": "check" if rank == 1 else None}[scenario]
+                "precondition_fails_on_rank1": "check" if rank == 1 else None,
+                "rows_refused_on_rank1": "rows" if rank == 1 else None, "agent_rows_differ": None}[scenario]
         ev = ShardedEvaluator.__new__(ShardedEvaluator)   # the agreement logic alone (the constructor needs a GPU for this path)
-        ev.torch, ev.dist, ev.group, ev.rank, ev.world = torch, dist, None, rank, world
+        ev.torch, ev.dist, ev.group, ev.rank, ev.world, ev.on_device = torch, dist, None, rank, world, False
         ev.engine = _CommStubEngine(fail)
         ok = ev._init_library_exchange(torch.device("cpu"))
+        if scenario == "agent_rows_differ":   # setup_agents with different agents per rank: nobody may use the library exchange
+            assert ok and ev.engine.rows == 1
+            ok = ev._agree_agent_rows(2 + rank)
         q.put((rank, ok, ev.engine.inits, ev.engine.destroys, ev.engine.uid_seen == bytes(range(128))))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("scenario", ["ok", "uid_fails_on_rank0", "init_fails_on_rank1", "precondition_fails_on_rank1"])
+@pytest.mark.parametrize("scenario", ["ok", "uid_fails_on_rank0", "init_fails_on_rank1", "precondition_fails_on_rank1",
+                                      "rows_refused_on_rank1", "agent_rows_differ"])
 def test_library_exchange_setup_is_agreed_by_all_ranks(scenario):
     """The in-library exchange is used only if EVERY rank could set it up: rank 0 draws the id (or says it could not), the id
     travels over the torch group, and one failing rank sends all of them to the torch.distributed path (communicators that
@@ -569,6 +579,10 @@ def test_library_exchange_setup_is_agreed_by_all_ranks(scenario):
         # nobody initialises without an id -- and nobody enters the (blocking, collective) initialisation when one rank's
         # local preconditions fail: its peers would wait inside ncclCommInitRank for a rank that never comes
         assert all(g[2] == 0 and g[3] == 0 for g in got)
+    elif scenario in ("rows_refused_on_rank1", "agent_rows_differ"):
+        # the element count of the library's all-gathers must be the same everywhere: one rank that cannot take the agreed agent
+        # rows -- or ranks that ask for different numbers -- and every communicator is destroyed again
+        assert all(g[2] == 1 and g[3] == 1 for g in got)
     else:
         assert got[0][2] == 1 and got[0][3] == 1                    # rank 0 had a communicator: destroyed again
         assert got[1][2] == 0 and got[1][3] == 0
@@ -618,3 +632,92 @@ def test_library_exchange_is_cross_checked_against_the_torch_exchange(scenario):
         assert [g[1:] for g in got] == [(1, True, 0), (1, True, 0)]
     else:
         assert [g[1:] for g in got] == [(0, False, 1), (0, False, 1)]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The RCCL path with TWO ranks on two devices: the in-library exchanges (fx_step_exchange, fx_step_exchange_topk) and the
+# torch.distributed exchange over nccl.  Needs >= 2 visible GPUs; skipped on the one-GPU boxes of the pool, there for the day
+# the suite runs on a node.
+# ---------------------------------------------------------------------------------------------------------
+def _nccl_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator, exit_on_timeout
+    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        out = {}
+        # candidate split, k = 1: the winner exchange inside the library, cross-checked against torch.distributed
+        inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(9, 21, 21), n_obstacles=8, hull_builder=build_obstacle_hulls)
+        with FrenetEngine(max_candidates=8192, device=rank) as eng:
+            eng.set_timeout_ms(60000)
+            ev = ShardedEvaluator(eng, k=1)
+            out["lib_exchange"] = bool(ev.lib_exchange)
+            out["comm"] = eng.comm_info() if ev.lib_exchange else None
+            res = exit_on_timeout(ev.plan_step, inp)
+            out["winner"] = (int(res["global_best_index"]), float(res["global_best_cost"]))
+            out["crosscheck"] = exit_on_timeout(ev.crosscheck_exchange)
+            r2 = exit_on_timeout(ev.step_enqueued)
+            out["winner_again"] = (int(r2["global_best_index"]), float(r2["global_best_cost"]))
+            eng.set_winner_buffer(0)
+        # agent sharding with the per-agent top-k gather (config 5's exchange): library path and torch path give the same survivors
+        agents = synthetic.stress_agents(3, grid=(7, 9, 9), n_obstacles=6, first_agent=3 * rank, hull_builder=build_obstacle_hulls)
+        with FrenetEngine(max_candidates=sum(a.n_candidates for a in agents) + 3 * 64, max_steps=50, max_agents=3, device=rank) as eng:
+            eng.set_timeout_ms(60000)
+            ev = ShardedEvaluator(eng, k=8)
+            ev.setup_agents(3)
+            eng.upload(agents)
+            out["lib_exchange_agents"] = bool(ev.lib_exchange_agents)
+            _, (sc, si) = exit_on_timeout(ev.step_agents_enqueued)
+            out["survivors"] = (sc.tolist(), si.tolist())
+            out["crosscheck_agents"] = exit_on_timeout(ev.crosscheck_exchange)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_rccl_world2_library_and_torch_exchange():
+    """Two ranks on two GPUs over RCCL: candidate split with the in-library winner exchange (every rank reports the single-GPU
+    winner, ncclCommCount = 2, library exchange == torch.distributed exchange) and agent sharding with the in-library per-agent
+    top-k gather (every rank holds every rank's survivors).  Skipped where fewer than two devices are visible."""
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls, device_count
+    if device_count() < 2:
+        pytest.skip("needs two GPUs (the pool's boxes have one): runs on a multi-GPU node")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=800) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(9, 21, 21), n_obstacles=8, hull_builder=build_obstacle_hulls)
+    with FrenetEngine(max_candidates=8192, device=0) as eng:
+        full = eng.plan_step(inp)
+    for rank in range(world):
+        o = got[rank]
+        assert o["winner"] == (full["best_index"], full["best_cost"]) == o["winner_again"]
+        assert o["crosscheck"] == 1 and o["crosscheck_agents"] == 1
+        if o["lib_exchange"]:
+            assert o["comm"]["world"] == 2 and o["comm"]["rank"] == rank and o["comm"]["rccl_ranks"] in (2, -1) and o["comm"]["agent_rows"] == 1
+    assert got[0]["survivors"] == got[1]["survivors"]   # [world][agents][k] on every rank
+    sc, si = (np.asarray(x) for x in got[0]["survivors"])
+    assert sc.shape == (2, 3, 8)
+    for r in range(world):   # rank r's rows are its own agents' top-k
+        agents = synthetic.stress_agents(3, grid=(7, 9, 9), n_obstacles=6, first_agent=3 * r, hull_builder=build_obstacle_hulls)
+        with FrenetEngine(max_candidates=sum(a.n_candidates for a in agents) + 3 * 64, max_steps=50, max_agents=3, device=0) as eng:
+            eng.plan_batch(agents)
+            tc, ti = eng.topk(8)
+        assert np.array_equal(si[r], ti) and np.array_equal(sc[r], tc)

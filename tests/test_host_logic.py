@@ -279,3 +279,40 @@ def test_adapter_recognises_a_product_sampling_matrix():
     assert product_grid_of(var) is None                      # a start state that differs between rows
     dup = generate_sampling_matrix(t1_range=t, ss1_range=np.array([1.0, 1.0]), d1_range=d, **kw)
     assert product_grid_of(dup) is None                      # repeated values: not a set product
+
+
+def test_cost_weights_edited_in_place_are_seen():
+    """The (names, ids, weights) derived from a cost_weights dict are memoised per dict object; an in-place edit that keeps the
+    length and the sum of the values -- two weights swapped -- must still be seen (the stale ids / weights would be uploaded and
+    the candidates costed with the old cost function)."""
+    from frenetix_motion_planner_amd import synthetic
+    w = {"lateral_jerk": 1.0, "longitudinal_jerk": 3.0, "distance_to_reference_path": 0.5}
+    a = synthetic.make_inputs(level=0, cost_weights=w)
+    assert a.cost_weights is not w   # make_inputs copies: edit the copy the inputs carry
+    cw = a.cost_weights
+    b = PlanInputs(**{f.name: getattr(a, f.name) for f in a.__dataclass_fields__.values() if f.init})
+    assert list(b._cost_w) == list(a._cost_w)
+    cw["lateral_jerk"], cw["longitudinal_jerk"] = cw["longitudinal_jerk"], cw["lateral_jerk"]   # same length, same sum
+    c = PlanInputs(**{f.name: getattr(a, f.name) for f in a.__dataclass_fields__.values() if f.init})
+    by_name = dict(zip(c.cost_names, c._cost_w))
+    assert by_name["lateral_jerk"] == 3.0 and by_name["longitudinal_jerk"] == 1.0
+    cw["velocity_offset"] = cw.pop("distance_to_reference_path")   # renamed key, same length and sum
+    d = PlanInputs(**{f.name: getattr(a, f.name) for f in a.__dataclass_fields__.values() if f.init})
+    assert "velocity_offset" in d.cost_names and "distance_to_reference_path" not in d.cost_names
+
+
+def test_dense_ranges_hands_out_read_only_cached_sets():
+    """dense_ranges caches the time and lateral sets per key and returns them by reference: they are read-only, and an edit of a
+    returned array cannot change the next call's result."""
+    from frenetix_motion_planner_amd.sampling import dense_ranges
+    t, v, d = dense_ranges(5, 7, 9, 1.0, 9.0, 3.0, 0.1, 0.0)   # d0 = 0.0 is one of the nine samples: the cached set itself
+    with pytest.raises(ValueError):
+        t[0] = 99.0
+    with pytest.raises(ValueError):
+        d.sort()
+    v[0] = -1.0   # the velocity range is built per call
+    t2, v2, d2 = dense_ranges(5, 7, 9, 1.0, 9.0, 3.0, 0.1, 0.0)
+    assert t2[0] == pytest.approx(1.1) and v2[0] == 1.0 and np.array_equal(d2, np.linspace(-3.0, 3.0, 9))
+    _, _, d3 = dense_ranges(5, 7, 9, 1.0, 9.0, 3.0, 0.1, 0.123)   # d0 appended: a fresh, writable array
+    d3[0] = 5.0
+    assert dense_ranges(5, 7, 9, 1.0, 9.0, 3.0, 0.1, 0.123)[2][0] == -3.0
