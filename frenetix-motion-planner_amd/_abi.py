@@ -46,6 +46,7 @@ FX_MODE_WRITE_BUNDLE = 1 << 2
 FX_MODE_WRITE_COSTMAP = 1 << 3
 FX_MODE_COLLISION = 1 << 4
 FX_MODE_ROAD_BOUNDARY = 1 << 5
+FX_MODE_PROJ_PSEUDO_NORMAL = 1 << 6
 
 _pd = C.POINTER(C.c_double)
 _pi32 = C.POINTER(C.c_int32)

@@ -48,12 +48,24 @@ def compute_curvature_from_polyline(polyline: np.ndarray) -> np.ndarray:
     return (x_d * y_dd - x_dd * y_d) / ((x_d ** 2 + y_d ** 2) ** (3. / 2.))
 
 
-def vertex_normals(polyline: np.ndarray) -> np.ndarray:
+def vertex_normals(polyline: np.ndarray, vertex_tangent: str = "chord") -> np.ndarray:
+    """Unit left normals at the vertices.  vertex_tangent: "chord" (default) -- direction of P[i+1] - P[i-1] -- or "bisector" --
+    the normalised sum of the two adjacent unit segment directions; the two agree on uniformly spaced polylines and differ by
+    up to 2 mm at d = 3 m when the knot spacing varies by 30 % (tools/projection_variants.py).  Which one CCosy uses is
+    decided by tests/golden/pin_third_party.py once commonroad_dc is importable (parity unpinned)."""
     p = np.asarray(polyline, dtype=np.float64)
     t = np.empty_like(p)
-    t[1:-1] = p[2:] - p[:-2]
-    t[0] = p[1] - p[0]
-    t[-1] = p[-1] - p[-2]
+    if vertex_tangent == "bisector":
+        u = p[1:] - p[:-1]
+        u = u / np.sqrt(u[:, 0] * u[:, 0] + u[:, 1] * u[:, 1])[:, None]
+        t[1:-1] = u[1:] + u[:-1]
+        t[0], t[-1] = u[0], u[-1]
+    elif vertex_tangent == "chord":
+        t[1:-1] = p[2:] - p[:-2]
+        t[0] = p[1] - p[0]
+        t[-1] = p[-1] - p[-2]
+    else:
+        raise ValueError(f"vertex_tangent must be 'chord' or 'bisector', not {vertex_tangent!r}")
     nrm = np.sqrt(t[:, 0] * t[:, 0] + t[:, 1] * t[:, 1])
     t = t / nrm[:, None]
     return np.stack([-t[:, 1], t[:, 0]], axis=1)
@@ -96,7 +108,12 @@ def interpolate_angle(x: float, x1: float, x2: float, y1: float, y2: float) -> f
 class CoordinateSystem:
     """Reference path + curvilinear frame (utils_coordinate_system.py:187-274)."""
 
-    def __init__(self, reference: np.ndarray):
+    def __init__(self, reference: np.ndarray, pseudo_normal: bool = False, vertex_tangent: str = "chord"):
+        """pseudo_normal / vertex_tangent: the two open readings of CCosy's projection.  Default: d along the
+        NORMALISED interpolated vertex normal, vertex tangent = chord.  pseudo_normal=True offsets along the un-normalised
+        interpolated normal (FX_MODE_PROJ_PSEUDO_NORMAL in the kernel and the oracle; the inverse map follows)."""
+        self.pseudo_normal = bool(pseudo_normal)
+        self.vertex_tangent = vertex_tangent
         ref = np.ascontiguousarray(np.asarray(reference, dtype=np.float64))
         if ref.ndim != 2 or ref.shape[1] != 2 or ref.shape[0] < 3:
             raise ValueError("<CoordinateSystem>: reference must be an (M>=3, 2) polyline")
@@ -108,7 +125,7 @@ class CoordinateSystem:
         self._ref_theta = np.unwrap(compute_orientation_from_polyline(ref))
         self._ref_curv_d = np.gradient(self._ref_curv, self._ref_pos)
         self._ref_curv_dd = np.gradient(self._ref_curv_d, self._ref_pos)
-        self._normals = vertex_normals(ref)
+        self._normals = vertex_normals(ref, vertex_tangent)
         self._c_args = None
         self.uid = next(_UIDS)   # identity that is never reused (id() of a collected object can be)
 
@@ -177,6 +194,8 @@ class CoordinateSystem:
         lam = (s - rp[k]) / (rp[k + 1] - rp[k])
         p = self._reference[k] + lam * (self._reference[k + 1] - self._reference[k])
         n = self._normals[k] + lam * (self._normals[k + 1] - self._normals[k])
+        if self.pseudo_normal:
+            return np.array([p[0] + d * n[0], p[1] + d * n[1]])
         nn = math.sqrt(n[0] * n[0] + n[1] * n[1])
         return np.array([p[0] + d * (n[0] / nn), p[1] + d * (n[1] / nn)])
 
@@ -191,6 +210,6 @@ class CoordinateSystem:
             keep = (np.ascontiguousarray(self._reference), np.ascontiguousarray(self._normals), np.ascontiguousarray(self._ref_pos))
             self._c_args = (keep, len(keep[0]), *[a.ctypes.data for a in keep], (C.c_double * 2)())
         _, M, p_ref, p_nrm, p_pos, out = self._c_args
-        if lib().fx_cs_to_curvilinear(M, p_ref, p_nrm, p_pos, float(x), float(y), C.addressof(out)) != 0:
+        if lib().fx_cs_to_curvilinear_ex(M, p_ref, p_nrm, p_pos, float(x), float(y), int(self.pseudo_normal), C.addressof(out)) != 0:
             raise ValueError("<CoordinateSystem>: point outside projection domain")
         return np.array([out[0], out[1]])

@@ -1619,6 +1619,10 @@ int32_t fx_plan_and_package(FxContext *c, const FxStateUpdate *upd, double yaw_r
 // segment k the foot point P_k + lam b and the interpolated normal n_k + lam dn are collinear with the point where
 // cross(a + lam b, n_k + lam dn) = 0, a quadratic in lam; of all roots in [0, 1] the one with the smallest |d| wins.
 int32_t fx_cs_to_curvilinear(int32_t M, const double *ref_xy, const double *normals, const double *ref_pos, double x, double y, double *sd) {
+    return fx_cs_to_curvilinear_ex(M, ref_xy, normals, ref_pos, x, y, 0, sd);
+}
+int32_t fx_cs_to_curvilinear_ex(int32_t M, const double *ref_xy, const double *normals, const double *ref_pos, double x, double y,
+                                int32_t pseudo_normal, double *sd) {
     if (M < 2 || !ref_xy || !normals || !ref_pos || !sd) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_cs_to_curvilinear: bad argument");
     bool have = false;
     double best_s = 0, best_d = 0;
@@ -1647,7 +1651,8 @@ int32_t fx_cs_to_curvilinear(int32_t M, const double *ref_xy, const double *norm
             lam = std::fmin(std::fmax(lam, 0.0), 1.0);
             const double fx = ref_xy[2 * k] + lam * bx, fy = ref_xy[2 * k + 1] + lam * by;
             double nx = n0x + lam * dnx, ny = n0y + lam * dny;
-            const double nn = std::sqrt(nx * nx + ny * ny);
+            // (x, y) = foot + d n / |n|  (or foot + d n: the pseudo-distance variant)  =>  d = (p - foot) . n / |n|  (/ |n|^2)
+            const double nn = pseudo_normal ? nx * nx + ny * ny : std::sqrt(nx * nx + ny * ny);
             nx = nx / nn; ny = ny / nn;
             const double dd = (x - fx) * nx + (y - fy) * ny;
             if (!have || std::fabs(dd) < std::fabs(best_d)) {

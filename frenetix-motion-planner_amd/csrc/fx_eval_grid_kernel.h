@@ -142,7 +142,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
                 kt.pos = q[0]; kt.theta = q[1]; kt.curv = q[2]; kt.curv_d = q[3]; kt.x = q[4]; kt.y = q[5]; kt.nx = q[6]; kt.ny = q[7];
                 return kt;
             },
-            [&](int k) { return rpos[k]; });
+            [&](int k) { return rpos[k]; }, (P.mode & FX_MODE_PROJ_PSEUDO_NORMAL) != 0);
     }
     __syncthreads();
     FX_STAMP(2);

@@ -640,7 +640,8 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     const bool want_trig = OBST && ((do_collision && P.K > 0) || ((P.mode & FX_MODE_ROAD_BOUNDARY) && P.n_bound > 0));
     auto row_at = [&](int i) {
         return make_lon_row(i, S, M, dt, a_max, cl0, cl1, cl2, cl3, cl4, cl5, traj_len, tp, rp_first, rp_last, guess_scale,
-                            want_trig, [&](int k) { return knots[k]; }, [&](int k) { return knots[k].pos; });
+                            want_trig, [&](int k) { return knots[k]; }, [&](int k) { return knots[k].pos; },
+                            (P.mode & FX_MODE_PROJ_PSEUDO_NORMAL) != 0);
     };
     auto lat_eval = [&](int i, double u_lowvel, double &d, double &dv, double &da) {
         LatU U;

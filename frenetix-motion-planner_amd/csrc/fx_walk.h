@@ -164,7 +164,8 @@ __device__ __forceinline__ void lon_coeffs(int lon_mode, double s0, double ss0, 
 template <typename KnotFn, typename PosFn>
 __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, double a_max, double cl0, double cl1, double cl2,
                                                double cl3, double cl4, double cl5, int traj_len, const double *tp, double rp_first,
-                                               double rp_last, double guess_scale, bool want_trig, KnotFn knot, PosFn kpos) {
+                                               double rp_last, double guess_scale, bool want_trig, KnotFn knot, PosFn kpos,
+                                               bool pseudo_normal = false) {
     const int ie = i < traj_len ? i : traj_len - 1;  // sample that is evaluated (the last one feeds the extension)
     const double *te = tp + ie * FX_TP;
     const double t1 = te[0], t2 = te[1], t3 = te[2], t4 = te[3], t5 = te[4];
@@ -224,8 +225,9 @@ __device__ __forceinline__ LonRow make_lon_row(int i, int S, int M, double dt, d
         const double nx = q0.nx + lam * (q1.nx - q0.nx), ny = q0.ny + lam * (q1.ny - q0.ny);
         double nn, r_nn;
         sqrt_rsqrt(nx * nx + ny * ny, nn, r_nn);
-        r.nhx = div_rcp(nx, nn, r_nn);
-        r.nhy = div_rcp(ny, nn, r_nn);
+        // FX_MODE_PROJ_PSEUDO_NORMAL: d runs along the interpolated normal itself (a pseudo-distance), not along its unit vector
+        r.nhx = pseudo_normal ? nx : div_rcp(nx, nn, r_nn);
+        r.nhy = pseudo_normal ? ny : div_rcp(ny, nn, r_nn);
     }
     r.pad1 = 0.0;
     r.c_ref = 1.0; r.s_ref = 0.0;

@@ -321,6 +321,8 @@ class PlanInputs:
             m |= _abi.FX_MODE_COLLISION
         if self._bound is not None and self._bound["n"] > 0:
             m |= _abi.FX_MODE_ROAD_BOUNDARY
+        if getattr(self.coordinate_system, "pseudo_normal", False):
+            m |= _abi.FX_MODE_PROJ_PSEUDO_NORMAL
         return m
 
     def structure_key(self):

@@ -95,7 +95,7 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
                 n_obstacles=0, n_pred=30, cost_weights=None, draw_traj_set=False, kinematic_debug=False,
                 write_bundle=True, write_costmap=True, collision=True, low_vel_threshold=2.0, hull_builder=None,
                 seed=SEED, vehicle=None, x0_orientation=None, as_matrix=False, stop_point_s=None, road_half_width=None,
-                obstacle_min_gap=0.0, lead_gap=0.0, knot_jitter=0.0):
+                obstacle_min_gap=0.0, lead_gap=0.0, knot_jitter=0.0, pseudo_normal=False, vertex_tangent="chord"):
     """One agent's PlanInputs on a synthetic reference.
 
     level: reference sampling level (set-ordered ranges, SamplingHandler) -- or
@@ -104,7 +104,8 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
     stop_point_s: distance ahead of s0 of a stop point -> stop-point sampling (end positions in
     [(s0 + s_stop) / 2, s_stop], reactive_planner.py:637) instead of end velocities."""
     veh = vehicle or VehicleParams()
-    cs = CoordinateSystem(reference_polyline(ref_kind, n_knots, spacing, kappa, knot_jitter, seed))
+    cs = CoordinateSystem(reference_polyline(ref_kind, n_knots, spacing, kappa, knot_jitter, seed), pseudo_normal=pseudo_normal,
+                          vertex_tangent=vertex_tangent)
     N = int(horizon / dt)
     s0 = float(cs.ref_pos[s_knot] + s_off)
     low_vel = v0 < low_vel_threshold

@@ -85,6 +85,10 @@ enum {
 #define FX_MODE_WRITE_COSTMAP   (1u << 3)  /* keep the per-name raw costs (TrajectorySample.costMap) */
 #define FX_MODE_COLLISION       (1u << 4)  /* run the OBB collision stage (planner.use_prediction) */
 #define FX_MODE_ROAD_BOUNDARY   (1u << 5)  /* test the ego footprint against the road boundary (planner.py:362-381) */
+/* (s, d) -> (x, y) offsets d along the UN-normalised interpolated vertex normal (d is a pseudo-distance) instead of along its
+ * unit vector -- the two readings of CCosy's construction differ by up to 7 mm on the ZAM_Tjunction route (DESIGN.md 4.1;
+ * tests/golden/pin_third_party.py decides which one the reference's CCosy is, once commonroad_dc is importable) */
+#define FX_MODE_PROJ_PSEUDO_NORMAL (1u << 6)
 
 /* longitudinal sampling mode.
  * FX_LON_VELOCITY_KEEPING: v_samp = sampled end velocities, quartic to (v, 0) -- _create_trajectory_bundle,
@@ -340,6 +344,9 @@ int32_t fx_plan_and_package(FxContext *ctx, const FxStateUpdate *upd, double yaw
  *      fx_build_obstacle_hulls_batch: fx_build_obstacle_hulls for K obstacles stored with stride P. */
 int32_t fx_cs_to_curvilinear(int32_t M, const double *ref_xy, const double *normals, const double *ref_pos, double x, double y,
                              double *sd /*[2]*/);
+/* the same with the projection variant spelled out: pseudo_normal != 0 inverts the FX_MODE_PROJ_PSEUDO_NORMAL map */
+int32_t fx_cs_to_curvilinear_ex(int32_t M, const double *ref_xy, const double *normals, const double *ref_pos, double x, double y,
+                                int32_t pseudo_normal, double *sd);
 /* n 2x2 matrices (row-major, 4 doubles each) inverted with the arithmetic of np.linalg.inv, bit for bit (collision_probability.py:281) */
 int32_t fx_invert_cov2(int32_t n, const double *m, double *out);
 /* K predicted obstacles -> the obstacle arrays of FxProblem / FxStateUpdate in one call (covariance inverses, hulls, padding

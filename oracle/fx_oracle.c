@@ -191,7 +191,7 @@ static int argmax_gt(const double *ref_pos, int M, double s) {
 }
 
 /* (s,d) -> (x,y): foot point on segment k at s, offset d along the normalised interpolated vertex
- * normal.  Returns 0 outside the projection domain [ref_pos[0], ref_pos[M-1]]. */
+ * normal (FX_MODE_PROJ_PSEUDO_NORMAL: along the interpolated normal itself).  Returns 0 outside the projection domain [ref_pos[0], ref_pos[M-1]]. */
 static int project_in(const FxProblem *p, double s, double d, double *x, double *y, int in_domain) {
     int M = p->M;
     if (!in_domain) return 0;
@@ -208,6 +208,11 @@ static int project_in(const FxProblem *p, double s, double d, double *x, double 
     double py = p->ref_y[k] + lam * (p->ref_y[k + 1] - p->ref_y[k]);
     double nx = p->ref_nx[k] + lam * (p->ref_nx[k + 1] - p->ref_nx[k]);
     double ny = p->ref_ny[k] + lam * (p->ref_ny[k + 1] - p->ref_ny[k]);
+    if (p->mode & FX_MODE_PROJ_PSEUDO_NORMAL) { /* d as a pseudo-distance along the un-normalised interpolated normal */
+        *x = px + d * nx;
+        *y = py + d * ny;
+        return 1;
+    }
     double nn = sqrt(nx * nx + ny * ny);
     *x = px + d * (nx / nn);
     *y = py + d * (ny / nn);

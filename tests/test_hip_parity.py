@@ -230,6 +230,14 @@ CASES = {
                               kinematic_debug=True),
     "stop_scurve_kd": dict(ref_kind="scurve", kappa=0.02, v0=9.0, grid=(7, 15, 17), stop_point_s=35.0, v_des=0.0,
                            kinematic_debug=True, seed=5),
+    # the other readings of CCosy's projection: d along the un-normalised interpolated normal
+    # (FX_MODE_PROJ_PSEUDO_NORMAL), vertex tangents from the bisector of the adjacent segments -- tight curve, jittered knots
+    "proj_pseudo_normal": dict(ref_kind="arc", kappa=0.05, knot_jitter=0.3, v0=8.0, grid=(7, 11, 13), n_obstacles=4,
+                               draw_traj_set=True, kinematic_debug=True, pseudo_normal=True),
+    "proj_pseudo_bisector_prod": dict(ref_kind="arc", kappa=0.05, knot_jitter=0.3, v0=8.0, grid=(7, 11, 13), n_obstacles=4,
+                                      pseudo_normal=True, vertex_tangent="bisector"),
+    "proj_bisector": dict(ref_kind="arc", kappa=0.05, knot_jitter=0.3, v0=8.0, grid=(7, 11, 13), n_obstacles=4,
+                          draw_traj_set=True, kinematic_debug=True, vertex_tangent="bisector"),
 }
 
 
@@ -245,6 +253,11 @@ def test_synthetic_cases_vs_oracle(eng, name):
     if name == "dense_prod_obs":
         # a meaningful share of otherwise-best candidates must collide
         assert out["collision"].sum() > 0
+    if name == "proj_pseudo_normal":
+        # the variant is not a no-op: against the default projection the (x, y) planes move by more than the north star's 1e-6 m
+        base = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **dict(kw, pseudo_normal=False)))
+        m = out["returned"] & out["costed"] & base["returned"] & base["costed"]
+        assert np.abs(out["planes"][m][:, :2] - base["planes"][m][:, :2]).max() > 1e-5
 
 
 @pytest.mark.parametrize("variant", [1, 2])

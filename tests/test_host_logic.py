@@ -67,9 +67,22 @@ def test_time_grid_and_traj_len_quirk():
     assert abs(a - 5 * 0.1 / 12) < 1e-15 and abs(b - 2 * 0.1 / 3) < 1e-15 and abs(e - 0.1 / 12) < 1e-15
 
 
+@pytest.mark.parametrize("variant", [dict(), dict(pseudo_normal=True), dict(vertex_tangent="bisector"),
+                                     dict(pseudo_normal=True, vertex_tangent="bisector")])
 @pytest.mark.parametrize("kind", ["straight", "arc", "scurve"])
-def test_coordinate_system_roundtrip(kind):
-    cs = CoordinateSystem(synthetic.reference_polyline(kind, 300, 0.5, 0.02))
+def test_coordinate_system_roundtrip(kind, variant):
+    """(s, d) -> (x, y) -> (s, d) for every reading of the projection: normalised / un-normalised interpolated
+    normal, chord / bisector vertex tangents; the forward map equals the formula it is documented with."""
+    ref = synthetic.reference_polyline(kind, 300, 0.5, 0.02, knot_jitter=0.0 if kind == "scurve" else 0.3)
+    cs = CoordinateSystem(ref, **variant)
+    k = 17
+    lam, d = 0.3, 2.0
+    n = cs.normals[k] + lam * (cs.normals[k + 1] - cs.normals[k])
+    if not variant.get("pseudo_normal"):
+        n = n / np.linalg.norm(n)
+    want = ref[k] + lam * (ref[k + 1] - ref[k]) + d * n
+    assert np.allclose(cs.convert_to_cartesian_coords(cs.ref_pos[k] + lam * (cs.ref_pos[k + 1] - cs.ref_pos[k]), d), want, atol=1e-12)
+    assert np.allclose(np.linalg.norm(cs.normals, axis=1), 1.0)
     rng = np.random.default_rng(3)
     for _ in range(200):
         s = rng.uniform(cs.ref_pos[2], cs.ref_pos[-3])
@@ -80,6 +93,8 @@ def test_coordinate_system_roundtrip(kind):
     assert cs.convert_to_cartesian_coords(cs.ref_pos[-1] + 1.0, 0.0) is None
     with pytest.raises(ValueError):
         CoordinateSystem(np.zeros((2, 2)))
+    with pytest.raises(ValueError):
+        CoordinateSystem(ref, vertex_tangent="secant")
 
 
 def test_initial_state_roundtrip():
