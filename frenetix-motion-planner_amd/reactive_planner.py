@@ -66,7 +66,12 @@ class PlannerConfig:
     sampling_min: int = 2
     sampling_max: int = 3
     emergency_mode: str = "stopping"
-    emergency_selection: bool = False  # C++ back-end only (reactive_planner_cpp.py:404-413); the Python back-end returns None
+    # C++ back-end's stopping-trajectory selection when nothing is collision-free (reactive_planner_cpp.py:404-413).  The Python
+    # back-end instead takes, at the LAST sampling level, the feasible trajectory with the lowest ego + obstacle risk
+    # (reactive_planner.py:262-269, set_risk_costs): the harm model behind that is out of scope, the hook is
+    # ReactivePlannerHip.set_fallback_selector / min_risk_selector below.  With neither configured a plan step whose feasible
+    # candidates all collide returns None (plus the standstill trajectory at v <= 0.1, reactive_planner.py:105-109).
+    emergency_selection: bool = False
     cost_weights: Dict[str, float] = field(default_factory=lambda: dict(DEFAULT_COST_WEIGHTS))
     draw_traj_set: bool = True       # debug.yaml:8
     kinematic_debug: bool = True     # debug.yaml:20
@@ -92,6 +97,7 @@ class ReactivePlannerHip:
         self._device = device
         self._engine = engine
         self.road_boundary_check = road_boundary_check
+        self.fallback_selector: Optional[Callable] = None   # last-level selection among colliding candidates (set_fallback_selector)
         self.road_boundary = None          # segments [n][4]; checked on the GPU (set_road_boundary)
         self._packed_boundary = None
         self.params_harm = {"log_reg": {"ignore_angle": {"const": -4.591, "speed": 0.185}}}  # configurations/harm_parameters.json
@@ -190,6 +196,24 @@ class ReactivePlannerHip:
     def set_cost_function(self, cost_weights):
         self.cost_weights = dict(cost_weights)
         self._weights_nz = None
+
+    def set_fallback_selector(self, selector: Optional[Callable]):
+        """What happens at the LAST sampling level when no feasible candidate is collision-free.  The reference's Python
+        back-end computes `set_risk_costs` for every feasible trajectory and returns
+        `sorted(feasible_trajectories, key=lambda traj: traj._ego_risk + traj._obst_risk)[0]` (reactive_planner.py:262-269).
+        `selector(feasible)` is called with the feasible trajectories in creation order -- a lazy sequence of TrajectorySample
+        views over the step's device results (valid and feasible, every one of them colliding) -- and returns the chosen
+        sample or None.  `min_risk_selector(risk)` builds the reference's rule from a per-trajectory risk function; the harm
+        model that computes the reference's risk is outside this package (out of scope)."""
+        self.fallback_selector = selector
+
+    @staticmethod
+    def min_risk_selector(risk: Callable[[TrajectorySample], float]) -> Callable:
+        """sorted(feasible, key=risk)[0] -- the first trajectory of the lowest risk, in creation order (Python's sort is stable,
+        so this is min() over the sequence)."""
+        def select(feasible):
+            return min(feasible, key=risk) if len(feasible) else None
+        return select
 
     def set_road_boundary(self, segments):
         """Road boundary as straight segments [n][4] = (ax, ay, bx, by) (planner.py:550-565 builds it once per
@@ -315,7 +339,7 @@ class ReactivePlannerHip:
         """Take this planner's share of a batched launch (first sampling level); returns the chosen trajectory
         (materialised -- the batch engine's buffers are reused) or None when the level has to escalate."""
         package = engine.package(agent, self.x_0.yaw_rate) if getattr(engine, "packaging", False) else None
-        best = self._consume_result(inputs, res, engine, agent, package)
+        best = self._consume_result(inputs, res, engine, agent, package, self._sampling_min)
         if best is not None:
             best.materialise()
         return best
@@ -401,9 +425,21 @@ class ReactivePlannerHip:
             res, pkg = self.engine.plan_step_packaged(inputs, self.x_0.yaw_rate)
         else:
             res = self.engine.plan_step(inputs)
-        return self._consume_result(inputs, res, self.engine, 0, pkg)
+        return self._consume_result(inputs, res, self.engine, 0, pkg, samp_lvl)
 
-    def _consume_result(self, inputs: PlanInputs, res: dict, engine, agent: int, package=None):
+    def _fallback(self, step, samp_lvl):
+        """reactive_planner.py:262-269: last level, nothing collision-free, feasible trajectories exist -> the selector's choice"""
+        if self.fallback_selector is None or samp_lvl is None or samp_lvl < self._sampling_max - 1:
+            return None
+        ids = np.nonzero(step.mask(_abi.FX_FLAG_VALID) & step.mask(_abi.FX_FLAG_FEASIBLE) & step.mask(_abi.FX_FLAG_RETURNED))[0]
+        if len(ids) == 0:
+            return None
+        chosen = self.fallback_selector(_LazySamples(step, ids))
+        if chosen is not None:
+            self.msg_logger.warning("No optimal trajectory available. Select lowest risk trajectory!")
+        return chosen
+
+    def _consume_result(self, inputs: PlanInputs, res: dict, engine, agent: int, package=None, samp_lvl=None):
         if self.last_step is not None:
             self.last_step.invalidate()
         step = PlanStepResult(engine, inputs, res, agent)
@@ -420,7 +456,9 @@ class ReactivePlannerHip:
         if self._draw_traj_set or self.save_all_traj:
             self.all_traj = _LazySortedList(step)
         best = step.best
-        if best is None or self.road_boundary_check is None:
+        if best is None:
+            return self._fallback(step, samp_lvl)
+        if self.road_boundary_check is None:
             return best
         # host-side walk over the GPU's survivors for checks that stay on the host (planner.py:362-390)
         _, idx = engine.topk(self.config.survivors)
@@ -433,7 +471,7 @@ class ReactivePlannerHip:
             cand._coll_detected = False
             if harm == 0:
                 return cand
-        return None
+        return self._fallback(step, samp_lvl)
 
     # ------------------------------------------------------------------ standstill (reactive_planner.py:579-626)
     def _compute_standstill_trajectory(self) -> StandstillSample:
@@ -598,6 +636,26 @@ class _LazySortedList:
 
     def __iter__(self):
         for g in self._order():
+            yield self._step.sample(int(g))
+
+
+class _LazySamples:
+    """A fixed list of candidates of one step as TrajectorySample views, created on demand (the fallback selector's argument:
+    the feasible trajectories in creation order)."""
+
+    def __init__(self, step: PlanStepResult, ids):
+        self._step, self._ids = step, np.asarray(ids)
+
+    def __len__(self):
+        return len(self._ids)
+
+    def __getitem__(self, j):
+        if isinstance(j, slice):
+            return [self._step.sample(int(g)) for g in self._ids[j]]
+        return self._step.sample(int(self._ids[j]))
+
+    def __iter__(self):
+        for g in self._ids:
             yield self._step.sample(int(g))
 
 

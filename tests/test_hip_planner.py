@@ -263,3 +263,25 @@ def test_scenario_file_to_plan(tmp_path):
     x = np.array([st.position[0] for st in pair[0]])
     assert np.all(np.diff(x) > 0) and abs(pair[0][0].position[1] - 0.2) < 1e-9
     rp.close()
+
+
+def test_last_level_fallback_selector_on_the_engine():
+    """The Python back-end's last-level selection among colliding feasible trajectories (reactive_planner.py:262-269) through the
+    hook, on the real engine: same choice as on the oracle-backed stand-in."""
+    from frenetix_motion_planner_amd.reactive_planner import ReactivePlannerHip
+    from tests.test_planner_host import blocked_planner
+
+    def risk(tr):
+        sp = tr.sampling_parameters
+        return round(abs(sp[10]), 3) + sp[5] / 100.0
+
+    got = []
+    for engine in (None, "oracle"):
+        rp = blocked_planner(engine=engine, sampling_min=1, sampling_max=3)
+        rp.set_fallback_selector(ReactivePlannerHip.min_risk_selector(risk))
+        pair = rp.plan()
+        best = rp.optimal_trajectory
+        assert pair is not None and best is not None and rp.last_step.result["best_index"] == -1
+        got.append((best.uniqueId, rp.last_step.result["n_collisions"], rp.last_step.result["n_feasible"]))
+        rp.close()
+    assert got[0] == got[1] and got[0][1] == got[0][2] > 0

@@ -9,9 +9,10 @@ from frenetix_motion_planner_amd.reactive_planner import PlannerConfig, Reactive
 from tests.oracle_engine import OracleEngine
 
 
-def blocked_planner(**cfg):
-    """An ego whose every candidate collides: one wide obstacle parked across the lane right in front of it."""
-    rp = ReactivePlannerHip(PlannerConfig(**cfg), VehicleParams(), engine=OracleEngine())
+def blocked_planner(engine="oracle", **cfg):
+    """An ego whose every candidate collides: one wide obstacle parked across the lane right in front of it.
+    engine: "oracle" (CPU stand-in) or None (the planner creates its FrenetEngine: GPU tests)."""
+    rp = ReactivePlannerHip(PlannerConfig(**cfg), VehicleParams(), engine=OracleEngine() if engine == "oracle" else engine)
     ref = synthetic.reference_polyline("straight", 400, 0.5)
     x0 = ReactivePlannerState(time_step=0, position=np.array([20.0, 0.2]), orientation=0.0, velocity=8.0)
     n = 31
@@ -48,6 +49,45 @@ def test_emergency_stopping_selection():
     # the Python back-end's behaviour (no emergency selection): no trajectory
     rp2 = blocked_planner()
     assert rp2.plan() is None and rp2.optimal_trajectory is None
+
+
+def test_last_level_fallback_selector_min_risk():
+    """reactive_planner.py:262-269: at the LAST sampling level, when every feasible trajectory collides, the Python back-end
+    returns sorted(feasible, key=ego risk + obstacle risk)[0].  The hook gets the feasible trajectories in creation order; with a
+    toy risk function (|lateral end offset| + end velocity / 100) the choice equals the restated rule, ties go to the first."""
+    calls = []
+
+    def risk(tr):
+        sp = tr.sampling_parameters
+        return round(abs(sp[10]), 3) + sp[5] / 100.0
+
+    rp = blocked_planner(sampling_min=1, sampling_max=3)   # levels 1 and 2: the hook may only fire at level 2
+    sel = ReactivePlannerHip.min_risk_selector(risk)
+
+    def selector(feasible):
+        calls.append((rp.last_step.inputs.n_candidates, len(feasible)))
+        return sel(feasible)
+
+    rp.set_fallback_selector(selector)
+    pair = rp.plan()
+    step = rp.last_step
+    assert len(calls) == 1 and calls[0][0] == step.inputs.n_candidates   # once, on the last level's step
+    assert step.result["best_index"] == -1 and step.result["n_collisions"] == step.result["n_feasible"] == calls[0][1] > 0
+    feas = [step.sample(int(g)) for g in np.nonzero(step.mask(_abi.FX_FLAG_FEASIBLE) & step.mask(_abi.FX_FLAG_VALID) &
+                                                    step.mask(_abi.FX_FLAG_RETURNED))[0]]
+    want = sorted(feas, key=risk)[0]
+    best = rp.optimal_trajectory
+    assert pair is not None and best is not None and best.uniqueId == want.uniqueId and best.feasible
+    assert len(pair[0]) == rp.N + 1
+    # the batched path's phases take the same decision (single-level planner: the first level is the last)
+    rp1 = blocked_planner(sampling_min=2, sampling_max=3)
+    rp1.set_fallback_selector(ReactivePlannerHip.min_risk_selector(risk))
+    inp = rp1.plan_begin()
+    res = rp1.engine.plan_batch([inp])[0]
+    best1 = rp1.plan_consume(inp, res, rp1.engine, 0)
+    assert best1 is not None and best1.uniqueId == want.uniqueId
+    # without a selector (and without the C++ back-end's emergency selection) the step has no trajectory
+    assert blocked_planner(sampling_min=1, sampling_max=3).plan() is None
 
 
 def test_plan_phases_equal_plan():
