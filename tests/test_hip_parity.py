@@ -28,7 +28,11 @@ PARITY_STATS = dict(checked=0, fixed=0, scaled=0, escaped=0, fragile=0)
 WELL_CONDITIONED = 1e3
 MAX_ESCAPED_FRACTION = 1e-2     # per compare(): at most this share of the stored candidates (or 2 of them) asserted to magnitude only
 #                                 (a (t, v) pair that drives backwards from standstill in LOW_VEL_MODE takes its ~10 lateral siblings along:
-#                                 tools/dbg_escaped.py on soak case 920156: 9 of 1 260, d' = 1e16, v = 1e29); the soak bounds the total at 5e-4
+#                                 tools/soak_case.py, round-3 soak case 920156: 9 of 1 260, d' = 1e16, v = 1e29): the bound is on such PAIRS per case; the soak bounds the
+#                                 candidates of a whole run at 5e-4
+# raw cost terms formed from the planes that divide by cos(theta_cl) (v, a): conditioning-scaled tolerance; all others fixed
+KINEMATIC_COSTS = ("velocity_offset", "acceleration", "jerk", "path_length")
+NO_LEADING_DIGIT = 1e15         # conditioning from which cos(theta_cl) has not even a leading digit (1 / eps = 4.5e15)
 MAGNITUDE_DECADES = 4.0         # what "order of magnitude" means for those planes: peak |value| within 10^+-4 of the oracle's, finite alike
 
 
@@ -93,11 +97,25 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
         assert (err[wellc] < 1.05 * COST_RTOL * np.maximum(np.abs(out["cost"][c][wellc]), 1e-12)).all(), \
             "cost of a well-conditioned candidate beyond 1e-9 relative"
         if cm is not None:
+            # raw terms: only those built on the planes that divide by cos(theta_cl) -- v and a -- get the conditioning-scaled
+            # tolerance; every other term (jerk integrals of the coefficients, |d|, the prediction term on (x, y), theta_cl
+            # itself) is held to the fixed 1e-8 whatever the candidate's conditioning.  Where the scaled relative tolerance
+            # reaches 1 the reference's own term carries no digit (theta_cl = pi/2 to the last bit: v = x / cos with cos =
+            # rounding noise, 1e15 m/s) and only finiteness is compared, as for the planes of such a candidate (found by the
+            # round-4 soak, case 801049: velocity_offset 1.2e20 against 8.4e15 at a conditioning of 1.6e16, every other term
+            # of the same candidate equal to 3e-16)
             errm = np.abs(cm[c] - out["costmap"][c])
-            limm = (1e-8 + 4e-14 * cond_kin[c][:, None]) * np.maximum(np.abs(out["costmap"][c]), 1e-9)
+            kin_cols = np.array([n in KINEMATIC_COSTS for n in inp.cost_names])
+            rtolm = np.full(errm.shape, 1e-8)
+            rtolm[:, kin_cols] += 4e-14 * cond_kin[c][:, None]
+            limm = rtolm * np.maximum(np.abs(out["costmap"][c]), 1e-9)
             if j_pl is not None:
                 limm[:, j_pl] += slack[c]
-            assert (errm < limm).all(), f"costmap rel err {(errm / np.maximum(np.abs(out['costmap'][c]), 1e-9)).max()}"
+            no_digit = rtolm >= 1.0
+            assert np.array_equal(np.isfinite(cm[c][no_digit]), np.isfinite(out["costmap"][c][no_digit])), \
+                "a cost term without digits is finite on one side only"
+            bad_m = (errm >= limm) & ~no_digit
+            assert not bad_m.any(), f"costmap rel err {(errm / np.maximum(np.abs(out['costmap'][c]), 1e-9))[bad_m].max()}"
     # winner: identical unless a fragile candidate or a sub-tolerance cost gap is involved
     if res["best_index"] != ref["best_index"]:
         a, b = res["best_index"], ref["best_index"]
@@ -129,15 +147,29 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
             pk_ref, pk_dev = np.abs(refp).max(axis=2)[esc_planes], np.abs(got).max(axis=2)[esc_planes]
             fin = np.isfinite(pk_ref)
             assert np.array_equal(np.isfinite(pk_dev), fin), "a plane without digits is finite on one side only"
+            # the order of magnitude is compared while cos(theta_cl) still has a leading digit; at a conditioning of 1 / eps
+            # (theta_cl = pi/2 to the LAST bit: the cosine is rounding noise of either libm, 6e-17 or 1e-16 or 0) the quotient's
+            # magnitude is arbitrary too and only finiteness is left (round-4 soak, case 801049: conditioning 1.6e16, v = 7e15
+            # against 3e9 m/s)
+            lead = (np.repeat(cond_kin[:, None], esc_planes.shape[1], axis=1)[esc_planes] < NO_LEADING_DIGIT)[fin]
             dec = np.abs(np.log10(np.maximum(pk_dev[fin], 1e-300) / np.maximum(pk_ref[fin], 1e-300)))
-            assert (dec < MAGNITUDE_DECADES).all(), f"a plane without digits differs by {dec.max():.1f} decades"
+            assert (dec[lead] < MAGNITUDE_DECADES).all(), f"a plane without digits differs by {dec[lead].max():.1f} decades"
         escaped = esc_planes.any(axis=1)
         PARITY_STATS["checked"] += int(stored.sum())
         PARITY_STATS["fixed"] += int(well.sum())
         PARITY_STATS["scaled"] += int((stored & ~well).sum())
         PARITY_STATS["escaped"] += int(escaped.sum())
-        assert escaped.sum() <= max(2, MAX_ESCAPED_FRACTION * stored.sum()), \
-            f"{int(escaped.sum())} of {int(stored.sum())} candidates have a plane whose tolerance reached 1 (magnitude only)"
+        # per case: a degenerate (t, v) pair takes its lateral siblings along (the ego rolls backwards from standstill in
+        # LOW_VEL_MODE: ds/dt = 0 to the last bit at some step, every d of the pair hits theta_cl = pi/2 there), so what is
+        # bounded per case is the number of such PAIRS; the number of candidates stays bounded over a whole run
+        # (tests/test_soak_parity.py, tools/soak_parity.py: <= 5e-4 of everything checked)
+        if inp.sampling_matrix is None:
+            n_groups = len(set((np.nonzero(escaped)[0] // len(inp.d_samp)).tolist()))
+        else:   # rows of the C x 13 matrix: (t1, ss1) identify the longitudinal polynomial
+            rows = inp.sampling_matrix[np.nonzero(escaped)[0]]
+            n_groups = len(set(zip(rows[:, 1].tolist(), rows[:, 5].tolist())))
+        assert n_groups <= max(2, MAX_ESCAPED_FRACTION * stored.sum()), \
+            f"{int(escaped.sum())} of {int(stored.sum())} candidates in {n_groups} (t, v) pairs have a plane whose tolerance reached 1 (magnitude only)"
         # coefficients / traj_len of a few candidates
         for g in np.linspace(0, inp.n_candidates - 1, 5).astype(int):
             lon, lat, tl = eng.coeffs(int(g), agent)

@@ -1,44 +1,54 @@
 #!/bin/bash
-# usage (GPU box, repo root): bash tools/collect_profiles.sh <label>
-# Runs the headline bench (config2 Mode B with cpu_baseline, Mode A, config3), a rocprofv3 kernel-trace of the
-# same bench command and separate PMC passes (FETCH_SIZE, WRITE_SIZE, an SQ group), then writes the summaries
-# to gpurun_out/<label>/ (copy the ones to be judged into profiles/).
-label=${1:-final}
+# usage (GPU box, repo root): bash tools/collect_profiles.sh [label]
+# rocprofv3 evidence for the bench line: kernel-trace stats of the default bench command and separate PMC passes (no trace
+# domain combined with --pmc) for every fx_* kernel of the workloads the line reports.  Writes gpurun_out/<label>/summary.json
+# (+ kernel_stats.csv); copy both into profiles/r<round>/ to have bench.py read them.  Per section the summary holds
+# "kernels": {<kernel name as rocprofv3 prints it>: {counter: mean per launch}} -- bench.py looks a kernel up by the name
+# fx_step_info_ex reports and marks its figures "stale" when the summary holds another specialisation.
+label=${1:-prof}
 R=$(pwd); O=$R/gpurun_out/$label; mkdir -p $O
 export TMPDIR=/tmp
-python3 bench.py --steps 300 --warmup 30 > $O/bench_config2_modeB.json 2> $O/bench_config2_modeB.err
-python3 bench.py --steps 300 --warmup 30 --select-only --no-cpu-baseline > $O/bench_config2_modeA.json 2>/dev/null
-python3 bench.py --steps 200 --warmup 20 --workload config3 > $O/bench_config3.json 2>/dev/null
-python3 bench.py --steps 30 --warmup 3 --workload config5 > $O/bench_config5.json 2>/dev/null
-python3 bench.py --steps 60 --warmup 6 --workload config4 > $O/bench_config4.json 2>/dev/null
-python3 bench.py --steps 300 --warmup 30 --workload config1 > $O/bench_config1.json 2>/dev/null
-python3 tools/e2e_step.py > $O/e2e_step.json 2>/dev/null
-python3 tools/obst_split.py > $O/obst_split.txt 2>/dev/null
-BENCH="python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline"
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH > $O/stats.log 2>&1)
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" \
-           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
-  n=$(echo $grp | tr ' ' '_' | cut -c1-24)
-  (cd /tmp && rocprofv3 --pmc $grp --output-format csv -d $O/pmc_$n -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/pmc_$n.log 2>&1)
+BENCH="python3 $R/bench.py --no-cpu-baseline"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH --steps 200 --warmup 20 > $O/stats.log 2>&1)
+declare -A CMD
+CMD[config3_modeB]="$R/tools/run_bench_workload.py config3 20"
+CMD[config2_modeB]="$R/tools/run_bench_workload.py config2 20"
+CMD[north_star_obstacles]="$R/tools/run_bench_workload.py north_star_obstacles 8"
+CMD[north_star_bundle]="$R/tools/run_bench_workload.py north_star_bundle 8"
+CMD[config5_modeA]="$R/bench.py --workload config5 --agents-per-gpu 32 --steps 4 --warmup 1 --no-cpu-baseline --preheat 0"
+GROUPS_PMC=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM")
+for sec in config3_modeB config2_modeB north_star_obstacles north_star_bundle config5_modeA; do
+  i=0
+  for grp in "${GROUPS_PMC[@]}"; do
+    (cd /tmp && rocprofv3 --pmc $grp --output-format csv -d $O/pmc_${sec}_$i -- python3 ${CMD[$sec]} > $O/pmc_${sec}_$i.log 2>&1)
+    i=$((i+1))
+  done
 done
 python3 - <<PY
 import csv, glob, json, collections
 O = "$O"
-out = {"command": "python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline (PMC passes: --steps 20 --warmup 5)"}
+out = {"kernel_stats_command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 200 --warmup 20"}
 rows = []
 for f in glob.glob(O + "/stats/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     open(O + "/kernel_stats.csv", "w").write(open(f).read())
 out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev") if k in r}
-                       for r in rows if r["Name"].startswith("fx_") or "fx_" in r["Name"]]
-agg = collections.defaultdict(list)
-for f in glob.glob(O + "/pmc_*/**/*_counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "fx_eval" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            out["pmc_kernel"] = r["Kernel_Name"]
-out["pmc_per_launch_mean"] = {c: sum(v) / len(v) for c, v in sorted(agg.items())}
-out["pmc_launches"] = {c: len(v) for c, v in sorted(agg.items())}
+                       for r in rows if "fx_" in r["Name"]]
+cmds = {"config3_modeB": "python3 tools/run_bench_workload.py config3 20", "config2_modeB": "python3 tools/run_bench_workload.py config2 20",
+        "north_star_obstacles": "python3 tools/run_bench_workload.py north_star_obstacles 8",
+        "north_star_bundle": "python3 tools/run_bench_workload.py north_star_bundle 8",
+        "config5_modeA": "python3 bench.py --workload config5 --agents-per-gpu 32 --steps 4 --warmup 1 --no-cpu-baseline --preheat 0"}
+for sec, cmd in cmds.items():
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(O + f"/pmc_{sec}_*/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "fx_eval" in k or "fx_obstacle" in k or "fx_select" in k:
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out[sec] = {"command": "rocprofv3 --pmc <group> -- " + cmd + "  (one pass per counter group)",
+                "kernels": {k: {c: sum(v) / len(v) for c, v in sorted(d.items())} for k, d in agg.items()},
+                "launches": {k: {c: len(v) for c, v in sorted(d.items())} for k, d in agg.items()}}
+out["config5_modeA"]["units_per_launch"] = 32   # agents per launch of that command (bench.py scales the counts to its own)
 json.dump(out, open(O + "/summary.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
+print(json.dumps({k: (v if k == "kernel_stats" else list(v.get("kernels", {})) if isinstance(v, dict) else v) for k, v in out.items()}, indent=1)[:4000])
 PY

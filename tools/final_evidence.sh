@@ -1,7 +1,17 @@
 #!/bin/bash
-# the bench lines and measurement tools of tools/r3_final.sh without the rocprofv3 collection (profiles/r3/summary.json stays)
+# The round's evidence on ONE box: usage tools/final_evidence.sh <round, e.g. r4> [--no-profiles]
+# rocprofv3 kernel-trace stats + per-kernel PMC passes (tools/collect_profiles.sh), then the bench lines of every workload and the
+# small measurement tools; everything lands in gpurun_out/<round>final -- copy what is judged into profiles/<round>/.
 cd $GRAFT_REPO_ROOT 2>/dev/null || true
-O=gpurun_out/r3final; mkdir -p $O
+R=${1:-r4}
+O=gpurun_out/${R}final; mkdir -p $O profiles/$R
+if [ "$2" != "--no-profiles" ]; then
+  bash tools/collect_profiles.sh ${R}final_prof > $O/collect.log 2>&1
+  tail -3 $O/collect.log
+  cp gpurun_out/${R}final_prof/summary.json profiles/$R/summary.json      # bench.py reads the PMC figures of THIS build
+  cp gpurun_out/${R}final_prof/kernel_stats.csv profiles/$R/kernel_stats.csv
+  cp gpurun_out/${R}final_prof/summary.json gpurun_out/${R}final_prof/kernel_stats.csv $O/
+fi
 timeout 900 python bench.py > $O/bench_config3.json 2>$O/bench_config3.err
 timeout 600 python bench.py --workload config2 --no-north-star > $O/bench_config2.json 2>/dev/null
 timeout 600 python bench.py --workload config2 --select-only --no-north-star --no-cpu-baseline > $O/bench_config2_modeA.json 2>/dev/null
@@ -14,4 +24,6 @@ timeout 300 python tools/closed_loop_timing.py 2>&1 | grep level > $O/closed_loo
 timeout 300 python tools/closed_loop_segments.py 2>&1 | grep -v amdgpu > $O/closed_loop_segments.txt
 timeout 300 python tools/seg_config4.py 2>&1 | grep -v amdgpu > $O/config4_segments.txt
 timeout 300 python tools/adapter_matrix_timing.py 2>&1 | grep -v amdgpu > $O/adapter_matrix.txt
-ls $O | wc -l
+FX_SPLIT_STEPS=2,3,5 timeout 600 python tools/c3_split.py c3B c5B c4 m1oB 2>&1 | grep -v amdgpu | grep -v '^{' > $O/obstacle_stage_ab.txt
+timeout 300 python tools/cull_stats.py m1o c5 c3A sparse 2>&1 | grep -v amdgpu > $O/cull_stats.txt || true
+ls -la $O

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""One case of tools/soak_parity.py, with what a failure needs to be understood: the candidates whose planes carry no digit
+(tolerance >= 1: count, their (t, v) pairs, conditioning) and, for cost / cost-map disagreements, the offending candidates with
+their conditioning and terms.  usage: [FX_SOAK_*=..] python tools/soak_case.py <case>"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from frenetix_motion_planner_amd import synthetic, _abi
+from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+from oracle import oracle
+from tests.test_hip_parity import _random_case, compare, FRAGILE, STATE_TOL
+from tests.admissible import conditioning_many, kinematic_conditioning_many
+
+case = int(sys.argv[1])
+rng = np.random.default_rng([20241008, case])
+kw = _random_case(rng)
+if os.environ.get("FX_SOAK_MANY"):
+    kw["n_obstacles"] = int(rng.integers(9, 49)) if os.environ["FX_SOAK_MANY"] != "2" else int(rng.integers(49, 257))
+    if "grid" in kw:
+        kw["grid"] = (min(kw["grid"][0], 4), kw["grid"][1], kw["grid"][2])
+if os.environ.get("FX_SOAK_COSTS"):
+    from frenetix_motion_planner_amd._abi import COST_NAMES
+    w = {n: float(rng.uniform(0.1, 5.0)) for n in COST_NAMES if rng.uniform() < 0.5}
+    kw["cost_weights"] = w or {"lateral_jerk": 1.0}
+if os.environ.get("FX_SOAK_MATRIX") and "stop_point_s" not in kw:
+    kw["as_matrix"] = True
+print(kw)
+inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
+out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
+with FrenetEngine(max_candidates=max(inp.n_candidates, 64), max_steps=inp.N, max_pred_steps=max(64, inp.N + 2), max_obstacles=256) as e:
+    res = e.plan_step(inp)
+    cost, flags = e.costs()
+    cm = e.costmap() if inp.write_costmap and len(inp.cost_names) else None
+    try:
+        compare(e, inp, out, res)
+        print("compare: ok")
+    except AssertionError as ex:
+        print("compare FAILED:", ex)
+cond, ck = conditioning_many(out["planes"]), kinematic_conditioning_many(out["planes"])
+robust = out["margin"] >= FRAGILE
+stored = out["returned"] & robust & (out["costed"] | inp.draw_traj_set)
+tol = STATE_TOL + 2e-14 * ck
+esc = stored & (tol >= 1.0)
+nD = len(inp.d_samp) if inp.sampling_matrix is None else 1
+print(f"{inp.n_candidates} candidates, {int(stored.sum())} stored, {int(esc.sum())} with a kinematic tolerance >= 1; their (t, v) pairs: "
+      f"{sorted(set((np.nonzero(esc)[0] // max(nD, 1)).tolist()))}; low_vel_mode {inp.low_vel_mode}, v0 {kw.get('v0')}")
+for g in np.nonzero(esc)[0][:8]:
+    print(f"   candidate {g}: conditioning {ck[g]:.3e}, peak |theta_cl| {np.abs(out['planes'][g, 9]).max():.6f}, peak |v| {np.abs(out['planes'][g, 3]).max():.3e}")
+if cm is not None:
+    c = out["costed"] & robust & ((flags & _abi.FX_FLAG_COSTED) != 0)
+    rel = np.abs(cm - out["costmap"]) / np.maximum(np.abs(out["costmap"]), 1e-9)
+    rel[~c] = 0
+    g, j = np.unravel_index(np.argmax(rel), rel.shape)
+    print(f"largest cost-map disagreement: candidate {g} term {inp.cost_names[j]}: device {cm[g, j]!r} oracle {out['costmap'][g, j]!r} rel {rel[g, j]:.3e}; "
+          f"kinematic conditioning {ck[g]:.3e}; cost device {cost[g]!r} oracle {out['cost'][g]!r}")
+    print("   the candidate's terms (device | oracle):", {n: (float(cm[g, k]), float(out["costmap"][g, k])) for k, n in enumerate(inp.cost_names)})

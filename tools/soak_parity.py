@@ -26,6 +26,11 @@ for case in range(first, first + n):
         kw["cost_weights"] = w or {"lateral_jerk": 1.0}
     if os.environ.get("FX_SOAK_MATRIX") and "stop_point_s" not in kw:   # the adapter's C x 13 sampling matrix
         kw["as_matrix"] = True
+    if os.environ.get("FX_SOAK_PROJ"):   # the other readings of the projection on jittered knots
+        kw["pseudo_normal"] = bool(rng.integers(0, 2))
+        kw["vertex_tangent"] = "bisector" if rng.integers(0, 2) else "chord"
+        if kw.get("ref_kind", "arc") != "scurve":
+            kw["knot_jitter"] = 0.3
     try:
         inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
         out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
@@ -45,6 +50,17 @@ for case in range(first, first + n):
             else:
                 res = e.plan_step(inp)
             compare(e, inp, out, res)
+            if os.environ.get("FX_SOAK_TOPK"):   # the k best collision-free candidates against NumPy on the engine's own costs / flags
+                from frenetix_motion_planner_amd import _abi
+                k = int(rng.integers(1, 65))
+                tc, ti = e.topk(k)
+                cost, flags = e.costs()
+                ok = ((flags & _abi.FX_FLAG_SELECTABLE) != 0) & ((flags & (_abi.FX_FLAG_COLLISION | _abi.FX_FLAG_BOUNDARY)) == 0) & ~np.isnan(cost)
+                ids = np.nonzero(ok)[0]
+                order = ids[np.lexsort((ids, cost[ids]))][:k]
+                assert list(ti[0][:len(order)]) == list(order + inp.shard_begin) and np.all(ti[0][len(order):] == -1), ("topk", k)
+                assert np.array_equal(tc[0][:len(order)], cost[order])
+                stats["topk"] = stats.get("topk", 0) + 1
             robust = bool(np.all(out["margin"] >= FRAGILE))
             if robust:
                 assert res["best_index"] == out["result"]["best_index"], (res["best_index"], out["result"]["best_index"])
