@@ -32,7 +32,7 @@ import numpy as np
 from .commonroad_xml import GoalState, PlanningProblem, Scenario, State
 from .distributed import hybrid_assignment, merge_agent_parts, shard_range
 from .frenet_interface import FrenetPlannerInterfaceHip
-from .problem import VehicleParams
+from .problem import PackedPredictions, VehicleParams, pack_predictions
 from .reactive_planner import PlannerConfig
 
 
@@ -231,6 +231,8 @@ class MultiAgentSimulation:
         self.plans = np.zeros((len(self.agent_ids), self.S, self.FIELDS))
         self.history: Dict[int, list] = {i: [] for i in self.agent_ids}
         self._shared = None
+        self._shared_packed = None
+        self.shared_packing = True   # predictions packed once per step for all agents (packed_predictions_for)
         self._cov_tiles: Dict[int, np.ndarray] = {}
 
     def _cfg(self) -> PlannerConfig:
@@ -270,6 +272,37 @@ class MultiAgentSimulation:
                     own[aid] = gt
         self._shared = (t, base, own)
         return base, own
+
+    def packed_predictions_for(self, agent_id: int):
+        """The same predictions as `predictions_for`, packed: ALL entries of the step (non-agent obstacles, then the agents in
+        order) are packed once -- covariance inverses and OBB-sum hulls included -- and every agent takes the rows without its
+        own.  Identical arrays to packing the agent's dict on its own, except that the stored prediction length P is the
+        step's longest instead of the longest among the agent's entries (padding only)."""
+        t = self.time_step
+        sh = getattr(self, "_shared_packed", None)
+        if sh is None or sh[0] != t:
+            base, own = self._shared_predictions()
+            allp = dict(base)
+            for aid in self.agent_ids:
+                if aid in own:
+                    allp[aid] = own[aid]
+            keys = list(allp)
+            packed = pack_predictions(allp, self.S, self._hull_builder()) if allp else None
+            sh = self._shared_packed = (t, keys, packed)
+        _, keys, packed = sh
+        if packed is None:
+            return PackedPredictions(PackedPredictions.subset({}, []), lambda: {})
+        rows = [j for j, k in enumerate(keys) if k != agent_id]
+        return PackedPredictions(PackedPredictions.subset(packed, rows), lambda: self.predictions_for(agent_id))
+
+    def _hull_builder(self):
+        """what the agents' own planners pack with: the engine library's host geometry, or the engine object's own builder
+        (tests inject an oracle-backed engine)"""
+        hb = getattr(self.batch.engine, "hull_builder", None)
+        if hb is not None:
+            return hb
+        from .engine import build_obstacle_hulls
+        return build_obstacle_hulls
 
     def predictions_for(self, agent_id: int) -> dict:
         base, own = self._shared_predictions()
@@ -320,7 +353,8 @@ class MultiAgentSimulation:
     def step(self) -> Dict[int, Optional[list]]:
         """One simulation step of every agent (simulation.py:621-663 + agent_batch.py:140-189)."""
         # predictions are only read by agents that replan in this step (two of three steps just advance, :261-277)
-        preds = {a.id: self.predictions_for(a.id) for a in self.batch.agents if a.needs_plan()}
+        preds = {a.id: (self.packed_predictions_for(a.id) if self.shared_packing else self.predictions_for(a.id))
+                 for a in self.batch.agents if a.needs_plan()}
         selected = self.batch.step(self.time_step, preds)
         local = np.zeros((len(self.batch.agents), self.S, self.FIELDS))
         for j, a in enumerate(self.batch.agents):

@@ -90,6 +90,60 @@ _COST_MEMO: dict = {}   # id(weights dict) -> (the dict, (len, sum of values), (
 MAX_OBSTACLES = 256  # obstacles per agent (FX_MAX_OBSTACLES; beyond 64 the step runs on the generic kernel)
 
 
+class PackedPredictions:
+    """Predictions that arrive packed (the arrays `pack_predictions` produces) together with a way to build the reference's
+    dict form on demand.  A batch of agents shares almost all of its predictions -- everything but the agent itself -- so the
+    simulation packs ALL entries once per step (covariance inverses, OBB-sum hulls) and hands every agent the rows without its
+    own (`subset`): a few fancy-index copies instead of a dict walk, inversions and hull building per agent.  Behaves like the
+    dict for whoever reads it (the logger: `items()`, `len`, truthiness); the dict is built at the first such access."""
+
+    def __init__(self, packed: dict, make_dict=None):
+        self.packed = packed
+        self._make, self._dict = make_dict, None
+
+    @staticmethod
+    def subset(packed: dict, rows) -> dict:
+        """the packed arrays of the obstacles `rows` (in that order) of `packed`"""
+        rows = np.asarray(rows, dtype=np.intp)
+        if len(rows) == 0:
+            z = np.zeros(0)
+            return dict(K=0, P=0, pos=z, cov_inv=z, npred=np.zeros(0, np.int32), hull=z, nhull=np.zeros(0, np.int32))
+        return dict(K=len(rows), P=packed["P"], pos=packed["pos"][rows], cov_inv=packed["cov_inv"][rows], npred=packed["npred"][rows],
+                    hull=packed["hull"][rows], nhull=packed["nhull"][rows])
+
+    def as_dict(self) -> dict:
+        if self._dict is None:
+            self._dict = self._make() if self._make is not None else {}
+        return self._dict
+
+    def __len__(self):
+        return int(self.packed["K"])
+
+    def __bool__(self):
+        return int(self.packed["K"]) > 0
+
+    def __iter__(self):
+        return iter(self.as_dict())
+
+    def __getitem__(self, k):
+        return self.as_dict()[k]
+
+    def __contains__(self, k):
+        return k in self.as_dict()
+
+    def keys(self):
+        return self.as_dict().keys()
+
+    def items(self):
+        return self.as_dict().items()
+
+    def values(self):
+        return self.as_dict().values()
+
+    def get(self, k, default=None):
+        return self.as_dict().get(k, default)
+
+
 def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
     """predictions dict {id: {'pos_list' [P,2], 'cov_list' [P,2,2], 'orientation_list' [P],
     'shape': {'length','width'}}} (prediction_helpers.py:209-261) -> packed arrays.
@@ -98,6 +152,8 @@ def pack_predictions(predictions: Optional[Dict], n_samples: int, build_hulls):
     cov is inverted with np.linalg.inv exactly like :281.  build_hulls(n, pos, yaw, L, W) returns the
     OBB-sum hulls [n-1, 6] (fx_build_obstacle_hulls).  Collision uses the first min(S, P_k)
     predictions (collision_check.py:150)."""
+    if isinstance(predictions, PackedPredictions):
+        return predictions.packed
     if not predictions:
         z = np.zeros(0)
         return dict(K=0, P=0, pos=z, cov_inv=z, npred=np.zeros(0, np.int32), hull=z, nhull=np.zeros(0, np.int32))

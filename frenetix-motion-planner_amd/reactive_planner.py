@@ -223,9 +223,11 @@ class ReactivePlannerHip:
         self._packed_boundary = None
 
     def set_predictions(self, predictions: dict):
+        """predictions: the reference's dict (prediction_helpers.py:209-261) -- or problem.PackedPredictions, the same content
+        already packed (a batch of agents packs its shared predictions once)."""
         self.use_prediction = True
         self.predictions = predictions
-        self._packed_predictions = None
+        self._packed_predictions = predictions.packed if hasattr(predictions, "packed") else None
 
     def set_sampling_parameters(self, t_min: float, horizon: float, delta_d_min: float, delta_d_max: float):
         self.sampling_handler.update_static_params(t_min, horizon, delta_d_min, delta_d_max)

@@ -290,3 +290,30 @@ def test_config4_sized_batch(scenario):
             assert np.array_equal(f, costs[j][1]) and np.allclose(c, costs[j][0], rtol=1e-12, atol=0)
     finally:
         sim.close()
+
+
+def test_shared_prediction_packing_equals_per_agent_packing(scenario):
+    """MultiAgentSimulation packs the step's predictions ONCE (all non-agent obstacles and all agents) and hands every agent the
+    rows without its own: the same arrays as packing the agent's own dict -- up to the padded length P -- and a dict view that is
+    the reference's predictions dict when somebody (the logger) reads it."""
+    from frenetix_motion_planner_amd.engine import build_obstacle_hulls
+    from frenetix_motion_planner_amd.problem import PackedPredictions, pack_predictions
+    sim, _ = _run_sim(scenario, 4, engine_factory=OracleEngine)   # plans exist: the agents predict each other
+    for a in sim.batch.agents:
+        pp = sim.packed_predictions_for(a.id)
+        want = pack_predictions(sim.predictions_for(a.id), sim.S, build_obstacle_hulls)
+        got = pp.packed
+        assert isinstance(pp, PackedPredictions) and got["K"] == want["K"] == len(pp) and got["P"] >= want["P"]
+        P = want["P"]
+        assert np.array_equal(got["npred"], want["npred"]) and np.array_equal(got["nhull"], want["nhull"])
+        assert np.array_equal(got["pos"][:, :P], want["pos"]) and np.array_equal(got["cov_inv"][:, :P], want["cov_inv"])
+        assert np.array_equal(got["hull"][:, :P - 1], want["hull"])
+        assert not got["pos"][:, P:].any() and not got["hull"][:, P - 1:].any()
+        d = sim.predictions_for(a.id)
+        assert list(pp.keys()) == list(d) and a.id not in pp and all(np.array_equal(pp[k]["pos_list"], d[k]["pos_list"]) for k in d)
+    # the closed loop with and without the shared packing takes the same decisions
+    sim2 = multiagent.MultiAgentSimulation(scenario, engine_factory=OracleEngine)
+    sim2.shared_packing = False
+    for _ in range(4):
+        sim2.step()
+    assert np.array_equal(sim2.plans, sim.plans)

@@ -5,7 +5,16 @@ survivors per such step, share that reaches the exact axis test, obstacles per s
 usage: cull_stats.py [m1o c5 c3A ...]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["FXPLAN_SO"] = os.path.join(ROOT, "tools", "probe_build", "libfxplan_cstat.so")
+PROBE = os.path.join(ROOT, "tools", "probe_build", "libfxplan_cstat.so")
+CSRC = os.path.join(ROOT, "frenetix-motion-planner_amd", "csrc")
+srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "fxplan.h")]
+if not os.path.exists(PROBE) or os.path.getmtime(PROBE) < max(os.path.getmtime(f) for f in srcs):
+    # the probe build of the CURRENT sources (hipcc is on the GPU box too; about a minute)
+    import subprocess
+    os.makedirs(os.path.dirname(PROBE), exist_ok=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                    "-Wno-unused-function", "-DFX_CULL_STATS", "-shared", "-o", PROBE, "fx_kernels.hip", "fx_api.hip"], cwd=CSRC, check=True)
+os.environ["FXPLAN_SO"] = PROBE
 sys.path.insert(0, ROOT)
 import numpy as np
 from frenetix_motion_planner_amd import synthetic, _lib
