@@ -225,8 +225,17 @@ class Scenario:
         for oid in (obstacle_ids if obstacle_ids is not None else list(self.obstacles)):
             ob = self.obstacles[oid]
             len_pred = len(ob.state_list) if ob.role == "dynamic" else pred_horizon
+            t1 = min(pred_horizon + time_step, len_pred)
+            tab = self._gt_table(oid, max(t1, 0))
+            if tab is not None:
+                # per-step tables of the obstacle built once (every step exists): a closed loop asks for a window per step
+                pos_all, yaw_all, vel_all, cov_all = tab
+                sl = slice(min(time_step, t1), t1)
+                out[oid] = dict(pos_list=pos_all[sl], cov_list=cov_all[sl], orientation_list=yaw_all[sl], v_list=vel_all[sl],
+                                shape=dict(length=ob.length, width=ob.width))
+                continue
             pos, cov, yaw, vel = [], [], [], []
-            for ts in range(time_step, min(pred_horizon + time_step, len_pred)):
+            for ts in range(time_step, t1):
                 st = ob.state_at_time(ts)
                 if st is None:
                     continue
@@ -241,6 +250,31 @@ class Scenario:
                             orientation_list=np.array(yaw, dtype=np.float64), v_list=np.array(vel, dtype=np.float64),
                             shape=dict(length=ob.length, width=ob.width))
         return out
+
+    def _gt_table(self, oid: int, upto: int):
+        """(positions [T, 2], orientations [T], velocities [T], covariances [T, 2, 2]) of obstacle `oid` for the steps 0 .. T-1,
+        T >= upto -- or None when some step in that range has no state (then the caller walks the steps one by one).  Read-only
+        arrays, cached on the scenario: the windows handed out are views."""
+        cache = self.__dict__.setdefault("_gt_tables", {})
+        tab = cache.get(oid)
+        if tab is not None and (tab is False or len(tab[1]) >= upto):
+            return tab or None
+        ob = self.obstacles[oid]
+        pos, yaw, vel = [], [], []
+        for ts in range(upto):
+            st = ob.state_at_time(ts)
+            if st is None:
+                cache[oid] = False
+                return None
+            pos.append(st.position)
+            yaw.append(st.orientation)
+            vel.append(ob.state_list[ts].velocity if ob.role == "dynamic" else ob.initial_state.velocity)
+        tab = (np.array(pos, dtype=np.float64).reshape(-1, 2), np.array(yaw, dtype=np.float64), np.array(vel, dtype=np.float64),
+               np.tile(np.array([[0.1, 0.0], [0.0, 0.1]]), (upto, 1, 1)))
+        for a in tab:
+            a.setflags(write=False)
+        cache[oid] = tab
+        return tab
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -148,6 +148,7 @@ struct FxContext {
     int comm_rows_clean = 0;               // send-buffer rows [comm_rows_clean, comm_agents) hold "no survivor"
     int comm_k_clean = 0;                  // ... for this k (0: the winner buffer)
     bool comm_init_failed = false;         // an fx_comm_init on this context timed out: never retried
+    int exchange_mode = 0;                 // fx_set_exchange_mode: 0 receive in device memory + publication kernel, 1 receive straight in the pinned block
     double *d_gather = nullptr;            // [world][max_agents][2] (grown to [world][max_agents][2 k] by the top-k exchange)
     size_t gather_cap = 0;                 // doubles
     double *d_xsend = nullptr;             // [max_agents][2][64]: a rank's survivors, [cost n k | index n k], the all-gather's send buffer
@@ -1411,6 +1412,27 @@ static hipError_t fill_no_survivor(FxContext *c, int first, int k) {
     return hipMemcpyAsync(reinterpret_cast<long long *>(c->d_xsend + e1) + e0, hi + e0, sizeof(long long) * (e1 - e0), hipMemcpyHostToDevice, c->stream);
 }
 
+// Where the all-gather lands and how its arrival is signalled.  Mode 0: receive buffer in device memory, then fx_publish_kernel
+// copies it into the pinned block and releases the sequence word (one more launch: + 7.5 us at one rank).  Mode 1: the receive
+// buffer IS the pinned, mapped block (its device address), and the sequence word behind it is written by a stream-ordered memory
+// operation (hipStreamWriteValue64) -- no launch.  Mode 1 is only used after it has agreed with the torch.distributed exchange
+// on every rank (distributed.ShardedEvaluator.crosscheck_exchange tries it first and falls back to mode 0, then to torch).
+int32_t fx_set_exchange_mode(FxContext *c, int32_t mode) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (mode != 0 && mode != 1) return set_err(FX_ERR_INVALID_ARGUMENT, "exchange mode must be 0 (device receive + publication kernel) or 1 (receive in the pinned block)");
+    c->exchange_mode = mode;
+    return FX_OK;
+}
+static double *exchange_recv(FxContext *c) { return c->exchange_mode == 1 ? c->h_pub_dev : c->d_gather; }
+static int exchange_signal(FxContext *c, int32_t total) {
+    if (c->exchange_mode != 1) return fx_publish(c, c->d_gather, total);
+    c->pub_seq++;
+    c->pub_n = total;
+    HIP_TRY(hipStreamWriteValue64(c->stream, c->h_pub_dev + FX_PUB_MAX, c->pub_seq, 0));
+    c->in_flight = true;
+    return FX_OK;
+}
+
 // One plan step of every rank: evaluation (+ selection), ONE all-gather of the ranks' winners (cost f64, global index i64 per
 // agent row; 16 B per rank and row) on the context's stream, publication to pinned host memory -- enqueued back to back, then the
 // host takes the local result block while the collective runs and waits (bounded in time) for the gathered winners.
@@ -1446,9 +1468,9 @@ int32_t fx_step_exchange(FxContext *c, FxResult *res, double *cost, int64_t *ind
     }
     c->comm_rows_clean = n_mine;
     const int n = A * 2, total = n * c->comm_world;
-    RCCL_TRY(rccl()->AllGather(c->d_winner_own, c->d_gather, (size_t)n, /*ncclDouble*/ 8, c->comm, c->stream));
+    RCCL_TRY(rccl()->AllGather(c->d_winner_own, exchange_recv(c), (size_t)n, /*ncclDouble*/ 8, c->comm, c->stream));
     int rc;
-    if ((rc = fx_publish(c, c->d_gather, total))) return rc;
+    if ((rc = exchange_signal(c, total))) return rc;
     if (evaluated && (rc = fx_finish_batch(c, res))) keep(rc);
     if ((rc = wait_seq(c, reinterpret_cast<const unsigned long long *>(c->h_pub + FX_PUB_MAX), c->pub_seq))) return rc;
     for (int r = 0; r < c->comm_world; r++)
@@ -1509,9 +1531,9 @@ int32_t fx_step_exchange_topk(FxContext *c, int32_t k, FxResult *res, double *co
         c->comm_k_clean = k;
     }
     c->comm_rows_clean = n_mine;
-    RCCL_TRY(rccl()->AllGather(c->d_xsend, c->d_gather, n, /*ncclDouble*/ 8, c->comm, c->stream));
+    RCCL_TRY(rccl()->AllGather(c->d_xsend, exchange_recv(c), n, /*ncclDouble*/ 8, c->comm, c->stream));
     int rc;
-    if ((rc = fx_publish(c, c->d_gather, (int32_t)total))) return rc;
+    if ((rc = exchange_signal(c, (int32_t)total))) return rc;
     if (evaluated && (rc = fx_finish_batch(c, res))) keep(rc);
     if ((rc = wait_seq(c, reinterpret_cast<const unsigned long long *>(c->h_pub + FX_PUB_MAX), c->pub_seq))) return rc;
     const size_t nk = (size_t)A * k;

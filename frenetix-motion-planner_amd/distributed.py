@@ -334,36 +334,52 @@ class ShardedEvaluator:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         return int(t.item())
 
+    def _exchanges_agree(self) -> bool:
+        """one step through the library exchange and once more through torch.distributed: the same survivors?  (local answer)"""
+        if self.lib_exchange_agents and getattr(self, "n_local", 0):
+            _, a = self.step_agents_enqueued()
+            self.lib_exchange_agents, keep = False, self.lib_exchange_agents
+            try:
+                _, b = self.step_agents_enqueued()
+            finally:
+                self.lib_exchange_agents = keep
+            return a is not None and b is not None and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        a = self.step_enqueued()
+        self.lib_exchange, keep = False, self.lib_exchange
+        try:
+            b = self.step_enqueued()
+        finally:
+            self.lib_exchange = keep
+        return a["global_best_index"] == b["global_best_index"] and a["global_best_cost"] == b["global_best_cost"]
+
     def crosscheck_exchange(self) -> int:
         """One step exchanged through the library and once more through torch.distributed, on the resident inputs: 1 = both
         agree on every rank, 0 = they differ somewhere (the library exchange is switched off on every rank), -1 = the library
-        exchange did not come back within the time bound on this rank (the context is lost).  Collective: every rank calls it."""
-        from ._lib import FxTimeoutError
+        exchange did not come back within the time bound on this rank (the context is lost).  Collective: every rank calls it.
+        The library's direct mode -- the all-gather received straight in the pinned block, a stream-ordered write instead of the
+        publication launch (fx_set_exchange_mode 1) -- is tried first and kept only if every rank saw it agree; otherwise the
+        device-buffer mode is checked the same way; otherwise torch.distributed carries the exchange."""
+        from ._lib import FxError, FxTimeoutError
         if not self.uses_library_exchange():
             return 1
-        state = 1
-        try:
-            if self.lib_exchange_agents and getattr(self, "n_local", 0):
-                _, a = self.step_agents_enqueued()
-                self.lib_exchange_agents, keep = False, self.lib_exchange_agents
-                try:
-                    _, b = self.step_agents_enqueued()
-                finally:
-                    self.lib_exchange_agents = keep
-                same = a is not None and b is not None and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-            else:
-                a = self.step_enqueued()
-                self.lib_exchange, keep = False, self.lib_exchange
-                try:
-                    b = self.step_enqueued()
-                finally:
-                    self.lib_exchange = keep
-                same = a["global_best_index"] == b["global_best_index"] and a["global_best_cost"] == b["global_best_cost"]
-            state = 1 if same else 0
-        except FxTimeoutError:
-            return -1   # (every rank waits on the same collective: they all end here)
-        state = self._agree_min(state)
-        if state == 0:   # wrong answers somewhere: nobody uses it
+        import os
+        modes = [1, 0] if hasattr(self.engine, "set_exchange_mode") and os.environ.get("FX_EXCHANGE_MODE", "1") != "0" else [0]
+        state = 0
+        for mode in modes:
+            ok = 1
+            try:
+                if hasattr(self.engine, "set_exchange_mode"):
+                    self.engine.set_exchange_mode(mode)
+                ok = 1 if self._exchanges_agree() else 0
+            except FxTimeoutError:
+                return -1   # (every rank waits on the same collective: they all end here)
+            except (FxError, ValueError):   # this mode is not available here (e.g. the stream-ordered write is refused)
+                ok = 0
+            state = self._agree_min(ok)
+            if state == 1:
+                self.exchange_mode = mode
+                break
+        if state == 0:   # wrong answers somewhere in every mode: nobody uses the library exchange
             self.lib_exchange = self.lib_exchange_agents = False
             try:
                 self.engine.comm_destroy()
@@ -484,5 +500,6 @@ def verified_evaluator(make_engine, k: int, prepare):
     if state < 0:
         from ._lib import FxTimeoutError
         raise FxTimeoutError("the library-side exchange did not come back in the cross-check")
-    return eng, ev, ("library (RCCL communicator of the engine), cross-checked against torch.distributed" if state == 1 else
+    how = {1: "received straight in the pinned block", 0: "device receive buffer + publication kernel"}.get(getattr(ev, "exchange_mode", 0))
+    return eng, ev, (f"library (RCCL communicator of the engine, {how}), cross-checked against torch.distributed" if state == 1 else
                      "torch.distributed (the library exchange disagreed in the cross-check)")

@@ -466,6 +466,12 @@ class FrenetEngine:
         check(lib().fx_comm_set_agents(self._ctx, int(n_agents)))
         self._comm_agents = int(n_agents)
 
+    def set_exchange_mode(self, mode: int):
+        """0: the library's all-gather lands in device memory and a publication kernel copies it out; 1: it lands straight in the
+        pinned block and a stream-ordered write signals it (fx_set_exchange_mode)."""
+        check(lib().fx_set_exchange_mode(self._ctx, int(mode)))
+        self._exchange_mode = int(mode)
+
     def comm_info(self) -> dict:
         """rank, world, the rank count RCCL itself reports (ncclCommCount; -1 if unavailable), agent rows per rank"""
         v = (C.c_int32 * 4)()

@@ -251,21 +251,32 @@ class MultiAgentSimulation:
         base = {k: v for k, v in self.scenario.ground_truth_predictions(t, horizon, obstacle_ids=others).items() if len(v["pos_list"])}
         own = {}
         wb = self.vehicle.wb_rear_axle
+        # the box centres of ALL agents' plans in three array operations (state.py:30-39), windows handed out per agent
+        th_all = np.ascontiguousarray(self.plans[:, :, 2])
+        pos_all = np.empty(self.plans.shape[:2] + (2,))
+        pos_all[:, :, 0] = self.plans[:, :, 0] + wb * np.cos(th_all)
+        pos_all[:, :, 1] = self.plans[:, :, 1] + wb * np.sin(th_all)
+        vel_all = np.ascontiguousarray(self.plans[:, :, 3])
+        n_valid = np.count_nonzero(self.plans[:, :, 4] > 0, axis=1)
         for k, aid in enumerate(self.agent_ids):
             rows = self.plans[k]
-            valid = rows[:, 4] > 0
-            n = int(np.count_nonzero(valid))
-            if n:
-                r = rows[:n] if valid[n - 1] else rows[valid]   # (the valid rows are a prefix: what lies ahead of the agent)
+            n = int(n_valid[k])
+            if n and rows[n - 1, 4] > 0:   # the valid rows are a prefix (what lies ahead of the agent): views of the shared arrays
+                th, pos, vel = th_all[k, :n], pos_all[k, :n], vel_all[k, :n]
+            elif n:
+                valid = rows[:, 4] > 0
+                r = rows[valid]
                 th = r[:, 2].copy()
                 pos = np.empty((n, 2))
                 pos[:, 0] = r[:, 0] + wb * np.cos(th)
                 pos[:, 1] = r[:, 1] + wb * np.sin(th)
+                vel = r[:, 3].copy()
+            if n:
                 cov = self._cov_tiles.get(n)
                 if cov is None:   # covariance 0.1 I per step (prediction_helpers.py:245): one read-only block per length
                     cov = self._cov_tiles[n] = np.tile(np.eye(2) * 0.1, (n, 1, 1))
                     cov.setflags(write=False)
-                own[aid] = dict(pos_list=pos, cov_list=cov, orientation_list=th, v_list=r[:, 3].copy(), shape=dict(self.shapes[aid]))
+                own[aid] = dict(pos_list=pos, cov_list=cov, orientation_list=th, v_list=vel, shape=dict(self.shapes[aid]))
             elif aid in self.scenario.obstacles:  # no plan yet: the recorded future (first step)
                 gt = self.scenario.ground_truth_predictions(t, horizon, obstacle_ids=[aid])[aid]
                 if len(gt["pos_list"]):

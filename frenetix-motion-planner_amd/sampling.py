@@ -24,7 +24,9 @@ class Sampling:
         if not isinstance(max_density, int) or max_density <= 0:
             raise AssertionError("max_density must be a positive int")
         self.minimum, self.maximum, self.max_density = minimum, maximum, max_density
-        self._sampling_vec = [self._level(i) for i in range(max_density)]
+        # the level sets are built when they are asked for: a planner renews its velocity sampling every step
+        # (set_desired_velocity) and reads one level of it -- or none, with a dense grid
+        self._sampling_vec = [None] * max_density
 
     def _level(self, level: int) -> set:
         raise NotImplementedError
@@ -32,7 +34,10 @@ class Sampling:
     def to_range(self, sampling_stage: int = 0) -> set:
         if not 0 <= sampling_stage < self.max_density:
             raise AssertionError(f"<Sampling/to_range>: stage {sampling_stage} out of range")
-        return self._sampling_vec[sampling_stage]
+        s = self._sampling_vec[sampling_stage]
+        if s is None:
+            s = self._sampling_vec[sampling_stage] = self._level(sampling_stage)
+        return s
 
     def ordered(self, sampling_stage: int, extra=None) -> np.ndarray:
         """Iteration order of to_range(stage) (optionally .union({extra})) as an f64 array."""

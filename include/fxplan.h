@@ -296,6 +296,10 @@ int32_t fx_comm_destroy(FxContext *ctx);
  * uploaded fewer agents sends "no survivor" (inf, -1) in the remaining rows, a rank that uploaded more gets FX_ERR_CAPACITY
  * from the exchange (after having entered it) */
 int32_t fx_comm_set_agents(FxContext *ctx, int32_t n_agents);
+/* where the exchanges' all-gather lands: 0 (default) a device buffer + the publication kernel, 1 straight in the pinned, mapped
+ * block with a stream-ordered write of the sequence word (no launch behind the collective).  Use mode 1 only after it has
+ * agreed with an independent exchange on every rank (distributed.ShardedEvaluator does that). */
+int32_t fx_set_exchange_mode(FxContext *ctx, int32_t mode);
 /* out[0] rank, [1] world, [2] the ranks RCCL itself reports for the communicator (ncclCommCount, -1 if unavailable), [3] agent
  * rows per rank */
 int32_t fx_comm_info(const FxContext *ctx, int32_t *out4);

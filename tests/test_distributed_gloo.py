@@ -258,6 +258,10 @@ def test_library_side_exchange_single_rank():
                 assert r2["global_best_index"] == ref["best_index"] and r2["best_index"] == ref["best_index"]
                 # what bench.py does before it times anything: library exchange against the torch.distributed exchange
                 assert ev.crosscheck_exchange() == 1 and ev.lib_exchange
+                # ... which tries the direct mode first (all-gather received in the pinned block, stream-ordered sequence write)
+                assert ev.exchange_mode == 1
+                assert ev.step_enqueued()["global_best_index"] == ref["best_index"]
+                eng.set_exchange_mode(0)
                 assert ev.step_enqueued()["global_best_index"] == ref["best_index"]
                 eng.set_winner_buffer(0)
         os.environ["FX_EXCHANGE"] = "torch"
