@@ -197,3 +197,37 @@ def test_config3_full_size_on_the_obstacle_kernel(eng):
     assert eng.step_info()["obstacle_kernel"] == 1
     compare(eng, inp, out, res)
     assert res["n_collisions"] > 0
+
+
+def test_obstacle_kernel_list_of_costed_candidates(eng):
+    """The obstacle kernel visits the walk's list of COSTED candidates, not the grid (production flag set: infeasible candidates
+    have neither a prediction cost nor a collision check): results equal the oracle and the fused stage whatever the list's order;
+    a step whose list is EMPTY (nothing feasible: non-finite ego state) ends with no winner and leaves the list empty for the
+    next, ordinary step; repeated steps are bit-identical."""
+    from oracle import oracle
+    kw = dict(ref_kind="arc", v0=10.0, grid=(9, 21, 21), n_obstacles=12, lead_gap=20.0)
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    ref_inp = synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw)
+    out = oracle.plan_step(ref_inp)
+    assert 0 < out["costed"].sum() < inp.n_candidates   # a real mix of costed and infeasible candidates
+    eng.set_obstacle_stage(2, 3)
+    try:
+        res = eng.plan_step(inp)
+        assert eng.step_info()["obstacle_kernel"] == 1
+        compare(eng, inp, out, res, ref_inp=ref_inp)
+        c0, f0 = eng.costs()
+        for _ in range(3):   # the list is rebuilt in another order every step: nothing that is computed from it may move
+            eng.evaluate(); r = eng.finish()[0]
+            c, f = eng.costs()
+            assert np.array_equal(c, c0) and np.array_equal(f, f0) and r["best_index"] == res["best_index"] and r["n_collisions"] == res["n_collisions"]
+        # nothing feasible at all: an empty list
+        bad = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+        bad.x0_lon = np.array([bad.x0_lon[0], float("nan"), 0.0])
+        rb = eng.plan_step(bad)
+        assert rb["best_index"] == -1 and rb["n_feasible"] == 0 and rb["n_collisions"] == 0
+        # ... and the next ordinary step is unaffected
+        res2 = eng.plan_step(inp)
+        compare(eng, inp, out, res2, ref_inp=ref_inp)
+        assert {k: res2[k] for k in RESULT_KEYS} == {k: res[k] for k in RESULT_KEYS}
+    finally:
+        eng.set_obstacle_stage(0)
