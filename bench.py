@@ -85,7 +85,8 @@ def kernel_names(info, bundle, obstacles_fused, extra=False):
                 f"{b(info['wave_split'])}>")
     else:
         walk = f"fx_eval_kernel<{info['lanes_per_candidate']}, {b(bundle)}, {b(obstacles_fused)}, {b(extra)}, {info['waves_per_simd']}>"
-    obst = f"fx_obstacle_kernel<{info['obstacle_steps_per_item']}, 4>" if info.get("obstacle_kernel") else None
+    obst = (f"fx_obstacle_kernel<{info['obstacle_steps_per_item']}, 4, {b(info.get('obstacle_workgroup_waves', 0) > 0)}>"
+            if info.get("obstacle_kernel") else None)
     return walk, obst
 
 

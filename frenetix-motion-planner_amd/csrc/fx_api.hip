@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+
 #include <memory>
 #include <mutex>
 #include <new>
@@ -30,7 +31,7 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
                                           size_t lds_bytes, int G, bool bundle, bool obst, int wpe, bool wsplit,
                                           hipEvent_t ev_start, hipEvent_t ev_stop, FuseArgs fuse, hipStream_t stream);
 extern "C" hipError_t fx_launch_obstacle(const DevProblem *d_probs, int n_agents, int max_items, size_t lds_bytes, int CH,
-                                         hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t stream);
+                                         hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t stream, int wg_waves, int max_tiles);
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, int64_t max_candidates, unsigned long long *host_result,
                                        unsigned long long seq, double *dev_winner, double *host_pkg, int pkg_stride, int pkg_plane_rows,
                                        hipStream_t stream);
@@ -191,6 +192,8 @@ struct FxContext {
     int obst_CH = 0;                       // steps per work item of the obstacle kernel (0 auto)
     bool split_step = false;               // current step runs fx_obstacle_kernel behind the walk
     int split_CH = 3, obs_blocks_step = 0;
+    int obs_wg_waves = 0, obs_tiles_step = 0;   // obstacle kernel with one workgroup per tile: waves per workgroup (0: one wave per (tile, chunk) item), tiles
+    int obs_wg_step = 0;                        // waves per workgroup of the last obstacle-kernel launch (0: single-wave items)
     size_t obs_lds_step = 0;
     int store_force = 0;                   // 0 auto, 1 write-back, 2 write-through plane stores
     bool wsplit_step = false;
@@ -809,6 +812,8 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     c->fusable_step = true;
     c->max_blocks_step = 0;
     c->obs_blocks_step = 0;
+    c->obs_tiles_step = 0;
+    c->obs_wg_waves = 0;
     c->M_max_step = 0;
     c->K_max_step = 0;
     c->S_max_step = 0;
@@ -940,6 +945,8 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             const int n_tiles = (int)((C + 63) / 64), NC = (S - 1 + c->split_CH - 1) / c->split_CH;
             d.n_blocks = n_tiles;
             c->obs_blocks_step = std::max(c->obs_blocks_step, n_tiles * NC);
+            c->obs_tiles_step = std::max(c->obs_tiles_step, n_tiles);
+            c->obs_wg_waves = std::max(c->obs_wg_waves, NC);
             d.obs_part = reinterpret_cast<double *>(obs_part_need);      // offsets for now, patched below
             d.obs_colm = reinterpret_cast<unsigned long long *>(obs_colm_need);
             d.obs_ticket = reinterpret_cast<unsigned int *>(obs_tick_need);
@@ -1091,8 +1098,18 @@ int32_t fx_evaluate(FxContext *c) {
     if (timed) ts->obst_timed = false;
     if (c->split_step && c->obs_blocks_step > 0) {
         const bool t_obs = timed && c->timing == FX_TIMING_KERNEL;
-        HIP_TRY(fx_launch_obstacle(c->d_probs, c->n_agents, c->obs_blocks_step, c->obs_lds_step, c->split_CH,
-                                   t_obs ? ts->e_obs0 : nullptr, t_obs ? ts->e_obs1 : nullptr, c->stream));
+        // one workgroup per tile (the chunks meet in LDS) where the horizon's chunks fit a workgroup; else single-wave items
+        // (measured, tools/c3_split.py: config 3 34.2 -> 32.5 us, config 4's batch 15.6 -> 13.2 us; a config-5 agent with a bundle
+        // -- 1 617 tiles -- 102 -> 159 us and the 1 M grid 374 -> 524 us: ten-wave workgroups schedule badly once there are more
+        // tiles than the chip holds at once, so the automatic choice takes them up to 1 024 tiles per launch)
+        const char *wg_env = getenv("FX_OBST_WG");   // experiments: 0 / 1 force single-wave items / workgroups
+        const int wg_mode = wg_env ? (atoi(wg_env) ? 2 : 1) : ((int64_t)c->obs_tiles_step * c->n_agents <= 1024 ? 2 : 1);
+        const bool wg = wg_mode == 2 && c->obs_wg_waves >= 1 && c->obs_wg_waves <= 16;
+        c->obs_wg_step = wg ? c->obs_wg_waves : 0;
+        const size_t lds_wg = align_up((size_t)c->obs_wg_waves * (c->obs_lds_step + 64 * sizeof(double) + sizeof(unsigned long long)), 16);
+        HIP_TRY(fx_launch_obstacle(c->d_probs, c->n_agents, c->obs_blocks_step, wg ? lds_wg : c->obs_lds_step, c->split_CH,
+                                   t_obs ? ts->e_obs0 : nullptr, t_obs ? ts->e_obs1 : nullptr, c->stream, wg ? c->obs_wg_waves : 0,
+                                   c->obs_tiles_step));
         if (timed) ts->obst_timed = t_obs;
     }
     if (!c->fused_step) {
@@ -2096,13 +2113,14 @@ int32_t fx_read_obstacle_kernel_times(FxContext *c, int32_t max_n, double *obst_
     return FX_OK;
 }
 // fx_step_info, extended: out[0 .. 9] as fx_step_info, [10] obstacle stage as its own kernel, [11] steps per work item, [12] work
-// items (waves) per agent (max) and [13] dynamic LDS bytes of that kernel, [14 .. 15] reserved
+// items (waves) per agent (max) and [13] dynamic LDS bytes of that kernel, [14] waves per workgroup when a tile's chunks share one
+// workgroup (0: one wave per (tile, chunk) item), [15] reserved
 int32_t fx_step_info_ex(const FxContext *c, int64_t *out16) {
     if (!c || !out16) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_step_info_ex: NULL argument");
     int rc = fx_step_info(c, out16);
     if (rc) return rc;
     out16[10] = c->split_step; out16[11] = c->split_CH; out16[12] = c->obs_blocks_step; out16[13] = (int64_t)c->obs_lds_step;
-    out16[14] = out16[15] = 0;
+    out16[14] = c->obs_wg_step; out16[15] = 0;
     return FX_OK;
 }
 

@@ -662,11 +662,25 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
 // The obstacle stage as its own kernel (fx_obstacle_kernel.h): grid = (max tiles x chunks, n_agents), one wave per item,
 // dynamic LDS = CH * K * 48 B.
 extern "C" hipError_t fx_launch_obstacle(const DevProblem *d_probs, int n_agents, int max_items, size_t lds_bytes, int CH,
-                                         hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t stream) {
+                                         hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t stream, int wg_waves, int max_tiles) {
+    // wg_waves > 0: one workgroup of wg_waves waves per tile (the chunks meet in LDS), grid = (max_tiles, n_agents)
 #define FX_LAUNCH(CHv)                                                                                                                \
     do {                                                                                                                            \
-        hipExtLaunchKernelGGL((fxk::fx_obstacle_kernel<CHv, 4>), dim3(max_items, n_agents), dim3(64), lds_bytes, stream, ev_start, ev_stop, \
-                              0, d_probs);                                                                                          \
+        if (wg_waves > 0) {                                                                                                         \
+            static std::atomic<size_t> lds_set_[FX_MAX_DEVICES];                                                                    \
+            std::atomic<size_t> &hw_ = lds_set_[fx_device_slot()];                                                                  \
+            if (lds_bytes > 48 * 1024 && lds_bytes > hw_.load(std::memory_order_relaxed)) {                                         \
+                hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&fxk::fx_obstacle_kernel<CHv, 4, true>),          \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                    \
+                if (e_ != hipSuccess) return e_;                                                                                    \
+                hw_.store(lds_bytes, std::memory_order_relaxed);                                                                    \
+            }                                                                                                                       \
+            hipExtLaunchKernelGGL((fxk::fx_obstacle_kernel<CHv, 4, true>), dim3(max_tiles, n_agents), dim3(64 * wg_waves), lds_bytes, stream, \
+                                  ev_start, ev_stop, 0, d_probs);                                                                   \
+        } else {                                                                                                                    \
+            hipExtLaunchKernelGGL((fxk::fx_obstacle_kernel<CHv, 4, false>), dim3(max_items, n_agents), dim3(64), lds_bytes, stream, ev_start, \
+                                  ev_stop, 0, d_probs);                                                                             \
+        }                                                                                                                           \
         return hipGetLastError();                                                                                                   \
     } while (0)
     if (CH == 2) FX_LAUNCH(2);

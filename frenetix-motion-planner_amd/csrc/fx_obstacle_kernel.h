@@ -66,19 +66,30 @@ __device__ __forceinline__ double obs_four(double a, double b, double c, double 
 
 // grid = (max tiles x chunks, n_agents), block = 64, dynamic LDS = CH * K * 48 B.  CH: steps per item (compile time: the rows
 // live in registers), WPS: waves per SIMD handed to the register allocator.
-template <int CH, int WPS>
-__global__ __launch_bounds__(64, WPS) void fx_obstacle_kernel(const DevProblem *__restrict__ probs) {
-    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];  // (cu, cw) [CH][K][2] | hull circles [CH][K][4]
+// WG (round 4): ALL chunks of a tile in ONE workgroup -- grid = (max tiles, n_agents), block = 64 x (chunks of the longest
+// horizon of the launch), wave = chunk.  The chunks then meet in LDS behind one workgroup barrier and wave 0 closes the tile:
+// no partial sums and ballots through global memory, no acknowledged stores, no ticket, no device-coherent re-loads -- the
+// chain that the last chunk of every tile walked at ~1 us per hop.  Dynamic LDS = waves x (CH * K * 48 B) + waves x 64 x 8 B
+// (partial sums) + waves x 8 B (collision ballots).
+template <int CH, int WPS, bool WG = false>
+__global__ __launch_bounds__(WG ? 1024 : 64, WG ? 1 : WPS) void fx_obstacle_kernel(const DevProblem *__restrict__ probs) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];  // per wave: (cu, cw) [CH][K][2] | hull circles [CH][K][4]
     const DevProblem &P = probs[blockIdx.y];
     const uint32_t mode = P.mode;
     if (!(mode & FX_MODE_INT_DEFER_OBST)) return;
     const int S = P.S, K = P.K;
     const int NC = (S - 1 + CH - 1) / CH;
     const int64_t C = P.C, ld = P.ld;
-    const int tile = blockIdx.x / NC, chunk = blockIdx.x - tile * NC;
+    const int n_wave = WG ? (int)(blockDim.x >> 6) : 1;
+    const int tile = WG ? (int)blockIdx.x : (int)(blockIdx.x / NC);
+    const int chunk = WG ? (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(blockIdx.x - tile * NC);
     const int64_t c0 = (int64_t)tile * 64;
     if (c0 >= C) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    // this wave's slice of the dynamic LDS; WG: the meeting area behind the waves' slices
+    double *__restrict__ lds_dyn = lds_all + (WG ? (size_t)chunk * 6 * CH * (size_t)K : 0);
+    double *__restrict__ sh_part = lds_all + (size_t)n_wave * 6 * CH * (size_t)K;                       // [n_wave][64]
+    unsigned long long *__restrict__ sh_colm = reinterpret_cast<unsigned long long *>(sh_part + (size_t)n_wave * 64);   // [n_wave]
     FX_OSTAMP(0);
     // The tile's candidates: 64 entries of the list of costed candidates the walk has left (fx_eval_kernel.h, finish_candidate;
     // the walk is complete, plain loads).  Tiles past the end of the list only leave a neutral arg-min partial.
@@ -150,8 +161,8 @@ __global__ __launch_bounds__(64, WPS) void fx_obstacle_kernel(const DevProblem *
     double acc = 0.0;
     bool collided = false;
     const bool work = do_pred || do_col;
-    if (!work && chunk != 0) return;   // nothing to add: chunk 0 closes the tile on its own
-    if (work) {
+    if (!work && chunk != 0) return;   // nothing to add: chunk 0 closes the tile on its own (tile-uniform: no barrier is skipped)
+    if (work && chunk < NC) {          // (WG: a launch sized for a longer horizon has waves without a chunk of this agent)
         const FX_GLOBAL double *__restrict__ rec = as_global(P.obs_rec);
         const FX_GLOBAL unsigned long long *__restrict__ pmask = as_global(P.obs_pmask);
         const FX_GLOBAL unsigned long long *__restrict__ hmask = as_global(P.obs_hmask);
@@ -294,7 +305,16 @@ __global__ __launch_bounds__(64, WPS) void fx_obstacle_kernel(const DevProblem *
     FX_GLOBAL unsigned long long *__restrict__ colm = as_global(P.obs_colm);
     FX_GLOBAL unsigned int *__restrict__ ticket = as_global(P.obs_ticket);
     const int64_t n_tiles = (C + 63) / 64;
-    if (work) {
+    if (WG) {
+        // ---- the chunks meet in LDS: partial sums and ballots, one barrier, wave 0 goes on ----
+        if (work) {
+            sh_part[chunk * 64 + lane] = acc;
+            const unsigned long long cm = __builtin_amdgcn_ballot_w64(collided);
+            if (lane == 0) sh_colm[chunk] = cm;
+            __syncthreads();
+            if (chunk != 0) return;
+        }
+    } else if (work) {
         // hand-off: agent-scope stores, acknowledged (vmcnt 0) before the ticket is taken -- whoever draws the last ticket
         // sees every chunk's partial
         if (act) __hip_atomic_store(part + (int64_t)chunk * ld + g_raw, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -311,7 +331,12 @@ __global__ __launch_bounds__(64, WPS) void fx_obstacle_kernel(const DevProblem *
     // ---- close the tile: partials in chunk order ----
     double pred = 0.0;
     unsigned long long cmask = 0ULL;
-    if (work) {
+    if (work && WG) {
+        for (int q = 0; q < NC; q++) {   // chunk order, as the other variant adds them: the two agree bit for bit
+            pred += sh_part[q * 64 + lane];
+            cmask |= sh_colm[q];
+        }
+    } else if (work) {
         for (int q = 0; q < NC; q++) {
             pred += __hip_atomic_load(part + (int64_t)q * ld + g_raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             cmask |= __hip_atomic_load(colm + (int64_t)q * n_tiles + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -273,7 +273,8 @@ class FrenetEngine:
         v = np.zeros(16, np.int64)
         check(lib().fx_step_info_ex(self._ctx, v.ctypes.data))
         keys = ("grid_kernel", "lanes_per_candidate", "waves_per_simd", "block", "wave_split", "fused_selection", "blocks", "agents",
-                "package", "lds_bytes", "obstacle_kernel", "obstacle_steps_per_item", "obstacle_items", "obstacle_lds_bytes")
+                "package", "lds_bytes", "obstacle_kernel", "obstacle_steps_per_item", "obstacle_items", "obstacle_lds_bytes",
+                "obstacle_workgroup_waves")
         return dict(zip(keys, (int(x) for x in v)))
 
     def obstacle_kernel_times(self, max_n: int = 256):

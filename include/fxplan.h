@@ -436,7 +436,8 @@ int32_t fx_set_fused_selection(FxContext *ctx, int32_t enabled);
  * selection, workgroups per agent, agents, winner package, dynamic LDS bytes */
 int32_t fx_step_info(const FxContext *ctx, int64_t *out10);
 /* the same ten values, then: [10] obstacle stage ran as its own kernel, [11] its steps per work item, [12] work items (waves) per
- * agent (max), [13] dynamic LDS bytes, [14 .. 15] reserved */
+ * agent (max), [13] dynamic LDS bytes, [14] waves per workgroup when the chunks of a tile share one workgroup (0: one wave per
+ * (tile, chunk) item), [15] reserved */
 int32_t fx_step_info_ex(const FxContext *ctx, int64_t *out16);
 /* HIP-event time of the obstacle kernel of the latest timed step / of the most recent <= max_n timed steps (FX_TIMING_KERNEL;
  * 0 where the stage ran fused into the walk) */

@@ -132,7 +132,30 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
         stored = out["returned"] & robust & (out["costed"] | (inp.draw_traj_set))
         got = eng.bundle(agent)
         refp = out["planes"]
-        err = (np.abs(got - refp) / (1.0 + np.abs(refp).max(axis=2, keepdims=True))).max(axis=2)   # [C, 14]
+        errs = np.abs(got - refp) / (1.0 + np.abs(refp).max(axis=2, keepdims=True))   # [C, 14, S]
+        # Steps that CRAWL (high-speed mode, s_dot between the "moving" literal 1e-3 and 1e-2 m/s): d'' = (d_ddot - d' s_ddot) / s_dot^2
+        # divides the evaluation noise of two second derivatives -- sums of terms of order 1 .. 100 that cancel to 1e-4 at the end
+        # of a stopping trajectory, 1e-15 .. 1e-14 absolute whatever their value -- by 1e-6 .. 1e-4.  The slowest sampled end
+        # velocity is max(0.001, ...) (planner.py:304), so a seventh of a planner's candidates ends on such a step; their a, kappa
+        # and kappa_dot there agree to ~3e-10 typically and, once in the 6.4e7 candidates of the round-4 soak, to 2.0e-9 (case
+        # 1012012: 3.2 mm/s, horizon 5 s).  Those steps of those three planes get (1 / s_dot)^2 ulps of 2e-14 on top of the
+        # fixed bound (2e-10 at 1 cm/s ... 2e-8 at 1 mm/s); every other step and plane of the candidate stays where it was.
+        if not inp.low_vel_mode:
+            sd = refp[:, 10, :]
+            crawl = (sd > 1e-3) & (sd < 1e-2)
+            crawl_next = crawl.copy()
+            crawl_next[:, 1:] |= crawl[:, :-1]          # kappa_dot[i] = kappa[i] - kappa[i-1]
+            with np.errstate(divide="ignore"):
+                amp = np.where(crawl, 1.0 / (sd * sd), 0.0)
+            amp_next = amp.copy()
+            amp_next[:, 1:] = np.maximum(amp[:, 1:], amp[:, :-1])
+            for pl, msk, am in ((4, crawl, amp), (5, crawl, amp), (6, crawl_next, amp_next)):
+                e = errs[:, pl, :]
+                over = stored[:, None] & msk & (e >= STATE_TOL + 2e-14 * am)
+                assert not over.any(), f"plane {pl} err {e[over].max()} at a crawling step beyond 1e-9 + 2e-14 / s_dot^2"
+                PARITY_STATS["crawl_steps"] = PARITY_STATS.get("crawl_steps", 0) + int((stored[:, None] & msk).sum())
+                e[msk] = 0.0
+        err = errs.max(axis=2)   # [C, 14]
         err[~stored] = 0
         tol = np.repeat((STATE_TOL + 2e-14 * cond)[:, None], err.shape[1], axis=1)
         tol[:, KINEMATIC_PLANES] = (STATE_TOL + 2e-14 * cond_kin)[:, None]

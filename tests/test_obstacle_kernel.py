@@ -40,6 +40,29 @@ def test_obstacle_kernel_vs_oracle(eng, name, steps):
         eng.set_obstacle_stage(0)
 
 
+@pytest.mark.parametrize("wg", ["0", "1"])
+@pytest.mark.parametrize("steps", STEPS_PER_ITEM)
+@pytest.mark.parametrize("name", ["dense_debug_obs", "dense_prod_obs", "dense_horizon5", "stop_dense_obs"])
+def test_obstacle_kernel_items_and_workgroups(eng, monkeypatch, name, steps, wg):
+    """the chunks of a tile as single-wave items meeting in the selection kernel, and as the waves of one workgroup meeting in
+    LDS (the launch picks by tile count; FX_OBST_WG forces either): the same result, and step_info names the one that ran"""
+    from oracle import oracle
+    kw = CASES[name]
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
+    monkeypatch.setenv("FX_OBST_WG", wg)
+    eng.set_obstacle_stage(2, steps)
+    try:
+        res = eng.plan_step(inp)
+        info = eng.step_info()
+        assert info["obstacle_kernel"] == 1
+        chunks = -(-(inp.N + 1) // steps)
+        assert info["obstacle_workgroup_waves"] == (chunks if wg == "1" and chunks <= 16 else 0)
+        compare(eng, inp, out, res)
+    finally:
+        eng.set_obstacle_stage(0)
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("lanes", [1, 2, 4, 8, 32])
 @pytest.mark.parametrize("name", ["dense_debug_obs", "dense_prod_obs", "dense_horizon5", "stop_dense_obs"])

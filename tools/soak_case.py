@@ -24,12 +24,32 @@ if os.environ.get("FX_SOAK_COSTS"):
     kw["cost_weights"] = w or {"lateral_jerk": 1.0}
 if os.environ.get("FX_SOAK_MATRIX") and "stop_point_s" not in kw:
     kw["as_matrix"] = True
+if os.environ.get("FX_SOAK_PROJ"):
+    kw["pseudo_normal"] = bool(rng.integers(0, 2))
+    kw["vertex_tangent"] = "bisector" if rng.integers(0, 2) else "chord"
+    if kw.get("ref_kind", "arc") != "scurve":
+        kw["knot_jitter"] = 0.3
 print(kw)
 inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
 out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
 with FrenetEngine(max_candidates=max(inp.n_candidates, 64), max_steps=inp.N, max_pred_steps=max(64, inp.N + 2), max_obstacles=256) as e:
-    res = e.plan_step(inp)
+    if os.environ.get("FX_SOAK_TUNING"):   # the forced decomposition soak_parity.py draws for this case
+        tn = (int(rng.choice([0, 1, 2, 4, 8, 16, 32])), int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 1, 2])),
+              int(rng.choice([0, 64, 128, 256])), int(rng.choice([0, 1, 2])))
+        sm, ob = int(rng.integers(0, 3)), (int(rng.choice([0, 1, 2])), int(rng.choice([0, 2, 3, 5])))
+        print("tuning", tn, "store mode", sm, "obstacle stage", ob)
+        e.set_tuning(*tn); e.set_store_mode(sm); e.set_obstacle_stage(*ob)
+        try:
+            res = e.plan_step(inp)
+        except ValueError:
+            print("   (does not apply: automatic)")
+            e.set_tuning(0, 0, 0, 0, 0); e.set_obstacle_stage(0)
+            res = e.plan_step(inp)
+    else:
+        res = e.plan_step(inp)
+    print("launch:", e.step_info())
     cost, flags = e.costs()
+    planes_dev = e.bundle() if inp.write_bundle else None
     cm = e.costmap() if inp.write_costmap and len(inp.cost_names) else None
     try:
         compare(e, inp, out, res)
@@ -54,3 +74,17 @@ if cm is not None:
     print(f"largest cost-map disagreement: candidate {g} term {inp.cost_names[j]}: device {cm[g, j]!r} oracle {out['costmap'][g, j]!r} rel {rel[g, j]:.3e}; "
           f"kinematic conditioning {ck[g]:.3e}; cost device {cost[g]!r} oracle {out['cost'][g]!r}")
     print("   the candidate's terms (device | oracle):", {n: (float(cm[g, k]), float(out["costmap"][g, k])) for k, n in enumerate(inp.cost_names)})
+
+ref = out["result"]
+print(f"winner device {res['best_index']} (cost {res['best_cost']!r}) oracle {ref['best_index']} (cost {ref['best_cost']!r}); collisions {res['n_collisions']} / {ref['n_collisions']}")
+if res["best_index"] != ref["best_index"] and min(res["best_index"], ref["best_index"]) >= 0:
+    a, b = res["best_index"], ref["best_index"]
+    print(f"   oracle costs of the two: {out['cost'][a]!r} {out['cost'][b]!r} (gap {abs(out['cost'][a] - out['cost'][b]):.3e}); device costs {cost[a]!r} {cost[b]!r}; "
+          f"margins {out['margin'][a]:.3e} {out['margin'][b]:.3e}; collision flags oracle {out['collision'][a]} {out['collision'][b]}")
+if planes_dev is not None:
+    err = (np.abs(planes_dev - out["planes"]) / (1.0 + np.abs(out["planes"]).max(axis=2, keepdims=True))).max(axis=2)
+    err[~stored] = 0
+    g, pl = np.unravel_index(np.argmax(np.where((ck < 1e3)[:, None], err, 0)), err.shape)
+    i = int(np.argmax(np.abs(planes_dev[g, pl] - out["planes"][g, pl])))
+    print(f"largest plane error among well-conditioned candidates: candidate {g} plane {pl}: {err[g, pl]:.3e} at step {i}: device {planes_dev[g, pl, i]!r} oracle {out['planes'][g, pl, i]!r}; "
+          f"conditioning {ck[g]:.3e}; theta_cl there {out['planes'][g, 9, i]!r}, v {out['planes'][g, 3, i]!r}, d {out['planes'][g, 8, i]!r}, kappa row {out['planes'][g, 5, max(i-1,0):i+2]}")

@@ -62,8 +62,14 @@ for case in range(first, first + n):
                 assert np.array_equal(tc[0][:len(order)], cost[order])
                 stats["topk"] = stats.get("topk", 0) + 1
             robust = bool(np.all(out["margin"] >= FRAGILE))
-            if robust:
-                assert res["best_index"] == out["result"]["best_index"], (res["best_index"], out["result"]["best_index"])
+            if robust and res["best_index"] != out["result"]["best_index"]:
+                # compare() has asserted that the two winners' costs lie within 1e-9 relative of each other; what may still differ
+                # is a TIE: two candidates whose costs agree to the last ulp or two (mirror-image lateral offsets) sort by index
+                # on one side and by that ulp on the other.  Counted, and bounded at the end of the run.
+                a, b = res["best_index"], out["result"]["best_index"]
+                assert a >= 0 and b >= 0 and abs(out["cost"][a] - out["cost"][b]) <= 8 * np.spacing(abs(out["cost"][b])), (a, b)
+                stats["tie_decided"] = stats.get("tie_decided", 0) + 1
+            elif robust:
                 assert res["n_collisions"] == out["result"]["n_collisions"]
         stats["cands"] += inp.n_candidates
         stats["winners"] += out["result"]["best_index"] >= 0
@@ -76,6 +82,9 @@ print(f"soak: {n} cases from {first}: {bad} failures; {stats}; how they were che
 ck = max(PARITY_STATS["checked"], 1)
 print(f"   fixed 1e-9: {PARITY_STATS['fixed'] / ck:.4%}  conditioning-scaled: {PARITY_STATS['scaled'] / ck:.4%}  magnitude only (tolerance >= 1): "
       f"{PARITY_STATS['escaped'] / ck:.5%}  fragile (admissible outcomes): {stats['fragile'] / max(stats['cands'], 1):.3%} of all candidates", flush=True)
+if stats.get("tie_decided", 0) > max(1, 2e-4 * n):
+    print("soak: too many winners decided by a last-ulp tie", flush=True)
+    bad += 1
 if PARITY_STATS["escaped"] > max(3, 5e-4 * ck) or PARITY_STATS["fixed"] < 0.97 * ck:
     print("soak: TOO MANY candidates went through the scaled / unasserted doors", flush=True)
     bad += 1
