@@ -24,6 +24,11 @@ from typing import Dict, List, Optional
 import numpy as np
 
 
+try:   # the CPython helper built next to the package (csrc/fx_host_ext.c); the NumPy expression below is the same test
+    from ._fxhost import point_in_polygon as _PIP
+except ImportError:
+    _PIP = None
+
 @dataclass
 class State:
     time_step: int
@@ -59,12 +64,15 @@ class Lanelet:
         if c is None:
             poly = np.vstack([self.left_vertices, self.right_vertices[::-1]])
             xi, yi = poly[:, 0], poly[:, 1]
+            xi, yi = np.ascontiguousarray(xi), np.ascontiguousarray(yi)
             c = self.__dict__["_outline"] = (xi, yi, np.roll(xi, 1), np.roll(yi, 1), float(xi.min()), float(xi.max()),
                                              float(yi.min()), float(yi.max()))
         xi, yi, xj, yj, x0, x1, y0, y1 = c
         x, y = float(p[0]), float(p[1])
         if x < x0 or x > x1 or y < y0 or y > y1:
             return False
+        if _PIP is not None:   # the same expression, term by term, in C (_fxhost.point_in_polygon): no temporaries
+            return _PIP(xi, yi, x, y)
         cross = (yi > y) != (yj > y)
         if not cross.any():
             return False
@@ -260,6 +268,9 @@ class Scenario:
         if tab is not None and (tab is False or len(tab[1]) >= upto):
             return tab or None
         ob = self.obstacles[oid]
+        # a closed loop asks for a window that ends a few steps later every time: the table is built once over everything the
+        # obstacle has (a static obstacle's prediction has no end: in blocks of 256 steps)
+        upto = max(upto, len(ob.state_list)) if ob.role == "dynamic" else (upto + 255) // 256 * 256
         pos, yaw, vel = [], [], []
         for ts in range(upto):
             st = ob.state_at_time(ts)

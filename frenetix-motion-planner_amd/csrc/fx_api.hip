@@ -1653,6 +1653,27 @@ int32_t fx_plan_and_package(FxContext *c, const FxStateUpdate *upd, double yaw_r
 #endif
 }
 
+int32_t fx_plan_batch_packaged(FxContext *c, int32_t n_agents, const FxStateUpdate *const *upd, const double *yaw_rate0, FxResult *res,
+                               FxPackage *pkg, double *const *blocks) {
+    if (!c || !res || !pkg) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_plan_batch_packaged: NULL argument");
+    if (!c->uploaded) return set_err(FX_ERR_NOT_READY, "fx_plan_batch_packaged before fx_upload");
+    if (n_agents != c->n_agents)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "fx_plan_batch_packaged: %d agents, the uploaded batch has %d", n_agents, c->n_agents);
+    int rc;
+    if (upd)
+        for (int a = 0; a < n_agents; a++)
+            if (upd[a] && (rc = fx_update_state(c, a, upd[a]))) return rc;
+    const bool was = c->package_enabled;
+    c->package_enabled = true;
+    rc = fx_evaluate(c);
+    c->package_enabled = was;
+    if (rc) return rc;
+    if ((rc = fx_finish_batch(c, res))) return rc;
+    for (int a = 0; a < n_agents; a++)
+        if ((rc = fx_read_package(c, a, yaw_rate0 ? yaw_rate0[a] : 0.0, pkg + a, blocks ? blocks[a] : nullptr))) return rc;
+    return FX_OK;
+}
+
 // ---- host geometry of the callers either side of the path ----
 // (s, d) of a Cartesian point along the reference polyline (planner.py:574-578 convert_to_curvilinear_coords): on every
 // segment k the foot point P_k + lam b and the interpolated normal n_k + lam dn are collinear with the point where

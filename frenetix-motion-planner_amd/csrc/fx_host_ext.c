@@ -173,7 +173,222 @@ static PyObject *state_update(PyObject *self, PyObject *args) {
     Py_RETURN_NONE;
 }
 
+/* ---- the plan steps of a batch of agents: one call from the planners' inputs to their results ----
+ * plan_batch(fn_addr, ctx_addr, inputs, yaw_rates, blocks, pkg_addr, update) -> [result dict per agent]  |  int (library error code)
+ *   fn_addr   address of fx_plan_batch_packaged, ctx_addr the FxContext*
+ *   inputs    sequence of PlanInputs (attributes x0_lon, x0_lat, x0_orientation, v_des, low_vel_mode, t_samp, v_samp, d_samp,
+ *             obstacles = packed predictions dict); read only when `update` is true: every agent's state is rewritten in place
+ *             (fx_update_state) in front of the evaluation
+ *   yaw_rates sequence of floats (row 0 of the packaged yaw-rate column), blocks one C-contiguous float64 buffer
+ *             [n][FX_PKG_ROWS][S] the winners' blocks are written to, pkg_addr the address of an FxPackage[n]
+ * What engine.plan_batch does with 2 n + 2 ctypes calls and n dict comprehensions (agent_batch.py:140-189's loop over planners). */
+typedef int32_t (*fx_batch_fn)(FxContext *, int32_t, const FxStateUpdate *const *, const double *, FxResult *, FxPackage *, double *const *);
+
+#define FXH_MAX_AGENTS 256
+static PyObject *s_x0_lon, *s_x0_lat, *s_x0_orientation, *s_v_des, *s_low_vel_mode, *s_t_samp, *s_v_samp, *s_d_samp, *s_obstacles;
+static PyObject *s_K, *s_kpos, *s_cov_inv, *s_npred, *s_hull, *s_nhull;
+static PyObject *r_keys[10];
+
+/* address of a contiguous buffer attribute / dict item (borrowed lifetime: the inputs outlive the call); *len_out = bytes */
+static int addr_of(PyObject *obj, char fmt, Py_ssize_t itemsize, const void **out, Py_ssize_t *len_out) {
+    Py_buffer view;
+    *out = NULL;
+    if (len_out) *len_out = 0;
+    if (obj == NULL || obj == Py_None) return 0;
+    if (PyObject_GetBuffer(obj, &view, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) return -1;
+    const char *f = view.format ? view.format : "B";
+    if (*f == '=' || *f == '<' || *f == '@') f++;
+    const int ok = view.itemsize == itemsize && (f[0] == fmt || (fmt == 'i' && f[0] == 'l' && itemsize == 4)) && f[1] == 0;
+    *out = view.buf;
+    if (len_out) *len_out = view.len;
+    PyBuffer_Release(&view);
+    if (!ok) {
+        PyErr_SetString(PyExc_TypeError, "expected a C-contiguous float64 / int32 array");
+        return -1;
+    }
+    return 0;
+}
+
+static int fill_update(PyObject *inp, FxStateUpdate *u) {
+    memset(u, 0, sizeof(*u));
+    PyObject *a;
+    const void *p;
+    Py_ssize_t len;
+#define FXH_ATTR(name, field, type, fmt, size, min_len)                                   \
+    if (!(a = PyObject_GetAttr(inp, name))) return -1;                                    \
+    if (addr_of(a, fmt, size, &p, &len) != 0 || len < (Py_ssize_t)(min_len)) {            \
+        Py_DECREF(a);                                                                     \
+        if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "plan_batch: array too short"); \
+        return -1;                                                                        \
+    }                                                                                     \
+    Py_DECREF(a);                                                                         \
+    u->field = (const type *)p
+    FXH_ATTR(s_x0_lon, x0_lon, double, 'd', 8, 24);
+    FXH_ATTR(s_x0_lat, x0_lat, double, 'd', 8, 24);
+    FXH_ATTR(s_t_samp, t_samp, double, 'd', 8, 8);
+    FXH_ATTR(s_v_samp, v_samp, double, 'd', 8, 8);
+    FXH_ATTR(s_d_samp, d_samp, double, 'd', 8, 8);
+#undef FXH_ATTR
+    if (!(a = PyObject_GetAttr(inp, s_x0_orientation))) return -1;
+    u->x0_orientation = PyFloat_AsDouble(a);
+    Py_DECREF(a);
+    if (!(a = PyObject_GetAttr(inp, s_v_des))) return -1;
+    u->v_des = PyFloat_AsDouble(a);
+    Py_DECREF(a);
+    if (PyErr_Occurred()) return -1;
+    if (!(a = PyObject_GetAttr(inp, s_low_vel_mode))) return -1;
+    const int lv = PyObject_IsTrue(a);
+    Py_DECREF(a);
+    if (lv < 0) return -1;
+    u->low_vel_mode = lv;
+    PyObject *o = PyObject_GetAttr(inp, s_obstacles);
+    if (!o) return -1;
+    int rc = 0;
+    if (PyDict_Check(o)) {
+        PyObject *k = PyDict_GetItemWithError(o, s_K);
+        const long K = k ? PyLong_AsLong(k) : 0;
+        if (K > 0) {
+            if (addr_of(PyDict_GetItemWithError(o, s_kpos), 'd', 8, &p, NULL)) rc = -1; else u->obs_pos = (const double *)p;
+            if (!rc && addr_of(PyDict_GetItemWithError(o, s_cov_inv), 'd', 8, &p, NULL)) rc = -1; else u->obs_cov_inv = (const double *)p;
+            if (!rc && addr_of(PyDict_GetItemWithError(o, s_npred), 'i', 4, &p, NULL)) rc = -1; else u->obs_npred = (const int32_t *)p;
+            if (!rc) {
+                if (addr_of(PyDict_GetItemWithError(o, s_hull), 'd', 8, &p, &len)) rc = -1;
+                else if (p && len > 0) {   /* (also when no hull is left: the old ones must go -- the counts say so) */
+                    u->obs_hull = (const double *)p;
+                    if (addr_of(PyDict_GetItemWithError(o, s_nhull), 'i', 4, &p, NULL)) rc = -1; else u->obs_nhull = (const int32_t *)p;
+                }
+            }
+        }
+        if (PyErr_Occurred()) rc = -1;
+    } else if (o != Py_None) {
+        PyErr_SetString(PyExc_TypeError, "plan_batch: inputs.obstacles must be the packed predictions dict");
+        rc = -1;
+    }
+    Py_DECREF(o);
+    return rc;
+}
+
+static PyObject *result_dict(const FxResult *r) {
+    PyObject *hist = PyList_New(FX_NUM_REASONS);
+    if (!hist) return NULL;
+    for (int k = 0; k < FX_NUM_REASONS; k++) PyList_SET_ITEM(hist, k, PyLong_FromLongLong(r->reason_hist[k]));
+    PyObject *vals[10] = {PyLong_FromLongLong(r->n_candidates), PyLong_FromLongLong(r->best_index), PyFloat_FromDouble(r->best_cost),
+                          PyLong_FromLongLong(r->n_returned),   PyLong_FromLongLong(r->n_feasible), PyLong_FromLongLong(r->n_infeasible),
+                          PyLong_FromLongLong(r->n_collisions), PyFloat_FromDouble(r->feasible_percentage),
+                          PyFloat_FromDouble(r->kernel_ms),     hist};
+    PyObject *d = PyDict_New();
+    int bad = d == NULL;
+    for (int k = 0; k < 10; k++) {
+        if (!vals[k] || (!bad && PyDict_SetItem(d, r_keys[k], vals[k]) != 0)) bad = 1;
+        Py_XDECREF(vals[k]);
+    }
+    if (bad) {
+        Py_XDECREF(d);
+        return NULL;
+    }
+    return d;
+}
+
+static PyObject *plan_batch(PyObject *self, PyObject *args) {
+    unsigned long long fn_addr, ctx_addr, pkg_addr;
+    PyObject *inputs, *yaws, *blocks;
+    int update;
+    if (!PyArg_ParseTuple(args, "KKOOOKp", &fn_addr, &ctx_addr, &inputs, &yaws, &blocks, &pkg_addr, &update)) return NULL;
+    if (!fn_addr || !ctx_addr || !pkg_addr) {
+        PyErr_SetString(PyExc_ValueError, "plan_batch: NULL address");
+        return NULL;
+    }
+    PyObject *seq = PySequence_Fast(inputs, "plan_batch: inputs must be a sequence"), *yseq = NULL, *out = NULL;
+    if (!seq) return NULL;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    FxStateUpdate upd[FXH_MAX_AGENTS];
+    const FxStateUpdate *updp[FXH_MAX_AGENTS];
+    double yaw[FXH_MAX_AGENTS], *blk[FXH_MAX_AGENTS];
+    FxResult res[FXH_MAX_AGENTS];
+    const void *bp;
+    Py_ssize_t blen;
+    if (n < 1 || n > FXH_MAX_AGENTS) {
+        PyErr_SetString(PyExc_ValueError, "plan_batch: 1 .. 256 agents");
+        goto done;
+    }
+    if (!(yseq = PySequence_Fast(yaws, "plan_batch: yaw_rates must be a sequence"))) goto done;
+    if (PySequence_Fast_GET_SIZE(yseq) != n) {
+        PyErr_SetString(PyExc_ValueError, "plan_batch: one yaw rate per agent");
+        goto done;
+    }
+    if (addr_of(blocks, 'd', 8, &bp, &blen) != 0) goto done;
+    if (bp && blen % (n * (Py_ssize_t)sizeof(double) * FX_PKG_ROWS) != 0) {
+        PyErr_SetString(PyExc_ValueError, "plan_batch: blocks must be [n][FX_PKG_ROWS][S] doubles");
+        goto done;
+    }
+    for (Py_ssize_t a = 0; a < n; a++) {
+        yaw[a] = PyFloat_AsDouble(PySequence_Fast_GET_ITEM(yseq, a));
+        if (yaw[a] == -1.0 && PyErr_Occurred()) goto done;
+        blk[a] = bp ? (double *)bp + a * (blen / (Py_ssize_t)sizeof(double) / n) : NULL;
+        updp[a] = NULL;
+        if (update) {
+            if (fill_update(PySequence_Fast_GET_ITEM(seq, a), &upd[a]) != 0) goto done;
+            updp[a] = &upd[a];
+        }
+    }
+    {
+        int32_t rc;
+        Py_BEGIN_ALLOW_THREADS
+        rc = ((fx_batch_fn)(uintptr_t)fn_addr)((FxContext *)(uintptr_t)ctx_addr, (int32_t)n, update ? updp : NULL, yaw, res,
+                                               (FxPackage *)(uintptr_t)pkg_addr, bp ? blk : NULL);
+        Py_END_ALLOW_THREADS
+        if (rc != 0) {
+            out = PyLong_FromLong(rc);   /* the caller words the error (fx_last_error) */
+            goto done;
+        }
+    }
+    out = PyList_New(n);
+    for (Py_ssize_t a = 0; out && a < n; a++) {
+        PyObject *d = result_dict(&res[a]);
+        if (!d) {
+            Py_CLEAR(out);
+            break;
+        }
+        PyList_SET_ITEM(out, a, d);
+    }
+done:
+    Py_XDECREF(yseq);
+    Py_DECREF(seq);
+    return out;
+}
+
+/* point_in_polygon(xi, yi, x, y) -> bool: ray casting over the closed outline (xi, yi), the arithmetic of
+ * commonroad_xml.Lanelet.contains' array expression term by term (edge k runs from vertex k-1 to vertex k):
+ * crossing <=> (yi > y) != (yj > y) and x < (xj - xi) * (y - yi) / (yj - yi) + xi; inside <=> an odd number of crossings.
+ * (the goal test of the velocity planner, velocity_planner.py:104-109, once per agent and plan step) */
+static PyObject *point_in_polygon(PyObject *self, PyObject *args) {
+    PyObject *ox, *oy;
+    double x, y;
+    if (!PyArg_ParseTuple(args, "OOdd", &ox, &oy, &x, &y)) return NULL;
+    const void *px, *py;
+    Py_ssize_t lx, ly;
+    if (addr_of(ox, 'd', 8, &px, &lx) != 0 || addr_of(oy, 'd', 8, &py, &ly) != 0) return NULL;
+    if (!px || !py || lx != ly) {
+        PyErr_SetString(PyExc_ValueError, "point_in_polygon: two float64 arrays of one length");
+        return NULL;
+    }
+    const double *xi = (const double *)px, *yi = (const double *)py;
+    const Py_ssize_t n = lx / 8;
+    int odd = 0;
+    for (Py_ssize_t k = 0; k < n; k++) {
+        const Py_ssize_t j = k ? k - 1 : n - 1;
+        if ((yi[k] > y) != (yi[j] > y)) {
+            const double t = (xi[j] - xi[k]) * (y - yi[k]) / (yi[j] - yi[k]) + xi[k];
+            if (x < t) odd ^= 1;
+        }
+    }
+    return PyBool_FromLong(odd);
+}
+
 static PyMethodDef methods[] = {
+    {"point_in_polygon", point_in_polygon, METH_VARARGS, "point_in_polygon(xi, yi, x, y) -> bool (ray casting, closed outline)"},
+    {"plan_batch", plan_batch, METH_VARARGS,
+     "plan_batch(fn_addr, ctx_addr, inputs, yaw_rates, blocks, pkg_addr, update) -> [result dict per agent] | error code"},
     {"state_update", state_update, METH_VARARGS,
      "state_update(struct_addr, x0_lon, x0_lat, x0_orientation, v_des, low_vel_mode, t, v, d, pos, cov_inv, npred, hull, nhull): fill an FxStateUpdate"},
     {"pack_predictions", pack_predictions, METH_VARARGS,
@@ -189,5 +404,25 @@ PyMODINIT_FUNC PyInit__fxhost(void) {
     s_shape = PyUnicode_InternFromString("shape");
     s_length = PyUnicode_InternFromString("length");
     s_width = PyUnicode_InternFromString("width");
+    s_x0_lon = PyUnicode_InternFromString("x0_lon");
+    s_x0_lat = PyUnicode_InternFromString("x0_lat");
+    s_x0_orientation = PyUnicode_InternFromString("x0_orientation");
+    s_v_des = PyUnicode_InternFromString("v_des");
+    s_low_vel_mode = PyUnicode_InternFromString("low_vel_mode");
+    s_t_samp = PyUnicode_InternFromString("t_samp");
+    s_v_samp = PyUnicode_InternFromString("v_samp");
+    s_d_samp = PyUnicode_InternFromString("d_samp");
+    s_obstacles = PyUnicode_InternFromString("obstacles");
+    s_K = PyUnicode_InternFromString("K");
+    s_kpos = PyUnicode_InternFromString("pos");
+    s_cov_inv = PyUnicode_InternFromString("cov_inv");
+    s_npred = PyUnicode_InternFromString("npred");
+    s_hull = PyUnicode_InternFromString("hull");
+    s_nhull = PyUnicode_InternFromString("nhull");
+    {
+        static const char *names[10] = {"n_candidates", "best_index", "best_cost", "n_returned", "n_feasible", "n_infeasible",
+                                        "n_collisions", "feasible_percentage", "kernel_ms", "reason_hist"};
+        for (int k = 0; k < 10; k++) r_keys[k] = PyUnicode_InternFromString(names[k]);
+    }
     return PyModule_Create(&moduledef);
 }

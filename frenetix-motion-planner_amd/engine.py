@@ -89,7 +89,7 @@ def _fxhost():
     if _FXHOST is None:
         try:
             from . import _fxhost as m
-            _FXHOST = (m, C.cast(lib().fx_pack_predictions, C.c_void_p).value)
+            _FXHOST = (m, C.cast(lib().fx_pack_predictions, C.c_void_p).value, C.cast(lib().fx_plan_batch_packaged, C.c_void_p).value)
         except ImportError:
             _FXHOST = False
     return _FXHOST
@@ -537,6 +537,34 @@ class FrenetEngine:
             self._resident_keys = keys
         self.evaluate()
         return self.finish()
+
+    def plan_batch_packaged(self, inputs: Sequence[PlanInputs], yaw_rates: Sequence[float]):
+        """plan_batch + every agent's winner package in ONE call across the boundary (fx_plan_batch_packaged through
+        `_fxhost.plan_batch`: the inputs' arrays are read in C, the results come back as dicts): ([result dict],
+        [WinnerPackage or None]).  The general path -- different structures, a sampling matrix, horizons of different
+        lengths, no extension -- is plan_batch() followed by package() per agent."""
+        inputs = list(inputs)
+        n = len(inputs)
+        keys = [inp.structure_key() if inp.sampling_matrix is None else None for inp in inputs]
+        h = _fxhost()
+        S = inputs[0].n_samples if n else 0
+        fast = bool(h) and n > 0 and None not in keys and all(inp.n_samples == S and inp.write_bundle for inp in inputs)
+        if not fast:
+            res = self.plan_batch(inputs)
+            return res, [self.package(a, yaw_rates[a]) if inputs[a].write_bundle and getattr(self, "packaging", False) else None
+                         for a in range(n)]
+        update = self._resident_keys is not None and keys == self._resident_keys
+        if not update:
+            self.upload(inputs)
+            self._resident_keys = keys
+        else:
+            self._inputs = inputs
+        pkgs = (_abi.FxPackage * n)()
+        blocks = np.empty((n, _abi.FX_PKG_ROWS, S))
+        out = h[0].plan_batch(h[2], self._ctx.value, inputs, yaw_rates, blocks, C.addressof(pkgs), update)
+        if out.__class__ is int:
+            check(out)
+        return out, [WinnerPackage(pkgs[a], blocks[a], inputs[a]) if pkgs[a].found else None for a in range(n)]
 
     # -- read-back --
     def costs(self, agent: int = 0):

@@ -205,22 +205,24 @@ class FrenetPlannerInterfaceHip:
 
     def finish_step(self, pair, current_timestep=None):
         """pair: the planner's trajectory pair of this step (ignored on non-planning steps)."""
+        planner = self.planner
         if self.replanning_counter == 0 or self.config_plan.replanning_frequency < 2:
             if not pair:
                 self.msg_logger.critical("No Kinematic Feasible and Optimal Trajectory Available!")
                 return None, self.replanning_counter
-            self.planner.record_state_and_input(pair[0][1])
-            self.x_0 = copy.deepcopy(self.planner.record_state_list[-1])
-            self.x_cl = (pair[2][1], pair[3][1])
+            k = 1
             self.replanning_traj = pair
             selected = pair[0]
         else:
             k = 1 + self.replanning_counter
-            self.planner.record_state_and_input(self.replanning_traj[0][k])
-            self.x_0 = copy.deepcopy(self.planner.record_state_list[-1])
-            self.x_cl = (self.replanning_traj[2][k], self.replanning_traj[3][k])
-            self.planner.plan_postprocessing(self.planner.optimal_trajectory, 0.0, replanning_counter=self.replanning_counter)
-            selected = self.replanning_traj
+            pair = selected = self.replanning_traj
+        state = pair[0][k]
+        planner.record_state_and_input(state)
+        # (copy.deepcopy(record_state_list[-1]) in the reference, :262,274: the state's own __deepcopy__, without the generic walk)
+        self.x_0 = state.__deepcopy__() if state.__class__ is ReactivePlannerState else copy.deepcopy(state)
+        self.x_cl = (pair[2][k], pair[3][k])
+        if k > 1:
+            planner.plan_postprocessing(planner.optimal_trajectory, 0.0, replanning_counter=self.replanning_counter)
         if self.msg_logger.isEnabledFor(logging.INFO):   # (three formatted strings per agent and step otherwise)
             self.msg_logger.info("current time step: %s", current_timestep)
             self.msg_logger.info("current velocity: %s", self.x_0.velocity)

@@ -132,14 +132,21 @@ class AgentBatchHip:
         out: Dict[int, Optional[list]] = {}
         t0 = time.time()
         results = []
+        packages = None
         if planning:
-            results = self.engine.plan_batch([inp for _, inp, _ in planning])
+            if hasattr(self.engine, "plan_batch_packaged") and getattr(self.engine, "packaging", False):
+                # one call across the boundary: states rewritten in place, evaluation, results, every winner packaged
+                results, packages = self.engine.plan_batch_packaged([inp for _, inp, _ in planning],
+                                                                    [a.planner.x_0.yaw_rate for a, _, _ in planning])
+            else:
+                results = self.engine.plan_batch([inp for _, inp, _ in planning])
             self.launches += 1
             self.last_batch_ms = (time.time() - t0) * 1e3
 
-        def conclude(a, inp, res, j):
+        def conclude(a, inp, res, j, packages=packages):
             p = a.planner
-            best = p.plan_consume(inp, res, self.engine, j) if res is not None else None
+            best = (p.plan_consume(inp, res, self.engine, j, package=packages[j] if packages is not None else False)
+                    if res is not None else None)
             if best is None and p._sampling_min + 1 < p._sampling_max:
                 self.escalations += 1
                 pair = p.plan_escalate(t0)   # the whole next level on the planner's own engine (identical on every replica)
@@ -170,7 +177,7 @@ class AgentBatchHip:
                 res1 = self.engine.plan_batch([one for _, one in again])
                 self.launches += 1
                 for j1, (a, one) in enumerate(again):
-                    conclude(a, one, res1[j1], j1)
+                    conclude(a, one, res1[j1], j1, None)
         for a, _, _ in passive:
             sel, _ = a.finish_step(None, global_timestep)
             out[a.id] = sel[0] if sel is not None else None
@@ -286,9 +293,11 @@ class MultiAgentSimulation:
 
     def packed_predictions_for(self, agent_id: int):
         """The same predictions as `predictions_for`, packed: ALL entries of the step (non-agent obstacles, then the agents in
-        order) are packed once -- covariance inverses and OBB-sum hulls included -- and every agent takes the rows without its
-        own.  Identical arrays to packing the agent's dict on its own, except that the stored prediction length P is the
-        step's longest instead of the longest among the agent's entries (padding only)."""
+        order) are packed once -- covariance inverses and OBB-sum hulls included -- and every agent reads the SAME position,
+        covariance and hull arrays; only the two count arrays are its own, with its own row set to zero predictions and zero
+        hulls.  An obstacle without predictions contributes to no step of the prediction cost (collision_probability.py:287,
+        `i < len(pos_list)`) and is skipped by the collision stage (collision_check.py:165-168), so the step's result is that of
+        the dict without the agent; the dict view (`predictions_for`) is built when somebody reads it."""
         t = self.time_step
         sh = getattr(self, "_shared_packed", None)
         if sh is None or sh[0] != t:
@@ -297,14 +306,19 @@ class MultiAgentSimulation:
             for aid in self.agent_ids:
                 if aid in own:
                     allp[aid] = own[aid]
-            keys = list(allp)
             packed = pack_predictions(allp, self.S, self._hull_builder()) if allp else None
-            sh = self._shared_packed = (t, keys, packed)
-        _, keys, packed = sh
+            sh = self._shared_packed = (t, {k: j for j, k in enumerate(allp)}, packed)
+        _, row_of, packed = sh
         if packed is None:
             return PackedPredictions(PackedPredictions.subset({}, []), lambda: {})
-        rows = [j for j, k in enumerate(keys) if k != agent_id]
-        return PackedPredictions(PackedPredictions.subset(packed, rows), lambda: self.predictions_for(agent_id))
+        j = row_of.get(agent_id)
+        if j is None:
+            return PackedPredictions(packed, lambda: self.predictions_for(agent_id))
+        npred, nhull = packed["npred"].copy(), packed["nhull"].copy()
+        npred[j] = nhull[j] = 0
+        return PackedPredictions(dict(K=packed["K"], P=packed["P"], pos=packed["pos"], cov_inv=packed["cov_inv"], npred=npred,
+                                      hull=packed["hull"], nhull=nhull, muted_row=j),
+                                 lambda: self.predictions_for(agent_id))
 
     def _hull_builder(self):
         """what the agents' own planners pack with: the engine library's host geometry, or the engine object's own builder
@@ -350,6 +364,8 @@ class MultiAgentSimulation:
     def _exchange(self, local_rows: np.ndarray) -> np.ndarray:
         """ONE all-gather per simulation step: [items_per_rank][S][FIELDS] from every rank -> plans of all agents (the replicas
         of a split agent hold the same plan: part 0's is taken)."""
+        if self.world == 1 and len(local_rows) == len(self.agent_ids) and not self.split:
+            return local_rows   # one rank holds every agent whole, in order: its rows are the plans
         per = max(len(it) for it in self.items)
         buf = np.zeros((per, self.S, self.FIELDS))
         buf[:len(local_rows)] = local_rows

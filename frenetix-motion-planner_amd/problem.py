@@ -116,11 +116,11 @@ class PackedPredictions:
             self._dict = self._make() if self._make is not None else {}
         return self._dict
 
-    def __len__(self):
-        return int(self.packed["K"])
+    def __len__(self):   # entries of the dict form: a muted row (MultiAgentSimulation.packed_predictions_for) is not one
+        return int(self.packed["K"]) - ("muted_row" in self.packed)
 
     def __bool__(self):
-        return int(self.packed["K"]) > 0
+        return len(self) > 0
 
     def __iter__(self):
         return iter(self.as_dict())
@@ -384,12 +384,39 @@ class PlanInputs:
     def structure_key(self):
         """Everything of a plan step that fx_update_state cannot change: two inputs with equal keys differ only in the ego
         state, the desired velocity, the sampling values and the obstacle predictions (same counts)."""
-        o = self.obstacles
-        return (self.N, self.dt, self.mode, bool(self.stop_point), (self.vehicle.length, self.vehicle.width, self.vehicle.wheelbase, self.vehicle.wb_rear_axle, self.vehicle.a_max,
-                 self.vehicle.v_switch, self.vehicle.delta_max), getattr(self.coordinate_system, "uid", None) or id(self.coordinate_system),
+        k = self.__dict__.get("_skey")   # (without the shard, which a batch sets after construction; kept by next_step)
+        if k is None:
+            o = self.obstacles
+            k = self._skey = (
+                self.N, self.dt, self.mode, bool(self.stop_point),
+                (self.vehicle.length, self.vehicle.width, self.vehicle.wheelbase, self.vehicle.wb_rear_axle, self.vehicle.a_max,
+                 self.vehicle.v_switch, self.vehicle.delta_max),
+                getattr(self.coordinate_system, "uid", None) or id(self.coordinate_system),
                 None if self.sampling_matrix is not None else (len(self.t_samp), len(self.v_samp), len(self.d_samp)),
                 tuple(self.cost_names), self._cost_w.tobytes(), int(o["K"]), int(o["P"]), self._dto.tobytes(),
-                None if self._bound is None else self._bound.setdefault("uid", next(_BOUND_UIDS)), self.shard)
+                None if self._bound is None else self._bound.setdefault("uid", next(_BOUND_UIDS)))
+        return k + (self.shard,)
+
+    def next_step(self, *, low_vel_mode, x0_lon, x0_lat, x0_orientation, v_des, t_samp, v_samp, d_samp, obstacles):
+        """The inputs of the same planner's NEXT plan step: everything a closed-loop step changes -- ego state, desired velocity,
+        sampling values, predictions -- replaced on a shallow copy; horizon, vehicle, reference, cost function, flags, road
+        boundary stay (the caller vouches for that: ReactivePlannerHip._inputs_for_level checks what it can replace).  Skips
+        the conversions and look-ups of __post_init__ that cannot have changed; the structure key survives when the new
+        arrays have the old lengths and the predictions the old (K, P)."""
+        prev = self.__dict__
+        new = object.__new__(PlanInputs)
+        d = new.__dict__
+        d.update(prev)
+        o_prev = prev["obstacles"]
+        if obstacles is None:
+            obstacles = o_prev if not o_prev["K"] else pack_predictions(None, self.N + 1, None)
+        d["low_vel_mode"], d["x0_orientation"], d["v_des"], d["obstacles"], d["shard"] = low_vel_mode, x0_orientation, v_des, obstacles, None
+        d["x0_lon"], d["x0_lat"] = _f64(x0_lon), _f64(x0_lat)
+        d["t_samp"], d["v_samp"], d["d_samp"] = t, v, dd = _f64(t_samp), _f64(v_samp), _f64(d_samp)
+        if (len(t) != len(prev["t_samp"]) or len(v) != len(prev["v_samp"]) or len(dd) != len(prev["d_samp"])
+                or obstacles["K"] != o_prev["K"] or obstacles["P"] != o_prev["P"]):
+            d.pop("_skey", None)
+        return new
 
     def candidate_params(self, g: int):
         """(t0, t1, s0, ss0, sss0, ss1, sss1, d0, dd0, ddd0, d1, dd1, ddd1) of candidate g -- the

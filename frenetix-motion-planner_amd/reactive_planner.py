@@ -133,6 +133,7 @@ class ReactivePlannerHip:
         self.last_step: Optional[PlanStepResult] = None
         self.planning_time = None
         self._packed_predictions = None
+        self._prev_inputs = None          # the last PlanInputs built (a closed loop's next step differs in a few fields)
         self.logger = None               # logging_formats.DataLoggingCosts (planner.py:150-158)
         self.record_state_list = []
         self.record_input_list = []
@@ -284,16 +285,24 @@ class ReactivePlannerHip:
         if weights is None or self._weights_src is not cw or self._weights_sig != sig:   # replaced, or edited in place
             weights = self._weights_nz = {k: w for k, w in cw.items() if w != 0}
             self._weights_src, self._weights_sig = cw, sig
-        if not self._packed_predictions["K"]:
-            # prediction_costs over an empty predictions dict is 0 for every candidate
-            pass
-        return PlanInputs(N=self.N, dt=self.dT, low_vel_mode=self._LOW_VEL_MODE, x0_lon=x_lon, x0_lat=x_lat,
-                          x0_orientation=self.x_0.orientation, v_des=self.desired_velocity, vehicle=self.vehicle_params,
-                          coordinate_system=self.coordinate_system, t_samp=t, v_samp=v, d_samp=d,
-                          stop_point=stop_point_s is not None, cost_weights=weights,
-                          draw_traj_set=self._draw_traj_set, kinematic_debug=self._kinematic_debug, write_bundle=True,
-                          write_costmap=True, collision=self.use_prediction, obstacles=self._packed_predictions,
-                          road_boundary=boundary)
+        prev = self._prev_inputs
+        if (prev is not None and prev.cost_weights is weights and prev.coordinate_system is self.coordinate_system
+                and prev.road_boundary is boundary and prev.vehicle is self.vehicle_params and prev.N == self.N and prev.dt == self.dT
+                and prev.stop_point == (stop_point_s is not None) and prev.draw_traj_set == self._draw_traj_set
+                and prev.kinematic_debug == self._kinematic_debug and prev.collision == self.use_prediction):
+            # the closed loop's usual step: only the state, the sampling values and the predictions differ from the last inputs
+            inp = prev.next_step(low_vel_mode=self._LOW_VEL_MODE, x0_lon=x_lon, x0_lat=x_lat, x0_orientation=self.x_0.orientation,
+                                 v_des=self.desired_velocity, t_samp=t, v_samp=v, d_samp=d, obstacles=self._packed_predictions)
+        else:
+            inp = PlanInputs(N=self.N, dt=self.dT, low_vel_mode=self._LOW_VEL_MODE, x0_lon=x_lon, x0_lat=x_lat,
+                             x0_orientation=self.x_0.orientation, v_des=self.desired_velocity, vehicle=self.vehicle_params,
+                             coordinate_system=self.coordinate_system, t_samp=t, v_samp=v, d_samp=d,
+                             stop_point=stop_point_s is not None, cost_weights=weights,
+                             draw_traj_set=self._draw_traj_set, kinematic_debug=self._kinematic_debug, write_bundle=True,
+                             write_costmap=True, collision=self.use_prediction, obstacles=self._packed_predictions,
+                             road_boundary=boundary)
+        self._prev_inputs = inp
+        return inp
 
     def _create_end_point_trajectory_bundle(self, x_0_lon, x_0_lat, stop_point_s, samp_level: int) -> PlanInputs:
         """Stop-point sampling set of reactive_planner.py:628-671 as engine inputs: T x S x (D u {d0}) with the
@@ -337,10 +346,13 @@ class ReactivePlannerHip:
         self._stop_point_s = stop_point_s
         return self._inputs_for_level(self._sampling_min, stop_point_s)
 
-    def plan_consume(self, inputs: PlanInputs, res: dict, engine, agent: int = 0):
+    def plan_consume(self, inputs: PlanInputs, res: dict, engine, agent: int = 0, package=False):
         """Take this planner's share of a batched launch (first sampling level); returns the chosen trajectory
-        (materialised -- the batch engine's buffers are reused) or None when the level has to escalate."""
-        package = engine.package(agent, self.x_0.yaw_rate) if getattr(engine, "packaging", False) else None
+        (materialised -- the batch engine's buffers are reused) or None when the level has to escalate.
+        package: the winner as the batched call already packaged it (engine.plan_batch_packaged; None = nothing found);
+        False: read it here."""
+        if package is False:
+            package = engine.package(agent, self.x_0.yaw_rate) if getattr(engine, "packaging", False) else None
         best = self._consume_result(inputs, res, engine, agent, package, self._sampling_min)
         if best is not None:
             best.materialise()
@@ -508,21 +520,34 @@ class ReactivePlannerHip:
             b = pkg.block
             n, t0 = b.shape[1], self.x_0.time_step
             YR, ST, OR = _abi.PKG_ROW_YAW_RATE, _abi.PKG_ROW_STEERING, _abi.PKG_ROW_ORIENTATION
+            cols = {}
 
-            def cart(i):   # one column of the block -> one state (a closed-loop step reads one or two of them)
-                c = b[:, i].tolist()
+            def col(i):   # one column of the block as floats, shared by the four lists (a closed-loop step reads one or two)
+                c = cols.get(i)
+                if c is None:
+                    c = cols[i] = b[:, i].tolist()
+                return c
+
+            def cart(i):
+                c = col(i)
                 return ReactivePlannerState(t0 + i, np.array((c[0], c[1])), c[OR], c[3], c[4], c[YR], c[ST])
 
             def curv(i):
-                c = b[:, i].tolist()
+                c = col(i)
                 return dict(time_step=t0 + i, position=np.array((c[7], c[8])), velocity=c[3], acceleration=c[4], orientation=c[2],
                             yaw_rate=c[5])
 
+            def lon(i):   # (s, s', s''): x_cl of the next cycle is entry 1 (+ replanning counter)
+                c = col(i)
+                return [c[7], c[10], c[11]]
+
+            def lat(i):   # (d, d', d'')
+                c = col(i)
+                return [c[8], c[12], c[13]]
+
             states = _LazyStates(n, cart)
-            states._rows_src = (b, [0, 1, OR, 3])   # [n][x, y, orientation, velocity]: what a batch of agents shares as predictions
-            # (s, s', s'') and (d, d', d'') per step: x_cl of the next cycle is entry 1 (+ replanning counter) -- built on access
-            return (states, _LazyStates(n, curv), _LazyStates(n, lambda i: b[_LON_ROWS, i].tolist()),
-                    _LazyStates(n, lambda i: b[_LAT_ROWS, i].tolist()))
+            states._rows_src = (b, _ROWS_XYOV)   # [n][x, y, orientation, velocity]: what a batch of agents shares as predictions
+            return (states, _LazyStates(n, curv), _LazyStates(n, lon), _LazyStates(n, lat))
         c, k = trajectory.cartesian, trajectory.curvilinear
         n = len(c.x)
         theta = np.asarray(c.theta, dtype=np.float64)
@@ -571,7 +596,7 @@ class ReactivePlannerHip:
             self._engine = None
 
 
-_LON_ROWS, _LAT_ROWS = np.array([7, 10, 11]), np.array([8, 12, 13])   # planes s, s', s'' / d, d', d'' of the package block
+_ROWS_XYOV = [0, 1, _abi.PKG_ROW_ORIENTATION, 3]   # x, y, shifted heading, velocity of the package block
 
 
 class _LazyStates:
@@ -606,6 +631,11 @@ class _LazyStates:
         return it
 
     def __getitem__(self, j):
+        if j.__class__ is int:
+            it = self._items[j]
+            if it is None:
+                it = self._items[j] = self._make(j if j >= 0 else j + len(self._items))
+            return it
         if isinstance(j, slice):
             return [self._get(i) for i in range(*j.indices(len(self._items)))]
         return self._get(j)

@@ -117,8 +117,7 @@ class TrajectorySample:
             # the winner: the library has already delivered everything (fx_read_package), nothing is fetched
             flags, self._cost = pkg.flags, pkg.cost
             self._planes = pkg.planes
-            self._coeffs = (pkg.lon, pkg.lat, pkg.traj_len)
-            self._pkg = pkg   # (the cost map is built from the package's raw costs when it is asked for)
+            self._pkg = pkg   # (coefficients and the cost map are built from the package when they are asked for)
         elif step.have_arrays:
             flags = int(step.flags[index])
             self._cost = float(step.cost[index])
@@ -231,7 +230,8 @@ class TrajectorySample:
 
     def _need_coeffs(self):
         if self._coeffs is None:
-            self._coeffs = self._step.fetch_coeffs(self.uniqueId)
+            pkg = self._pkg
+            self._coeffs = (pkg.lon, pkg.lat, pkg.traj_len) if pkg is not None else self._step.fetch_coeffs(self.uniqueId)
         return self._coeffs
 
     @property

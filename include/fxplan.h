@@ -341,6 +341,13 @@ typedef struct FxPackage {
 int32_t fx_set_package(FxContext *ctx, int32_t enabled);
 int32_t fx_read_package(FxContext *ctx, int32_t agent, double yaw_rate0, FxPackage *pkg, double *block /*[FX_PKG_ROWS][S] or NULL*/);
 int32_t fx_plan_and_package(FxContext *ctx, const FxStateUpdate *upd, double yaw_rate0, FxResult *res, FxPackage *pkg, double *block);
+/* the plan steps of a batch of agents in ONE call (agent_batch.py:140-189 runs one planner after the other): fx_update_state for
+ * every agent whose upd[a] is not NULL (upd itself may be NULL), one evaluation with the winner package on, the results, every
+ * agent's package.  n_agents = the uploaded batch's; yaw_rate0 [n_agents] (NULL: zeros); blocks [n_agents] pointers to
+ * [FX_PKG_ROWS][S_a] doubles each (NULL, or NULL entries: no block).  A refused update leaves the context as the earlier
+ * agents' updates left it and nothing is evaluated. */
+int32_t fx_plan_batch_packaged(FxContext *ctx, int32_t n_agents, const FxStateUpdate *const *upd, const double *yaw_rate0, FxResult *res,
+                               FxPackage *pkg, double *const *blocks);
 
 /* ---- host geometry of the callers either side of the path (plain C, no device) ----
  *      fx_cs_to_curvilinear: (s, d) of a Cartesian point along a reference polyline with per-vertex normals (the projection

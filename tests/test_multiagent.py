@@ -303,12 +303,17 @@ def test_shared_prediction_packing_equals_per_agent_packing(scenario):
         pp = sim.packed_predictions_for(a.id)
         want = pack_predictions(sim.predictions_for(a.id), sim.S, build_obstacle_hulls)
         got = pp.packed
-        assert isinstance(pp, PackedPredictions) and got["K"] == want["K"] == len(pp) and got["P"] >= want["P"]
+        # the agent's own entry is still a row of the shared arrays, muted: zero predictions, zero hulls
+        j = got["muted_row"]
+        assert isinstance(pp, PackedPredictions) and got["K"] == want["K"] + 1 == len(pp) + 1 and got["P"] >= want["P"]
+        assert got["npred"][j] == 0 and got["nhull"][j] == 0
+        keep = np.arange(got["K"]) != j
         P = want["P"]
-        assert np.array_equal(got["npred"], want["npred"]) and np.array_equal(got["nhull"], want["nhull"])
-        assert np.array_equal(got["pos"][:, :P], want["pos"]) and np.array_equal(got["cov_inv"][:, :P], want["cov_inv"])
-        assert np.array_equal(got["hull"][:, :P - 1], want["hull"])
-        assert not got["pos"][:, P:].any() and not got["hull"][:, P - 1:].any()
+        assert np.array_equal(got["npred"][keep], want["npred"]) and np.array_equal(got["nhull"][keep], want["nhull"])
+        assert np.array_equal(got["pos"][keep][:, :P], want["pos"]) and np.array_equal(got["cov_inv"][keep][:, :P], want["cov_inv"])
+        assert np.array_equal(got["hull"][keep][:, :P - 1], want["hull"])
+        for k in np.nonzero(keep)[0]:   # beyond an obstacle's own predictions nothing is stored
+            assert not got["pos"][k, got["npred"][k]:].any() and not got["hull"][k, got["nhull"][k]:].any()
         d = sim.predictions_for(a.id)
         assert list(pp.keys()) == list(d) and a.id not in pp and all(np.array_equal(pp[k]["pos_list"], d[k]["pos_list"]) for k in d)
     # the closed loop with and without the shared packing takes the same decisions

@@ -185,7 +185,7 @@ def test_prediction_dict_walked_in_c_equals_the_general_path():
             for k in ("pos", "cov_inv", "npred", "hull", "nhull"):
                 assert np.array_equal(np.asarray(fast[k]), np.asarray(general[k])), (name, n_samples, k)
     # the C walk was really taken for the array-valued dicts and refused for the others
-    h, addr = eng._fxhost()
+    h, addr = eng._fxhost()[:2]
     assert h.pack_predictions(addr, base, 31, 256) is not None and h.pack_predictions(addr, lists, 31, 256) is None
     assert h.pack_predictions(addr, f32, 31, 256) is None and h.pack_predictions(addr, strided, 31, 256) is None
     assert h.pack_predictions(addr, base, 31, 3) is None      # more obstacles than allowed: the Python path words the error

@@ -18,5 +18,11 @@ print("sim step ms: planning steps", np.round(np.array(t[::3]) * 1e3, 3), "other
 pr = cProfile.Profile(); pr.enable()
 for _ in range(30): sim.step()
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(38)
+st = pstats.Stats(pr)
+st.sort_stats("cumulative").print_stats(38)
+if "--tottime" in sys.argv:   # own time per PLANNING step (10 of the 30 profiled steps plan), microseconds
+    rows = sorted(((tt, ct, nc, f"{os.path.basename(fn)}:{ln}({name})") for (fn, ln, name), (cc, nc, tt, ct, _) in st.stats.items()), reverse=True)
+    print(f"own time per planning step, us (total {sum(r[0] for r in rows) * 1e5:.0f})")
+    for tt, ct, nc, where in rows[:80]:
+        print(f"  {tt * 1e5:8.1f} own  {ct * 1e5:8.1f} incl  {nc / 10:7.1f} calls  {where}")
 sim.close()

@@ -28,7 +28,7 @@ def wrap(cls, name, label=None):
 for cls, names in ((frenet_interface.FrenetPlannerInterfaceHip, ("update_planner", "begin_step", "finish_step", "needs_plan")),
                    (reactive_planner.ReactivePlannerHip, ("plan_consume", "plan_finish", "_inputs_for_level", "update_externals",
                                                           "_compute_trajectory_pair", "_consume_result")),
-                   (engine.FrenetEngine, ("plan_batch", "package", "evaluate", "finish", "update_state")),
+                   (engine.FrenetEngine, ("plan_batch", "plan_batch_packaged", "package", "evaluate", "finish", "update_state")),
                    (multiagent.MultiAgentSimulation, ("predictions_for", "_shared_predictions", "_exchange")),
                    (multiagent.AgentBatchHip, ("step",))):
     for n in names:
