@@ -5,7 +5,7 @@ wrapper (oracle/oracle.py) can share the struct definitions.
 """
 import ctypes as C
 
-FX_ABI_VERSION = 6
+FX_ABI_VERSION = 7
 FX_LON_VELOCITY_KEEPING, FX_LON_STOP_POINT = 0, 1
 
 FX_OK = 0
@@ -22,12 +22,12 @@ FX_NUM_PLANES = len(PLANE_NAMES)
 PLANE_INDEX = {n: i for i, n in enumerate(PLANE_NAMES)}
 
 # alphabetical == evaluation order of cost_function.py:55-60
-COST_NAMES = ("acceleration", "distance_to_obstacles", "distance_to_reference_path", "jerk", "lateral_jerk",
+COST_NAMES = ("acceleration", "distance_to_obstacles", "distance_to_reference_path", "jerk", "lane_center_offset", "lateral_jerk",
               "longitudinal_jerk", "orientation_offset", "path_length", "prediction", "velocity_offset")
 FX_NUM_COSTS = len(COST_NAMES)
 COST_ID = {n: i for i, n in enumerate(COST_NAMES)}
 # reference cost names that exist upstream but need scenario / lanelet / reach-set objects (out of scope)
-UNSUPPORTED_COSTS = ("lane_center_offset", "velocity", "responsibility", "steering_angle", "steering_rate", "yaw",
+UNSUPPORTED_COSTS = ("velocity", "responsibility", "steering_angle", "steering_rate", "yaw",
                      "time", "inverse_duration", "longitudinal_velocity_offset")
 
 FX_FLAG_VALID = 1 << 0
@@ -77,6 +77,8 @@ class FxProblem(C.Structure):
         ("n_dto", C.c_int32), ("dto_pos", _pd),
         ("n_bound", C.c_int32), ("bound_piece", _pd), ("bound_bin", C.POINTER(C.c_int32)), ("bound_item", C.POINTER(C.c_int32)),
         ("bound_d_reach", C.c_double),
+        ("n_lane", C.c_int32), ("lane_bbox", _pd), ("lane_poly_off", _pi32), ("lane_poly", _pd), ("lane_ctr_off", _pi32),
+        ("lane_ctr", _pd),
     ]
 
 

@@ -342,6 +342,12 @@ int validate(const FxProblem *p) {
     if ((p->mode & FX_MODE_COLLISION) && p->K > 0 && (!p->obs_hull || !p->obs_nhull))
         return set_err(FX_ERR_INVALID_ARGUMENT, "collision stage requested without obstacle hulls");
     if (p->n_dto < 0 || (p->n_dto > 0 && !p->dto_pos)) return set_err(FX_ERR_INVALID_ARGUMENT, "dto_pos missing");
+    if (p->n_lane < 0 || (p->n_lane > 0 && (!p->lane_bbox || !p->lane_poly_off || !p->lane_poly || !p->lane_ctr_off || !p->lane_ctr)))
+        return set_err(FX_ERR_INVALID_ARGUMENT, "lanelet arrays missing (n_lane=%d)", p->n_lane);
+    for (int l = 0; l < p->n_lane; l++)
+        if (p->lane_poly_off[l + 1] < p->lane_poly_off[l] || p->lane_ctr_off[l + 1] < p->lane_ctr_off[l] || p->lane_poly_off[0] != 0 ||
+            p->lane_ctr_off[0] != 0)
+            return set_err(FX_ERR_INVALID_ARGUMENT, "lanelet offsets not ascending from 0 at lanelet %d", l);
     if (p->n_bound < 0 || (p->n_bound > 0 && (!p->bound_piece || !p->bound_bin || !p->bound_item)))
         return set_err(FX_ERR_INVALID_ARGUMENT, "road boundary arrays missing (n_bound=%d)", p->n_bound);
     if ((p->mode & FX_MODE_ROAD_BOUNDARY) && p->n_bound > 0) {
@@ -666,6 +672,10 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         if ((p->mode & FX_MODE_ROAD_BOUNDARY) && p->n_bound > 0 && p->bound_bin && p->M > 0)
             bound_need += align_up(sizeof(double) * 4 * (size_t)p->n_bound, 256) + align_up(sizeof(int32_t) * ((size_t)p->M + 1), 256) +
                           align_up(sizeof(int32_t) * (size_t)std::max(p->bound_bin[p->M], 0), 256);
+        if (p->n_lane > 0 && p->lane_poly_off && p->lane_ctr_off)   // the lanelets of the lane_center_offset cost live in the same block
+            bound_need += align_up(sizeof(double) * 4 * (size_t)p->n_lane, 256) + 2 * align_up(sizeof(int32_t) * ((size_t)p->n_lane + 1), 256) +
+                          align_up(sizeof(double) * 2 * (size_t)std::max(p->lane_poly_off[p->n_lane], 0), 256) +
+                          align_up(sizeof(double) * 2 * (size_t)std::max(p->lane_ctr_off[p->n_lane], 0), 256);
     }
     if (bound_need > c->bound_cap) {
         if (c->h_bound) (void)hipHostFree(c->h_bound);
@@ -691,7 +701,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             for (int n = 0; n < p->n_cost && p->cost_id; n++) {
                 const int id = p->cost_id[n];
                 extra_any |= id == FX_COST_ACCELERATION || id == FX_COST_JERK || id == FX_COST_ORIENTATION_OFFSET ||
-                             id == FX_COST_PATH_LENGTH || id == FX_COST_DISTANCE_TO_OBSTACLES;
+                             id == FX_COST_PATH_LENGTH || id == FX_COST_DISTANCE_TO_OBSTACLES || id == FX_COST_LANE_CENTER_OFFSET;
             }
         }
         // measured on MI355X (tools/quick.py): one lane per candidate once the grid gives >= 3 waves per SIMD,
@@ -854,7 +864,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             d.cost_w[n] = p->cost_w[n];
             const int id = p->cost_id[n];
             extra |= id == FX_COST_ACCELERATION || id == FX_COST_JERK || id == FX_COST_ORIENTATION_OFFSET ||
-                     id == FX_COST_PATH_LENGTH || id == FX_COST_DISTANCE_TO_OBSTACLES;
+                     id == FX_COST_PATH_LENGTH || id == FX_COST_DISTANCE_TO_OBSTACLES || id == FX_COST_LANE_CENTER_OFFSET;
         }
         memcpy(d.simpson_corr, p->simpson_corr, sizeof(d.simpson_corr));
         bool ok = true;
@@ -928,6 +938,14 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             d.bound_d_reach = p->bound_d_reach;
         } else {
             d.mode &= ~FX_MODE_ROAD_BOUNDARY;
+        }
+        if (p->n_lane > 0) {
+            d.n_lane = p->n_lane;
+            d.lane_bbox = br.put(p->lane_bbox, (size_t)4 * p->n_lane, &ok);
+            d.lane_poly_off = br.put(p->lane_poly_off, (size_t)p->n_lane + 1, &ok);
+            d.lane_poly = br.put(p->lane_poly, (size_t)2 * p->lane_poly_off[p->n_lane], &ok);
+            d.lane_ctr_off = br.put(p->lane_ctr_off, (size_t)p->n_lane + 1, &ok);
+            d.lane_ctr = br.put(p->lane_ctr, (size_t)2 * p->lane_ctr_off[p->n_lane], &ok);
         }
         if (!ok) return set_err(FX_ERR_CAPACITY, "input arena too small (%zu bytes)", c->in_bytes);
         d.cost = c->d_cost + cand_off;
@@ -1660,17 +1678,40 @@ int32_t fx_plan_batch_packaged(FxContext *c, int32_t n_agents, const FxStateUpda
     if (n_agents != c->n_agents)
         return set_err(FX_ERR_INVALID_ARGUMENT, "fx_plan_batch_packaged: %d agents, the uploaded batch has %d", n_agents, c->n_agents);
     int rc;
+#ifdef FX_HOST_PROBE   // probe builds: where the host side of a batched planner step goes (tools/probe_build)
+    static double acc[4]; static int n_acc;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+#endif
     if (upd)
         for (int a = 0; a < n_agents; a++)
             if (upd[a] && (rc = fx_update_state(c, a, upd[a]))) return rc;
+#ifdef FX_HOST_PROBE
+    const double t1 = now();
+#endif
     const bool was = c->package_enabled;
     c->package_enabled = true;
     rc = fx_evaluate(c);
     c->package_enabled = was;
     if (rc) return rc;
+#ifdef FX_HOST_PROBE
+    const double t2 = now();
+#endif
     if ((rc = fx_finish_batch(c, res))) return rc;
+#ifdef FX_HOST_PROBE
+    const double t3 = now();
+#endif
     for (int a = 0; a < n_agents; a++)
         if ((rc = fx_read_package(c, a, yaw_rate0 ? yaw_rate0[a] : 0.0, pkg + a, blocks ? blocks[a] : nullptr))) return rc;
+#ifdef FX_HOST_PROBE
+    const double t4 = now();
+    acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3;
+    if (++n_acc == 20) {
+        fprintf(stderr, "fx_plan_batch_packaged: update_state %.1f us, evaluate (launches) %.1f us, finish (wait) %.1f us, read_package %.1f us\n",
+                acc[0] / n_acc, acc[1] / n_acc, acc[2] / n_acc, acc[3] / n_acc);
+        acc[0] = acc[1] = acc[2] = acc[3] = 0; n_acc = 0;
+    }
+#endif
     return FX_OK;
 }
 

@@ -89,6 +89,13 @@ struct DevProblem {
     int64_t *part_idx;         // [n_blocks]
     unsigned long long *counters; // [FX_CNT_COUNT]
     int32_t n_blocks;
+    // lane_center_offset cost (generic kernel, windowed-cost path): the lanelets in network order (fxplan.h FxProblem.n_lane)
+    int32_t n_lane;
+    const double *lane_bbox;        // [n_lane][4] = (x min, x max, y min, y max)
+    const int32_t *lane_poly_off;   // [n_lane + 1]
+    const double *lane_poly;        // [.][2] closed outlines
+    const int32_t *lane_ctr_off;    // [n_lane + 1]
+    const double *lane_ctr;         // [.][2] centre polylines
 };
 
 // The same fields held in registers: a kernel loads them all at entry (one batch of scalar loads, one latency).
@@ -141,6 +148,12 @@ struct ProblemRegs {
     int64_t *part_idx;
     unsigned long long *counters;
     int32_t n_blocks;
+    int32_t n_lane;
+    const double *lane_bbox;
+    const int32_t *lane_poly_off;
+    const double *lane_poly;
+    const int32_t *lane_ctr_off;
+    const double *lane_ctr;
 
     __device__ __forceinline__ static ProblemRegs load(const DevProblem &g, const int32_t *cost_id, const double *cost_w) {
         ProblemRegs r;
@@ -161,6 +174,8 @@ struct ProblemRegs {
         r.cost = g.cost; r.cost_tail = g.cost_tail; r.obs_list = g.obs_list; r.flags = g.flags; r.costmap = g.costmap; r.planes = g.planes; r.coeffs = g.coeffs;
         r.traj_len = g.traj_len; r.part_cost = g.part_cost; r.part_idx = g.part_idx; r.counters = g.counters;
         r.n_blocks = g.n_blocks;
+        r.n_lane = g.n_lane; r.lane_bbox = g.lane_bbox; r.lane_poly_off = g.lane_poly_off; r.lane_poly = g.lane_poly;
+        r.lane_ctr_off = g.lane_ctr_off; r.lane_ctr = g.lane_ctr;
         return r;
     }
 };

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     WalkResult W;
     W.neg = A.neg; W.acc_viol = A.acc_viol; W.collided = A.collided;
     W.step_reasons = A.step_reasons; W.first_key = A.first_key; W.fail_step = A.fail_step; W.bound_step = A.bound_step;
-    W.sum_abs_d = A.sum_abs_d; W.sum_voff = A.sum_voff; W.pred = A.pred; W.dto = 0.0; W.d_end = A.d_end; W.v_end = A.v_end;
+    W.sum_abs_d = A.sum_abs_d; W.sum_voff = A.sum_voff; W.pred = A.pred; W.dto = 0.0; W.lane_off = 0.0; W.d_end = A.d_end; W.v_end = A.v_end;
     W.cl3 = cl3; W.cl4 = cl4; W.cl5 = cl5; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
     // wave split: the exchange block sits behind the rows in dynamic LDS
     double *xch = reinterpret_cast<double *>(rows + (size_t)n_pairs_max * S);

@@ -157,13 +157,59 @@ __device__ __forceinline__ uint32_t group_min(uint32_t v) {
 namespace fxk {
 
 // Per-lane results of the horizon walk, handed to the shared epilogue.
+// lane_center_offset, one point (partial_cost_functions.py:106-115; fxplan.h FxProblem.n_lane is the normative definition): the
+// first lanelet whose outline contains the point -- bounding box, then ray casting over the closed outline -- and the distance
+// to the closest point of its centre polyline; 5 when no lanelet contains it.  Every lane walks the lanelets on its own (the
+// generic kernel's windowed-cost path: one candidate per lane).
+template <typename PR>
+__device__ __forceinline__ double lane_center_distance(const PR &P, double x, double y) {
+    const FX_GLOBAL double *__restrict__ bbox = as_global(P.lane_bbox);
+    const FX_GLOBAL int32_t *__restrict__ poff = as_global(P.lane_poly_off);
+    const FX_GLOBAL double *__restrict__ poly = as_global(P.lane_poly);
+    const FX_GLOBAL int32_t *__restrict__ coff = as_global(P.lane_ctr_off);
+    const FX_GLOBAL double *__restrict__ ctr = as_global(P.lane_ctr);
+    for (int l = 0; l < P.n_lane; l++) {
+        if (x < bbox[4 * l] || x > bbox[4 * l + 1] || y < bbox[4 * l + 2] || y > bbox[4 * l + 3]) continue;
+        const int v0 = poff[l], v1 = poff[l + 1];
+        bool odd = false;
+        double xj = poly[2 * (v1 - 1)], yj = poly[2 * (v1 - 1) + 1];   // edge k runs from vertex k-1 to vertex k
+        for (int k = v0; k < v1; k++) {
+            const double xi = poly[2 * k], yi = poly[2 * k + 1];
+            if ((yi > y) != (yj > y)) {
+                const double t = (xj - xi) * (y - yi) / (yj - yi) + xi;
+                if (x < t) odd = !odd;
+            }
+            xj = xi; yj = yi;
+        }
+        if (!odd) continue;
+        const int c0 = coff[l], c1 = coff[l + 1];
+        double best = INFINITY;
+        for (int k = c0; k + 1 < c1; k++) {
+            const double ax = ctr[2 * k], ay = ctr[2 * k + 1];
+            const double bx = ctr[2 * k + 2] - ax, by = ctr[2 * k + 3] - ay;
+            const double len2 = bx * bx + by * by;
+            double t = len2 > 0.0 ? ((x - ax) * bx + (y - ay) * by) / len2 : 0.0;
+            t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+            const double ex = x - (ax + t * bx), ey = y - (ay + t * by);
+            const double d2 = ex * ex + ey * ey;
+            if (d2 < best) best = d2;
+        }
+        if (c1 - c0 == 1) {
+            const double ex = x - ctr[2 * c0], ey = y - ctr[2 * c0 + 1];
+            best = ex * ex + ey * ey;
+        }
+        return best < INFINITY ? sqrt(best) : 5.0;
+    }
+    return 5.0;
+}
+
 struct WalkResult {
     bool neg, acc_viol, collided;
     uint32_t step_reasons;  // dbg: OR of all violated checks
     uint32_t first_key;     // !dbg: (step << 4 | reason) of the first violated check, 0xffffffff if none
     int fail_step;          // first step of this lane's chunk outside the projection domain, INT_MAX if none
     int bound_step;         // first step of this lane's chunk whose footprint meets the road boundary, INT_MAX if none
-    double sum_abs_d, sum_voff, pred, dto, d_end, v_end;
+    double sum_abs_d, sum_voff, pred, dto, lane_off, d_end, v_end;
     double cl3, cl4, cl5, ct3, ct4, ct5;
     Simpson sim_acc, sim_jerk, sim_orient, sim_path;
 };
@@ -192,7 +238,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     uint32_t step_reasons = W.step_reasons, first_key = W.first_key;
     int fail_step = W.fail_step;
     uint32_t bound_step = (uint32_t)W.bound_step;
-    double sum_abs_d = W.sum_abs_d, sum_voff = W.sum_voff, pred = W.pred, dto = W.dto, d_end = W.d_end, v_end = W.v_end;
+    double sum_abs_d = W.sum_abs_d, sum_voff = W.sum_voff, pred = W.pred, dto = W.dto, lane_off = W.lane_off, d_end = W.d_end, v_end = W.v_end;
     const double cl3 = W.cl3, cl4 = W.cl4, cl5 = W.cl5, ct3 = W.ct3, ct4 = W.ct4, ct5 = W.ct5;
     Simpson &sim_acc = W.sim_acc, &sim_jerk = W.sim_jerk, &sim_orient = W.sim_orient, &sim_path = W.sim_path;
 
@@ -390,6 +436,7 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
             case FX_COST_JERK: c = EXTRA ? sim_jerk.finish(S - 1, dt, P.simpson_corr) : 0.0; break;
             case FX_COST_ORIENTATION_OFFSET: c = EXTRA ? sim_orient.finish(S - 1, dt, P.simpson_corr) : 0.0; break;
             case FX_COST_DISTANCE_TO_OBSTACLES: c = EXTRA ? dto : 0.0; break;
+            case FX_COST_LANE_CENTER_OFFSET: c = EXTRA ? lane_off / S : 0.0; break;   // partial_cost_functions.py:117
             default: break;
             }
             if (defer && id == FX_COST_PREDICTION) {
@@ -702,6 +749,10 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     if (EXTRA) { sim_acc.init(); sim_jerk.init(); sim_orient.init(); sim_path.init(); }
     const int n_dto = EXTRA ? P.n_dto : 0;
     const FX_GLOBAL double *__restrict__ dto_pos = as_global(P.dto_pos);
+    bool lane_on = false;   // lane_center_offset among the step's cost terms
+    if (EXTRA)
+        for (int n = 0; n < P.n_cost; n++) lane_on |= P.cost_id[n] == FX_COST_LANE_CENTER_OFFSET;
+    double lane_off = 0.0;
     FX_GLOBAL double *__restrict__ planes = as_global(P.planes);
     const int64_t ps = (int64_t)S * ld;
 
@@ -727,6 +778,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
                 const double dist = sqrt(ex * ex + ey * ey);
                 dto += 1.0 / (dist * dist);
             }
+            if (lane_on) lane_off += lane_center_distance(P, O.x, O.y);     // :106-115, a running sum over the points
         }
     }
 
@@ -734,7 +786,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     WalkResult W;
     W.neg = A.neg; W.acc_viol = A.acc_viol; W.collided = A.collided;
     W.step_reasons = A.step_reasons; W.first_key = A.first_key; W.fail_step = A.fail_step; W.bound_step = A.bound_step;
-    W.sum_abs_d = A.sum_abs_d; W.sum_voff = A.sum_voff; W.pred = A.pred; W.dto = dto; W.d_end = A.d_end; W.v_end = A.v_end;
+    W.sum_abs_d = A.sum_abs_d; W.sum_voff = A.sum_voff; W.pred = A.pred; W.dto = dto; W.lane_off = lane_off; W.d_end = A.d_end; W.v_end = A.v_end;
     W.cl3 = cl3; W.cl4 = cl4; W.cl5 = cl5; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
     if (EXTRA) { W.sim_acc = sim_acc; W.sim_jerk = sim_jerk; W.sim_orient = sim_orient; W.sim_path = sim_path; }
     finish_candidate<G, BUNDLE, OBST, EXTRA>(P, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D, red_cost,

@@ -138,10 +138,14 @@ CalculateDistanceToReferencePathCost = _cost_class("CalculateDistanceToReference
 
 
 class CalculateLaneCenterOffsetCost(_Cost):
+    """reactive_planner_cpp.py:135-137 constructs it with (name, weight) only.  partial_cost_functions.py:91-117 reads the
+    scenario's lanelet network per trajectory point; hand it over as `lanelets=` (a Scenario, or lanelets with left_vertices /
+    right_vertices) -- without it every point counts as off every lanelet (5 m, :112-115).  Parity unpinned."""
     cost_name = "lane_center_offset"
 
-    def __init__(self, name, weight, *a, **k):
-        raise NotImplementedError("lane_center_offset needs the lanelet network: outside the hot-path scope")
+    def __init__(self, name, weight, lanelets=None):
+        super().__init__(name, weight)
+        self.lanelets = lanelets
 
 
 class CalculateCollisionProbabilityFast(_Cost):
@@ -318,6 +322,10 @@ class TrajectoryHandler:
         weights = {n: f.weight for n, f in self._costs.items() if f.weight != 0}
         vo = self._costs.get("velocity_offset")
         dto = self._costs.get("distance_to_obstacles")
+        lco = self._costs.get("lane_center_offset")
+        if lco is not None and lco.lanelets is not None and not isinstance(lco.lanelets, dict):
+            from .problem import pack_lanelets
+            lco.lanelets = pack_lanelets(lco.lanelets)   # packed once per functor
         N = int(round(float(self._fill.horizon) / self.dt)) if float(self._fill.horizon) < 1000 else int(self._fill.horizon)
         preds = self._predictions()
         if self._stop is not None:
@@ -338,7 +346,7 @@ class TrajectoryHandler:
             vehicle=self._vehicle(), coordinate_system=self._fill.coordinateSystem, **sampling,
             cost_weights=weights, draw_traj_set=self.draw_traj_set, kinematic_debug=self.kinematic_debug,
             obstacles=pack_predictions(preds, N + 1, build_obstacle_hulls),
-            dto_pos=dto.obstacle_positions if dto is not None else None)
+            dto_pos=dto.obstacle_positions if dto is not None else None, lanelets=lco.lanelets if lco is not None else None)
         if self._step is not None:
             self._step.invalidate()
         if inputs.sampling_matrix is None and hasattr(self.engine, "plan_batch"):

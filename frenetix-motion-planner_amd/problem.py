@@ -90,6 +90,35 @@ _COST_MEMO: dict = {}   # id(weights dict) -> (the dict, (len, sum of values), (
 MAX_OBSTACLES = 256  # obstacles per agent (FX_MAX_OBSTACLES; beyond 64 the step runs on the generic kernel)
 
 
+def pack_lanelets(lanelets) -> dict:
+    """The lanelets the lane_center_offset cost reads (partial_cost_functions.py:91-117), in the order given -- the lanelet
+    network's: per lanelet the closed outline (left vertices, then the right ones reversed: commonroad-io's Lanelet.polygon), its
+    bounding box and the centre polyline.  `lanelets`: objects with left_vertices / right_vertices (/ center_vertices) [n][2] --
+    commonroad_xml.Lanelet, commonroad-io's Lanelet -- or a Scenario / dict of them.  fxplan.h FxProblem.n_lane defines how
+    they are read."""
+    if hasattr(lanelets, "lanelets"):
+        lanelets = lanelets.lanelets
+    if isinstance(lanelets, dict):
+        lanelets = list(lanelets.values())
+    lanelets = list(lanelets)
+    n = len(lanelets)
+    bbox = np.zeros((n, 4))
+    poly_off, ctr_off = np.zeros(n + 1, np.int32), np.zeros(n + 1, np.int32)
+    polys, ctrs = [], []
+    for k, ll in enumerate(lanelets):
+        left, right = _f64(ll.left_vertices).reshape(-1, 2), _f64(ll.right_vertices).reshape(-1, 2)
+        poly = np.vstack([left, right[::-1]])
+        cv = getattr(ll, "center_vertices", None)
+        ctr = _f64(cv).reshape(-1, 2) if cv is not None else 0.5 * (left + right)
+        bbox[k] = (poly[:, 0].min(), poly[:, 0].max(), poly[:, 1].min(), poly[:, 1].max())
+        polys.append(poly)
+        ctrs.append(ctr)
+        poly_off[k + 1] = poly_off[k] + len(poly)
+        ctr_off[k + 1] = ctr_off[k] + len(ctr)
+    return dict(n=n, bbox=_f64(bbox), poly_off=poly_off, poly=_f64(np.vstack(polys)) if n else np.zeros((0, 2)), ctr_off=ctr_off,
+                ctr=_f64(np.vstack(ctrs)) if n else np.zeros((0, 2)), uid=next(_BOUND_UIDS))
+
+
 class PackedPredictions:
     """Predictions that arrive packed (the arrays `pack_predictions` produces) together with a way to build the reference's
     dict form on demand.  A batch of agents shares almost all of its predictions -- everything but the agent itself -- so the
@@ -292,6 +321,8 @@ class PlanInputs:
     dto_pos: Optional[np.ndarray] = None
     # road boundary: segments [n][4] = (ax, ay, bx, by); the ego footprint must not touch them (planner.py:362-381)
     road_boundary: Optional[np.ndarray] = None
+    # lanelets of the lane_center_offset cost: pack_lanelets(...) (or anything pack_lanelets takes)
+    lanelets: Optional[dict] = None
     # candidate shard of the global grid handled by this engine (multi-GPU); None = everything
     shard: Optional[tuple] = None
 
@@ -334,6 +365,8 @@ class PlanInputs:
         if self.obstacles is None:
             self.obstacles = pack_predictions(None, S, None)
         self._dto = _f64(self.dto_pos).reshape(-1, 2) if self.dto_pos is not None else np.zeros((0, 2))
+        if self.lanelets is not None and not (isinstance(self.lanelets, dict) and "poly_off" in self.lanelets):
+            self.lanelets = pack_lanelets(self.lanelets)
         self._bound = None
         if self.road_boundary is not None and len(self.road_boundary):
             if isinstance(self.road_boundary, dict):
@@ -394,7 +427,8 @@ class PlanInputs:
                 getattr(self.coordinate_system, "uid", None) or id(self.coordinate_system),
                 None if self.sampling_matrix is not None else (len(self.t_samp), len(self.v_samp), len(self.d_samp)),
                 tuple(self.cost_names), self._cost_w.tobytes(), int(o["K"]), int(o["P"]), self._dto.tobytes(),
-                None if self._bound is None else self._bound.setdefault("uid", next(_BOUND_UIDS)))
+                None if self._bound is None else self._bound.setdefault("uid", next(_BOUND_UIDS)),
+                None if self.lanelets is None else self.lanelets.setdefault("uid", next(_BOUND_UIDS)))
         return k + (self.shard,)
 
     def next_step(self, *, low_vel_mode, x0_lon, x0_lat, x0_orientation, v_des, t_samp, v_samp, d_samp, obstacles):
@@ -469,6 +503,14 @@ class PlanInputs:
             p.bound_d_reach = bd["d_reach"]
         else:
             p.n_bound = 0
+        ln = self.lanelets
+        if ln is not None and ln["n"] > 0:
+            lp = _dict_ptrs(ln, (("bbox", C.c_double), ("poly_off", C.c_int32), ("poly", C.c_double), ("ctr_off", C.c_int32),
+                                 ("ctr", C.c_double)))
+            p.n_lane, p.lane_bbox, p.lane_poly_off, p.lane_poly = ln["n"], lp["bbox"], lp["poly_off"], lp["poly"]
+            p.lane_ctr_off, p.lane_ctr = lp["ctr_off"], lp["ctr"]
+        else:
+            p.n_lane = 0
         if self.shard is not None:
             b, n = int(self.shard[0]), int(self.shard[1])
             if b < 0 or n < 1 or b + n > self.n_candidates_global:

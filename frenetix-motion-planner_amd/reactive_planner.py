@@ -133,6 +133,7 @@ class ReactivePlannerHip:
         self.last_step: Optional[PlanStepResult] = None
         self.planning_time = None
         self._packed_predictions = None
+        self._packed_lanelets = None      # set_lanelets: the lane_center_offset cost's lanelets
         self._prev_inputs = None          # the last PlanInputs built (a closed loop's next step differs in a few fields)
         self.logger = None               # logging_formats.DataLoggingCosts (planner.py:150-158)
         self.record_state_list = []
@@ -223,6 +224,13 @@ class ReactivePlannerHip:
         self.road_boundary = None if segments is None else np.ascontiguousarray(segments, dtype=np.float64).reshape(-1, 4)
         self._packed_boundary = None
 
+    def set_lanelets(self, lanelets):
+        """The lanelet network the `lane_center_offset` cost reads (partial_cost_functions.py:91-117 asks the scenario's
+        lanelet_network per trajectory point): a Scenario, a dict / list of lanelets (left_vertices, right_vertices), or None.
+        Packed once (problem.pack_lanelets); without it every point counts as off every lanelet (5 m, :112-115)."""
+        from .problem import pack_lanelets
+        self._packed_lanelets = None if lanelets is None else pack_lanelets(lanelets)
+
     def set_predictions(self, predictions: dict):
         """predictions: the reference's dict (prediction_helpers.py:209-261) -- or problem.PackedPredictions, the same content
         already packed (a batch of agents packs its shared predictions once)."""
@@ -287,7 +295,7 @@ class ReactivePlannerHip:
             self._weights_src, self._weights_sig = cw, sig
         prev = self._prev_inputs
         if (prev is not None and prev.cost_weights is weights and prev.coordinate_system is self.coordinate_system
-                and prev.road_boundary is boundary and prev.vehicle is self.vehicle_params and prev.N == self.N and prev.dt == self.dT
+                and prev.road_boundary is boundary and prev.lanelets is self._packed_lanelets and prev.vehicle is self.vehicle_params and prev.N == self.N and prev.dt == self.dT
                 and prev.stop_point == (stop_point_s is not None) and prev.draw_traj_set == self._draw_traj_set
                 and prev.kinematic_debug == self._kinematic_debug and prev.collision == self.use_prediction):
             # the closed loop's usual step: only the state, the sampling values and the predictions differ from the last inputs
@@ -300,7 +308,7 @@ class ReactivePlannerHip:
                              stop_point=stop_point_s is not None, cost_weights=weights,
                              draw_traj_set=self._draw_traj_set, kinematic_debug=self._kinematic_debug, write_bundle=True,
                              write_costmap=True, collision=self.use_prediction, obstacles=self._packed_predictions,
-                             road_boundary=boundary)
+                             road_boundary=boundary, lanelets=self._packed_lanelets)
         self._prev_inputs = inp
         return inp
 

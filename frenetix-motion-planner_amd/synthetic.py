@@ -95,7 +95,7 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
                 n_obstacles=0, n_pred=30, cost_weights=None, draw_traj_set=False, kinematic_debug=False,
                 write_bundle=True, write_costmap=True, collision=True, low_vel_threshold=2.0, hull_builder=None,
                 seed=SEED, vehicle=None, x0_orientation=None, as_matrix=False, stop_point_s=None, road_half_width=None,
-                obstacle_min_gap=0.0, lead_gap=0.0, knot_jitter=0.0, pseudo_normal=False, vertex_tangent="chord"):
+                obstacle_min_gap=0.0, lead_gap=0.0, knot_jitter=0.0, pseudo_normal=False, vertex_tangent="chord", lanelets=None):
     """One agent's PlanInputs on a synthetic reference.
 
     level: reference sampling level (set-ordered ranges, SamplingHandler) -- or
@@ -139,6 +139,8 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
               write_costmap=write_costmap, collision=collision, obstacles=obstacles)
     if road_half_width is not None:
         kw["road_boundary"] = offset_road_boundary(cs, float(road_half_width))
+    if lanelets is not None:   # (lane width, knots per lanelet): two lanes along the reference (lane_center_offset cost)
+        kw["lanelets"] = lanes_along(cs, *lanelets)
     if as_matrix:
         from .sampling import generate_sampling_matrix
         m = generate_sampling_matrix(t0_range=0.0, t1_range=t, s0_range=s0, ss0_range=v0, sss0_range=a0, ss1_range=v,
@@ -149,6 +151,21 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
         inp = PlanInputs(t_samp=t, v_samp=v, d_samp=d, stop_point=stop_point_s is not None, **kw)
     inp.predictions = preds
     return inp
+
+
+def lanes_along(cs: CoordinateSystem, width: float = 3.5, knots_per_lanelet: int = 60):
+    """Lanelets for the lane_center_offset cost: the reference's own lane (|d| <= width / 2) and its left neighbour, cut into
+    pieces of `knots_per_lanelet` reference knots (consecutive pieces share their end vertices), in network order own lane
+    first.  Right of the own lane there is no lanelet (the cost's 5 m branch)."""
+    from types import SimpleNamespace
+    ref, nrm = np.asarray(cs.reference), np.asarray(cs.normals)
+    nrm = nrm / np.linalg.norm(nrm, axis=1)[:, None]
+    out = []
+    for lo, hi in ((-0.5 * width, 0.5 * width), (0.5 * width, 1.5 * width)):
+        for k0 in range(0, len(ref) - 1, knots_per_lanelet):
+            sl = slice(k0, min(k0 + knots_per_lanelet + 1, len(ref)))
+            out.append(SimpleNamespace(left_vertices=ref[sl] + hi * nrm[sl], right_vertices=ref[sl] + lo * nrm[sl]))
+    return out
 
 
 def stress_agents(n_agents: int, grid=(39, 51, 51), horizon: float = 5.0, n_obstacles: int = 20, first_agent: int = 0,

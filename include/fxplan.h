@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 6
+#define FX_ABI_VERSION 7
 
 /* ---- status codes (planner.py / reactive_planner_cpp.py raise Python exceptions; the shim maps
  *      <0 -> ValueError, >0 -> RuntimeError, see SURVEY 8b "Error conventions") ---- */
@@ -57,6 +57,7 @@ enum {
     FX_COST_DISTANCE_TO_OBSTACLES,       /* :172-186 */
     FX_COST_DISTANCE_TO_REFERENCE_PATH,  /* :154-169 */
     FX_COST_JERK,                        /* :36-46  */
+    FX_COST_LANE_CENTER_OFFSET,          /* :91-117 (needs the lanelets: FxProblem.n_lane ...; DESIGN.md 4.4, parity unpinned) */
     FX_COST_LATERAL_JERK,                /* :49-55  */
     FX_COST_LONGITUDINAL_JERK,           /* :58-64  */
     FX_COST_ORIENTATION_OFFSET,          /* :141-151 */
@@ -180,6 +181,19 @@ typedef struct FxProblem {
     const int32_t *bound_bin;
     const int32_t *bound_item;
     double bound_d_reach;   /* lateral reach the bins were built for; |d| beyond it counts as off the road */
+    /* lane_center_offset cost (partial_cost_functions.py:91-117): the lanelets in network order.  Per trajectory point the
+     * FIRST lanelet whose outline contains it (lane_poly[lane_poly_off[l] .. lane_poly_off[l+1]) = left vertices, then the
+     * right ones reversed; ray casting; lane_bbox[l] = (x min, x max, y min, y max) settles most lanelets) and the distance
+     * to that lanelet's centre polyline lane_ctr[lane_ctr_off[l] .. lane_ctr_off[l+1]) -- the closest point of its segments;
+     * 5 when no lanelet contains the point; the cost is the mean over the trajectory's points.  The reference asks
+     * commonroad-io (find_lanelet_by_position) and shapely (project / interpolate), neither of which is in the reference
+     * tree: which lanelet is "first" where lanelets overlap, and points exactly on an outline, are this header's definition. */
+    int32_t n_lane;
+    const double *lane_bbox;       /* [n_lane][4] */
+    const int32_t *lane_poly_off;  /* [n_lane + 1] */
+    const double *lane_poly;       /* [lane_poly_off[n_lane]][2] */
+    const int32_t *lane_ctr_off;   /* [n_lane + 1] */
+    const double *lane_ctr;        /* [lane_ctr_off[n_lane]][2] */
 } FxProblem;
 
 /* Result of one plan step (what _get_optimal_trajectory returns plus the counters it sets,

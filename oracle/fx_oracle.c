@@ -172,6 +172,47 @@ static double poly_acc(const double *c, double t, double t2, double t3) {
     return 2 * c[2] + 6 * c[3] * t + 12 * c[4] * t2 + 20 * c[5] * t3;
 }
 /* polynomial_trajectory.py:172-191 */
+/* lane_center_offset, one point (partial_cost_functions.py:106-115): the first lanelet of the network whose outline contains the
+ * point -- bounding box, then ray casting over the closed outline (edge k runs from vertex k-1 to vertex k) -- and the distance to
+ * the closest point of its centre polyline's segments (:320-338 ask shapely for project / interpolate, i.e. that point); 5 when no
+ * lanelet contains the point (:112-115).  fxplan.h FxProblem.n_lane is the normative definition (commonroad-io and shapely are not
+ * in the reference tree: parity unpinned). */
+static double lane_center_distance(const FxProblem *p, double x, double y) {
+    for (int l = 0; l < p->n_lane; l++) {
+        const double *bb = p->lane_bbox + 4 * (size_t)l;
+        if (x < bb[0] || x > bb[1] || y < bb[2] || y > bb[3]) continue;
+        const int v0 = p->lane_poly_off[l], v1 = p->lane_poly_off[l + 1];
+        int odd = 0;
+        for (int k = v0; k < v1; k++) {
+            const int j = k > v0 ? k - 1 : v1 - 1;
+            const double xi = p->lane_poly[2 * k], yi = p->lane_poly[2 * k + 1], xj = p->lane_poly[2 * j], yj = p->lane_poly[2 * j + 1];
+            if ((yi > y) != (yj > y)) {
+                const double t = (xj - xi) * (y - yi) / (yj - yi) + xi;
+                if (x < t) odd ^= 1;
+            }
+        }
+        if (!odd) continue;
+        const int c0 = p->lane_ctr_off[l], c1 = p->lane_ctr_off[l + 1];
+        double best = INFINITY;
+        for (int k = c0; k + 1 < c1; k++) {
+            const double ax = p->lane_ctr[2 * k], ay = p->lane_ctr[2 * k + 1];
+            const double bx = p->lane_ctr[2 * k + 2] - ax, by = p->lane_ctr[2 * k + 3] - ay;
+            const double len2 = bx * bx + by * by;
+            double t = len2 > 0.0 ? ((x - ax) * bx + (y - ay) * by) / len2 : 0.0;
+            t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+            const double ex = x - (ax + t * bx), ey = y - (ay + t * by);
+            const double d2 = ex * ex + ey * ey;
+            if (d2 < best) best = d2;
+        }
+        if (c1 - c0 == 1) {   /* a one-vertex centre line: the vertex */
+            const double ex = x - p->lane_ctr[2 * c0], ey = y - p->lane_ctr[2 * c0 + 1];
+            best = ex * ex + ey * ey;
+        }
+        return best < INFINITY ? sqrt(best) : 5.0;
+    }
+    return 5.0;
+}
+
 static double sq_jerk_integral(const double *c, double t) {
     double t2 = t * t, t3 = t2 * t, t4 = t3 * t, t5 = t4 * t;
     return (36 * c[3] * c[3] * t + 144 * c[3] * c[4] * t2 + 240 * c[3] * c[5] * t3 + 192 * c[4] * c[4] * t3 +
@@ -584,6 +625,12 @@ static uint32_t eval_candidate(const FxProblem *p, int64_t g, Cand *cd, double *
             for (int i = 0; i < S; i++) tmp[i] = fabs(d[i]);
             c = (np_sum(tmp, S) + fabs(d[S - 1]) * 5) / S;
             break;
+        case FX_COST_LANE_CENTER_OFFSET: { /* :106-117: a plain running sum over the points, 5 where no lanelet contains one */
+            double acc = 0.0;
+            for (int i = 0; i < S; i++) acc += lane_center_distance(p, x[i], y[i]);
+            c = acc / S;
+            break;
+        }
         case FX_COST_DISTANCE_TO_OBSTACLES: /* :177-184 */
             for (int o = 0; o < p->n_dto; o++) {
                 for (int i = 0; i < S; i++) {

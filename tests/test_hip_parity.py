@@ -276,6 +276,11 @@ CASES = {
                      cost_weights=dict(acceleration=0.3, jerk=0.15, orientation_offset=0.4, path_length=0.05,
                                        lateral_jerk=0.2, longitudinal_jerk=0.2, velocity_offset=1.0,
                                        distance_to_reference_path=5.0, prediction=0.2)),
+    # lane_center_offset (partial_cost_functions.py:91-117): own lane and left neighbour along the reference, nothing to the right
+    "lane_center": dict(ref_kind="scurve", v0=9.0, grid=(5, 9, 9), n_obstacles=3, draw_traj_set=True, kinematic_debug=True,
+                        lanelets=(3.5, 60), cost_weights=dict(lane_center_offset=2.0, lateral_jerk=0.2, velocity_offset=1.0,
+                                                              prediction=0.2, distance_to_reference_path=1.0)),
+    "lane_center_nolanes": dict(ref_kind="arc", v0=10.0, grid=(3, 5, 7), cost_weights=dict(lane_center_offset=1.0, jerk=0.1)),
     "ragged_tail": dict(ref_kind="arc", v0=10.0, grid=(3, 7, 13), n_obstacles=2),  # C not a multiple of 64
     "single_candidate": dict(ref_kind="arc", v0=10.0, grid=(1, 1, 1), d0=0.0),
     "no_costs": dict(ref_kind="arc", v0=10.0, grid=(3, 5, 5), cost_weights={}),
@@ -358,7 +363,8 @@ def test_one_or_two_steps_per_lane(eng, name, lanes, matrix):
     try:
         res = eng.plan_step(inp)
         info = eng.step_info()
-        windowed = set(inp.cost_names) & {"acceleration", "jerk", "orientation_offset", "path_length", "distance_to_obstacles"}
+        windowed = set(inp.cost_names) & {"acceleration", "jerk", "orientation_offset", "path_length", "distance_to_obstacles",
+                                               "lane_center_offset"}
         assert info["lanes_per_candidate"] == (1 if windowed else lanes)   # windowed costs keep the horizon in one lane
         compare(eng, inp, out, res)
     finally:
@@ -894,7 +900,12 @@ def test_random_cost_functions_vs_oracle(case):
     from oracle import oracle
     rng = np.random.default_rng([20241008, case])
     kw = _random_case(rng)
-    w = {n: float(rng.uniform(0.1, 5.0)) for n in COST_NAMES if rng.uniform() < 0.5}
+    # (lane_center_offset is drawn last, so that the cases above keep the draws that made the soak flag them)
+    w = {n: float(rng.uniform(0.1, 5.0)) for n in COST_NAMES if n != "lane_center_offset" and rng.uniform() < 0.5}
+    if rng.uniform() < 0.5:
+        w["lane_center_offset"] = float(rng.uniform(0.1, 5.0))
+        if rng.uniform() < 0.7:
+            kw["lanelets"] = (float(rng.uniform(2.5, 4.5)), int(rng.integers(10, 120)))
     kw["cost_weights"] = w or {"lateral_jerk": 1.0}
     inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
     out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))

@@ -127,8 +127,8 @@ def test_plan_inputs_packing_and_validation():
     assert inp.cost_names == sorted(inp.cost_names)
     p = inp.candidate_params(7)
     assert p.shape == (13,) and p[10] in inp.d_samp
-    with pytest.raises(NotImplementedError):
-        synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(2, 2, 2), cost_weights={"lane_center_offset": 1.0})
+    with pytest.raises(NotImplementedError):   # a cost term that needs objects outside the hot path (_abi.UNSUPPORTED_COSTS)
+        synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(2, 2, 2), cost_weights={"responsibility": 1.0})
     inp.shard = (5, 10)
     st = inp.as_struct()
     assert (st.shard_begin, st.shard_count) == (5, 10) and inp.n_candidates == 10

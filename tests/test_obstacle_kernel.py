@@ -56,7 +56,7 @@ def test_obstacle_kernel_items_and_workgroups(eng, monkeypatch, name, steps, wg)
         res = eng.plan_step(inp)
         info = eng.step_info()
         assert info["obstacle_kernel"] == 1
-        chunks = -(-(inp.N + 1) // steps)
+        chunks = -(-inp.N // steps)   # steps 1 .. N (step 0 is the current state)
         assert info["obstacle_workgroup_waves"] == (chunks if wg == "1" and chunks <= 16 else 0)
         compare(eng, inp, out, res)
     finally:

@@ -10,6 +10,7 @@ from frenetix_motion_planner_amd.multiagent import MultiAgentSimulation
 from frenetix_motion_planner_amd.reactive_planner import PlannerConfig
 
 ACC = collections.defaultdict(float)
+CALLS = collections.defaultdict(list)
 
 
 def wrap(cls, name, label=None):
@@ -21,7 +22,9 @@ def wrap(cls, name, label=None):
         try:
             return f(*a, **k)
         finally:
-            ACC[label] += time.perf_counter() - t0
+            dt = time.perf_counter() - t0
+            ACC[label] += dt
+            CALLS[label].append(dt)
     setattr(cls, name, g)
 
 
@@ -40,7 +43,7 @@ sc = crx.read_scenario_json(os.path.join(ROOT, "tests", "golden", "ZAM_Tjunction
 sim = MultiAgentSimulation(sc, config=PlannerConfig(sampling_min=0, sampling_max=1, dense_grid=(19, 23, 23)), device=0)
 for _ in range(6):
     sim.step()
-ACC.clear()
+ACC.clear(); CALLS.clear()
 t = []
 n = 60
 for _ in range(n):
@@ -49,5 +52,7 @@ t = np.array(t)
 plan = t[t > np.median(t) * 3]
 print(f"simulation step: mean {t.mean()*1e3:.3f} ms, planning steps ({len(plan)}) p50 {np.median(plan)*1e3:.3f} ms, others p50 {np.median(t[t <= np.median(t)*3])*1e3:.3f} ms")
 for k, v in sorted(ACC.items(), key=lambda kv: -kv[1]):
-    print(f"  {k:48s} {v / max(len(plan), 1) * 1e6:9.1f} us per planning step (inclusive)")
+    q = np.array(CALLS[k]) * 1e6
+    print(f"  {k:48s} {v / max(len(plan), 1) * 1e6:9.1f} us per planning step (inclusive)   per call: n {len(q):5d} p50 {np.median(q):7.1f} "
+          f"mean {q.mean():7.1f} max {q.max():8.1f}")
 sim.close()

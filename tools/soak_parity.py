@@ -20,9 +20,13 @@ for case in range(first, first + n):
         kw["n_obstacles"] = int(rng.integers(9, 49)) if os.environ["FX_SOAK_MANY"] != "2" else int(rng.integers(49, 257))
         if "grid" in kw:
             kw["grid"] = (min(kw["grid"][0], 4), kw["grid"][1], kw["grid"][2])
-    if os.environ.get("FX_SOAK_COSTS"):  # random cost functions over all ten terms (windowed costs -> generic kernel)
+    if os.environ.get("FX_SOAK_COSTS"):  # random cost functions over all eleven terms (windowed costs -> generic kernel)
         from frenetix_motion_planner_amd._abi import COST_NAMES
-        w = {n: float(rng.uniform(0.1, 5.0)) for n in COST_NAMES if rng.uniform() < 0.5}
+        w = {n: float(rng.uniform(0.1, 5.0)) for n in COST_NAMES if n != "lane_center_offset" and rng.uniform() < 0.5}
+        if rng.uniform() < 0.5:   # (drawn behind the ten terms of the earlier soaks: their cases keep their draws)
+            w["lane_center_offset"] = float(rng.uniform(0.1, 5.0))
+            if rng.uniform() < 0.7:
+                kw["lanelets"] = (float(rng.uniform(2.5, 4.5)), int(rng.integers(10, 120)))
         kw["cost_weights"] = w or {"lateral_jerk": 1.0}
     if os.environ.get("FX_SOAK_MATRIX") and "stop_point_s" not in kw:   # the adapter's C x 13 sampling matrix
         kw["as_matrix"] = True
