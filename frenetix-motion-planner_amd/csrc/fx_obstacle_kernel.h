@@ -93,24 +93,37 @@ __global__ __launch_bounds__(WG ? 1024 : 64, WG ? 1 : WPS) void fx_obstacle_kern
     FX_OSTAMP(0);
     // The tile's candidates: 64 entries of the list of costed candidates the walk has left (fx_eval_kernel.h, finish_candidate;
     // the walk is complete, plain loads).  Tiles past the end of the list only leave a neutral arg-min partial.
-    const int64_t n_live = (int64_t)as_global(P.counters)[FX_DCNT_LIVE];
-    if (c0 >= n_live) {
-        if (chunk == 0 && lane == 0) {
-            as_global(P.part_cost)[tile] = INFINITY;
-            as_global(P.part_idx)[tile] = 0x7fffffffffffffffLL;
-        }
-        return;
-    }
-    const bool act = c0 + lane < n_live;
-    const int64_t g = as_global(P.obs_list)[act ? c0 + lane : n_live - 1];
-    const int64_t g_raw = g;   // (scratch rows are indexed by the candidate: inactive lanes repeat the list's last entry and never store)
-    const uint32_t f = as_global(P.flags)[g];
+    // The kernel's floor is a chain of dependent round trips (problem -> count -> list -> rows), so the count, the tile's list
+    // entries and the chunk's slice of the hot table are requested TOGETHER: the list slot c0 + lane always exists (c0 < C <= ld);
+    // past the list's end it holds whatever an earlier step left -- clamped to a valid candidate, loaded from, never stored for.
+    const FX_GLOBAL unsigned long long *cnt_live = as_global(P.counters) + FX_DCNT_LIVE;
+    const unsigned long long n_live_raw = *cnt_live;
+    const int32_t g_listed = as_global(P.obs_list)[c0 + lane];
 
     const int i_a = 1 + chunk * CH, i_b = min(S, i_a + CH);
     const int64_t ps = (int64_t)S * ld;
     const FX_GLOBAL double *__restrict__ pl = as_global(P.planes);
     const bool col_mode = (mode & FX_MODE_COLLISION) != 0 && K > 0;
-    // ---- everything the chunk needs, requested before the flags are looked at (nearly every tile needs it) ----
+    // the chunk's slice of the hot table -> LDS: per (step, obstacle) the addends (cu, cw) as one 16-byte pair, then the hull
+    // circles (hx2, hy2, hr2, ck) as 32 bytes; entry e of the slice is handled by lane e, e + 64, ... (two entries in flight).
+    // The first round's loads go out here, its LDS writes follow the row requests below.
+    const FX_GLOBAL double *__restrict__ hot_a = as_global(P.obs_hot) + (size_t)i_a * K * FX_HOT_STRIDE;
+    fx_d2 *__restrict__ cc_tab = reinterpret_cast<fx_d2 *>(lds_dyn);   // [CH][K]
+    double *__restrict__ circ_tab = lds_dyn + 2 * (size_t)CH * K;       // [CH][K][4]
+    const int n_e = max((i_b - i_a) * K, 0);
+    double hv[2][6];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int e = max(min(lane + 64 * u, n_e - 1), 0);
+        const FX_GLOBAL double *q = hot_a + (size_t)e * FX_HOT_STRIDE;
+        const bool on = n_e > 0 && K > 0;
+        hv[u][0] = on ? q[FX_HOT_CU] : 0.0; hv[u][1] = on ? q[FX_HOT_CW] : 0.0;
+        hv[u][2] = on ? q[FX_HOT_HX2] : 0.0; hv[u][3] = on ? q[FX_HOT_HY2] : 0.0; hv[u][4] = on ? q[FX_HOT_HR2] : 0.0; hv[u][5] = on ? q[FX_HOT_CK] : 0.0;
+    }
+    // ---- everything the chunk needs, requested before the count and the flags are looked at (nearly every tile needs it) ----
+    const int64_t g = (uint32_t)g_listed < (uint64_t)C ? (int64_t)g_listed : 0;
+    const int64_t g_raw = g;   // (scratch rows are indexed by the candidate: lanes past the list's end hold SOME candidate and never store)
+    const uint32_t f = as_global(P.flags)[g];
     // rows i_a - 1 .. i_b - 1 of x, y (and theta with the collision stage)
     double xs[CH + 1], ys[CH + 1], ts[CH + 1];
 #pragma unroll
@@ -120,14 +133,31 @@ __global__ __launch_bounds__(WG ? 1024 : 64, WG ? 1 : WPS) void fx_obstacle_kern
         ys[j] = pl[(int64_t)FX_PL_Y * ps + (int64_t)i * ld + g];
         ts[j] = col_mode ? pl[(int64_t)FX_PL_THETA * ps + (int64_t)i * ld + g] : 0.0;
     }
-    // the chunk's slice of the hot table -> LDS: per (step, obstacle) the addends (cu, cw) as one 16-byte pair, then the hull
-    // circles (hx2, hy2, hr2, ck) as 32 bytes; entry e of the slice is handled by lane e, e + 64, ... (two entries in flight)
-    const FX_GLOBAL double *__restrict__ hot_a = as_global(P.obs_hot) + (size_t)i_a * K * FX_HOT_STRIDE;
-    fx_d2 *__restrict__ cc_tab = reinterpret_cast<fx_d2 *>(lds_dyn);   // [CH][K]
-    double *__restrict__ circ_tab = lds_dyn + 2 * (size_t)CH * K;       // [CH][K][4]
+    // the closing wave of a workgroup (chunk 0) continues the candidate's cost sum: its two operands come with the rows
+    double pre_cost = 0.0, pre_tail = 0.0;
+    if (WG && chunk == 0) {
+        pre_cost = as_global(P.cost)[g];
+        pre_tail = as_global(P.cost_tail)[g];
+    }
+    const int64_t n_live = (int64_t)n_live_raw;
+    if (c0 >= n_live) {
+        if (chunk == 0 && lane == 0) {
+            as_global(P.part_cost)[tile] = INFINITY;
+            as_global(P.part_idx)[tile] = 0x7fffffffffffffffLL;
+        }
+        return;
+    }
+    const bool act = c0 + lane < n_live;
     {
-        const int n_e = (i_b - i_a) * K;
-        for (int e0 = lane; e0 < n_e; e0 += 128) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = lane + 64 * u;
+            if (e < n_e) {
+                cc_tab[e] = fx_d2{hv[u][0], hv[u][1]};
+                circ_tab[4 * e + 0] = hv[u][2]; circ_tab[4 * e + 1] = hv[u][3]; circ_tab[4 * e + 2] = hv[u][4]; circ_tab[4 * e + 3] = hv[u][5];
+            }
+        }
+        for (int e0 = lane + 128; e0 < n_e; e0 += 128) {   // more than 128 (step, obstacle) entries: K > 42 at three steps per chunk
             double v[2][6];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -344,12 +374,12 @@ __global__ __launch_bounds__(WG ? 1024 : 64, WG ? 1 : WPS) void fx_obstacle_kern
     }
     uint32_t fl = f;
     const bool costed = (fl & FX_FLAG_COSTED) != 0, selectable = (fl & FX_FLAG_SELECTABLE) != 0;
-    double total = as_global(P.cost)[g];
+    double total = WG ? pre_cost : as_global(P.cost)[g];
     if (n_pred >= 0) {
         // the walk left the running sum in front of the prediction term: continue the same sequence of additions
         double sum = total;
         sum += w_pred * pred;
-        if (has_tail) sum += as_global(P.cost_tail)[g];
+        if (has_tail) sum += WG ? pre_tail : as_global(P.cost_tail)[g];
         total = 0.0 + sum;
         if (act) {
             as_global(P.cost)[g] = costed ? total : 0.0;
