@@ -831,6 +831,7 @@ def bench_multiagent(args, world, rank, local_rank, torch, dist):
                                    f"({'sampling level ' + str(lvl) if lvl >= 0 else 'dense 19 x 23 x 23(+1) grid'}), bundle materialised, collision stage; a step = one simulation step "
                                    "(replanning every 3rd step)",
                        "agents": n_agents, "candidates_per_agent": per_agent, "plan_steps_timed": plan_steps,
+                       "pipeline_groups": len(sim.batch.engines),
                        "parallelism": ("single GPU" if world == 1 else
                                        (f"{n_agents} agents over {world} GPUs: every GPU one contiguous part of an agent's candidates "
                                         f"({[len([1 for it in sim.items for k, _, _ in it if k == a]) for a in range(n_agents)]} parts), "

@@ -1671,48 +1671,56 @@ int32_t fx_plan_and_package(FxContext *c, const FxStateUpdate *upd, double yaw_r
 #endif
 }
 
-int32_t fx_plan_batch_packaged(FxContext *c, int32_t n_agents, const FxStateUpdate *const *upd, const double *yaw_rate0, FxResult *res,
-                               FxPackage *pkg, double *const *blocks) {
-    if (!c || !res || !pkg) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_plan_batch_packaged: NULL argument");
-    if (!c->uploaded) return set_err(FX_ERR_NOT_READY, "fx_plan_batch_packaged before fx_upload");
+int32_t fx_plan_batch_begin(FxContext *c, int32_t n_agents, const FxStateUpdate *const *upd) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_plan_batch_begin: NULL argument");
+    if (!c->uploaded) return set_err(FX_ERR_NOT_READY, "fx_plan_batch_begin before fx_upload");
     if (n_agents != c->n_agents)
-        return set_err(FX_ERR_INVALID_ARGUMENT, "fx_plan_batch_packaged: %d agents, the uploaded batch has %d", n_agents, c->n_agents);
+        return set_err(FX_ERR_INVALID_ARGUMENT, "fx_plan_batch_begin: %d agents, the uploaded batch has %d", n_agents, c->n_agents);
     int rc;
-#ifdef FX_HOST_PROBE   // probe builds: where the host side of a batched planner step goes (tools/probe_build)
-    static double acc[4]; static int n_acc;
-    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
-#endif
     if (upd)
         for (int a = 0; a < n_agents; a++)
             if (upd[a] && (rc = fx_update_state(c, a, upd[a]))) return rc;
-#ifdef FX_HOST_PROBE
-    const double t1 = now();
-#endif
     const bool was = c->package_enabled;
     c->package_enabled = true;
     rc = fx_evaluate(c);
     c->package_enabled = was;
-    if (rc) return rc;
-#ifdef FX_HOST_PROBE
-    const double t2 = now();
-#endif
+    return rc;
+}
+
+int32_t fx_plan_batch_end(FxContext *c, int32_t n_agents, const double *yaw_rate0, FxResult *res, FxPackage *pkg, double *const *blocks) {
+    if (!c || !res || !pkg) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_plan_batch_end: NULL argument");
+    if (n_agents != c->n_agents)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "fx_plan_batch_end: %d agents, the uploaded batch has %d", n_agents, c->n_agents);
+    int rc;
     if ((rc = fx_finish_batch(c, res))) return rc;
-#ifdef FX_HOST_PROBE
-    const double t3 = now();
-#endif
     for (int a = 0; a < n_agents; a++)
         if ((rc = fx_read_package(c, a, yaw_rate0 ? yaw_rate0[a] : 0.0, pkg + a, blocks ? blocks[a] : nullptr))) return rc;
+    return FX_OK;
+}
+
+int32_t fx_plan_batch_packaged(FxContext *c, int32_t n_agents, const FxStateUpdate *const *upd, const double *yaw_rate0, FxResult *res,
+                               FxPackage *pkg, double *const *blocks) {
+    if (!c || !res || !pkg) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_plan_batch_packaged: NULL argument");
+#ifdef FX_HOST_PROBE   // probe builds: where the host side of a batched planner step goes (tools/probe_build)
+    static double acc[2]; static int n_acc;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+#endif
+    int rc = fx_plan_batch_begin(c, n_agents, upd);
+    if (rc) return rc;
 #ifdef FX_HOST_PROBE
-    const double t4 = now();
-    acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3;
+    const double t1 = now();
+#endif
+    rc = fx_plan_batch_end(c, n_agents, yaw_rate0, res, pkg, blocks);
+#ifdef FX_HOST_PROBE
+    acc[0] += t1 - t0; acc[1] += now() - t1;
     if (++n_acc == 20) {
-        fprintf(stderr, "fx_plan_batch_packaged: update_state %.1f us, evaluate (launches) %.1f us, finish (wait) %.1f us, read_package %.1f us\n",
-                acc[0] / n_acc, acc[1] / n_acc, acc[2] / n_acc, acc[3] / n_acc);
-        acc[0] = acc[1] = acc[2] = acc[3] = 0; n_acc = 0;
+        fprintf(stderr, "fx_plan_batch_packaged: begin (state updates, launches) %.1f us, end (wait, packages) %.1f us\n", acc[0] / n_acc,
+                acc[1] / n_acc);
+        acc[0] = acc[1] = 0; n_acc = 0;
     }
 #endif
-    return FX_OK;
+    return rc;
 }
 
 // ---- host geometry of the callers either side of the path ----

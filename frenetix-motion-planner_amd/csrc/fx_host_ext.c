@@ -385,7 +385,118 @@ static PyObject *point_in_polygon(PyObject *self, PyObject *args) {
     return PyBool_FromLong(odd);
 }
 
+/* plan_batch_begin(fn_addr, ctx_addr, inputs, update) -> None | int (library error code): the first half of plan_batch --
+ * fx_plan_batch_begin: every agent's state rewritten from its inputs (update true) and the evaluation launched; returns without
+ * waiting.  plan_batch_end(fn_addr, ctx_addr, n, yaw_rates, blocks, pkg_addr) -> [result dict per agent] | int: the second half
+ * -- fx_plan_batch_end: the wait, the results, the packages.  A host with several contexts keeps one evaluating while it prepares
+ * the next one's inputs and consumes the previous one's results (multiagent.AgentBatchHip, pipeline_groups). */
+typedef int32_t (*fx_begin_fn)(FxContext *, int32_t, const FxStateUpdate *const *);
+typedef int32_t (*fx_end_fn)(FxContext *, int32_t, const double *, FxResult *, FxPackage *, double *const *);
+
+static PyObject *plan_batch_begin(PyObject *self, PyObject *args) {
+    unsigned long long fn_addr, ctx_addr;
+    PyObject *inputs;
+    int update;
+    if (!PyArg_ParseTuple(args, "KKOp", &fn_addr, &ctx_addr, &inputs, &update)) return NULL;
+    if (!fn_addr || !ctx_addr) {
+        PyErr_SetString(PyExc_ValueError, "plan_batch_begin: NULL address");
+        return NULL;
+    }
+    PyObject *seq = PySequence_Fast(inputs, "plan_batch_begin: inputs must be a sequence"), *out = NULL;
+    if (!seq) return NULL;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    FxStateUpdate upd[FXH_MAX_AGENTS];
+    const FxStateUpdate *updp[FXH_MAX_AGENTS];
+    if (n < 1 || n > FXH_MAX_AGENTS) {
+        PyErr_SetString(PyExc_ValueError, "plan_batch_begin: 1 .. 256 agents");
+        goto done;
+    }
+    for (Py_ssize_t a = 0; a < n; a++) {
+        updp[a] = NULL;
+        if (update) {
+            if (fill_update(PySequence_Fast_GET_ITEM(seq, a), &upd[a]) != 0) goto done;
+            updp[a] = &upd[a];
+        }
+    }
+    {
+        int32_t rc;
+        Py_BEGIN_ALLOW_THREADS
+        rc = ((fx_begin_fn)(uintptr_t)fn_addr)((FxContext *)(uintptr_t)ctx_addr, (int32_t)n, update ? updp : NULL);
+        Py_END_ALLOW_THREADS
+        if (rc != 0) out = PyLong_FromLong(rc);
+        else {
+            out = Py_None;
+            Py_INCREF(out);
+        }
+    }
+done:
+    Py_DECREF(seq);
+    return out;
+}
+
+static PyObject *plan_batch_end(PyObject *self, PyObject *args) {
+    unsigned long long fn_addr, ctx_addr, pkg_addr;
+    PyObject *yaws, *blocks;
+    int n_in;
+    if (!PyArg_ParseTuple(args, "KKiOOK", &fn_addr, &ctx_addr, &n_in, &yaws, &blocks, &pkg_addr)) return NULL;
+    if (!fn_addr || !ctx_addr || !pkg_addr) {
+        PyErr_SetString(PyExc_ValueError, "plan_batch_end: NULL address");
+        return NULL;
+    }
+    const Py_ssize_t n = n_in;
+    PyObject *yseq = NULL, *out = NULL;
+    double yaw[FXH_MAX_AGENTS], *blk[FXH_MAX_AGENTS];
+    FxResult res[FXH_MAX_AGENTS];
+    const void *bp;
+    Py_ssize_t blen;
+    if (n < 1 || n > FXH_MAX_AGENTS) {
+        PyErr_SetString(PyExc_ValueError, "plan_batch_end: 1 .. 256 agents");
+        return NULL;
+    }
+    if (!(yseq = PySequence_Fast(yaws, "plan_batch_end: yaw_rates must be a sequence"))) return NULL;
+    if (PySequence_Fast_GET_SIZE(yseq) != n) {
+        PyErr_SetString(PyExc_ValueError, "plan_batch_end: one yaw rate per agent");
+        goto done;
+    }
+    if (addr_of(blocks, 'd', 8, &bp, &blen) != 0) goto done;
+    if (bp && blen % (n * (Py_ssize_t)sizeof(double) * FX_PKG_ROWS) != 0) {
+        PyErr_SetString(PyExc_ValueError, "plan_batch_end: blocks must be [n][FX_PKG_ROWS][S] doubles");
+        goto done;
+    }
+    for (Py_ssize_t a = 0; a < n; a++) {
+        yaw[a] = PyFloat_AsDouble(PySequence_Fast_GET_ITEM(yseq, a));
+        if (yaw[a] == -1.0 && PyErr_Occurred()) goto done;
+        blk[a] = bp ? (double *)bp + a * (blen / (Py_ssize_t)sizeof(double) / n) : NULL;
+    }
+    {
+        int32_t rc;
+        Py_BEGIN_ALLOW_THREADS
+        rc = ((fx_end_fn)(uintptr_t)fn_addr)((FxContext *)(uintptr_t)ctx_addr, (int32_t)n, yaw, res, (FxPackage *)(uintptr_t)pkg_addr,
+                                             bp ? blk : NULL);
+        Py_END_ALLOW_THREADS
+        if (rc != 0) {
+            out = PyLong_FromLong(rc);
+            goto done;
+        }
+    }
+    out = PyList_New(n);
+    for (Py_ssize_t a = 0; out && a < n; a++) {
+        PyObject *d = result_dict(&res[a]);
+        if (!d) {
+            Py_CLEAR(out);
+            break;
+        }
+        PyList_SET_ITEM(out, a, d);
+    }
+done:
+    Py_XDECREF(yseq);
+    return out;
+}
+
 static PyMethodDef methods[] = {
+    {"plan_batch_begin", plan_batch_begin, METH_VARARGS, "plan_batch_begin(fn_addr, ctx_addr, inputs, update) -> None | error code"},
+    {"plan_batch_end", plan_batch_end, METH_VARARGS,
+     "plan_batch_end(fn_addr, ctx_addr, n, yaw_rates, blocks, pkg_addr) -> [result dict per agent] | error code"},
     {"point_in_polygon", point_in_polygon, METH_VARARGS, "point_in_polygon(xi, yi, x, y) -> bool (ray casting, closed outline)"},
     {"plan_batch", plan_batch, METH_VARARGS,
      "plan_batch(fn_addr, ctx_addr, inputs, yaw_rates, blocks, pkg_addr, update) -> [result dict per agent] | error code"},

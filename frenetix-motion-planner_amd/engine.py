@@ -89,7 +89,8 @@ def _fxhost():
     if _FXHOST is None:
         try:
             from . import _fxhost as m
-            _FXHOST = (m, C.cast(lib().fx_pack_predictions, C.c_void_p).value, C.cast(lib().fx_plan_batch_packaged, C.c_void_p).value)
+            _FXHOST = (m, C.cast(lib().fx_pack_predictions, C.c_void_p).value, C.cast(lib().fx_plan_batch_packaged, C.c_void_p).value,
+                       C.cast(lib().fx_plan_batch_begin, C.c_void_p).value, C.cast(lib().fx_plan_batch_end, C.c_void_p).value)
         except ImportError:
             _FXHOST = False
     return _FXHOST
@@ -562,6 +563,42 @@ class FrenetEngine:
         pkgs = (_abi.FxPackage * n)()
         blocks = np.empty((n, _abi.FX_PKG_ROWS, S))
         out = h[0].plan_batch(h[2], self._ctx.value, inputs, yaw_rates, blocks, C.addressof(pkgs), update)
+        if out.__class__ is int:
+            check(out)
+        return out, [WinnerPackage(pkgs[a], blocks[a], inputs[a]) if pkgs[a].found else None for a in range(n)]
+
+    def plan_batch_begin(self, inputs: Sequence[PlanInputs]):
+        """First half of plan_batch_packaged: the agents' states rewritten in place (or everything uploaded) and the evaluation
+        launched -- returns without waiting (fx_plan_batch_begin).  The token goes to plan_batch_end.  None when the batch
+        cannot take the packaged path (see plan_batch_packaged): the caller then uses that one."""
+        inputs = list(inputs)
+        n = len(inputs)
+        h = _fxhost()
+        if not h or n == 0 or any(inp.sampling_matrix is not None or not inp.write_bundle for inp in inputs):
+            return None
+        S = inputs[0].n_samples
+        if any(inp.n_samples != S for inp in inputs):
+            return None
+        keys = [inp.structure_key() for inp in inputs]
+        update = self._resident_keys is not None and keys == self._resident_keys
+        if not update:
+            self.upload(inputs)
+            self._resident_keys = keys
+        else:
+            self._inputs = inputs
+        rc = h[0].plan_batch_begin(h[3], self._ctx.value, inputs, update)
+        if rc is not None:
+            check(rc)
+        return (inputs, S)
+
+    def plan_batch_end(self, token, yaw_rates: Sequence[float]):
+        """Second half: wait for the evaluation plan_batch_begin launched, ([result dict], [WinnerPackage or None])"""
+        inputs, S = token
+        n = len(inputs)
+        h = _fxhost()
+        pkgs = (_abi.FxPackage * n)()
+        blocks = np.empty((n, _abi.FX_PKG_ROWS, S))
+        out = h[0].plan_batch_end(h[4], self._ctx.value, n, yaw_rates, blocks, C.addressof(pkgs))
         if out.__class__ is int:
             check(out)
         return out, [WinnerPackage(pkgs[a], blocks[a], inputs[a]) if pkgs[a].found else None for a in range(n)]

@@ -97,30 +97,99 @@ class AgentBatchHip:
     once per step by every rank when any agent of the simulation is split."""
 
     def __init__(self, agents: List[FrenetPlannerInterfaceHip], max_candidates: int, device: int = 0, max_ref_knots: int = 4096,
-                 max_obstacles: int = 64, engine=None, parts=None, slots=None, winner_exchange=None):
+                 max_obstacles: int = 64, engine=None, parts=None, slots=None, winner_exchange=None, pipeline_groups: Optional[int] = None):
+        """pipeline_groups: the agents are dealt to that many engine contexts (contiguous groups); a planning step prepares group
+        0's inputs, launches it, prepares group 1's while group 0 evaluates, ... and consumes the results in the same order -- the
+        host work of one group runs in the shadow of another group's kernels (planner-sized grids are host-bound: BASELINE config 4).
+        None: 2 for four or more agents with planner-sized grids (<= 40 000 candidates each), else 1; an injected `engine`, a
+        split agent (parts) or an engine without plan_batch_begin means one group."""
+        import os
         self.agents = list(agents)
         self.parts = list(parts) if parts is not None else [(0, 1)] * len(self.agents)
         self.slots = list(slots) if slots is not None else list(range(len(self.agents)))
         self.winner_exchange = winner_exchange
         N = max(a.planner.N for a in self.agents) if self.agents else 30
+        n = len(self.agents)
+        if pipeline_groups is None:
+            env = os.environ.get("FX_PIPELINE_GROUPS")
+            pipeline_groups = int(env) if env else (2 if n >= 4 and max_candidates <= 40_000 else 1)
+        if isinstance(engine, (list, tuple)):   # one engine object per group, handed in (tests)
+            pipeline_groups = len(engine)
+        elif engine is not None:
+            pipeline_groups = 1
+        if winner_exchange is not None or any(p[1] > 1 for p in self.parts):
+            pipeline_groups = 1
+        pipeline_groups = max(1, min(int(pipeline_groups), max(n, 1)))
+        # contiguous groups of (almost) equal size: agent k belongs to group self.group_of[k] as its local agent self.local_of[k]
+        # (the larger groups first: an early launch has the other groups' host work to hide behind)
+        bounds = [-((-g * n) // pipeline_groups) for g in range(pipeline_groups + 1)]
+        self.groups = [list(range(bounds[g], bounds[g + 1])) for g in range(pipeline_groups)]
+        self.group_of = [g for g, ks in enumerate(self.groups) for _ in ks]
+        self.local_of = [j for ks in self.groups for j in range(len(ks))]
         if engine is None:
             from .engine import FrenetEngine
-            # the context's capacity is the TOTAL over its agent slots (fx_create_batch)
-            engine = FrenetEngine(max_candidates=max_candidates * max(len(self.agents), 1), max_steps=N, max_ref_knots=max_ref_knots,
-                                  max_obstacles=max_obstacles, max_pred_steps=max(64, N + 2), device=device,
-                                  max_agents=max(len(self.agents), 1))
-        self.engine = engine
-        if hasattr(engine, "set_package"):   # every agent's winner arrives packaged with the result block: no read-back per agent
-            engine.set_package(True)
+            # a context's capacity is the TOTAL over its agent slots (fx_create_batch)
+            self.engines = [FrenetEngine(max_candidates=max_candidates * max(len(ks), 1), max_steps=N, max_ref_knots=max_ref_knots,
+                                         max_obstacles=max_obstacles, max_pred_steps=max(64, N + 2), device=device,
+                                         max_agents=max(len(ks), 1)) for ks in self.groups]
+        else:
+            self.engines = list(engine)[:pipeline_groups] if isinstance(engine, (list, tuple)) else [engine]
+        self.engine = self.engines[0]
+        for e in self.engines:
+            if hasattr(e, "set_package"):   # every agent's winner arrives packaged with the result block: no read-back per agent
+                e.set_package(True)
         self.launches = 0
         self.escalations = 0
         self.last_batch_ms = 0.0
+
+    def _step_pipelined(self, global_timestep: int, predictions: Dict[int, dict]) -> Dict[int, Optional[list]]:
+        """step() over several engine contexts: prepare and launch group after group, then consume in the same order."""
+        out: Dict[int, Optional[list]] = {}
+        t0 = time.time()
+        launched, passive = [], []
+        for g, ks in enumerate(self.groups):
+            planning = []
+            for k in ks:
+                a = self.agents[k]
+                if a.id in predictions or a.needs_plan():
+                    a.update_planner(None, predictions.get(a.id, {}))
+                inp = a.begin_step()
+                (planning if inp is not None else passive).append((a, inp))
+            if planning:
+                eng = self.engines[g]
+                token = eng.plan_batch_begin([inp for _, inp in planning])
+                launched.append((eng, planning, token))
+                self.launches += 1
+        for eng, planning, token in launched:
+            yaws = [a.planner.x_0.yaw_rate for a, _ in planning]
+            if token is not None:
+                results, packages = eng.plan_batch_end(token, yaws)
+            else:   # a batch the packaged path does not take (sampling matrix, mixed horizons): the general call
+                results, packages = eng.plan_batch_packaged([inp for _, inp in planning], yaws)
+            for j, (a, inp) in enumerate(planning):
+                p = a.planner
+                best = p.plan_consume(inp, results[j], eng, j, package=packages[j])
+                if best is None and p._sampling_min + 1 < p._sampling_max:
+                    self.escalations += 1
+                    pair = p.plan_escalate(t0)
+                else:
+                    pair = p.plan_finish(best, t0)
+                sel, _ = a.finish_step(pair, global_timestep)
+                out[a.id] = sel
+        if launched:
+            self.last_batch_ms = (time.time() - t0) * 1e3
+        for a, _ in passive:
+            sel, _ = a.finish_step(None, global_timestep)
+            out[a.id] = sel[0] if sel is not None else None
+        return out
 
     def step(self, global_timestep: int, predictions: Dict[int, dict]) -> Dict[int, Optional[list]]:
         """agent_batch.py:140-189: update every agent with its predictions, plan (batched), finish the step.
         predictions: {agent id: predictions dict of that agent}.  Returns {agent id: selected Cartesian state list
         (None: no trajectory found)}."""
         import copy
+        if len(self.engines) > 1:
+            return self._step_pipelined(global_timestep, predictions)
         planning, passive = [], []
         for k, a in enumerate(self.agents):
             if a.id in predictions or a.needs_plan():
@@ -184,7 +253,8 @@ class AgentBatchHip:
         return out
 
     def close(self):
-        self.engine.close()
+        for e in self.engines:
+            e.close()
         for a in self.agents:
             a.close()
 
@@ -196,8 +266,10 @@ class MultiAgentSimulation:
 
     def __init__(self, scenario: Scenario, config: Optional[PlannerConfig] = None, vehicle: Optional[VehicleParams] = None,
                  number_of_agents: int = -1, sampling_level: Optional[int] = None, device: int = 0, group=None,
-                 use_road_boundary: bool = False, max_candidates: Optional[int] = None, engine_factory=None):
-        """engine_factory: callable returning an engine object (tests inject a stand-in); default = FrenetEngine."""
+                 use_road_boundary: bool = False, max_candidates: Optional[int] = None, engine_factory=None,
+                 pipeline_groups: Optional[int] = None):
+        """engine_factory: callable returning an engine object (tests inject a stand-in); default = FrenetEngine.
+        pipeline_groups: see AgentBatchHip (None = automatic; with an engine_factory: that many injected engines, default one)."""
         import torch.distributed as dist
         self.scenario = scenario
         self.config = config or PlannerConfig()
@@ -228,8 +300,9 @@ class MultiAgentSimulation:
                 for k in self.my_slots]
         # per-agent capacity from the sampling sets the planners can really reach (the time set is not bounded by 16 values)
         cap = max_candidates or max([4096] + [a.planner.max_candidates_per_step() for a in mine])
-        self.batch = AgentBatchHip(mine, max_candidates=cap, device=device,
-                                   engine=engine_factory() if engine_factory else None,
+        self.batch = AgentBatchHip(mine, max_candidates=cap, device=device, pipeline_groups=pipeline_groups,
+                                   engine=(([engine_factory() for _ in range(pipeline_groups)] if pipeline_groups and pipeline_groups > 1
+                                            else engine_factory()) if engine_factory else None),
                                    parts=[(part, n_parts) for _, part, n_parts in my_items], slots=self.my_slots,
                                    winner_exchange=self._exchange_winners if self.split else None)
         self.S = self.batch.agents[0].planner.N + 1 if mine else int(self.config.planning_horizon / self.config.dt) + 1

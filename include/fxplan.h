@@ -362,6 +362,11 @@ int32_t fx_plan_and_package(FxContext *ctx, const FxStateUpdate *upd, double yaw
  * agents' updates left it and nothing is evaluated. */
 int32_t fx_plan_batch_packaged(FxContext *ctx, int32_t n_agents, const FxStateUpdate *const *upd, const double *yaw_rate0, FxResult *res,
                                FxPackage *pkg, double *const *blocks);
+/* the same in two halves, so that a host with several contexts keeps one evaluating while it prepares the next one's inputs and
+ * consumes the previous one's results: _begin = the state updates + the evaluation's launches (returns without waiting),
+ * _end = the wait, the results and the packages of THAT evaluation. */
+int32_t fx_plan_batch_begin(FxContext *ctx, int32_t n_agents, const FxStateUpdate *const *upd);
+int32_t fx_plan_batch_end(FxContext *ctx, int32_t n_agents, const double *yaw_rate0, FxResult *res, FxPackage *pkg, double *const *blocks);
 
 /* ---- host geometry of the callers either side of the path (plain C, no device) ----
  *      fx_cs_to_curvilinear: (s, d) of a Cartesian point along a reference polyline with per-vertex normals (the projection

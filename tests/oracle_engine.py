@@ -128,6 +128,17 @@ class PackagingOracleEngine(OracleEngine):
         self.engine_s += time.perf_counter() - t0
         return res, pk
 
+    def plan_batch_begin(self, inps):
+        import time
+        t0 = time.perf_counter()
+        res = self.plan_batch(list(inps))
+        self.engine_s += time.perf_counter() - t0
+        return (list(inps), res)
+
+    def plan_batch_end(self, token, yaw_rates):
+        inps, res = token
+        return res, [self.package(a, yaw_rates[a]) for a in range(len(inps))]
+
     def plan_step_packaged(self, inp, yaw_rate0=0.0):
         import time
         t0 = time.perf_counter()

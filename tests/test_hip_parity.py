@@ -24,7 +24,7 @@ FRAGILE = 1e-9
 #   scaled       cond > 1e3: conditioning-scaled tolerance  escaped  some plane's tolerance >= 1: that plane carries no digit in the
 #   fragile      decided by the last ulp: compared with every     reference either (theta_cl = pi/2 to the last bit: v = x / cos with
 #                admissible outcome                                cos = rounding noise) -- asserted to its ORDER OF MAGNITUDE only
-PARITY_STATS = dict(checked=0, fixed=0, scaled=0, escaped=0, fragile=0)
+PARITY_STATS = dict(checked=0, fixed=0, scaled=0, escaped=0, fragile=0, fragile_same=0)
 WELL_CONDITIONED = 1e3
 MAX_ESCAPED_FRACTION = 1e-2     # per compare(): at most this share of the stored candidates (or 2 of them) asserted to magnitude only
 #                                 (a (t, v) pair that drives backwards from standstill in LOW_VEL_MODE takes its ~10 lateral siblings along:
@@ -204,6 +204,8 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
     PARITY_STATS["fragile"] += n_frag
     src = ref_inp if ref_inp is not None else inp
     for g in np.nonzero(~robust)[0]:
+        # (how often the device took the very branches the reference's arithmetic took: the whole flag word equal)
+        PARITY_STATS["fragile_same"] += int(int(flags[g]) == int(out["flags"][g]))
         outs = oracle.admissible_outcomes(src, int(g), out["frag_sites"][g])
         stored = bool(flags[g] & _abi.FX_FLAG_RETURNED) and (bool(flags[g] & _abi.FX_FLAG_COSTED) or inp.draw_traj_set)
         ok = matches_one_outcome(outs, flags[g], cost[g] if flags[g] & _abi.FX_FLAG_COSTED else None,

@@ -257,21 +257,24 @@ def test_one_agent_split_over_two_processes_on_the_engine(scenario):
 @pytest.mark.gpu
 def test_closed_loop_on_the_engine_matches_the_oracle_engine(scenario):
     """Config 4 closed loop, 9 simulation steps (3 plan steps per agent): same winners, states within 1e-6."""
-    hip, w_hip = _run_sim(scenario, 9)
     ora, w_ora = _run_sim(scenario, 9, engine_factory=OracleEngine)
-    try:
-        assert w_hip == w_ora
-        assert np.abs(hip.plans - ora.plans).max() < 1e-6
-        assert hip.batch.launches == 3                      # one batched launch per plan step for all five agents
-    finally:
-        hip.close()
+    for groups in (1, 2, None):   # one batched launch; two engine contexts, pipelined; the automatic choice (two, for five agents)
+        hip, w_hip = _run_sim(scenario, 9, pipeline_groups=groups)
+        try:
+            assert w_hip == w_ora
+            assert np.abs(hip.plans - ora.plans).max() < 1e-6
+            n_groups = len(hip.batch.engines)
+            assert n_groups == (groups or 2)
+            assert hip.batch.launches == 3 * n_groups       # one batched launch per plan step and group
+        finally:
+            hip.close()
 
 
 @pytest.mark.gpu
 def test_config4_sized_batch(scenario):
     """Sampling level 4 (10 x 33 x 34 = 11 220 candidates per agent), five agents in one launch vs one agent at a time."""
     cfg = PlannerConfig(sampling_min=4, sampling_max=5)
-    sim = multiagent.MultiAgentSimulation(scenario, config=cfg)
+    sim = multiagent.MultiAgentSimulation(scenario, config=cfg, pipeline_groups=1)   # (all five on one engine context)
     try:
         preds = {a.id: sim.predictions_for(a.id) for a in sim.batch.agents}
         for a in sim.batch.agents:
@@ -322,3 +325,16 @@ def test_shared_prediction_packing_equals_per_agent_packing(scenario):
     for _ in range(4):
         sim2.step()
     assert np.array_equal(sim2.plans, sim.plans)
+
+
+def test_pipelined_groups_equal_one_batch_cpu(scenario):
+    """AgentBatchHip over several engine contexts (pipeline_groups: prepare and launch group after group, consume in the same
+    order) takes the decisions of the single batched launch: the agents are independent given the step's frozen predictions"""
+    from tests.oracle_engine import PackagingOracleEngine
+    one, w_one = _run_sim(scenario, 7, engine_factory=PackagingOracleEngine)
+    for groups in (2, 3, 5):
+        sim, w = _run_sim(scenario, 7, engine_factory=PackagingOracleEngine, pipeline_groups=groups)
+        assert len(sim.batch.engines) == groups and sorted(k for ks in sim.batch.groups for k in ks) == list(range(len(sim.batch.agents)))
+        assert w == w_one and np.array_equal(sim.plans, one.plans)
+        for a, b in zip(sim.batch.agents, one.batch.agents):
+            assert a.replanning_counter == b.replanning_counter and np.array_equal(a.x_0.position, b.x_0.position)

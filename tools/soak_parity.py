@@ -85,7 +85,8 @@ for case in range(first, first + n):
 print(f"soak: {n} cases from {first}: {bad} failures; {stats}; how they were checked: {PARITY_STATS}", flush=True)
 ck = max(PARITY_STATS["checked"], 1)
 print(f"   fixed 1e-9: {PARITY_STATS['fixed'] / ck:.4%}  conditioning-scaled: {PARITY_STATS['scaled'] / ck:.4%}  magnitude only (tolerance >= 1): "
-      f"{PARITY_STATS['escaped'] / ck:.5%}  fragile (admissible outcomes): {stats['fragile'] / max(stats['cands'], 1):.3%} of all candidates", flush=True)
+      f"{PARITY_STATS['escaped'] / ck:.5%}  fragile (admissible outcomes): {stats['fragile'] / max(stats['cands'], 1):.3%} of all candidates, "
+      f"{PARITY_STATS['fragile_same'] / max(PARITY_STATS['fragile'], 1):.3%} of them with the reference's own flag word", flush=True)
 if stats.get("tie_decided", 0) > max(1, 2e-4 * n):
     print("soak: too many winners decided by a last-ulp tie", flush=True)
     bad += 1
