@@ -123,6 +123,12 @@ class AgentBatchHip:
         # contiguous groups of (almost) equal size: agent k belongs to group self.group_of[k] as its local agent self.local_of[k]
         # (the larger groups first: an early launch has the other groups' host work to hide behind)
         bounds = [-((-g * n) // pipeline_groups) for g in range(pipeline_groups + 1)]
+        sizes = os.environ.get("FX_PIPELINE_SIZES")   # experiments: explicit group sizes, e.g. "1,2,2"
+        if sizes and engine is None and pipeline_groups > 1 and sum(int(x) for x in sizes.split(",")) == n:
+            bounds = [0]
+            for x in sizes.split(","):
+                bounds.append(bounds[-1] + int(x))
+            pipeline_groups = len(bounds) - 1
         self.groups = [list(range(bounds[g], bounds[g + 1])) for g in range(pipeline_groups)]
         self.group_of = [g for g, ks in enumerate(self.groups) for _ in ks]
         self.local_of = [j for ks in self.groups for j in range(len(ks))]

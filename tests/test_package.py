@@ -159,3 +159,65 @@ def test_plan_batch_in_place_update_equals_fresh_upload():
                 assert res[a][k] == ref[a][k], (a, k)
             if cands[a] is not None:
                 assert np.array_equal(cands[a]["planes"], eng2.candidate(ref[a]["best_index"], a)["planes"])
+
+
+def test_plan_batch_packaged_one_call_and_two_halves():
+    """fx_plan_batch_packaged (through _fxhost.plan_batch) and its halves fx_plan_batch_begin / fx_plan_batch_end against the piecewise
+    form (plan_batch + package per agent): first a fresh upload, then the in-place update of every agent; results as dicts with the
+    keys of FxResult.as_dict()."""
+    import ctypes as C
+    from frenetix_motion_planner_amd import _abi
+    from frenetix_motion_planner_amd._lib import lib
+    from frenetix_motion_planner_amd.engine import build_obstacle_hulls
+
+    def agents(shift):
+        out = []
+        for a in range(4):
+            out.append(synthetic.make_inputs(hull_builder=build_obstacle_hulls, ref_kind="arc", v0=6.0 + 2 * a + shift, grid=(3, 5, 7),
+                                             n_obstacles=1 + a % 3, seed=a + 10 * int(shift > 0), d0=0.1 * a + 0.05 * shift))
+        return out
+
+    first, second = agents(0.0), agents(0.7)
+    for a in range(4):
+        second[a].coordinate_system, second[a]._ref = first[a].coordinate_system, first[a]._ref
+    yaw = [0.01 * a for a in range(4)]
+    with _engine(max_candidates=4096, max_agents=4) as ref_eng:
+        ref_eng.set_package(True)
+        want = []
+        for batch in (first, second):
+            res = ref_eng.plan_batch(batch)
+            want.append((res, [ref_eng.package(a, yaw[a]) for a in range(4)]))
+
+    def same(got, exp):
+        (res, pk), (res0, pk0) = got, exp
+        for a in range(4):
+            assert set(res[a]) == set(res0[a])
+            for k in res0[a]:
+                if k != "kernel_ms":
+                    assert res[a][k] == res0[a][k], (a, k)
+            assert (pk[a] is None) == (pk0[a] is None)
+            if pk[a] is not None:
+                assert pk[a].index == pk0[a].index and pk[a].cost == pk0[a].cost and pk[a].flags == pk0[a].flags
+                assert np.array_equal(pk[a].block, pk0[a].block) and np.array_equal(pk[a].raw_costs, pk0[a].raw_costs)
+                assert np.array_equal(pk[a].lon, pk0[a].lon) and pk[a].traj_len == pk0[a].traj_len
+
+    with _engine(max_candidates=4096, max_agents=4) as eng:
+        same(eng.plan_batch_packaged(first, yaw), want[0])      # upload
+        same(eng.plan_batch_packaged(second, yaw), want[1])     # in place
+    with _engine(max_candidates=4096, max_agents=4) as eng:
+        tok = eng.plan_batch_begin(first)
+        same(eng.plan_batch_end(tok, yaw), want[0])
+        tok = eng.plan_batch_begin(second)
+        assert eng._resident_keys == [i.structure_key() for i in second]
+        same(eng.plan_batch_end(tok, yaw), want[1])
+        # the C-ABI refuses what does not fit the uploaded batch, and leaves the context usable
+        res = (_abi.FxResult * 3)()
+        pkg = (_abi.FxPackage * 3)()
+        assert lib().fx_plan_batch_packaged(eng._ctx, 3, None, None, res, pkg, None) != 0
+        assert b"agents" in lib().fx_last_error()
+        assert lib().fx_plan_batch_begin(eng._ctx, 5, None) != 0
+        same(eng.plan_batch_packaged(second, yaw), want[1])
+    with _engine(max_candidates=4096, max_agents=4) as fresh:
+        res = (_abi.FxResult * 4)()
+        pkg = (_abi.FxPackage * 4)()
+        assert lib().fx_plan_batch_packaged(fresh._ctx, 4, None, None, res, pkg, None) != 0   # nothing uploaded yet
