@@ -15,6 +15,8 @@
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+#define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
+#include <numpy/arrayobject.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -385,6 +387,123 @@ static PyObject *point_in_polygon(PyObject *self, PyObject *args) {
     return PyBool_FromLong(odd);
 }
 
+/* ---- the inputs of a planner's NEXT closed-loop step: problem.PlanInputs.next_step + sampling.dense_ranges in one call ----
+ * next_inputs(prev, low_vel_mode, x_lon, x_lat, x0_orientation, v_des, v_lo, v_hi, d_cached, d0, obstacles) -> PlanInputs | NotImplemented
+ *   prev        the planner's last PlanInputs (ranges, dense grid): everything a step does not change is carried over on a copy
+ *               of its instance dict, the cached structure key included when the new arrays have the old lengths and the
+ *               predictions the old (K, P)
+ *   x_lon/x_lat sequences of three floats -> fresh float64 arrays
+ *   v_lo, v_hi  the velocity sampling bounds: v = arange(n) * ((v_hi - v_lo) / (n - 1)) + v_lo with the end point set exactly
+ *               (np.linspace's arithmetic, sampling.dense_ranges), n = len(prev.v_samp)
+ *   d_cached    the grid's lateral set (read-only, shared); d0 is appended on a fresh array when it is not one of its values
+ *   obstacles   the packed predictions dict of the step
+ * NotImplemented: a case the Python path handles (n < 2, equal bounds, no predictions dict, foreign array types). */
+static PyObject *s_empty_tuple;
+static PyObject *s_v_samp_k, *s_d_samp_k, *s_t_samp_k, *s_x0_lon_k, *s_x0_lat_k, *s_lvm_k, *s_x0o_k, *s_vdes_k, *s_obst_k, *s_shard_k,
+                *s_skey_k, *s_P_k;
+
+static PyObject *array3(PyObject *seq) {
+    npy_intp dim = 3;
+    PyObject *a = PyArray_SimpleNew(1, &dim, NPY_DOUBLE);
+    if (!a) return NULL;
+    double *p = (double *)PyArray_DATA((PyArrayObject *)a);
+    PyObject *fast = PySequence_Fast(seq, "expected a sequence of three floats");
+    if (!fast || PySequence_Fast_GET_SIZE(fast) != 3) {
+        Py_XDECREF(fast);
+        Py_DECREF(a);
+        if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "expected a sequence of three floats");
+        return NULL;
+    }
+    for (int i = 0; i < 3; i++) {
+        p[i] = PyFloat_AsDouble(PySequence_Fast_GET_ITEM(fast, i));
+        if (p[i] == -1.0 && PyErr_Occurred()) {
+            Py_DECREF(fast);
+            Py_DECREF(a);
+            return NULL;
+        }
+    }
+    Py_DECREF(fast);
+    return a;
+}
+
+static int is_f64_vector(PyObject *o) {
+    return PyArray_Check(o) && PyArray_NDIM((PyArrayObject *)o) == 1 && PyArray_TYPE((PyArrayObject *)o) == NPY_DOUBLE &&
+           PyArray_IS_C_CONTIGUOUS((PyArrayObject *)o);
+}
+
+static PyObject *next_inputs(PyObject *self, PyObject *args) {
+    PyObject *prev, *lvm, *x_lon, *x_lat, *d_cached, *obstacles;
+    double x0o, v_des, v_lo, v_hi, d0;
+    if (!PyArg_ParseTuple(args, "OOOOddddOdO", &prev, &lvm, &x_lon, &x_lat, &x0o, &v_des, &v_lo, &v_hi, &d_cached, &d0, &obstacles))
+        return NULL;
+    PyObject *pd = PyObject_GenericGetDict(prev, NULL);   /* new reference */
+    if (!pd) return NULL;
+    PyObject *out = NULL, *nd = NULL, *v = NULL, *d = NULL, *lon = NULL, *lat = NULL, *tmp;
+    PyObject *pv = PyDict_GetItemWithError(pd, s_v_samp_k), *pdd = PyDict_GetItemWithError(pd, s_d_samp_k);
+    PyObject *pobs = PyDict_GetItemWithError(pd, s_obst_k);
+    if (!pv || !pdd || !pobs || !is_f64_vector(pv) || !is_f64_vector(pdd) || !is_f64_vector(d_cached) || !PyDict_Check(obstacles) ||
+        !PyDict_Check(pobs)) {
+        if (!PyErr_Occurred()) { out = Py_NotImplemented; Py_INCREF(out); }
+        goto done;
+    }
+    const npy_intp n_v = PyArray_DIM((PyArrayObject *)pv, 0);
+    if (n_v < 2 || v_hi == v_lo || !(v_hi == v_hi) || !(v_lo == v_lo)) { out = Py_NotImplemented; Py_INCREF(out); goto done; }
+    {
+        npy_intp dim = n_v;
+        if (!(v = PyArray_SimpleNew(1, &dim, NPY_DOUBLE))) goto done;
+        double *p = (double *)PyArray_DATA((PyArrayObject *)v);
+        const double step = (v_hi - v_lo) / (double)(n_v - 1);
+        for (npy_intp i = 0; i < n_v; i++) p[i] = (double)i * step + v_lo;
+        p[n_v - 1] = v_hi;
+    }
+    {
+        const npy_intp n_d = PyArray_DIM((PyArrayObject *)d_cached, 0);
+        const double *q = (const double *)PyArray_DATA((PyArrayObject *)d_cached);
+        int found = 0;
+        for (npy_intp i = 0; i < n_d; i++) found |= q[i] == d0;
+        if (found) { d = d_cached; Py_INCREF(d); }
+        else {
+            npy_intp dim = n_d + 1;
+            if (!(d = PyArray_SimpleNew(1, &dim, NPY_DOUBLE))) goto done;
+            double *p = (double *)PyArray_DATA((PyArrayObject *)d);
+            memcpy(p, q, sizeof(double) * (size_t)n_d);
+            p[n_d] = d0;
+        }
+    }
+    if (!(lon = array3(x_lon)) || !(lat = array3(x_lat))) goto done;
+    /* the copy: type(prev).__new__, its dict = prev's with the step's fields replaced */
+    out = PyBaseObject_Type.tp_new(Py_TYPE(prev), s_empty_tuple, NULL);
+    if (!out) goto done;
+    if (!(nd = PyObject_GenericGetDict(out, NULL)) || PyDict_Update(nd, pd) != 0) { Py_CLEAR(out); goto done; }
+    {
+        int bad = 0;
+        bad |= PyDict_SetItem(nd, s_lvm_k, lvm);
+        bad |= (tmp = PyFloat_FromDouble(x0o)) ? PyDict_SetItem(nd, s_x0o_k, tmp) : 1; Py_XDECREF(tmp);
+        bad |= (tmp = PyFloat_FromDouble(v_des)) ? PyDict_SetItem(nd, s_vdes_k, tmp) : 1; Py_XDECREF(tmp);
+        bad |= PyDict_SetItem(nd, s_obst_k, obstacles);
+        bad |= PyDict_SetItem(nd, s_shard_k, Py_None);
+        bad |= PyDict_SetItem(nd, s_x0_lon_k, lon);
+        bad |= PyDict_SetItem(nd, s_x0_lat_k, lat);
+        bad |= PyDict_SetItem(nd, s_v_samp_k, v);
+        bad |= PyDict_SetItem(nd, s_d_samp_k, d);
+        /* the structure key survives equal lengths and equal (K, P) */
+        PyObject *k0 = PyDict_GetItemWithError(pobs, s_K), *k1 = PyDict_GetItemWithError(obstacles, s_K);
+        PyObject *p0 = PyDict_GetItemWithError(pobs, s_P_k), *p1 = PyDict_GetItemWithError(obstacles, s_P_k);
+        int same = k0 && k1 && p0 && p1 && PyObject_RichCompareBool(k0, k1, Py_EQ) == 1 && PyObject_RichCompareBool(p0, p1, Py_EQ) == 1 &&
+                   PyArray_DIM((PyArrayObject *)d, 0) == PyArray_DIM((PyArrayObject *)pdd, 0);
+        if (!same && PyDict_GetItemWithError(nd, s_skey_k)) bad |= PyDict_DelItem(nd, s_skey_k);
+        if (bad || PyErr_Occurred()) Py_CLEAR(out);
+    }
+done:
+    Py_XDECREF(nd);
+    Py_XDECREF(pd);
+    Py_XDECREF(v);
+    Py_XDECREF(d);
+    Py_XDECREF(lon);
+    Py_XDECREF(lat);
+    return out;
+}
+
 /* plan_batch_begin(fn_addr, ctx_addr, inputs, update) -> None | int (library error code): the first half of plan_batch --
  * fx_plan_batch_begin: every agent's state rewritten from its inputs (update true) and the evaluation launched; returns without
  * waiting.  plan_batch_end(fn_addr, ctx_addr, n, yaw_rates, blocks, pkg_addr) -> [result dict per agent] | int: the second half
@@ -494,6 +613,8 @@ done:
 }
 
 static PyMethodDef methods[] = {
+    {"next_inputs", next_inputs, METH_VARARGS,
+     "next_inputs(prev, low_vel_mode, x_lon, x_lat, x0_orientation, v_des, v_lo, v_hi, d_cached, d0, obstacles) -> PlanInputs | NotImplemented"},
     {"plan_batch_begin", plan_batch_begin, METH_VARARGS, "plan_batch_begin(fn_addr, ctx_addr, inputs, update) -> None | error code"},
     {"plan_batch_end", plan_batch_end, METH_VARARGS,
      "plan_batch_end(fn_addr, ctx_addr, n, yaw_rates, blocks, pkg_addr) -> [result dict per agent] | error code"},
@@ -509,6 +630,20 @@ static PyMethodDef methods[] = {
 static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_fxhost", "host-side helpers of the planner (dict walking in C)", -1, methods};
 
 PyMODINIT_FUNC PyInit__fxhost(void) {
+    import_array();
+    s_empty_tuple = PyTuple_New(0);
+    s_v_samp_k = PyUnicode_InternFromString("v_samp");
+    s_d_samp_k = PyUnicode_InternFromString("d_samp");
+    s_t_samp_k = PyUnicode_InternFromString("t_samp");
+    s_x0_lon_k = PyUnicode_InternFromString("x0_lon");
+    s_x0_lat_k = PyUnicode_InternFromString("x0_lat");
+    s_lvm_k = PyUnicode_InternFromString("low_vel_mode");
+    s_x0o_k = PyUnicode_InternFromString("x0_orientation");
+    s_vdes_k = PyUnicode_InternFromString("v_des");
+    s_obst_k = PyUnicode_InternFromString("obstacles");
+    s_shard_k = PyUnicode_InternFromString("shard");
+    s_skey_k = PyUnicode_InternFromString("_skey");
+    s_P_k = PyUnicode_InternFromString("P");
     s_pos = PyUnicode_InternFromString("pos_list");
     s_cov = PyUnicode_InternFromString("cov_list");
     s_yaw = PyUnicode_InternFromString("orientation_list");

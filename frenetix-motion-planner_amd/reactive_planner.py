@@ -25,7 +25,12 @@ import numpy as np
 from . import _abi
 from .coordinate_system import CoordinateSystem, interpolate_angle
 from .problem import DEFAULT_COST_WEIGHTS, MAX_OBSTACLES, PlanInputs, VehicleParams, pack_predictions
-from .sampling import SamplingHandler, v_sampling_bounds
+from .sampling import SamplingHandler, dense_cached, v_sampling_bounds
+
+try:   # the CPython helper built next to the package (csrc/fx_host_ext.c); PlanInputs.next_step is the same thing in Python
+    from ._fxhost import next_inputs as _NEXT_INPUTS
+except ImportError:
+    _NEXT_INPUTS = None
 from .trajectories import (CartesianSample, CurviLinearSample, PlanStepResult, PolynomialView, StandstillSample,
                            TrajectorySample)
 
@@ -264,6 +269,30 @@ class ReactivePlannerHip:
     def _inputs_for_level(self, samp_level: int, stop_point_s: Optional[float] = None) -> PlanInputs:
         from .engine import build_obstacle_hulls
         x_lon, x_lat = self.x_cl
+        prev = self._prev_inputs
+        if self._packed_predictions is None:
+            self._packed_predictions = pack_predictions(self.predictions if self.use_prediction else None, self.N + 1,
+                                                        build_obstacle_hulls)
+        if (_NEXT_INPUTS is not None and prev is not None and stop_point_s is None and self.config.dense_grid is not None
+                and self.road_boundary is None and prev.road_boundary is None
+                and not prev.stop_point and prev.sampling_matrix is None):
+            # the closed loop's usual step on a dense grid, in ONE extension call (`_fxhost.next_inputs`): the velocity set from
+            # its bounds, the lateral set (+ the current d), the state arrays and the copy of the last inputs with those replaced
+            cw = self.cost_weights
+            if (self._weights_src is cw and self._weights_sig == tuple(cw.items()) and prev.cost_weights is self._weights_nz
+                    and prev.coordinate_system is self.coordinate_system and prev.lanelets is self._packed_lanelets
+                    and prev.vehicle is self.vehicle_params and prev.N == self.N and prev.dt == self.dT
+                    and prev.draw_traj_set == self._draw_traj_set and prev.kinematic_debug == self._kinematic_debug
+                    and prev.collision == self.use_prediction):
+                n_t, n_v, n_d = self.config.dense_grid
+                t_c, d_c, _, _ = dense_cached(n_t, n_v, n_d, self.horizon, self.dT, self.config.t_min, self.config.d_min, self.config.d_max)
+                vs = self.sampling_handler.v_sampling
+                if prev.t_samp is t_c and len(prev.v_samp) == n_v:
+                    inp = _NEXT_INPUTS(prev, self._LOW_VEL_MODE, x_lon, x_lat, self.x_0.orientation, self.desired_velocity,
+                                       vs.minimum, vs.maximum, d_c, x_lat[0], self._packed_predictions)
+                    if inp is not NotImplemented:
+                        self._prev_inputs = inp
+                        return inp
         if self.config.dense_grid is not None and stop_point_s is None:
             from .sampling import dense_ranges
             n_t, n_v, n_d = self.config.dense_grid

@@ -146,18 +146,7 @@ def dense_ranges(n_t: int, n_v: int, n_d: int, v_lo: float, v_hi: float, horizon
                  t_min: float = 1.1, d_min: float = -3.0, d_max: float = 3.0):
     """Dense grid in natural (ascending) order: T = t_min .. horizon step dt (first n_t), V = linspace(v_lo, v_hi, n_v),
     D = linspace(d_min, d_max, n_d) plus d0 appended if absent (BASELINE configs 2 - 5)."""
-    key = (n_t, n_v, n_d, horizon, dt, t_min, d_min, d_max)
-    c = _DENSE_CACHE.get(key)
-    if c is None:   # the time and lateral sets of a planner never change: built once
-        t = np.round(t_min + dt * np.arange(n_t), 2)
-        d = np.linspace(d_min, d_max, n_d)
-        t = t[t <= horizon + 1e-9]
-        # the cached sets are handed out by reference: read-only, so that a caller that sorts or edits "its" range in place
-        # gets an error instead of silently changing the sampling sets of every planner with the same key
-        t.setflags(write=False)
-        d.setflags(write=False)
-        c = _DENSE_CACHE[key] = (t, d, frozenset(d.tolist()), np.arange(0, n_v, dtype=np.float64))
-    t, d, d_set, ramp = c
+    t, d, d_set, ramp = dense_cached(n_t, n_v, n_d, horizon, dt, t_min, d_min, d_max)
     # np.linspace(v_lo, v_hi, n_v) with its arithmetic (function_base.py: arange * step + start, the end point set exactly)
     # on the cached ramp -- a third of the time of the call
     if n_v > 1 and v_hi != v_lo:
@@ -174,6 +163,22 @@ def dense_ranges(n_t: int, n_v: int, n_d: int, v_lo: float, v_hi: float, horizon
 
 
 _DENSE_CACHE: dict = {}
+
+
+def dense_cached(n_t: int, n_v: int, n_d: int, horizon: float, dt: float, t_min: float = 1.1, d_min: float = -3.0, d_max: float = 3.0):
+    """(T, D, frozenset(D), arange(n_v)) of a dense grid: the time and lateral sets of a planner never change -- built once per
+    key, handed out by reference and therefore read-only (a caller that sorts or edits "its" range in place gets an error instead
+    of silently changing the sampling sets of every planner with the same key)."""
+    key = (n_t, n_v, n_d, horizon, dt, t_min, d_min, d_max)
+    c = _DENSE_CACHE.get(key)
+    if c is None:
+        t = np.round(t_min + dt * np.arange(n_t), 2)
+        d = np.linspace(d_min, d_max, n_d)
+        t = t[t <= horizon + 1e-9]
+        t.setflags(write=False)
+        d.setflags(write=False)
+        c = _DENSE_CACHE[key] = (t, d, frozenset(d.tolist()), np.arange(0, n_v, dtype=np.float64))
+    return c
 
 
 def generate_sampling_matrix(*, t0_range, t1_range, s0_range, ss0_range, sss0_range, ss1_range, sss1_range,

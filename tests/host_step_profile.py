@@ -22,6 +22,7 @@ from tests.oracle_engine import PackagingOracleEngine   # noqa: E402
 
 
 ACC = {}
+CALLS = {}
 
 
 def wrap(cls, name):
@@ -33,7 +34,9 @@ def wrap(cls, name):
         try:
             return f(*a, **k)
         finally:
-            ACC[label] = ACC.get(label, 0.0) + time.perf_counter() - t0
+            dt = time.perf_counter() - t0
+            ACC[label] = ACC.get(label, 0.0) + dt
+            CALLS.setdefault(label, []).append(dt)
     setattr(cls, name, g)
 
 
@@ -58,7 +61,7 @@ def main():
     eng = sim.batch.engine
     for _ in range(6):
         sim.step()
-    ACC.clear()
+    ACC.clear(); CALLS.clear()
     n = int(os.environ.get("STEPS", "90"))
     host = []
     for _ in range(n):
@@ -72,7 +75,9 @@ def main():
           f"others p50 {np.median(host[host <= np.median(host) * 2]):.1f} us")
     if "--seg" in sys.argv:
         for k, v in sorted(ACC.items(), key=lambda kv: -kv[1]):
-            print(f"  {k:48s} {v / max(len(plan), 1) * 1e6:9.1f} us per planning step (inclusive; AgentBatchHip.step includes the engine)")
+            q = np.array(CALLS[k]) * 1e6
+            print(f"  {k:48s} {v / max(len(plan), 1) * 1e6:9.1f} us per planning step (inclusive)   per call: n {len(q):5d} p50 {np.median(q):7.1f} "
+                  f"min {q.min():7.1f}")
     if "--prof" in sys.argv:
         pr = cProfile.Profile()
         pr.enable()

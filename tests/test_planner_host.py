@@ -218,3 +218,59 @@ def test_state_update_struct_filled_in_c_equals_the_python_path():
         h[0].state_update(C.addressof(u), a, a, 0.0, 1.0, 0, b, b, np.arange(4, dtype=np.int32), None, None, None, None, None)
     with pytest.raises(ValueError):
         h[0].state_update(0, a, a, 0.0, 1.0, 0, b, b, b, None, None, None, None, None)
+
+
+def test_next_inputs_in_c_equals_the_python_path(monkeypatch):
+    """`_fxhost.next_inputs` (velocity set from its bounds, lateral set + current d, state arrays, copy of the last inputs -- one
+    extension call) against PlanInputs.next_step behind sampling.dense_ranges: every field of the inputs, the arrays bit for bit,
+    the structure key kept exactly when the Python path keeps it (same lengths, same (K, P)) and dropped when d0 joins or leaves
+    the lateral set."""
+    from frenetix_motion_planner_amd import reactive_planner as rpm
+    from frenetix_motion_planner_amd.coordinate_system import CoordinateSystem
+    assert rpm._NEXT_INPUTS is not None, "the _fxhost extension is part of the build (make -C frenetix-motion-planner_amd/csrc)"
+    ref = synthetic.reference_polyline("arc", 400, 0.5, 0.01)
+    cs = CoordinateSystem(ref)
+    rng = np.random.default_rng(5)
+
+    def planner():
+        p = ReactivePlannerHip(PlannerConfig(sampling_min=0, sampling_max=1, dense_grid=(5, 7, 9)), VehicleParams(), engine=OracleEngine())
+        s0 = float(cs.ref_pos[40] + 0.1)
+        x0 = ReactivePlannerState(0, np.asarray(cs.convert_to_cartesian_coords(s0, 0.2)), float(cs.ref_theta[40]), 9.0, 0.0, 0.0, 0.0)
+        p.update_externals(reference_path=ref, x_0=x0, desired_velocity=10.0, predictions=synthetic.synthetic_predictions(
+            cs, 3, 30, 0.1, s0, np.random.default_rng(1)))
+        return p, x0
+
+    pc, x0 = planner()
+    pp, _ = planner()
+    calls = []
+    real = rpm._NEXT_INPUTS
+    for step in range(8):
+        v = float(rng.uniform(1.0, 15.0))
+        d0 = [0.2, 0.0, -0.75, 0.31, 0.31, 3.0, 0.1234, 0.0][step]   # 0.0, -0.75, 3.0 are values of linspace(-3, 3, 9): no append
+        x_cl = ([float(cs.ref_pos[40] + 0.1 + step), v, float(rng.normal(0, 0.3))], [d0, float(rng.normal(0, 0.1)), 0.0])
+        st = ReactivePlannerState(step, x0.position.copy(), x0.orientation + 0.01 * step, v, 0.0, 0.0, 0.0)
+        preds = synthetic.synthetic_predictions(cs, 3, 30, 0.1, x_cl[0][0], np.random.default_rng(step))
+        out = []
+        for p, fn in ((pc, lambda *a: (calls.append(1), real(*a))[1]), (pp, None)):
+            monkeypatch.setattr(rpm, "_NEXT_INPUTS", fn)
+            p.update_externals(x_0=st, x_cl=x_cl, desired_velocity=v + 1.0, predictions=preds)
+            out.append(p.plan_begin())
+        a, b = out
+        assert type(a) is type(b) and set(a.__dict__) - {"_skey"} == set(b.__dict__) - {"_skey"}
+        for k, vb in b.__dict__.items():
+            va = a.__dict__.get(k)
+            if k == "_skey":
+                continue
+            if isinstance(vb, np.ndarray):
+                assert isinstance(va, np.ndarray) and va.dtype == vb.dtype and np.array_equal(va, vb), (step, k)
+            elif k == "obstacles":
+                assert all(np.array_equal(np.asarray(va[q]), np.asarray(vb[q])) for q in ("K", "P", "pos", "cov_inv", "npred", "hull", "nhull"))
+            elif k in ("coordinate_system", "vehicle", "_ref", "_tpow", "cost_names", "_cost_id", "_cost_w", "_bound", "lanelets"):
+                pass   # carried over by reference on both paths (per-planner objects)
+            else:
+                assert va == vb, (step, k, va, vb)
+        assert ("_skey" in a.__dict__) == ("_skey" in b.__dict__), step
+        ka, kb = a.structure_key(), b.structure_key()
+        assert [x for i, x in enumerate(ka) if i != 5] == [x for i, x in enumerate(kb) if i != 5]   # (entry 5: the planners' own coordinate systems)
+        assert a.t_samp.flags.c_contiguous and a.v_samp.flags.writeable and a.x0_lon.shape == (3,)
+    assert len(calls) == 7   # every step after the first took the extension call (the first has no previous inputs)
