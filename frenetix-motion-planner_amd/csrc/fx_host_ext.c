@@ -291,6 +291,59 @@ static PyObject *result_dict(const FxResult *r) {
     return d;
 }
 
+/* the agents' state updates from their inputs (borrowed pointers into the inputs' arrays); 0 on success */
+static int collect_updates(PyObject *seq, Py_ssize_t n, int update, FxStateUpdate *upd, const FxStateUpdate **updp) {
+    for (Py_ssize_t a = 0; a < n; a++) {
+        updp[a] = NULL;
+        if (update) {
+            if (fill_update(PySequence_Fast_GET_ITEM(seq, a), &upd[a]) != 0) return -1;
+            updp[a] = &upd[a];
+        }
+    }
+    return 0;
+}
+
+/* yaw rates and per-agent block pointers of a [n][FX_PKG_ROWS][S] buffer; *have_blocks = 0 for None; 0 on success */
+static int collect_outputs(PyObject *yaws, PyObject *blocks, Py_ssize_t n, double *yaw, double **blk, int *have_blocks) {
+    PyObject *yseq = PySequence_Fast(yaws, "yaw_rates must be a sequence");
+    if (!yseq) return -1;
+    int rc = -1;
+    const void *bp;
+    Py_ssize_t blen;
+    if (PySequence_Fast_GET_SIZE(yseq) != n) {
+        PyErr_SetString(PyExc_ValueError, "one yaw rate per agent");
+        goto out;
+    }
+    if (addr_of(blocks, 'd', 8, &bp, &blen) != 0) goto out;
+    if (bp && blen % (n * (Py_ssize_t)sizeof(double) * FX_PKG_ROWS) != 0) {
+        PyErr_SetString(PyExc_ValueError, "blocks must be [n][FX_PKG_ROWS][S] doubles");
+        goto out;
+    }
+    for (Py_ssize_t a = 0; a < n; a++) {
+        yaw[a] = PyFloat_AsDouble(PySequence_Fast_GET_ITEM(yseq, a));
+        if (yaw[a] == -1.0 && PyErr_Occurred()) goto out;
+        blk[a] = bp ? (double *)bp + a * (blen / (Py_ssize_t)sizeof(double) / n) : NULL;
+    }
+    *have_blocks = bp != NULL;
+    rc = 0;
+out:
+    Py_DECREF(yseq);
+    return rc;
+}
+
+static PyObject *results_list(const FxResult *res, Py_ssize_t n) {
+    PyObject *out = PyList_New(n);
+    for (Py_ssize_t a = 0; out && a < n; a++) {
+        PyObject *d = result_dict(&res[a]);
+        if (!d) {
+            Py_CLEAR(out);
+            break;
+        }
+        PyList_SET_ITEM(out, a, d);
+    }
+    return out;
+}
+
 static PyObject *plan_batch(PyObject *self, PyObject *args) {
     unsigned long long fn_addr, ctx_addr, pkg_addr;
     PyObject *inputs, *yaws, *blocks;
@@ -300,61 +353,28 @@ static PyObject *plan_batch(PyObject *self, PyObject *args) {
         PyErr_SetString(PyExc_ValueError, "plan_batch: NULL address");
         return NULL;
     }
-    PyObject *seq = PySequence_Fast(inputs, "plan_batch: inputs must be a sequence"), *yseq = NULL, *out = NULL;
+    PyObject *seq = PySequence_Fast(inputs, "plan_batch: inputs must be a sequence"), *out = NULL;
     if (!seq) return NULL;
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
     FxStateUpdate upd[FXH_MAX_AGENTS];
     const FxStateUpdate *updp[FXH_MAX_AGENTS];
     double yaw[FXH_MAX_AGENTS], *blk[FXH_MAX_AGENTS];
     FxResult res[FXH_MAX_AGENTS];
-    const void *bp;
-    Py_ssize_t blen;
+    int have_blocks = 0;
     if (n < 1 || n > FXH_MAX_AGENTS) {
         PyErr_SetString(PyExc_ValueError, "plan_batch: 1 .. 256 agents");
         goto done;
     }
-    if (!(yseq = PySequence_Fast(yaws, "plan_batch: yaw_rates must be a sequence"))) goto done;
-    if (PySequence_Fast_GET_SIZE(yseq) != n) {
-        PyErr_SetString(PyExc_ValueError, "plan_batch: one yaw rate per agent");
-        goto done;
-    }
-    if (addr_of(blocks, 'd', 8, &bp, &blen) != 0) goto done;
-    if (bp && blen % (n * (Py_ssize_t)sizeof(double) * FX_PKG_ROWS) != 0) {
-        PyErr_SetString(PyExc_ValueError, "plan_batch: blocks must be [n][FX_PKG_ROWS][S] doubles");
-        goto done;
-    }
-    for (Py_ssize_t a = 0; a < n; a++) {
-        yaw[a] = PyFloat_AsDouble(PySequence_Fast_GET_ITEM(yseq, a));
-        if (yaw[a] == -1.0 && PyErr_Occurred()) goto done;
-        blk[a] = bp ? (double *)bp + a * (blen / (Py_ssize_t)sizeof(double) / n) : NULL;
-        updp[a] = NULL;
-        if (update) {
-            if (fill_update(PySequence_Fast_GET_ITEM(seq, a), &upd[a]) != 0) goto done;
-            updp[a] = &upd[a];
-        }
-    }
+    if (collect_outputs(yaws, blocks, n, yaw, blk, &have_blocks) != 0 || collect_updates(seq, n, update, upd, updp) != 0) goto done;
     {
         int32_t rc;
         Py_BEGIN_ALLOW_THREADS
         rc = ((fx_batch_fn)(uintptr_t)fn_addr)((FxContext *)(uintptr_t)ctx_addr, (int32_t)n, update ? updp : NULL, yaw, res,
-                                               (FxPackage *)(uintptr_t)pkg_addr, bp ? blk : NULL);
+                                               (FxPackage *)(uintptr_t)pkg_addr, have_blocks ? blk : NULL);
         Py_END_ALLOW_THREADS
-        if (rc != 0) {
-            out = PyLong_FromLong(rc);   /* the caller words the error (fx_last_error) */
-            goto done;
-        }
-    }
-    out = PyList_New(n);
-    for (Py_ssize_t a = 0; out && a < n; a++) {
-        PyObject *d = result_dict(&res[a]);
-        if (!d) {
-            Py_CLEAR(out);
-            break;
-        }
-        PyList_SET_ITEM(out, a, d);
+        out = rc != 0 ? PyLong_FromLong(rc) /* the caller words the error (fx_last_error) */ : results_list(res, n);
     }
 done:
-    Py_XDECREF(yseq);
     Py_DECREF(seq);
     return out;
 }
@@ -530,13 +550,7 @@ static PyObject *plan_batch_begin(PyObject *self, PyObject *args) {
         PyErr_SetString(PyExc_ValueError, "plan_batch_begin: 1 .. 256 agents");
         goto done;
     }
-    for (Py_ssize_t a = 0; a < n; a++) {
-        updp[a] = NULL;
-        if (update) {
-            if (fill_update(PySequence_Fast_GET_ITEM(seq, a), &upd[a]) != 0) goto done;
-            updp[a] = &upd[a];
-        }
-    }
+    if (collect_updates(seq, n, update, upd, updp) != 0) goto done;
     {
         int32_t rc;
         Py_BEGIN_ALLOW_THREADS
@@ -563,53 +577,20 @@ static PyObject *plan_batch_end(PyObject *self, PyObject *args) {
         return NULL;
     }
     const Py_ssize_t n = n_in;
-    PyObject *yseq = NULL, *out = NULL;
     double yaw[FXH_MAX_AGENTS], *blk[FXH_MAX_AGENTS];
     FxResult res[FXH_MAX_AGENTS];
-    const void *bp;
-    Py_ssize_t blen;
+    int have_blocks = 0;
     if (n < 1 || n > FXH_MAX_AGENTS) {
         PyErr_SetString(PyExc_ValueError, "plan_batch_end: 1 .. 256 agents");
         return NULL;
     }
-    if (!(yseq = PySequence_Fast(yaws, "plan_batch_end: yaw_rates must be a sequence"))) return NULL;
-    if (PySequence_Fast_GET_SIZE(yseq) != n) {
-        PyErr_SetString(PyExc_ValueError, "plan_batch_end: one yaw rate per agent");
-        goto done;
-    }
-    if (addr_of(blocks, 'd', 8, &bp, &blen) != 0) goto done;
-    if (bp && blen % (n * (Py_ssize_t)sizeof(double) * FX_PKG_ROWS) != 0) {
-        PyErr_SetString(PyExc_ValueError, "plan_batch_end: blocks must be [n][FX_PKG_ROWS][S] doubles");
-        goto done;
-    }
-    for (Py_ssize_t a = 0; a < n; a++) {
-        yaw[a] = PyFloat_AsDouble(PySequence_Fast_GET_ITEM(yseq, a));
-        if (yaw[a] == -1.0 && PyErr_Occurred()) goto done;
-        blk[a] = bp ? (double *)bp + a * (blen / (Py_ssize_t)sizeof(double) / n) : NULL;
-    }
-    {
-        int32_t rc;
-        Py_BEGIN_ALLOW_THREADS
-        rc = ((fx_end_fn)(uintptr_t)fn_addr)((FxContext *)(uintptr_t)ctx_addr, (int32_t)n, yaw, res, (FxPackage *)(uintptr_t)pkg_addr,
-                                             bp ? blk : NULL);
-        Py_END_ALLOW_THREADS
-        if (rc != 0) {
-            out = PyLong_FromLong(rc);
-            goto done;
-        }
-    }
-    out = PyList_New(n);
-    for (Py_ssize_t a = 0; out && a < n; a++) {
-        PyObject *d = result_dict(&res[a]);
-        if (!d) {
-            Py_CLEAR(out);
-            break;
-        }
-        PyList_SET_ITEM(out, a, d);
-    }
-done:
-    Py_XDECREF(yseq);
-    return out;
+    if (collect_outputs(yaws, blocks, n, yaw, blk, &have_blocks) != 0) return NULL;
+    int32_t rc;
+    Py_BEGIN_ALLOW_THREADS
+    rc = ((fx_end_fn)(uintptr_t)fn_addr)((FxContext *)(uintptr_t)ctx_addr, (int32_t)n, yaw, res, (FxPackage *)(uintptr_t)pkg_addr,
+                                         have_blocks ? blk : NULL);
+    Py_END_ALLOW_THREADS
+    return rc != 0 ? PyLong_FromLong(rc) : results_list(res, n);
 }
 
 static PyMethodDef methods[] = {

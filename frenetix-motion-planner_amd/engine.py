@@ -424,6 +424,17 @@ class FrenetEngine:
         into pinned host memory behind the selection.  Returns (result dict, WinnerPackage or None)."""
         key = inputs.structure_key()
         upd = None
+        h = _fxhost()
+        if h and inputs.sampling_matrix is None and self._resident_key == key and len(self._inputs) == 1 and inputs.write_bundle:
+            # the closed loop's usual step through the extension (fx_plan_batch_packaged with one agent): the inputs' arrays are
+            # read in C, the result comes back as a dict -- no struct filling, no per-field conversion on this side
+            self._inputs = [inputs]
+            pkgs = (_abi.FxPackage * 1)()
+            block = np.empty((1, _abi.FX_PKG_ROWS, inputs.n_samples))
+            out = h[0].plan_batch(h[2], self._ctx.value, self._inputs, (float(yaw_rate0),), block, C.addressof(pkgs), True)
+            if out.__class__ is int:
+                check(out)
+            return out[0], (WinnerPackage(pkgs[0], block[0], inputs) if pkgs[0].found else None)
         if inputs.sampling_matrix is None and self._resident_key == key and len(self._inputs) == 1:
             upd = getattr(self, "_upd", None)
             if upd is None:

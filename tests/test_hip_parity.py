@@ -90,8 +90,17 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
     slack = signed_integral_slack(out["planes"], inp.dt, STATE_TOL) if w_pl and out.get("planes") is not None else np.zeros(len(flags))
     if c.any():
         err = np.abs(cost[c] - out["cost"][c])
-        lim = (COST_RTOL + 4e-14 * cond_kin[c]) * np.maximum(np.abs(out["cost"][c]), 1e-12) + abs(w_pl) * slack[c]
-        assert (err < lim).all(), f"cost rel err {(err / np.maximum(np.abs(out['cost'][c]), 1e-12)).max()}"
+        rtol_c = COST_RTOL + 4e-14 * cond_kin[c]
+        lim = rtol_c * np.maximum(np.abs(out["cost"][c]), 1e-12) + abs(w_pl) * slack[c]
+        # a total that contains a term built on v or a carries no digit where that term carries none (relative tolerance >= 1,
+        # the rule of the raw terms below): finiteness is what is left to compare.  (Case 2070349 of the 144 000-scenario soak:
+        # a standstill start in LOW_VEL_MODE, theta_cl = pi/2 to the last bit, jerk 3.6e80 against 2.0e68 at a conditioning of
+        # 1.6e16 -- the raw terms were accepted by that rule, the total was still held to 653 times its own size.)
+        no_digit_c = (rtol_c >= 1.0) & bool(set(inp.cost_names) & set(KINEMATIC_COSTS))
+        assert np.array_equal(np.isfinite(cost[c][no_digit_c]), np.isfinite(out["cost"][c][no_digit_c])), \
+            "a total cost without digits is finite on one side only"
+        PARITY_STATS["escaped_costs"] = PARITY_STATS.get("escaped_costs", 0) + int(no_digit_c.sum())
+        assert (err < lim)[~no_digit_c].all(), f"cost rel err {(err / np.maximum(np.abs(out['cost'][c]), 1e-12))[~no_digit_c].max()}"
         # well-conditioned candidates without a signed-integral term: the FIXED relative bound
         wellc = (cond_kin[c] <= WELL_CONDITIONED) & (abs(w_pl) * slack[c] == 0)
         assert (err[wellc] < 1.05 * COST_RTOL * np.maximum(np.abs(out["cost"][c][wellc]), 1e-12)).all(), \

@@ -1,7 +1,7 @@
 #!/bin/bash
 # every soak mode once (GPU box): usage tools/soak_all.sh [first_case] [n_per_mode]
 f=${1:-700000}; n=${2:-2000}
-run() { echo "== $1"; shift; env "$@" timeout 1500 python3 tools/soak_parity.py $f $n 2>&1 | grep -v amdgpu | tail -4; f=$((f + 10000)); }
+run() { echo "== $1"; shift; env "$@" timeout ${FX_SOAK_TIMEOUT:-1500} python3 tools/soak_parity.py $f $n 2>&1 | grep -v amdgpu | tail -4; f=$((f + 10000)); }
 run plain A=1
 run tuning FX_SOAK_TUNING=1
 run crowded FX_SOAK_MANY=1
