@@ -319,6 +319,7 @@ class MultiAgentSimulation:
         self._shared = None
         self._shared_packed = None
         self.shared_packing = True   # predictions packed once per step for all agents (packed_predictions_for)
+        self.shift_plans = True      # steps in which nobody replans: the plans are the previous ones shifted by one state
         self._cov_tiles: Dict[int, np.ndarray] = {}
         # the scenario, the planners and their reference paths live as long as the simulation: taken out of the garbage
         # collector's generations, so that the full collections a closed loop triggers every few hundred steps walk the step's
@@ -468,6 +469,15 @@ class MultiAgentSimulation:
         preds = {a.id: (self.packed_predictions_for(a.id) if self.shared_packing else self.predictions_for(a.id))
                  for a in self.batch.agents if a.needs_plan()}
         selected = self.batch.step(self.time_step, preds)
+        if not preds and self.shift_plans and self.world == 1 and not self.split and len(self.batch.agents) == len(self.agent_ids):
+            # nobody replanned: every agent moved one state along its stored trajectory, so what lies ahead of it is what lay
+            # ahead a step ago without its first row -- one shift for all agents instead of a window per agent
+            plans = np.zeros_like(self.plans)
+            plans[:, :-1] = self.plans[:, 1:]
+            self.plans = plans
+            self._record_history()
+            self.time_step += 1
+            return selected
         local = np.zeros((len(self.batch.agents), self.S, self.FIELDS))
         for j, a in enumerate(self.batch.agents):
             sel = selected.get(a.id)
@@ -484,11 +494,16 @@ class MultiAgentSimulation:
             for i, st in enumerate(ahead[:self.S]):
                 local[j, i] = (st.position[0], st.position[1], st.orientation, st.velocity, 1.0)
         self.plans = self._exchange(local)
-        for k, aid in enumerate(self.agent_ids):
-            if self.plans[k, 0, 4] > 0:
-                self.history[aid].append(self.plans[k, 0, :4].copy())
+        self._record_history()
         self.time_step += 1
         return selected
+
+    def _record_history(self):
+        """every agent's new state (x, y, orientation, velocity) of this step: rows of ONE copy of the plans' first states"""
+        first = self.plans[:, 0, :].copy()
+        for k, aid in enumerate(self.agent_ids):
+            if first[k, 4] > 0:
+                self.history[aid].append(first[k, :4])
 
     def run(self, n_steps: int):
         for _ in range(n_steps):

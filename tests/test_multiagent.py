@@ -338,3 +338,17 @@ def test_pipelined_groups_equal_one_batch_cpu(scenario):
         assert w == w_one and np.array_equal(sim.plans, one.plans)
         for a, b in zip(sim.batch.agents, one.batch.agents):
             assert a.replanning_counter == b.replanning_counter and np.array_equal(a.x_0.position, b.x_0.position)
+
+
+def test_shifted_plans_equal_windows_cpu(scenario):
+    """steps in which nobody replans take the plans of the step before, shifted by one state: the same arrays (and history) as
+    reading every agent's window off its stored trajectory"""
+    from tests.oracle_engine import PackagingOracleEngine
+    a = multiagent.MultiAgentSimulation(scenario, engine_factory=PackagingOracleEngine)
+    b = multiagent.MultiAgentSimulation(scenario, engine_factory=PackagingOracleEngine)
+    b.shift_plans = False
+    for step in range(10):
+        a.step(); b.step()
+        assert np.array_equal(a.plans, b.plans), step
+    for aid in a.agent_ids:
+        assert len(a.history[aid]) == len(b.history[aid]) and all(np.array_equal(x, y) for x, y in zip(a.history[aid], b.history[aid]))
