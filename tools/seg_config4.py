@@ -32,7 +32,7 @@ for cls, names in ((frenet_interface.FrenetPlannerInterfaceHip, ("update_planner
                    (reactive_planner.ReactivePlannerHip, ("plan_consume", "plan_finish", "_inputs_for_level", "update_externals",
                                                           "_compute_trajectory_pair", "_consume_result")),
                    (engine.FrenetEngine, ("plan_batch", "plan_batch_packaged", "package", "evaluate", "finish", "update_state")),
-                   (multiagent.MultiAgentSimulation, ("predictions_for", "_shared_predictions", "_exchange")),
+                   (multiagent.MultiAgentSimulation, ("predictions_for", "packed_predictions_for", "_shared_predictions", "_pack_shared_arrays", "_exchange")),
                    (multiagent.AgentBatchHip, ("step",))):
     for n in names:
         if hasattr(cls, n):
