@@ -186,8 +186,7 @@ class FrenetPlannerInterfaceHip:
         if scenario is not None:
             self.scenario = scenario
         self.desired_velocity = self.velocity_planner.calculate_desired_velocity(self.x_0, self.x_cl[0][0])
-        self.planner.update_externals(x_0=self.x_0, x_cl=self.x_cl, desired_velocity=self.desired_velocity,
-                                      predictions=predictions)
+        self.planner.update_step(self.x_0, self.x_cl, self.desired_velocity, predictions)
 
     # -- one step (frenet_interface.py:207-287), split around the plan step --
     def _plans_now(self) -> bool:

@@ -185,6 +185,24 @@ class ReactivePlannerHip:
         if self.sampling_handler.d_ego_pos:
             self.sampling_handler.set_d_sampling(self.x_cl[1][0])
 
+    def update_step(self, x_0: ReactivePlannerState, x_cl, desired_velocity: float, predictions):
+        """update_externals(x_0=, x_cl=, desired_velocity=, predictions=) as a closed-loop step calls it (planner.py:172-217 from
+        frenet_interface.py:172-205) with the four setters inlined; anything else -- a new reference path, no x_cl yet, lateral
+        sampling around the ego -- goes through update_externals."""
+        if self.x_cl is None or self.set_new_ref_path or x_cl is None or self.sampling_handler.d_ego_pos or desired_velocity is None:
+            return self.update_externals(x_0=x_0, x_cl=x_cl, desired_velocity=desired_velocity, predictions=predictions)
+        self.x_0 = x_0
+        v = x_0.velocity
+        self._LOW_VEL_MODE = bool(v < self._low_vel_mode_threshold)
+        self.x_cl = x_cl
+        self.desired_velocity = desired_velocity
+        vp = self.vehicle_params
+        self.sampling_handler.set_v_sampling(*v_sampling_bounds(v, vp.a_max, self.horizon, vp.v_max, 36))
+        if predictions is not None:
+            self.use_prediction = True
+            self.predictions = predictions
+            self._packed_predictions = predictions.packed if hasattr(predictions, "packed") else None
+
     def set_reference_and_coordinate_system(self, reference_path: np.ndarray):
         self.coordinate_system = CoordinateSystem(reference_path)
         self.set_new_ref_path = True

@@ -145,7 +145,8 @@ class TrajectorySample:
     @property
     def leaves_road(self) -> Optional[bool]:
         """True/False for walked candidates when the step ran the road-boundary stage, else None"""
-        if not (self._step.inputs.mode & _abi.FX_MODE_ROAD_BOUNDARY) or not (self._flags & _abi.FX_FLAG_SELECTABLE):
+        bound = self._step.inputs._bound   # (FX_MODE_ROAD_BOUNDARY <=> a packed boundary with pieces: PlanInputs.mode)
+        if bound is None or bound["n"] <= 0 or not (self._flags & _abi.FX_FLAG_SELECTABLE):
             return None
         return bool(self._flags & _abi.FX_FLAG_BOUNDARY)
 

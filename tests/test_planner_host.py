@@ -274,3 +274,35 @@ def test_next_inputs_in_c_equals_the_python_path(monkeypatch):
         assert [x for i, x in enumerate(ka) if i != 5] == [x for i, x in enumerate(kb) if i != 5]   # (entry 5: the planners' own coordinate systems)
         assert a.t_samp.flags.c_contiguous and a.v_samp.flags.writeable and a.x0_lon.shape == (3,)
     assert len(calls) == 7   # every step after the first took the extension call (the first has no previous inputs)
+
+
+def test_update_step_equals_update_externals():
+    """the closed loop's inlined update (ReactivePlannerHip.update_step) leaves the planner exactly where update_externals does,
+    and hands everything it does not cover to update_externals"""
+    from frenetix_motion_planner_amd.coordinate_system import CoordinateSystem
+    ref = synthetic.reference_polyline("arc", 400, 0.5, 0.01)
+    cs = CoordinateSystem(ref)
+    s0 = float(cs.ref_pos[40] + 0.1)
+    x0 = ReactivePlannerState(0, np.asarray(cs.convert_to_cartesian_coords(s0, 0.2)), float(cs.ref_theta[40]), 9.0, 0.0, 0.0, 0.0)
+    preds = synthetic.synthetic_predictions(cs, 3, 30, 0.1, s0, np.random.default_rng(1))
+
+    def fresh():
+        p = ReactivePlannerHip(PlannerConfig(sampling_min=1, sampling_max=2), VehicleParams(), engine=OracleEngine())
+        p.update_externals(reference_path=ref, x_0=x0, desired_velocity=10.0, predictions=preds)
+        return p
+
+    a, b = fresh(), fresh()
+    for v in (9.5, 1.2, 0.0, 30.0):
+        st = ReactivePlannerState(1, x0.position.copy(), x0.orientation, v, 0.1, 0.0, 0.0)
+        x_cl = ([s0 + 1.0, v, 0.1], [0.3, 0.0, 0.0])
+        a.update_externals(x_0=st, x_cl=x_cl, desired_velocity=v + 1.0, predictions=preds)
+        b.update_step(st, x_cl, v + 1.0, preds)
+        for k in ("x_0", "x_cl", "_LOW_VEL_MODE", "desired_velocity", "use_prediction", "predictions", "_packed_predictions"):
+            assert getattr(a, k) is getattr(b, k) or getattr(a, k) == getattr(b, k), k
+        va, vb = a.sampling_handler.v_sampling, b.sampling_handler.v_sampling
+        assert (va.minimum, va.maximum, va.max_density) == (vb.minimum, vb.maximum, vb.max_density)
+    # what it does not cover takes the long way: no x_cl yet (the initial state is computed), a new reference path
+    c = ReactivePlannerHip(PlannerConfig(sampling_min=1, sampling_max=2), VehicleParams(), engine=OracleEngine())
+    c.set_reference_and_coordinate_system(ref)
+    c.update_step(x0, None, 10.0, preds)
+    assert c.x_cl is not None and np.allclose(c.x_cl[0], a_cl0 := fresh().x_cl[0])
