@@ -273,9 +273,11 @@ class MultiAgentSimulation:
     def __init__(self, scenario: Scenario, config: Optional[PlannerConfig] = None, vehicle: Optional[VehicleParams] = None,
                  number_of_agents: int = -1, sampling_level: Optional[int] = None, device: int = 0, group=None,
                  use_road_boundary: bool = False, max_candidates: Optional[int] = None, engine_factory=None,
-                 pipeline_groups: Optional[int] = None):
+                 pipeline_groups: Optional[int] = None, freeze_gc: bool = True):
         """engine_factory: callable returning an engine object (tests inject a stand-in); default = FrenetEngine.
-        pipeline_groups: see AgentBatchHip (None = automatic; with an engine_factory: that many injected engines, default one)."""
+        pipeline_groups: see AgentBatchHip (None = automatic; with an engine_factory: that many injected engines, default one).
+        freeze_gc: take what exists once the simulation is set up out of the garbage collector's generations (gc.freeze(): a
+        process-wide setting -- pass False where the host program manages the collector itself)."""
         import torch.distributed as dist
         self.scenario = scenario
         self.config = config or PlannerConfig()
@@ -324,9 +326,10 @@ class MultiAgentSimulation:
         # the scenario, the planners and their reference paths live as long as the simulation: taken out of the garbage
         # collector's generations, so that the full collections a closed loop triggers every few hundred steps walk the step's
         # own objects only (0.6 ms pauses inside a 0.35 ms planning step otherwise -- tools/seg_config4.py, per-call maxima)
-        import gc
-        gc.collect()
-        gc.freeze()
+        if freeze_gc:
+            import gc
+            gc.collect()
+            gc.freeze()
 
     def _cfg(self) -> PlannerConfig:
         import copy
