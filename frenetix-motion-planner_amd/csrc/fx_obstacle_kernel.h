@@ -8,13 +8,16 @@
 // open at the prediction term; this kernel reads x / y / theta back from the planes, visits every (candidate, step, obstacle),
 // closes the cost sum, sets the collision flag and writes the per-tile (cost, index) arg-min partials the selection reduces.
 //
-// Work items.  One wave = one (tile of 64 candidates, chunk of CH steps): no workgroup barrier, a wave-private operand table in
-// LDS, items small enough for the dispatcher to balance (config 3: 788 tiles x 10 chunks over 1 024 SIMDs).  The rows of
-// x / y / theta the chunk needs are requested in ONE round of global loads at entry, together with the chunk's slice of the hot
-// obstacle table.  The chunks of a tile meet through global memory: every wave stores its partial prediction sum per candidate
-// and its collision ballot (agent-scope stores), waits for them, and takes the tile's ticket; the wave that draws the last
-// ticket adds the partials in chunk order (deterministic), closes the candidates and leaves the ticket zeroed for the next
-// step.
+// Work items.  A tile = 64 entries of the agent's list of COSTED candidates (the walk appends them, fx_eval_kernel.h
+// finish_candidate: a third of a production step's candidates is infeasible and has neither a prediction cost nor a collision
+// check); a chunk = CH steps of the horizon; one wave = one (tile, chunk), with a wave-private operand table in LDS.  The list's
+// length, the tile's list entries and the chunk's slice of the hot obstacle table are requested together at entry, the rows of
+// x / y / theta behind them: problem -> (count, list, table) -> rows is the whole chain of dependent round trips.  The chunks of a
+// tile meet either through global memory (WG = false: every wave stores its partial prediction sum per candidate and its
+// collision ballot with agent-scope stores, waits for them and takes the tile's ticket; the wave that draws the last ticket
+// closes the tile) or -- launches of at most 1 024 tiles whose chunks fit a workgroup -- in LDS (WG = true: the chunks are the
+// waves of one workgroup, one barrier, wave 0 closes).  Either way the partials are added in chunk order: deterministic, and
+// the two variants agree bit for bit.
 //
 // Operands.  The step index of a wave is uniform, so are the obstacle operands.  Of the five per (step, obstacle) -- the
 // Cholesky-whitened inverse covariance l11, l12, l22 and the transformed centre cu, cw (fx_walk.h, ObsHot) -- the three
@@ -27,11 +30,10 @@
 // per lane for the survivors, the exact 4-axis test on the raw records for what is still near (same obb_hull / obb_overlap as
 // the walk: decisions are those of the brute-force definition).
 //
-// Measured (MI355X, tools/c3_split.py): config 3 walk 39.8 us + this kernel 41 us against 85 - 91 us fused (step 94.7 vs
-// 98.6 - 105 us); config 5's agent with a bundle 240 vs 280 us; 10 000-candidate grids equal; 3 060 candidates and 1 M
-// candidates slower (44 vs 35 us, 1.10 vs 1.07 ms) -- the host picks it where two lanes share a candidate (200 ... 3 072 waves).
-// Of its 25 us without the collision stage ~5 are launch and the first round of loads, ~6 the hand-off chain (stores ->
-// ticket -> partials -> closing stores) at the kernel's tail; the visits themselves run at the FP64 issue rate.
+// Measured (MI355X, tools/c3_split.py, profiles/r4): config 3 walk 40.9 us + this kernel 31.7 us (+ selection 6.2) = 85 us per
+// step against 89 us fused; config 4's batch of five agents 31.6 us; a config-5 agent with a bundle 97 vs 120 us fused; 3 060
+// candidates and 1 M candidates slower -- the host picks it where two lanes share a candidate (200 ... 3 072 waves).  Its pure
+// issue time is ~14 us; the rest is launch ramp, the three dependent round trips at entry and the closing stores.
 #pragma once
 
 #include "fx_eval_kernel.h"
