@@ -42,6 +42,7 @@ steps (HIP events attached to every evaluation launch), because an instrumented 
 Prints ONE JSON line (rank 0).  `value` = candidates evaluated by all ranks / wall time of the K timed steps.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -434,13 +435,21 @@ def main():
         res = step()
     barrier()
     lat = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        res = step()
-        lat.append(time.perf_counter() - ts)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    gc_was = gc.isenabled()
+    gc.disable()   # (as timeit does: a collector pass inside K = 20 steps of 85 us is a 20 - 50 us outlier in the mean)
+    try:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ts = time.perf_counter()
+            res = step()
+            lat.append(time.perf_counter() - ts)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        if gc_was:
+            gc.enable()
+    if os.environ.get("FX_BENCH_LAT") and rank == 0:   # the K host latencies themselves (microseconds), for looking at outliers
+        print("step latencies us:", " ".join(f"{x * 1e6:.1f}" for x in lat), file=sys.stderr)
     # Kernel durations: the same K steps once more, now with HIP events attached to EVERY evaluation launch (an instrumented
     # launch costs 6 - 9 us of host time, which has no place in `value`; the events live in a ring and are read afterwards)
     eng.set_timing(args.timing, every=1)
@@ -624,13 +633,19 @@ def _timed(args, world, dist, torch, step, est_step_s=1e-4):
         step()
     barrier()
     lat = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        step()
-        lat.append(time.perf_counter() - ts)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    gc_was = gc.isenabled()
+    gc.disable()   # (as timeit does)
+    try:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ts = time.perf_counter()
+            step()
+            lat.append(time.perf_counter() - ts)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        if gc_was:
+            gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
