@@ -306,3 +306,107 @@ def test_update_step_equals_update_externals():
     c.set_reference_and_coordinate_system(ref)
     c.update_step(x0, None, 10.0, preds)
     assert c.x_cl is not None and np.allclose(c.x_cl[0], a_cl0 := fresh().x_cl[0])
+
+
+def test_plan_batch_marshalling_against_a_stand_in_library():
+    """`_fxhost.plan_batch` / `plan_batch_begin` / `plan_batch_end` without a GPU: the function pointer they are handed is a ctypes
+    callback with the C-ABI's signature (fx_plan_batch_packaged / _begin / _end) that checks what arrives -- every agent's
+    FxStateUpdate pointing at the inputs' own arrays, yaw rates, one block pointer per agent -- and fills results, packages and
+    blocks; the extension must hand those back as the result dicts of FxResult.as_dict(), pass an error code through, and refuse
+    malformed arguments."""
+    import ctypes as C
+    from frenetix_motion_planner_amd import _fxhost
+    agents = [synthetic.make_inputs(ref_kind="arc", v0=6.0 + a, grid=(2, 3, 3), n_obstacles=a % 2 + 1, seed=a,
+                                    hull_builder=__import__("frenetix_motion_planner_amd.engine", fromlist=["x"]).build_obstacle_hulls)
+              for a in range(3)]
+    S = agents[0].n_samples
+    seen = {}
+    PU = C.POINTER(C.POINTER(_abi.FxStateUpdate))
+    PD, PPD = C.POINTER(C.c_double), C.POINTER(C.POINTER(C.c_double))
+
+    def check_updates(n, upd):
+        for a in range(n):
+            u, inp = upd[a].contents, agents[a]
+            assert u.x0_lon == inp.x0_lon.ctypes.data and u.x0_lat == inp.x0_lat.ctypes.data and u.t_samp == inp.t_samp.ctypes.data
+            assert u.v_samp == inp.v_samp.ctypes.data and u.d_samp == inp.d_samp.ctypes.data
+            assert u.v_des == inp.v_des and u.low_vel_mode == int(inp.low_vel_mode)
+            assert u.obs_pos == inp.obstacles["pos"].ctypes.data and u.obs_cov_inv == inp.obstacles["cov_inv"].ctypes.data
+            assert u.obs_npred == inp.obstacles["npred"].ctypes.data and u.obs_hull == inp.obstacles["hull"].ctypes.data
+            assert u.obs_nhull == inp.obstacles["nhull"].ctypes.data
+            assert abs(u.x0_orientation - inp.x0_orientation) == 0.0
+
+    def fill(n, yaw, res, pkg, blocks):
+        for a in range(n):
+            res[a].n_candidates, res[a].best_index, res[a].best_cost = 18, 7 + a, 1.5 * (a + 1)
+            res[a].n_returned, res[a].n_feasible, res[a].n_infeasible, res[a].n_collisions = 18, 12, 6, a
+            for k in range(_abi.FX_NUM_REASONS):
+                res[a].reason_hist[k] = 10 * a + k
+            res[a].feasible_percentage, res[a].kernel_ms = 66.5, -1.0
+            pkg[a].found, pkg[a].index, pkg[a].cost = 1, 7 + a, 1.5 * (a + 1)
+            for i in range(_abi.FX_PKG_ROWS * S):
+                blocks[a][i] = 1000.0 * a + i + yaw[a]
+
+    @C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, PU, PD, C.POINTER(_abi.FxResult), C.POINTER(_abi.FxPackage), PPD)
+    def whole(ctx, n, upd, yaw, res, pkg, blocks):
+        try:
+            seen["ctx"], seen["n"], seen["upd"] = ctx, n, bool(upd)
+            if upd:
+                check_updates(n, upd)
+            fill(n, yaw, res, pkg, blocks)
+            return 0
+        except Exception as ex:   # (an exception cannot cross the C frame: reported through the return code)
+            seen["error"] = repr(ex)
+            return -99
+
+    @C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, PU)
+    def begin(ctx, n, upd):
+        try:
+            check_updates(n, upd)
+            seen["begun"] = n
+            return 0
+        except Exception as ex:
+            seen["error"] = repr(ex)
+            return -99
+
+    @C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, PD, C.POINTER(_abi.FxResult), C.POINTER(_abi.FxPackage), PPD)
+    def end(ctx, n, yaw, res, pkg, blocks):
+        fill(n, yaw, res, pkg, blocks)
+        return 0
+
+    @C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, PU, PD, C.POINTER(_abi.FxResult), C.POINTER(_abi.FxPackage), PPD)
+    def failing(ctx, n, upd, yaw, res, pkg, blocks):
+        return 3
+
+    addr = lambda f: C.cast(f, C.c_void_p).value
+    yaw = [0.25, 0.5, 0.75]
+
+    def verify(out, pkgs, blocks):
+        assert "error" not in seen, seen.get("error")
+        assert len(out) == 3
+        for a, d in enumerate(out):
+            assert set(d) == set(_abi.FxResult().as_dict())
+            assert d["best_index"] == 7 + a and d["best_cost"] == 1.5 * (a + 1) and d["n_collisions"] == a
+            assert d["reason_hist"] == [10 * a + k for k in range(_abi.FX_NUM_REASONS)] and d["kernel_ms"] == -1.0
+            assert pkgs[a].found == 1 and pkgs[a].index == 7 + a
+            assert blocks[a, 0, 0] == 1000.0 * a + yaw[a] and blocks[a, -1, -1] == 1000.0 * a + _abi.FX_PKG_ROWS * S - 1 + yaw[a]
+
+    pkgs, blocks = (_abi.FxPackage * 3)(), np.zeros((3, _abi.FX_PKG_ROWS, S))
+    out = _fxhost.plan_batch(addr(whole), 0x1234, agents, yaw, blocks, C.addressof(pkgs), True)
+    assert seen["ctx"] == 0x1234 and seen["n"] == 3 and seen["upd"] is True
+    verify(out, pkgs, blocks)
+    out = _fxhost.plan_batch(addr(whole), 0x1234, agents, yaw, blocks, C.addressof(pkgs), False)   # resident inputs: no updates
+    assert seen["upd"] is False
+    verify(out, pkgs, blocks)
+    pkgs, blocks = (_abi.FxPackage * 3)(), np.zeros((3, _abi.FX_PKG_ROWS, S))
+    assert _fxhost.plan_batch_begin(addr(begin), 0x1234, agents, True) is None and seen["begun"] == 3
+    verify(_fxhost.plan_batch_end(addr(end), 0x1234, 3, yaw, blocks, C.addressof(pkgs)), pkgs, blocks)
+    # a library error comes back as its code; malformed arguments are refused before anything is called
+    assert _fxhost.plan_batch(addr(failing), 0x1234, agents, yaw, blocks, C.addressof(pkgs), True) == 3
+    with pytest.raises(ValueError):
+        _fxhost.plan_batch(addr(whole), 0x1234, agents, yaw[:2], blocks, C.addressof(pkgs), True)
+    with pytest.raises(ValueError):
+        _fxhost.plan_batch(addr(whole), 0x1234, agents, yaw, np.zeros(7), C.addressof(pkgs), True)
+    with pytest.raises(ValueError):
+        _fxhost.plan_batch(0, 0x1234, agents, yaw, blocks, C.addressof(pkgs), True)
+    with pytest.raises((TypeError, ValueError, AttributeError)):
+        _fxhost.plan_batch(addr(whole), 0x1234, [object()], [0.0], np.zeros((1, _abi.FX_PKG_ROWS, S)), C.addressof(pkgs), True)
