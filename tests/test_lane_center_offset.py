@@ -155,3 +155,27 @@ def test_planner_with_lanelets_closed_loop():
         assert k == p.last_step.inputs.cost_names.index("lane_center_offset")
     finally:
         p.close()
+
+
+@pytest.mark.gpu
+def test_batched_agents_with_their_own_lanelets():
+    """every agent of a batched launch brings its own lanelets (they share the grown-on-demand staging block of the road
+    boundary): the batch's results are those of the single launches, also after the in-place state update"""
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    from tests.test_hip_parity import CASES, hip_hulls
+    kws = [dict(CASES["lane_center"], v0=8.0 + a, seed=a, lanelets=(3.0 + 0.5 * a, 40 + 20 * a)) for a in range(3)]
+    kws[2] = dict(kws[2], lanelets=None)   # one agent without lanelets: 5 m everywhere
+    agents = [synthetic.make_inputs(hull_builder=hip_hulls(), **kw) for kw in kws]
+    with FrenetEngine(max_candidates=4096, max_steps=agents[0].N, max_agents=3) as batch:
+        got = batch.plan_batch(agents)
+        got2 = batch.plan_batch(agents)            # resident: the in-place update path
+        maps = [batch.costmap(a) for a in range(3)]
+    for a, inp in enumerate(agents):
+        with FrenetEngine(max_candidates=1024, max_steps=inp.N) as one:
+            ref = one.plan_step(inp)
+            cm = one.costmap()
+        for k in ("best_index", "best_cost", "n_feasible", "n_collisions"):
+            assert got[a][k] == ref[k] == got2[a][k], (a, k)
+        assert np.array_equal(maps[a], cm)
+    col = agents[2].cost_names.index("lane_center_offset")
+    assert np.all(maps[2][:, col][maps[2][:, col] != 0] == 5.0)
