@@ -5,7 +5,7 @@ wrapper (oracle/oracle.py) can share the struct definitions.
 """
 import ctypes as C
 
-FX_ABI_VERSION = 7
+FX_ABI_VERSION = 8
 FX_LON_VELOCITY_KEEPING, FX_LON_STOP_POINT = 0, 1
 
 FX_OK = 0
@@ -103,7 +103,7 @@ class FxPackage(C.Structure):
         ("index", C.c_int64), ("cost", C.c_double),
         ("coeff_lon", C.c_double * 6), ("coeff_lat", C.c_double * 6),
         ("n_cost", C.c_int32), ("reserved", C.c_int32),
-        ("raw_costs", C.c_double * FX_NUM_COSTS),
+        ("raw_costs", C.c_double * FX_NUM_COSTS), ("tau_lat", C.c_double),
     ]
 
 

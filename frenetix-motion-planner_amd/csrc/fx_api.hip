@@ -491,7 +491,7 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     if ((rc = dev_alloc(c, &c->d_cost_tail, c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_flags, c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_costmap, (size_t)FX_NUM_COSTS * c->total_ld))) return rc;
-    if ((rc = dev_alloc(c, &c->d_coeffs, (size_t)12 * c->total_ld))) return rc;
+    if ((rc = dev_alloc(c, &c->d_coeffs, (size_t)FX_COEFF_ROWS * c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_trajlen, c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_bstep, c->total_ld))) return rc;
     if ((rc = dev_alloc(c, &c->d_part_cost, c->max_blocks_total))) return rc;
@@ -520,7 +520,7 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     memset(c->h_pkg, 0, sizeof(double) * (size_t)max_agents * c->pkg_stride);
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_pkg_dev), c->h_pkg, 0));
     if ((rc = dev_alloc(c, &c->d_winner_own, (size_t)max_agents * 2))) return rc;
-    c->h_cand_doubles = (size_t)FX_NUM_PLANES * (max_steps + 1) + 12 + FX_NUM_COSTS + 4;
+    c->h_cand_doubles = (size_t)FX_NUM_PLANES * (max_steps + 1) + FX_COEFF_ROWS + FX_NUM_COSTS + 4;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_cand), sizeof(double) * c->h_cand_doubles, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_topk_idx), sizeof(long long) * max_agents * 64, hipHostMallocDefault));
     c->slots.resize(max_agents);
@@ -952,7 +952,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         d.cost_tail = c->d_cost_tail + cand_off;
         d.flags = c->d_flags + cand_off;
         d.costmap = c->d_costmap + (size_t)FX_NUM_COSTS * cand_off;  // [n_cost][ld] inside this agent's slab
-        d.coeffs = c->d_coeffs + (size_t)12 * cand_off;
+        d.coeffs = c->d_coeffs + (size_t)FX_COEFF_ROWS * cand_off;
         d.traj_len = c->d_trajlen + cand_off;
         d.bound_step = c->d_bstep + cand_off;
         const int walk_blocks = (int)((C + CPB - 1) / CPB);
@@ -1614,6 +1614,7 @@ int32_t fx_read_package(FxContext *c, int32_t agent, double yaw_rate0, FxPackage
     pkg->traj_len = (int32_t)tail[13 + FX_NUM_COSTS];
     pkg->flags = (uint32_t)tail[14 + FX_NUM_COSTS];
     pkg->index = (int64_t)tail[15 + FX_NUM_COSTS];
+    pkg->tau_lat = tail[17 + FX_NUM_COSTS];
     if (!block) return FX_OK;
     memcpy(block, src, sizeof(double) * FX_NUM_PLANES * S);
     // the derived columns of planner.py:394-447 (_compute_trajectory_pair): yaw rate by backward differences of the heading,
@@ -1887,20 +1888,28 @@ int32_t fx_read_costmap_agent(FxContext *c, int32_t agent, double *raw) {
 }
 int32_t fx_read_costmap(FxContext *c, double *raw) { return fx_read_costmap_agent(c, 0, raw); }
 
-int32_t fx_read_coeffs_agent(FxContext *c, int32_t agent, int64_t index, double *lon6, double *lat6, int32_t *traj_len) {
+static int32_t read_coeff_rows(FxContext *c, int32_t agent, int64_t index, double *lon6, double *lat6, double *tau_lat, int32_t *traj_len) {
     int rc = check_agent(c, agent);
     if (rc) return rc;
     const FxAgentSlot &s = c->slots[agent];
     if (!(s.mode & FX_MODE_WRITE_BUNDLE)) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_BUNDLE");
     if (index < 0 || index >= s.C) return set_err(FX_ERR_INVALID_ARGUMENT, "candidate %lld out of range", (long long)index);
-    double tmp[12];
+    double tmp[FX_COEFF_ROWS];
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy2D(tmp, sizeof(double), c->d_coeffs + (size_t)12 * s.cand_off + index, sizeof(double) * s.ld,
-                        sizeof(double), 12, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(tmp, sizeof(double), c->d_coeffs + (size_t)FX_COEFF_ROWS * s.cand_off + index, sizeof(double) * s.ld,
+                        sizeof(double), FX_COEFF_ROWS, hipMemcpyDeviceToHost));
     if (lon6) memcpy(lon6, tmp, 6 * sizeof(double));
     if (lat6) memcpy(lat6, tmp + 6, 6 * sizeof(double));
+    if (tau_lat) *tau_lat = tmp[12];
     if (traj_len) HIP_TRY(hipMemcpy(traj_len, c->d_trajlen + s.cand_off + index, sizeof(int32_t), hipMemcpyDeviceToHost));
     return FX_OK;
+}
+int32_t fx_read_coeffs_agent(FxContext *c, int32_t agent, int64_t index, double *lon6, double *lat6, int32_t *traj_len) {
+    return read_coeff_rows(c, agent, index, lon6, lat6, nullptr, traj_len);
+}
+int32_t fx_read_lat_tau_agent(FxContext *c, int32_t agent, int64_t index, double *tau_lat) {
+    if (!tau_lat) return set_err(FX_ERR_INVALID_ARGUMENT, "tau_lat is NULL");
+    return read_coeff_rows(c, agent, index, nullptr, nullptr, tau_lat, nullptr);
 }
 int32_t fx_read_boundary_steps_agent(FxContext *c, int32_t agent, int32_t *steps) {
     int rc = check_agent(c, agent);
@@ -1932,28 +1941,28 @@ int32_t fx_read_sample_agent(FxContext *c, int32_t agent, int64_t index, double 
 }
 int32_t fx_read_sample(FxContext *c, int64_t index, double *planes) { return fx_read_sample_agent(c, 0, index, planes); }
 
-int32_t fx_read_candidate_agent(FxContext *c, int32_t agent, int64_t index, double *planes, double *coeffs12, int32_t *traj_len,
+int32_t fx_read_candidate_agent(FxContext *c, int32_t agent, int64_t index, double *planes, double *coeffs13, int32_t *traj_len,
                                 double *raw_costs, double *cost, uint32_t *flags) {
     int rc = check_agent(c, agent);
     if (rc) return rc;
     const FxAgentSlot &s = c->slots[agent];
     if (index < 0 || index >= s.C) return set_err(FX_ERR_INVALID_ARGUMENT, "candidate %lld out of range", (long long)index);
     const bool bundle = (s.mode & FX_MODE_WRITE_BUNDLE) != 0, cmap = (s.mode & FX_MODE_WRITE_COSTMAP) != 0;
-    if ((planes || coeffs12 || traj_len) && !bundle) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_BUNDLE");
+    if ((planes || coeffs13 || traj_len) && !bundle) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_BUNDLE");
     if (raw_costs && !cmap) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_COSTMAP");
     // all pieces go to one pinned block with asynchronous copies; ONE synchronisation
     double *hp = c->h_cand;
     const size_t n_pl = (size_t)FX_NUM_PLANES * s.S;
-    double *h_co = hp + n_pl, *h_rc = h_co + 12, *h_c = h_rc + FX_NUM_COSTS;
+    double *h_co = hp + n_pl, *h_rc = h_co + FX_COEFF_ROWS, *h_c = h_rc + FX_NUM_COSTS;
     int32_t *h_tl = reinterpret_cast<int32_t *>(h_c + 1);
     uint32_t *h_fl = reinterpret_cast<uint32_t *>(h_c + 2);
-    if (n_pl + 12 + FX_NUM_COSTS + 4 > c->h_cand_doubles) return set_err(FX_ERR_CAPACITY, "candidate staging block too small");
+    if (n_pl + FX_COEFF_ROWS + FX_NUM_COSTS + 4 > c->h_cand_doubles) return set_err(FX_ERR_CAPACITY, "candidate staging block too small");
     if (planes)
         HIP_TRY(hipMemcpy2DAsync(hp, sizeof(double), c->h_probs[agent].planes + index, sizeof(double) * s.ld, sizeof(double), n_pl,
                                  hipMemcpyDeviceToHost, c->stream));
-    if (coeffs12)
-        HIP_TRY(hipMemcpy2DAsync(h_co, sizeof(double), c->d_coeffs + (size_t)12 * s.cand_off + index, sizeof(double) * s.ld,
-                                 sizeof(double), 12, hipMemcpyDeviceToHost, c->stream));
+    if (coeffs13)
+        HIP_TRY(hipMemcpy2DAsync(h_co, sizeof(double), c->d_coeffs + (size_t)FX_COEFF_ROWS * s.cand_off + index, sizeof(double) * s.ld,
+                                 sizeof(double), FX_COEFF_ROWS, hipMemcpyDeviceToHost, c->stream));
     if (traj_len) HIP_TRY(hipMemcpyAsync(h_tl, c->d_trajlen + s.cand_off + index, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (raw_costs && s.n_cost > 0)
         HIP_TRY(hipMemcpy2DAsync(h_rc, sizeof(double), c->d_costmap + (size_t)FX_NUM_COSTS * s.cand_off + index, sizeof(double) * s.ld,
@@ -1962,7 +1971,7 @@ int32_t fx_read_candidate_agent(FxContext *c, int32_t agent, int64_t index, doub
     if (flags) HIP_TRY(hipMemcpyAsync(h_fl, c->d_flags + s.cand_off + index, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (planes) memcpy(planes, hp, sizeof(double) * n_pl);
-    if (coeffs12) memcpy(coeffs12, h_co, sizeof(double) * 12);
+    if (coeffs13) memcpy(coeffs13, h_co, sizeof(double) * FX_COEFF_ROWS);
     if (traj_len) *traj_len = *h_tl;
     if (raw_costs) memcpy(raw_costs, h_rc, sizeof(double) * s.n_cost);
     if (cost) *cost = *h_c;

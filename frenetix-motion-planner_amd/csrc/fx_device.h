@@ -82,7 +82,7 @@ struct DevProblem {
     uint32_t *flags;           // [ld]
     double *costmap;           // [n_cost][ld]      (FX_MODE_WRITE_COSTMAP)
     double *planes;            // [14][S][ld]       (FX_MODE_WRITE_BUNDLE)
-    double *coeffs;            // [12][ld]          (FX_MODE_WRITE_BUNDLE)
+    double *coeffs;            // [FX_COEFF_ROWS][ld]: lon6 | lat6 | delta_tau of the lateral polynomial (FX_MODE_WRITE_BUNDLE)
     int32_t *traj_len;         // [ld]              (FX_MODE_WRITE_BUNDLE)
     // ---- selection scratch ----
     double *part_cost;         // [n_blocks]
@@ -205,8 +205,11 @@ extern __device__ unsigned long long fx_probe_stamps_obs[FX_PROBE_WAVES * FX_PRO
 #define FX_OSTAMP(k) do { } while (0)
 #endif
 
-// winner package tail behind the [14][S] planes (doubles): lon6 lat6 | raw[FX_NUM_COSTS] | cost | traj_len | flags | index | found
-#define FX_PKG_TAIL (12 + FX_NUM_COSTS + 5)
+// rows of the per-candidate coefficient table: lon[6] | lat[6] | tau_lat (the lateral polynomial's delta_tau: t, or s_lon_goal in
+// LOW_VEL_MODE -- reactive_planner.py:161-171)
+#define FX_COEFF_ROWS 13
+// winner package tail behind the [14][S] planes (doubles): lon6 lat6 | raw[FX_NUM_COSTS] | cost | traj_len | flags | index | found | tau_lat
+#define FX_PKG_TAIL (12 + FX_NUM_COSTS + 6)
 
 // counters[] layout
 enum {

@@ -678,6 +678,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
         FX_GLOBAL double *__restrict__ co = as_global(P.coeffs) + g;
         co[0 * ld] = cl0; co[1 * ld] = cl1; co[2 * ld] = cl2; co[3 * ld] = cl3; co[4 * ld] = cl4; co[5 * ld] = cl5;
         co[6 * ld] = L.c0; co[7 * ld] = L.c1; co[8 * ld] = L.c2; co[9 * ld] = L.c3; co[10 * ld] = L.c4; co[11 * ld] = L.c5;
+        co[12 * ld] = tau;  // PolynomialTrajectory.delta_tau of the lateral polynomial (reactive_planner.py:161-171)
         as_global(P.traj_len)[g] = traj_len;
     }
 

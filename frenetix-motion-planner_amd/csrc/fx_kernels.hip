@@ -73,7 +73,7 @@ extern "C" int fx_probe_read_obs(unsigned long long *out, size_t n_words) {
 // plan step ends with ONE wait instead of a second round of strided copies and a stream synchronisation
 // (reactive_planner_cpp.py:355-357 reads the optimal trajectory's arrays, planner.py:394-447 packages them).
 // grid = n_agents, block = 256.  Layout per agent (doubles): planes | lon6 lat6 | raw[FX_NUM_COSTS] | cost | traj_len | flags |
-// index | found, then the sequence word at stride - 1.
+// index | found | tau_lat, then the sequence word at stride - 1.
 // The gather itself, for one agent, by the 256 threads of a workgroup; every wave leaves with its stores performed at system
 // scope (the caller orders the sequence word behind a barrier).
 __device__ __forceinline__ void fx_package_gather(const DevProblem &P, long long gi, double *out, int plane_rows) {
@@ -94,6 +94,7 @@ __device__ __forceinline__ void fx_package_gather(const DevProblem &P, long long
             tail[14 + FX_NUM_COSTS] = (double)as_global(P.flags)[l];
             tail[15 + FX_NUM_COSTS] = (double)gi;
         }
+        if (tid == 130) tail[17 + FX_NUM_COSTS] = as_global(P.coeffs)[(size_t)12 * ld + l];
     }
     if (tid == 129) tail[16 + FX_NUM_COSTS] = found ? 1.0 : 0.0;
     __threadfence_system();

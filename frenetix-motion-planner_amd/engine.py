@@ -159,6 +159,7 @@ class WinnerPackage:
         self.cost = pkg.cost
         self.flags = pkg.flags
         self.traj_len = pkg.traj_len
+        self.tau_lat = pkg.tau_lat   # delta_tau of the lateral polynomial (reactive_planner.py:161-171)
         self._pkg = pkg
         self._costmap = bool(inputs.write_costmap)
 
@@ -641,7 +642,9 @@ class FrenetEngine:
         tl = C.c_int32(0)
         check(lib().fx_read_coeffs_agent(self._ctx, agent, int(index), lon.ctypes.data_as(C.POINTER(C.c_double)),
                                          lat.ctypes.data_as(C.POINTER(C.c_double)), C.byref(tl)))
-        return lon, lat, tl.value
+        tau = C.c_double(0.0)
+        check(lib().fx_read_lat_tau_agent(self._ctx, agent, int(index), C.byref(tau)))
+        return lon, lat, tl.value, tau.value
 
     def sample(self, index: int, agent: int = 0) -> np.ndarray:
         """[14, S] planes of one candidate (gathered from the SoA bundle)."""
@@ -652,10 +655,10 @@ class FrenetEngine:
 
     def candidate(self, index: int, agent: int = 0) -> dict:
         """Everything one trajectory object exposes, with one synchronisation: planes [14, S], lon / lat coefficients,
-        traj_len, raw partial costs (inputs.cost_names order), total cost, flag word."""
+        the lateral polynomial's delta_tau, traj_len, raw partial costs (inputs.cost_names order), total cost, flag word."""
         inp = self._inputs[agent]
         planes = np.zeros((_abi.FX_NUM_PLANES, inp.n_samples))
-        co = np.zeros(12)
+        co = np.zeros(13)
         raw = np.zeros(max(len(inp.cost_names), 1))
         tl, cost, flags = C.c_int32(0), C.c_double(0.0), C.c_uint32(0)
         pd = C.POINTER(C.c_double)
@@ -663,7 +666,7 @@ class FrenetEngine:
         check(lib().fx_read_candidate_agent(self._ctx, agent, int(index), planes.ctypes.data_as(pd) if have_b else None,
                                             co.ctypes.data_as(pd) if have_b else None, C.byref(tl) if have_b else None,
                                             raw.ctypes.data_as(pd) if have_c else None, C.byref(cost), C.byref(flags)))
-        return dict(planes=planes if have_b else None, lon=co[:6].copy(), lat=co[6:].copy(), traj_len=tl.value,
+        return dict(planes=planes if have_b else None, lon=co[:6].copy(), lat=co[6:12].copy(), tau_lat=float(co[12]), traj_len=tl.value,
                     raw_costs=raw[:len(inp.cost_names)] if have_c else None, cost=cost.value, flags=flags.value)
 
     def plane(self, name_or_index, agent: int = 0) -> np.ndarray:

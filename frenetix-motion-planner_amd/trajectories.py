@@ -128,7 +128,7 @@ class TrajectorySample:
             self._cost = float(rec["cost"])
             if rec["planes"] is not None:
                 self._planes = rec["planes"]
-                self._coeffs = (rec["lon"], rec["lat"], rec["traj_len"])
+                self._coeffs = (rec["lon"], rec["lat"], rec["traj_len"], rec["tau_lat"])
             if rec["raw_costs"] is not None:
                 names, w = step.inputs.cost_names, step.inputs.cost_weights
                 self._costmap = {n: (float(rec["raw_costs"][k]), float(w[n] * rec["raw_costs"][k])) for k, n in enumerate(names)}
@@ -232,18 +232,21 @@ class TrajectorySample:
     def _need_coeffs(self):
         if self._coeffs is None:
             pkg = self._pkg
-            self._coeffs = (pkg.lon, pkg.lat, pkg.traj_len) if pkg is not None else self._step.fetch_coeffs(self.uniqueId)
+            self._coeffs = ((pkg.lon, pkg.lat, pkg.traj_len, pkg.tau_lat) if pkg is not None
+                            else self._step.fetch_coeffs(self.uniqueId))
         return self._coeffs
 
     @property
     def trajectory_long(self) -> PolynomialView:
-        lon, _, _ = self._need_coeffs()
+        lon = self._need_coeffs()[0]
         return PolynomialView(lon, float(self.sampling_parameters[1] - self.sampling_parameters[0]))
 
     @property
     def trajectory_lat(self) -> PolynomialView:
-        _, lat, _ = self._need_coeffs()
-        return PolynomialView(lat, float(self.sampling_parameters[1] - self.sampling_parameters[0]))
+        # delta_tau is what the device built the quintic over: t at speed, the arc length s_lon_goal in LOW_VEL_MODE
+        # (reactive_planner.py:161-171, stop-point bundle :650-659)
+        co = self._need_coeffs()
+        return PolynomialView(co[1], float(co[3]))
 
     @property
     def actual_traj_length(self) -> int:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 7
+#define FX_ABI_VERSION 8
 
 /* ---- status codes (planner.py / reactive_planner_cpp.py raise Python exceptions; the shim maps
  *      <0 -> ValueError, >0 -> RuntimeError, see SURVEY 8b "Error conventions") ---- */
@@ -351,6 +351,8 @@ typedef struct FxPackage {
     double coeff_lon[6], coeff_lat[6];
     int32_t n_cost, reserved;
     double raw_costs[FX_NUM_COSTS];
+    double tau_lat;   /* delta_tau of the lateral polynomial: t, or in LOW_VEL_MODE s_lon_goal (reactive_planner.py:161-171, :650-659);
+                       * the longitudinal polynomial's delta_tau is always t = sampling_parameters[1] - [0] */
 } FxPackage;
 int32_t fx_set_package(FxContext *ctx, int32_t enabled);
 int32_t fx_read_package(FxContext *ctx, int32_t agent, double yaw_rate0, FxPackage *pkg, double *block /*[FX_PKG_ROWS][S] or NULL*/);
@@ -419,13 +421,17 @@ int32_t fx_finish_batch(FxContext *ctx, FxResult *res);
 int32_t fx_read_costs_agent(FxContext *ctx, int32_t agent, double *cost, uint32_t *flags);
 int32_t fx_read_costmap_agent(FxContext *ctx, int32_t agent, double *raw);
 int32_t fx_read_coeffs_agent(FxContext *ctx, int32_t agent, int64_t index, double *lon6, double *lat6, int32_t *traj_len);
+/* PolynomialTrajectory.delta_tau of one candidate's LATERAL polynomial as the device used it (polynomial_trajectory.py:17-60):
+ * the sampled t, or -- LOW_VEL_MODE -- the arc length s_lon_goal = s(t) - s(0) of its longitudinal polynomial, t when that is
+ * not positive (reactive_planner.py:161-171; stop-point bundle :650-659) */
+int32_t fx_read_lat_tau_agent(FxContext *ctx, int32_t agent, int64_t index, double *tau_lat);
 int32_t fx_read_sample_agent(FxContext *ctx, int32_t agent, int64_t index, double *planes);
 int32_t fx_read_plane_agent(FxContext *ctx, int32_t agent, int32_t plane, double *out);
 /* Everything a trajectory object of ONE candidate exposes (frenetix TrajectorySample: cartesian / curvilinear arrays,
  * coefficients, costMap, cost, feasibility -- reactive_planner_cpp.py:355-357,456,470-482) in one call with one stream
- * synchronisation: planes [FX_NUM_PLANES][S], coeffs12 = lon[6] | lat[6], traj_len, raw partial costs [n_cost], total
+ * synchronisation: planes [FX_NUM_PLANES][S], coeffs13 = lon[6] | lat[6] | tau_lat (fx_read_lat_tau_agent), traj_len, raw partial costs [n_cost], total
  * cost and flag word.  Any output pointer may be NULL.  What the planner reads back for the chosen trajectory. */
-int32_t fx_read_candidate_agent(FxContext *ctx, int32_t agent, int64_t index, double *planes, double *coeffs12,
+int32_t fx_read_candidate_agent(FxContext *ctx, int32_t agent, int64_t index, double *planes, double *coeffs13,
                                 int32_t *traj_len, double *raw_costs, double *cost, uint32_t *flags);
 int32_t fx_read_topk_batch(FxContext *ctx, int32_t k, double *cost /*[n_agents][k]*/, int64_t *index /*[n_agents][k]*/);
 

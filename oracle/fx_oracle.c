@@ -687,6 +687,7 @@ static uint32_t eval_one(const FxProblem *p, int64_t g, Cand *cd, double *pl, do
 /* sites that took a decision closer than FXO_FRAGILE to its threshold, per candidate of the next fxo_plan_step_b call (NULL:
  * not wanted); set by fxo_plan_step_c */
 static __thread uint32_t *g_frag_out = NULL;
+static __thread double *g_tau_out = NULL; /* fxo_plan_step_d: delta_tau of every candidate's lateral polynomial */
 
 /* ---------------------------------------------------------------- whole plan step */
 
@@ -746,6 +747,7 @@ int32_t fxo_plan_step_b(const FxProblem *p, double *coeff_lon, double *coeff_lat
         if (bound_step) bound_step[g] = bstep;
         if (margin) margin[g] = dc.margin;
         if (g_frag_out) g_frag_out[g] = dc.fragile;
+        if (g_tau_out) g_tau_out[g] = cd.tau_lat;
         flags[g] = f;
         cost[g] = (f & FX_FLAG_COSTED) ? total : 0.0;
         if (coeff_lon) memcpy(coeff_lon + 6 * g, cd.cl, sizeof(cd.cl));
@@ -912,6 +914,17 @@ int32_t fxo_plan_step_c(const FxProblem *p, double *coeff_lon, double *coeff_lat
     g_frag_out = frag_sites;
     int32_t rc = fxo_plan_step_b(p, coeff_lon, coeff_lat, traj_len, planes, flags, cost, costmap, order, margin, bound_step, res);
     g_frag_out = NULL;
+    return rc;
+}
+
+/* fxo_plan_step_c plus tau_lat[C]: the delta_tau the candidate's lateral QuinticTrajectory was built with -- t, or in
+ * LOW_VEL_MODE s_lon_goal (reactive_planner.py:161-171, stop-point variant :650-659) */
+int32_t fxo_plan_step_d(const FxProblem *p, double *coeff_lon, double *coeff_lat, int32_t *traj_len, double *planes,
+                        uint32_t *flags, double *cost, double *costmap, int64_t *order, double *margin, int32_t *bound_step,
+                        uint32_t *frag_sites, double *tau_lat, FxResult *res) {
+    g_tau_out = tau_lat;
+    int32_t rc = fxo_plan_step_c(p, coeff_lon, coeff_lat, traj_len, planes, flags, cost, costmap, order, margin, bound_step, frag_sites, res);
+    g_tau_out = NULL;
     return rc;
 }
 

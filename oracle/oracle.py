@@ -38,6 +38,9 @@ def lib():
         L.fxo_plan_step_c.argtypes = [C.POINTER(_abi.FxProblem), pd, pd, pi32, pd, pu32, pd, pd, pi64, pd, pi32, pu32,
                                       C.POINTER(_abi.FxResult)]
         L.fxo_plan_step_c.restype = C.c_int32
+        L.fxo_plan_step_d.argtypes = [C.POINTER(_abi.FxProblem), pd, pd, pi32, pd, pu32, pd, pd, pi64, pd, pi32, pu32, pd,
+                                      C.POINTER(_abi.FxResult)]
+        L.fxo_plan_step_d.restype = C.c_int32
         L.fxo_eval_forced.argtypes = [C.POINTER(_abi.FxProblem), C.c_int64, C.c_uint32, C.c_uint32, pd, pu32, pd, pd, pi32, pu32]
         L.fxo_eval_forced.restype = C.c_int32
         L.fxo_plan_range.argtypes = [C.POINTER(_abi.FxProblem), C.c_int64, C.c_int64, pu32, pd, pi64, pd]
@@ -87,12 +90,13 @@ def plan_step(inputs, want_planes=True):
         planes=np.zeros((Cn, _abi.FX_NUM_PLANES, S)) if want_planes else None,
         flags=np.zeros(Cn, np.uint32), cost=np.zeros(Cn), costmap=np.zeros((Cn, max(nc, 1))),
         order=np.zeros(Cn, np.int64), margin=np.zeros(Cn), boundary_step=np.full(Cn, -1, np.int32),
-        frag_sites=np.zeros(Cn, np.uint32))
+        frag_sites=np.zeros(Cn, np.uint32), tau_lat=np.zeros(Cn))
     res = _abi.FxResult()
-    rc = lib().fxo_plan_step_c(C.byref(prob), _p(out["coeff_lon"]), _p(out["coeff_lat"]), _p(out["traj_len"], C.c_int32),
+    rc = lib().fxo_plan_step_d(C.byref(prob), _p(out["coeff_lon"]), _p(out["coeff_lat"]), _p(out["traj_len"], C.c_int32),
                                _p(out["planes"]) if want_planes else None, _p(out["flags"], C.c_uint32),
                                _p(out["cost"]), _p(out["costmap"]), _p(out["order"], C.c_int64), _p(out["margin"]),
-                               _p(out["boundary_step"], C.c_int32), _p(out["frag_sites"], C.c_uint32), C.byref(res))
+                               _p(out["boundary_step"], C.c_int32), _p(out["frag_sites"], C.c_uint32), _p(out["tau_lat"]),
+                               C.byref(res))
     if rc != 0:
         raise ValueError(f"fxo_plan_step failed: {rc}")
     out["costmap"] = out["costmap"][:, :nc]

@@ -53,7 +53,8 @@ class OracleEngine:
 
     def coeffs(self, index, agent=0):
         out = self.last[agent][1]
-        return out["coeff_lon"][index].copy(), out["coeff_lat"][index].copy(), int(out["traj_len"][index])
+        return (out["coeff_lon"][index].copy(), out["coeff_lat"][index].copy(), int(out["traj_len"][index]),
+                float(out["tau_lat"][index]))
 
     def sample(self, index, agent=0):
         return self.last[agent][1]["planes"][index].copy()
@@ -87,6 +88,7 @@ class _OraclePackage:
         self.block, self.index = block, int(g) + inp.shard_begin
         self.cost, self.flags, self.traj_len = float(out["cost"][g]), int(out["flags"][g]), int(out["traj_len"][g])
         self.lon, self.lat = out["coeff_lon"][g].copy(), out["coeff_lat"][g].copy()
+        self.tau_lat = float(out["tau_lat"][g])
         self._raw = out["costmap"][g].copy() if inp.write_costmap else None
 
     @property

@@ -204,10 +204,11 @@ def compare(eng, inp, out, res, *, check_planes=True, agent=0, ref_inp=None):
             f"{int(escaped.sum())} of {int(stored.sum())} candidates in {n_groups} (t, v) pairs have a plane whose tolerance reached 1 (magnitude only)"
         # coefficients / traj_len of a few candidates
         for g in np.linspace(0, inp.n_candidates - 1, 5).astype(int):
-            lon, lat, tl = eng.coeffs(int(g), agent)
+            lon, lat, tl, tau = eng.coeffs(int(g), agent)
             assert np.allclose(lon, out["coeff_lon"][g], rtol=1e-13, atol=0)
             assert np.allclose(lat, out["coeff_lat"][g], rtol=1e-13, atol=0)
             assert tl == out["traj_len"][g]
+            assert abs(tau - out["tau_lat"][g]) <= 1e-13 * abs(out["tau_lat"][g])   # delta_tau of the lateral polynomial
             assert np.array_equal(eng.sample(int(g), agent), got[g])
     # fragile candidates: one of the admissible outcomes, nothing skipped
     PARITY_STATS["fragile"] += n_frag
@@ -274,6 +275,21 @@ def test_golden_cases_vs_reference_vectors(eng, name):
                                    state_tol=FRAGILE_STATE_TOL, planes_stored=st), g
     if len(fx["walk_ids"]):
         assert res["best_index"] == int(fx["walk_ids"][0])
+    # the boundary attributes of the sample views (polynomial_trajectory.py:17-60): delta_tau of the lateral polynomial is the
+    # reference's own (t at speed, s_lon_goal in LOW_VEL_MODE -- reactive_planner.py:161-171, :650-659), the longitudinal one's t
+    from frenetix_motion_planner_amd.trajectories import PlanStepResult
+    step = PlanStepResult(eng, inp, res)
+    nVD = len(inp.v_samp) * len(inp.d_samp)
+    for g in np.unique(np.concatenate([np.linspace(0, inp.n_candidates - 1, 24).astype(int), fx["walk_ids"][:1].astype(int)])):
+        tr = step.sample(int(g))
+        assert abs(tr.trajectory_lat.delta_tau - fx["tau_lat"][g]) <= 1e-10 * abs(fx["tau_lat"][g]), (name, g)
+        assert tr.trajectory_long.delta_tau == inp.t_samp[int(g) // nVD]
+        assert np.allclose(tr.trajectory_lat.coeffs, fx["coeff_lat"][g], rtol=1e-9, atol=1e-12)
+    # ... and the packaged winner carries it too (fx_read_package)
+    if len(fx["walk_ids"]):
+        res2, pkg = eng.plan_step_packaged(inp)
+        assert pkg is not None and pkg.index == int(fx["walk_ids"][0])
+        assert abs(pkg.tau_lat - fx["tau_lat"][pkg.index]) <= 1e-10 * abs(fx["tau_lat"][pkg.index])
 
 
 CASES = {

@@ -91,6 +91,11 @@ def test_coefficients_and_traj_len(case):
         assert np.max(np.abs(ref - got) / scale) < COEFF_RTOL, k
     stored = fx["has_cart"]
     assert np.array_equal(out["traj_len"][stored], fx["traj_len"][stored])
+    # delta_tau the reference built every lateral polynomial with (reactive_planner.py:161-171, :650-659): t, or s_lon_goal
+    assert np.max(np.abs(out["tau_lat"] - fx["tau_lat"]) / np.abs(fx["tau_lat"])) < COEFF_RTOL
+    if not bool(fx["low_vel_mode"]):
+        nVD = len(fx["v_order"]) * len(fx["d_order"])
+        assert np.array_equal(out["tau_lat"], np.repeat(fx["t_order"], nVD))
 
 
 def test_masks_exact(case):
@@ -167,3 +172,23 @@ def test_threaded_range_leg_equals_the_sequential_one():
         assert np.array_equal(f, f1) and np.array_equal(c, c1) and (b, bc) == (b1, bc1)
     out = oracle.plan_step(inp, want_planes=False)
     assert b1 == out["result"]["best_index"] and np.array_equal(f1, out["flags"])
+
+
+def test_sample_views_carry_the_reference_delta_tau(case):
+    """TrajectorySample.trajectory_lat / trajectory_long as the planner's callers see them (polynomial_trajectory.py:17-60
+    `delta_tau`, `coeffs`): the lateral polynomial's delta_tau is the reference's -- t at speed, s_lon_goal in LOW_VEL_MODE
+    (reactive_planner.py:161-171, stop-point bundle :650-659) --, the longitudinal one's is t.  The view class is the product's;
+    the arrays behind it here are the oracle's (tests/oracle_engine.py); test_hip_parity.py repeats it on the device's."""
+    from frenetix_motion_planner_amd.trajectories import PlanStepResult
+    from tests.oracle_engine import PackagingOracleEngine
+    name, fx, inp, out = case
+    eng = PackagingOracleEngine()
+    res = eng.plan_step(inp)
+    step = PlanStepResult(eng, inp, res)
+    nVD = len(fx["v_order"]) * len(fx["d_order"])
+    for g in np.linspace(0, inp.n_candidates - 1, 40).astype(int):
+        tr = step.sample(int(g))
+        assert abs(tr.trajectory_lat.delta_tau - fx["tau_lat"][g]) <= COEFF_RTOL * abs(fx["tau_lat"][g]), (name, g)
+        assert tr.trajectory_long.delta_tau == fx["t_order"][g // nVD]
+    if bool(fx["low_vel_mode"]) and "stop" not in name:   # the arc-length parameter is not the sampled time
+        assert np.abs(fx["tau_lat"] - np.repeat(fx["t_order"], nVD)).max() > 1e-3
