@@ -820,7 +820,7 @@ def bench_multiagent(args, world, rank, local_rank, torch, dist):
         cfg = PlannerConfig(sampling_min=lvl, sampling_max=lvl + 1)
     else:  # dense 19 x 23 x 23 (+ the current d) grid per agent
         cfg = PlannerConfig(sampling_min=0, sampling_max=1, dense_grid=(19, 23, 23))
-    sim = MultiAgentSimulation(sc, config=cfg, device=local_rank)
+    sim = MultiAgentSimulation(sc, config=cfg, device=local_rank, freeze_gc=True)
     counts = {"cands": 0, "batch_ms": []}
 
     from frenetix_motion_planner_amd.distributed import exit_on_timeout

@@ -89,6 +89,8 @@ class FxStateUpdate(C.Structure):
         ("x0_lon", C.c_void_p), ("x0_lat", C.c_void_p), ("x0_orientation", C.c_double), ("v_des", C.c_double), ("low_vel_mode", C.c_int32),
         ("t_samp", C.c_void_p), ("v_samp", C.c_void_p), ("d_samp", C.c_void_p),
         ("obs_pos", C.c_void_p), ("obs_cov_inv", C.c_void_p), ("obs_npred", C.c_void_p), ("obs_hull", C.c_void_p), ("obs_nhull", C.c_void_p),
+        # the shapes of the caller's arrays (0 = not stated): a mismatch with the upload is refused instead of read out of bounds
+        ("nT", C.c_int32), ("nV", C.c_int32), ("nD", C.c_int32), ("K", C.c_int32), ("P", C.c_int32),
     ]
 
 

@@ -1122,9 +1122,11 @@ int32_t fx_evaluate(FxContext *c) {
         // tiles than the chip holds at once, so the automatic choice takes them up to 1 024 tiles per launch)
         const char *wg_env = getenv("FX_OBST_WG");   // experiments: 0 / 1 force single-wave items / workgroups
         const int wg_mode = wg_env ? (atoi(wg_env) ? 2 : 1) : ((int64_t)c->obs_tiles_step * c->n_agents <= 1024 ? 2 : 1);
-        const bool wg = wg_mode == 2 && c->obs_wg_waves >= 1 && c->obs_wg_waves <= 16;
-        c->obs_wg_step = wg ? c->obs_wg_waves : 0;
         const size_t lds_wg = align_up((size_t)c->obs_wg_waves * (c->obs_lds_step + 64 * sizeof(double) + sizeof(unsigned long long)), 16);
+        // the workgroup's waves each keep their slice of the staging area: five steps per item with 64 obstacles and eleven or more
+        // chunks would ask for more than a CU's 160 KB (minus the kernel's static LDS) -- such a step runs as single-wave items
+        const bool wg = wg_mode == 2 && c->obs_wg_waves >= 1 && c->obs_wg_waves <= 16 && lds_wg <= (size_t)160 * 1024 - 1024;
+        c->obs_wg_step = wg ? c->obs_wg_waves : 0;
         HIP_TRY(fx_launch_obstacle(c->d_probs, c->n_agents, c->obs_blocks_step, wg ? lds_wg : c->obs_lds_step, c->split_CH,
                                    t_obs ? ts->e_obs0 : nullptr, t_obs ? ts->e_obs1 : nullptr, c->stream, wg ? c->obs_wg_waves : 0,
                                    c->obs_tiles_step));
@@ -1219,6 +1221,12 @@ int32_t fx_update_state(FxContext *c, int32_t agent, const FxStateUpdate *u) {
         return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d was uploaded without obstacles: upload again", agent);
     if ((u->obs_hull || u->obs_nhull) && !sl.have_hull)
         return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d was uploaded without obstacle hulls: upload again", agent);
+    if ((u->t_samp && u->nT && u->nT != sl.nT) || (u->v_samp && u->nV && u->nV != sl.nV) || (u->d_samp && u->nD && u->nD != sl.nD))
+        return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d: sampling arrays of %d x %d x %d values, uploaded %d x %d x %d: upload again", agent,
+                       u->nT, u->nV, u->nD, sl.nT, sl.nV, sl.nD);
+    if ((u->obs_pos || u->obs_cov_inv || u->obs_npred || u->obs_hull || u->obs_nhull) && ((u->K && u->K != sl.K) || (u->P && u->P != sl.P)))
+        return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d: obstacle arrays for K = %d, P = %d, uploaded K = %d, P = %d: upload again", agent,
+                       u->K, u->P, sl.K, sl.P);
     auto touch = [&](size_t off, size_t bytes) {
         c->dirty_lo = std::min(c->dirty_lo, off);
         c->dirty_hi = std::max(c->dirty_hi, off + bytes);

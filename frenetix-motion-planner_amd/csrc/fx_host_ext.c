@@ -122,8 +122,9 @@ static PyObject *pack_predictions(PyObject *self, PyObject *args) {
 }
 
 /* address of a C-contiguous buffer of the given item format ('d' or 'i'), NULL for None; -1 on anything else */
-static int buf_addr(PyObject *obj, char fmt, Py_ssize_t itemsize, const void **out) {
+static int buf_addr_len(PyObject *obj, char fmt, Py_ssize_t itemsize, const void **out, Py_ssize_t *n_items) {
     *out = NULL;
+    *n_items = 0;
     if (obj == Py_None) return 0;
     Py_buffer view;
     if (PyObject_GetBuffer(obj, &view, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) return -1;
@@ -131,6 +132,7 @@ static int buf_addr(PyObject *obj, char fmt, Py_ssize_t itemsize, const void **o
     if (*f == '=' || *f == '<' || *f == '@') f++;
     const int ok = view.itemsize == itemsize && (f[0] == fmt || (fmt == 'i' && f[0] == 'l' && itemsize == 4)) && f[1] == 0;
     *out = view.buf;
+    *n_items = view.len / itemsize;
     PyBuffer_Release(&view);   /* (the caller keeps the arrays alive; the address stays valid) */
     if (!ok) {
         PyErr_SetString(PyExc_TypeError, "expected a C-contiguous float64 / int32 array");
@@ -154,20 +156,41 @@ static PyObject *state_update(PyObject *self, PyObject *args) {
     FxStateUpdate u;
     memset(&u, 0, sizeof(u));
     const void *p;
-#define FXH_PTR(field, obj, fmt, size, type)                 \
-    if (buf_addr(obj, fmt, size, &p) != 0) return NULL; \
+    Py_ssize_t n, n_pos, n_cov, n_np, n_hull, n_nh;
+#define FXH_PTR(field, obj, fmt, size, type, count)                 \
+    if (buf_addr_len(obj, fmt, size, &p, &count) != 0) return NULL; \
     u.field = (const type *)p
-    FXH_PTR(x0_lon, x0_lon, 'd', 8, double);
-    FXH_PTR(x0_lat, x0_lat, 'd', 8, double);
-    FXH_PTR(t_samp, t, 'd', 8, double);
-    FXH_PTR(v_samp, v, 'd', 8, double);
-    FXH_PTR(d_samp, d, 'd', 8, double);
-    FXH_PTR(obs_pos, pos, 'd', 8, double);
-    FXH_PTR(obs_cov_inv, cov, 'd', 8, double);
-    FXH_PTR(obs_npred, npred, 'i', 4, int32_t);
-    FXH_PTR(obs_hull, hull, 'd', 8, double);
-    FXH_PTR(obs_nhull, nhull, 'i', 4, int32_t);
+    FXH_PTR(x0_lon, x0_lon, 'd', 8, double, n);
+    if (p && n < 3) goto too_short;
+    FXH_PTR(x0_lat, x0_lat, 'd', 8, double, n);
+    if (p && n < 3) goto too_short;
+    FXH_PTR(t_samp, t, 'd', 8, double, n);
+    u.nT = (int32_t)n;
+    FXH_PTR(v_samp, v, 'd', 8, double, n);
+    u.nV = (int32_t)n;
+    FXH_PTR(d_samp, d, 'd', 8, double, n);
+    u.nD = (int32_t)n;
+    FXH_PTR(obs_pos, pos, 'd', 8, double, n_pos);
+    FXH_PTR(obs_cov_inv, cov, 'd', 8, double, n_cov);
+    FXH_PTR(obs_npred, npred, 'i', 4, int32_t, n_np);
+    FXH_PTR(obs_hull, hull, 'd', 8, double, n_hull);
+    FXH_PTR(obs_nhull, nhull, 'i', 4, int32_t, n_nh);
 #undef FXH_PTR
+    /* the obstacle arrays state their own (K, P): npred [K], pos [K][P][2]; the others must agree (fx_update_state then holds
+     * (K, P) against the upload's) */
+    if (u.obs_npred && u.obs_pos && n_np > 0 && n_pos % (2 * n_np) == 0) {
+        const Py_ssize_t K = n_np, P = n_pos / (2 * n_np);
+        if ((u.obs_cov_inv && n_cov != 4 * K * P) || (u.obs_hull && n_hull != 6 * K * (P - 1)) || (u.obs_nhull && n_nh != K)) goto too_short;
+        u.K = (int32_t)K;
+        u.P = (int32_t)P;
+    } else if (u.obs_pos || u.obs_cov_inv || u.obs_npred || u.obs_hull || u.obs_nhull) {
+        goto too_short;
+    }
+    if (0) {
+    too_short:
+        PyErr_SetString(PyExc_ValueError, "state_update: array shapes do not fit together");
+        return NULL;
+    }
     u.x0_orientation = orient;
     u.v_des = v_des;
     u.low_vel_mode = low_vel;
@@ -228,8 +251,11 @@ static int fill_update(PyObject *inp, FxStateUpdate *u) {
     FXH_ATTR(s_x0_lon, x0_lon, double, 'd', 8, 24);
     FXH_ATTR(s_x0_lat, x0_lat, double, 'd', 8, 24);
     FXH_ATTR(s_t_samp, t_samp, double, 'd', 8, 8);
+    u->nT = (int32_t)(len / 8);   /* the shapes travel with the pointers: fx_update_state refuses what does not match the upload */
     FXH_ATTR(s_v_samp, v_samp, double, 'd', 8, 8);
+    u->nV = (int32_t)(len / 8);
     FXH_ATTR(s_d_samp, d_samp, double, 'd', 8, 8);
+    u->nD = (int32_t)(len / 8);
 #undef FXH_ATTR
     if (!(a = PyObject_GetAttr(inp, s_x0_orientation))) return -1;
     u->x0_orientation = PyFloat_AsDouble(a);
@@ -250,14 +276,26 @@ static int fill_update(PyObject *inp, FxStateUpdate *u) {
         PyObject *k = PyDict_GetItemWithError(o, s_K);
         const long K = k ? PyLong_AsLong(k) : 0;
         if (K > 0) {
-            if (addr_of(PyDict_GetItemWithError(o, s_kpos), 'd', 8, &p, NULL)) rc = -1; else u->obs_pos = (const double *)p;
-            if (!rc && addr_of(PyDict_GetItemWithError(o, s_cov_inv), 'd', 8, &p, NULL)) rc = -1; else u->obs_cov_inv = (const double *)p;
-            if (!rc && addr_of(PyDict_GetItemWithError(o, s_npred), 'i', 4, &p, NULL)) rc = -1; else u->obs_npred = (const int32_t *)p;
+            Py_ssize_t l_pos = 0, l_cov = 0, l_np = 0, l_nh = 0;
+            if (addr_of(PyDict_GetItemWithError(o, s_kpos), 'd', 8, &p, &l_pos)) rc = -1; else u->obs_pos = (const double *)p;
+            if (!rc && addr_of(PyDict_GetItemWithError(o, s_cov_inv), 'd', 8, &p, &l_cov)) rc = -1; else u->obs_cov_inv = (const double *)p;
+            if (!rc && addr_of(PyDict_GetItemWithError(o, s_npred), 'i', 4, &p, &l_np)) rc = -1; else u->obs_npred = (const int32_t *)p;
             if (!rc) {
                 if (addr_of(PyDict_GetItemWithError(o, s_hull), 'd', 8, &p, &len)) rc = -1;
                 else if (p && len > 0) {   /* (also when no hull is left: the old ones must go -- the counts say so) */
                     u->obs_hull = (const double *)p;
-                    if (addr_of(PyDict_GetItemWithError(o, s_nhull), 'i', 4, &p, NULL)) rc = -1; else u->obs_nhull = (const int32_t *)p;
+                    if (addr_of(PyDict_GetItemWithError(o, s_nhull), 'i', 4, &p, &l_nh)) rc = -1; else u->obs_nhull = (const int32_t *)p;
+                }
+            }
+            if (!rc) {   /* (K, P) as the arrays have them: pos [K][P][2], cov_inv [K][P][4], npred [K], hull [K][P-1][6], nhull [K] */
+                const Py_ssize_t P = l_pos / (16 * (Py_ssize_t)K);
+                if (l_np != 4 * K || P < 1 || l_pos != 16 * K * P || l_cov != 32 * K * P ||
+                    (u->obs_hull && (len != 48 * K * (P - 1) || l_nh != 4 * K))) {
+                    PyErr_SetString(PyExc_ValueError, "plan_batch: the packed predictions' arrays do not have the shapes their K says");
+                    rc = -1;
+                } else {
+                    u->K = (int32_t)K;
+                    u->P = (int32_t)P;
                 }
             }
         }

@@ -334,52 +334,79 @@ class ShardedEvaluator:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         return int(t.item())
 
-    def _exchanges_agree(self) -> bool:
-        """one step through the library exchange and once more through torch.distributed: the same survivors?  (local answer)"""
+    def _exchange_once(self, library: bool):
+        """one step on the resident inputs through ONE of the two exchanges; returns what it reports as the survivors"""
         if self.lib_exchange_agents and getattr(self, "n_local", 0):
-            _, a = self.step_agents_enqueued()
-            self.lib_exchange_agents, keep = False, self.lib_exchange_agents
+            keep = self.lib_exchange_agents
+            self.lib_exchange_agents = keep if library else False
             try:
-                _, b = self.step_agents_enqueued()
+                _, surv = self.step_agents_enqueued()
             finally:
                 self.lib_exchange_agents = keep
-            return a is not None and b is not None and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-        a = self.step_enqueued()
-        self.lib_exchange, keep = False, self.lib_exchange
+            return None if surv is None else (np.array(surv[0]), np.array(surv[1]))
+        keep = self.lib_exchange
+        self.lib_exchange = keep if library else False
         try:
-            b = self.step_enqueued()
+            r = self.step_enqueued()
         finally:
             self.lib_exchange = keep
-        return a["global_best_index"] == b["global_best_index"] and a["global_best_cost"] == b["global_best_cost"]
+        return (np.array([r["global_best_cost"]]), np.array([r["global_best_index"]]))
+
+    @staticmethod
+    def _same_survivors(a, b) -> bool:
+        return a is not None and b is not None and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
     def crosscheck_exchange(self) -> int:
         """One step exchanged through the library and once more through torch.distributed, on the resident inputs: 1 = both
         agree on every rank, 0 = they differ somewhere (the library exchange is switched off on every rank), -1 = the library
-        exchange did not come back within the time bound on this rank (the context is lost).  Collective: every rank calls it.
+        exchange did not come back within the time bound on some rank (the context is lost).  Collective: every rank calls it.
         The library's direct mode -- the all-gather received straight in the pinned block, a stream-ordered write instead of the
         publication launch (fx_set_exchange_mode 1) -- is tried first and kept only if every rank saw it agree; otherwise the
-        device-buffer mode is checked the same way; otherwise torch.distributed carries the exchange."""
+        device-buffer mode is checked the same way; otherwise torch.distributed carries the exchange.
+
+        Every rank issues the SAME sequence of collectives whatever happens locally: per mode (1) the ranks agree that the mode
+        could be set everywhere -- a rank on which it is refused never lets its peers enter the library's all-gather alone --,
+        (2) the library half, whose local failures (the library enters its all-gather first and reports afterwards:
+        fx_step_exchange*) are caught and MIN-reduced, (3) the torch.distributed half only if the library half succeeded on EVERY
+        rank -- a rank that failed in (2) would otherwise go straight to the agreement round while its peers sit in torch's
+        all-gather: mismatched collectives on one group --, (4) the agreement on the comparison.  An error inside (3) is not
+        swallowed: it may have been raised ahead of torch's collective, the job ends as it did before this check existed."""
         from ._lib import FxError, FxTimeoutError
         if not self.uses_library_exchange():
             return 1
         import os
-        modes = [1, 0] if hasattr(self.engine, "set_exchange_mode") and os.environ.get("FX_EXCHANGE_MODE", "1") != "0" else [0]
+        can_set = hasattr(self.engine, "set_exchange_mode")
+        modes = [1, 0] if can_set and os.environ.get("FX_EXCHANGE_MODE", "1") != "0" else [0]
         state = 0
         for mode in modes:
             ok = 1
-            try:
-                if hasattr(self.engine, "set_exchange_mode"):
+            if can_set:
+                try:
                     self.engine.set_exchange_mode(mode)
-                ok = 1 if self._exchanges_agree() else 0
+                except (FxError, ValueError):   # this mode is not available here (e.g. the stream-ordered write is refused)
+                    ok = 0
+            if self._agree_min(ok) == 0:
+                state = 0
+                continue
+            a, ok = None, 1
+            try:
+                a = self._exchange_once(library=True)
             except FxTimeoutError:
-                return -1   # (every rank waits on the same collective: they all end here)
-            except (FxError, ValueError):   # this mode is not available here (e.g. the stream-ordered write is refused)
+                ok = -1
+            except (FxError, ValueError):   # local failure, reported by the library AFTER its all-gather: the peers are not waiting
                 ok = 0
-            state = self._agree_min(ok)
+            first = self._agree_min(ok)
+            if first < 0:
+                return -1   # some rank's library exchange ran out of time: its context is lost, nobody goes on
+            if first == 0:
+                state = 0
+                continue
+            b = self._exchange_once(library=False)
+            state = self._agree_min(1 if self._same_survivors(a, b) else 0)
             if state == 1:
                 self.exchange_mode = mode
                 break
-        if state == 0:   # wrong answers somewhere in every mode: nobody uses the library exchange
+        if state == 0:   # wrong answers or failures somewhere in every mode: nobody uses the library exchange
             self.lib_exchange = self.lib_exchange_agents = False
             try:
                 self.engine.comm_destroy()

@@ -339,10 +339,15 @@ class FrenetEngine:
         u.x0_orientation = float("nan") if x0_orientation is None else float(x0_orientation)
         u.v_des = float("nan") if v_des is None else float(v_des)
         u.low_vel_mode = -1 if low_vel_mode is None else int(bool(low_vel_mode))
-        if t_samp is not None: u.t_samp = arr(t_samp)
-        if v_samp is not None: u.v_samp = arr(v_samp)
-        if d_samp is not None: u.d_samp = arr(d_samp)
+        # (the shapes travel with the pointers: fx_update_state refuses arrays that are not the upload's size)
+        if t_samp is not None: u.t_samp, u.nT = arr(t_samp), len(keep[-1])
+        if v_samp is not None: u.v_samp, u.nV = arr(v_samp), len(keep[-1])
+        if d_samp is not None: u.d_samp, u.nD = arr(d_samp), len(keep[-1])
         if obstacles is not None and obstacles["K"] > 0:
+            u.K, u.P = int(obstacles["K"]), int(obstacles["P"])
+            if np.shape(obstacles["pos"]) != (u.K, u.P, 2) or np.size(obstacles["cov_inv"]) != 4 * u.K * u.P \
+                    or np.size(obstacles["npred"]) != u.K:
+                raise ValueError("packed predictions: array shapes do not match their K / P")
             u.obs_pos, u.obs_cov_inv = arr(obstacles["pos"]), arr(obstacles["cov_inv"])
             u.obs_npred = arr(obstacles["npred"], np.int32)
             if obstacles.get("hull") is not None and obstacles["hull"].size:  # also when no hull is left: the old ones must go
@@ -373,7 +378,11 @@ class FrenetEngine:
         u.x0_lon, u.x0_lat = inp.x0_lon.ctypes.data, inp.x0_lat.ctypes.data
         u.x0_orientation, u.v_des, u.low_vel_mode = float(inp.x0_orientation), float(inp.v_des), int(bool(inp.low_vel_mode))
         u.t_samp, u.v_samp, u.d_samp = inp.t_samp.ctypes.data, inp.v_samp.ctypes.data, inp.d_samp.ctypes.data
+        u.nT, u.nV, u.nD = len(inp.t_samp), len(inp.v_samp), len(inp.d_samp)
         if o["K"] > 0:
+            u.K, u.P = int(o["K"]), int(o["P"])
+            if o["pos"].shape != (u.K, u.P, 2) or o["cov_inv"].size != 4 * u.K * u.P or o["npred"].size != u.K:
+                raise ValueError("packed predictions: array shapes do not match their K / P")
             u.obs_pos, u.obs_cov_inv, u.obs_npred = o["pos"].ctypes.data, o["cov_inv"].ctypes.data, o["npred"].ctypes.data
             if o["hull"].size:
                 u.obs_hull, u.obs_nhull = o["hull"].ctypes.data, o["nhull"].ctypes.data

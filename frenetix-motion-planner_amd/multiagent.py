@@ -273,11 +273,11 @@ class MultiAgentSimulation:
     def __init__(self, scenario: Scenario, config: Optional[PlannerConfig] = None, vehicle: Optional[VehicleParams] = None,
                  number_of_agents: int = -1, sampling_level: Optional[int] = None, device: int = 0, group=None,
                  use_road_boundary: bool = False, max_candidates: Optional[int] = None, engine_factory=None,
-                 pipeline_groups: Optional[int] = None, freeze_gc: bool = True):
+                 pipeline_groups: Optional[int] = None, freeze_gc: bool = False):
         """engine_factory: callable returning an engine object (tests inject a stand-in); default = FrenetEngine.
         pipeline_groups: see AgentBatchHip (None = automatic; with an engine_factory: that many injected engines, default one).
         freeze_gc: take what exists once the simulation is set up out of the garbage collector's generations (gc.freeze(): a
-        process-wide setting -- pass False where the host program manages the collector itself)."""
+        PROCESS-WIDE setting, so it is off unless asked for -- bench.py and the timing tools ask; close() undoes it)."""
         import torch.distributed as dist
         self.scenario = scenario
         self.config = config or PlannerConfig()
@@ -326,10 +326,12 @@ class MultiAgentSimulation:
         # the scenario, the planners and their reference paths live as long as the simulation: taken out of the garbage
         # collector's generations, so that the full collections a closed loop triggers every few hundred steps walk the step's
         # own objects only (0.6 ms pauses inside a 0.35 ms planning step otherwise -- tools/seg_config4.py, per-call maxima)
+        self._froze_gc = False
         if freeze_gc:
             import gc
             gc.collect()
             gc.freeze()
+            self._froze_gc = True
 
     def _cfg(self) -> PlannerConfig:
         import copy
@@ -385,8 +387,12 @@ class MultiAgentSimulation:
         order) are packed once -- covariance inverses and OBB-sum hulls included -- and every agent reads the SAME position,
         covariance and hull arrays; only the two count arrays are its own, with its own row set to zero predictions and zero
         hulls.  An obstacle without predictions contributes to no step of the prediction cost (collision_probability.py:287,
-        `i < len(pos_list)`) and is skipped by the collision stage (collision_check.py:165-168), so the step's result is that of
-        the dict without the agent; the dict view (`predictions_for`) is built when somebody reads it."""
+        `i < len(pos_list)`) and is skipped by the collision stage (collision_check.py:165-168), so the step's decisions are those
+        of the dict without the agent; the dict view (`predictions_for`) is built when somebody reads it.
+        Not bit for bit: a row that is never present keeps the device's per-step presence mask from ever being full, so the
+        prediction sum is accumulated one obstacle per reciprocal instead of four (fx_walk.h) -- costs differ from packing the
+        agent's own dict in the last bits (within the parity tolerance; the GPU test
+        test_shared_packing_on_the_engine_equals_per_agent_packing_within_tolerance holds winners equal and states to 1e-9)."""
         t = self.time_step
         sh = getattr(self, "_shared_packed", None)
         if sh is None or sh[0] != t:
@@ -515,3 +521,7 @@ class MultiAgentSimulation:
 
     def close(self):
         self.batch.close()
+        if self._froze_gc:   # give the frozen objects back to the collector: a process that builds many simulations must not
+            import gc        # accumulate their cyclic garbage in the permanent generation
+            gc.unfreeze()
+            self._froze_gc = False

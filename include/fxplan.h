@@ -287,6 +287,11 @@ typedef struct FxStateUpdate {
     const int32_t *obs_npred;                  /* [K] */
     const double *obs_hull;                    /* [K][P-1][6] */
     const int32_t *obs_nhull;                  /* [K] */
+    /* the array shapes as the CALLER holds them (0 = not stated, nothing is checked): the library copies nT / nV / nD doubles and
+     * K x P obstacle rows out of the borrowed pointers with the counts of the UPLOAD -- a caller whose arrays were built for another
+     * grid or another (K, P) would be read past their end.  A stated count that differs from the upload's is refused with
+     * FX_ERR_INVALID_ARGUMENT before anything is rewritten (upload again). */
+    int32_t nT, nV, nD, K, P;
 } FxStateUpdate;
 int32_t fx_update_state(FxContext *ctx, int32_t agent, const FxStateUpdate *upd);
 int32_t fx_update_step(FxContext *ctx, const FxStateUpdate *upd, FxResult *res);

@@ -596,31 +596,56 @@ def _crosscheck_worker(rank, world, port, q, scenario):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
+    from frenetix_motion_planner_amd._lib import FxError
     from frenetix_motion_planner_amd.distributed import ShardedEvaluator
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     try:
+        calls = []
+
         class Ev(ShardedEvaluator):
             def step_enqueued(self):   # what the two exchanges report as the global winner
-                wrong = scenario == "library_wrong_on_rank1" and self.lib_exchange and self.rank == 1
-                return {"global_best_index": 41 if wrong else 42, "global_best_cost": 1.5}
+                if self.lib_exchange:
+                    # the library's own all-gather is not the torch group's: entered by every rank, local errors reported after it
+                    calls.append("lib")
+                    if scenario == "library_raises_on_rank1" and self.rank == 1:
+                        raise FxError("FX_ERR_CAPACITY (reported behind the all-gather)")
+                    wrong = scenario == "library_wrong_on_rank1" and self.rank == 1
+                    return {"global_best_index": 41 if wrong else 42, "global_best_cost": 1.5}
+                # the torch.distributed exchange IS a collective on the group the agreement rounds use: a rank that skipped it
+                # while its peer entered it would pair this all_gather with the peer's all_reduce (a hang or garbage)
+                calls.append("torch")
+                got = [None] * self.world
+                self.dist.all_gather_object(got, ("torch-half", self.rank))
+                assert got == [("torch-half", r) for r in range(self.world)], got
+                return {"global_best_index": 42, "global_best_cost": 1.5}
+
+        class Eng(_CommStubEngine):
+            def set_exchange_mode(self, mode):
+                if scenario == "direct_mode_refused_on_rank1" and rank == 1 and mode == 1:
+                    raise ValueError("stream-ordered write refused")
+                self.mode = mode
 
         ev = Ev.__new__(Ev)
         ev.torch, ev.dist, ev.group, ev.rank, ev.world, ev.on_device = torch, dist, None, rank, world, False
-        ev.engine = _CommStubEngine()
+        ev.engine = Eng()
         ev.lib_exchange, ev.lib_exchange_agents = True, False
         state = ev.crosscheck_exchange()
-        q.put((rank, state, ev.lib_exchange, ev.engine.destroys))
+        q.put((rank, state, ev.lib_exchange, ev.engine.destroys, getattr(ev, "exchange_mode", None), calls))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("scenario", ["agree", "library_wrong_on_rank1"])
+@pytest.mark.parametrize("scenario", ["agree", "library_wrong_on_rank1", "library_raises_on_rank1", "direct_mode_refused_on_rank1"])
 def test_library_exchange_is_cross_checked_against_the_torch_exchange(scenario):
     """Before anything is timed the library-side exchange has to report the winner the torch.distributed exchange reports; one
-    rank that sees a difference switches it off on every rank (bench.py: `exchange` in the line says which one ran)."""
+    rank that sees a difference switches it off on every rank (bench.py: `exchange` in the line says which one ran).  Whatever
+    fails on ONE rank, every rank issues the same collectives in the same order: a rank whose library half raises keeps its
+    peers out of the torch half (mismatched collectives on one group), a rank that cannot set the direct mode keeps
+    them out of the library's all-gather."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -633,9 +658,13 @@ def test_library_exchange_is_cross_checked_against_the_torch_exchange(scenario):
         p.join(timeout=60)
         assert p.exitcode == 0
     if scenario == "agree":
-        assert [g[1:] for g in got] == [(1, True, 0), (1, True, 0)]
-    else:
-        assert [g[1:] for g in got] == [(0, False, 1), (0, False, 1)]
+        assert [g[1:] for g in got] == [(1, True, 0, 1, ["lib", "torch"])] * 2
+    elif scenario == "library_wrong_on_rank1":   # both modes are tried, both disagree on rank 1
+        assert [g[1:] for g in got] == [(0, False, 1, None, ["lib", "torch", "lib", "torch"])] * 2
+    elif scenario == "library_raises_on_rank1":   # nobody enters the torch half in either mode
+        assert [g[1:] for g in got] == [(0, False, 1, None, ["lib", "lib"])] * 2
+    else:   # mode 1 is skipped by BOTH ranks before anything collective runs in it; mode 0 agrees
+        assert [g[1:] for g in got] == [(1, True, 0, 0, ["lib", "torch"])] * 2
 
 
 # ---------------------------------------------------------------------------------------------------------

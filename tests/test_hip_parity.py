@@ -880,6 +880,23 @@ def test_update_state_rejects_what_needs_a_new_upload(eng):
     with_obs = synthetic.make_inputs(hull_builder=hip_hulls(), ref_kind="arc", v0=10.0, grid=(3, 5, 5), n_obstacles=2)
     with pytest.raises(ValueError):
         eng.update_state(eng.make_state_update(obstacles=with_obs.obstacles))  # uploaded without obstacles
+    # arrays of another shape than the upload's are refused before anything is read or rewritten (FxStateUpdate.nT .. P, ABI 8):
+    # the library copies with the upload's counts out of the borrowed pointers
+    eng.plan_step(with_obs)
+    before = eng.plan_step(with_obs)
+    with pytest.raises(ValueError):
+        eng.update_state(eng.make_state_update(d_samp=np.linspace(-1.0, 1.0, len(with_obs.d_samp) - 1)))   # one lateral sample short
+    with pytest.raises(ValueError):
+        eng.update_state(eng.make_state_update(t_samp=np.concatenate([with_obs.t_samp, [2.9]])))
+    three = synthetic.make_inputs(hull_builder=hip_hulls(), ref_kind="arc", v0=10.0, grid=(3, 5, 5), n_obstacles=3)
+    with pytest.raises(ValueError):
+        eng.update_state(eng.make_state_update(obstacles=three.obstacles))   # K = 3 arrays into a K = 2 upload
+    short = synthetic.make_inputs(hull_builder=hip_hulls(), ref_kind="arc", v0=10.0, grid=(3, 5, 5), n_obstacles=2, n_pred=12)
+    assert short.obstacles["P"] != with_obs.obstacles["P"]
+    with pytest.raises(ValueError):
+        eng.update_state(eng.make_state_update(obstacles=short.obstacles))   # another prediction stride P
+    after = eng.step_raw()[0].as_dict()   # the refused updates left the resident step as it was
+    assert all(after[k] == before[k] for k in ("best_index", "best_cost", "n_feasible", "n_returned", "n_collisions"))
 
 
 @pytest.mark.gpu

@@ -327,6 +327,27 @@ def test_shared_prediction_packing_equals_per_agent_packing(scenario):
     assert np.array_equal(sim2.plans, sim.plans)
 
 
+@pytest.mark.gpu
+def test_shared_packing_on_the_engine_equals_per_agent_packing_within_tolerance(scenario):
+    """On the device a muted row is never `present`, so the step's presence mask is never full and the prediction sum runs per
+    obstacle instead of four terms per reciprocal (fx_walk.h): against packing every agent's own dict the cost sums differ in the
+    last bits -- the decisions (winners) are the same, the planned states agree to the parity tolerance, and that is all
+    `packed_predictions_for` promises (its docstring)."""
+    a, w_a = _run_sim(scenario, 9)
+    b = multiagent.MultiAgentSimulation(scenario)
+    try:
+        b.shared_packing = False
+        w_b = []
+        for _ in range(9):
+            b.step()
+            w_b.append([t.optimal_trajectory.global_id if t.optimal_trajectory is not None else -1 for t in b.batch.agents])
+        assert w_a == w_b
+        assert np.abs(a.plans - b.plans).max() < 1e-9
+    finally:
+        a.close()
+        b.close()
+
+
 def test_pipelined_groups_equal_one_batch_cpu(scenario):
     """AgentBatchHip over several engine contexts (pipeline_groups: prepare and launch group after group, consume in the same
     order) takes the decisions of the single batched launch: the agents are independent given the step's frozen predictions"""

@@ -410,3 +410,36 @@ def test_plan_batch_marshalling_against_a_stand_in_library():
         _fxhost.plan_batch(0, 0x1234, agents, yaw, blocks, C.addressof(pkgs), True)
     with pytest.raises((TypeError, ValueError, AttributeError)):
         _fxhost.plan_batch(addr(whole), 0x1234, [object()], [0.0], np.zeros((1, _abi.FX_PKG_ROWS, S)), C.addressof(pkgs), True)
+
+
+def test_state_update_states_the_array_shapes_and_refuses_arrays_that_do_not_fit_together():
+    """FxStateUpdate carries nT / nV / nD / K / P of the caller's arrays (ABI 8): fx_update_state copies with the UPLOAD's counts out of
+    borrowed pointers, so a stale structure key must end in FX_ERR_INVALID_ARGUMENT, not in a read past the arrays' end.
+    Here: the counts are filled by both host paths, and obstacle arrays whose lengths contradict each other are refused in C."""
+    import ctypes as C
+    from frenetix_motion_planner_amd import _abi, engine, synthetic
+    inp = synthetic.make_inputs(ref_kind="arc", v0=8.0, grid=(3, 5, 7), n_obstacles=3)
+    o = inp.obstacles
+    for use_c in (True, False):
+        saved = engine._FXHOST
+        if not use_c:
+            engine._FXHOST = False
+        try:
+            u = engine.FrenetEngine._state_update_of(inp)
+        finally:
+            engine._FXHOST = saved
+        assert (u.nT, u.nV, u.nD) == (len(inp.t_samp), len(inp.v_samp), len(inp.d_samp))
+        assert (u.K, u.P) == (o["K"], o["P"]) == (3, o["pos"].shape[1])
+    m = engine.FrenetEngine.make_state_update(t_samp=inp.t_samp, d_samp=inp.d_samp, obstacles=o)
+    assert (m.nT, m.nV, m.nD, m.K, m.P) == (len(inp.t_samp), 0, len(inp.d_samp), o["K"], o["P"])
+    h = engine._fxhost()
+    if not h:
+        pytest.skip("_fxhost extension not built")
+    a, t = np.arange(3.0), np.arange(4.0)
+    u = _abi.FxStateUpdate()
+    with pytest.raises(ValueError):   # cov_inv for another (K, P) than pos / npred say
+        h[0].state_update(C.addressof(u), a, a, 0.0, 1.0, 0, t, t, t, o["pos"], o["cov_inv"][:2], o["npred"], None, None)
+    with pytest.raises(ValueError):   # hulls for another P
+        h[0].state_update(C.addressof(u), a, a, 0.0, 1.0, 0, t, t, t, o["pos"], o["cov_inv"], o["npred"], o["hull"][:, :-1].copy(), o["nhull"])
+    with pytest.raises(ValueError):   # a state of two values
+        h[0].state_update(C.addressof(u), a[:2], a, 0.0, 1.0, 0, t, t, t, None, None, None, None, None)

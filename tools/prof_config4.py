@@ -9,7 +9,7 @@ from frenetix_motion_planner_amd.reactive_planner import PlannerConfig
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sc = crx.read_scenario_json(os.path.join(ROOT, "tests", "golden", "ZAM_Tjunction-1_42_T-1.scenario.json"))
 cfg = PlannerConfig(sampling_min=0, sampling_max=1, dense_grid=(19, 23, 23))
-sim = MultiAgentSimulation(sc, config=cfg, device=0)
+sim = MultiAgentSimulation(sc, config=cfg, device=0, freeze_gc=True)
 for _ in range(6): sim.step()
 t = []
 for _ in range(30):

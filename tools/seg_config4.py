@@ -40,7 +40,7 @@ for cls, names in ((frenet_interface.FrenetPlannerInterfaceHip, ("update_planner
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sc = crx.read_scenario_json(os.path.join(ROOT, "tests", "golden", "ZAM_Tjunction-1_42_T-1.scenario.json"))
-sim = MultiAgentSimulation(sc, config=PlannerConfig(sampling_min=0, sampling_max=1, dense_grid=(19, 23, 23)), device=0)
+sim = MultiAgentSimulation(sc, config=PlannerConfig(sampling_min=0, sampling_max=1, dense_grid=(19, 23, 23)), device=0, freeze_gc=True)
 for _ in range(6):
     sim.step()
 ACC.clear(); CALLS.clear()
