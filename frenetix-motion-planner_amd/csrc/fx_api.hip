@@ -204,6 +204,11 @@ struct FxContext {
     int timing = FX_TIMING_OFF;
     bool timed_step = false, eval_launched = false;
     bool fuse_enabled = true, fusable_step = false, fused_step = false;
+    // fused tail (fx_tail.h): the step's last workgroup also counts the collisions in front of the winner / gathers the package
+    bool fuse_any_size = false;       // fx_set_fused_selection(ctx, 2): no candidate bound on the in-kernel collision count
+    bool count_step = false;          // some agent of the upload runs the collision stage inside the evaluation kernel
+    bool wt_step = false;             // the upload's plane stores are write-through
+    uint32_t tail_step = 0;           // FX_TAIL_* of the last evaluation
     int64_t dev_bytes = 0;
 };
 
@@ -766,6 +771,8 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             size_t hot_block = 0;
             for (int a = 0; a < n_agents && !c->split_step; a++)   // (no staging blocks when the obstacle stage is its own kernel)
                 hot_block = std::max(hot_block, align_up(sizeof(double) * FX_HOT_STRIDE * (size_t)std::max(probs[a].K, 0), 16));
+            // whether a workgroup of blk lanes will run the wave split (the rule further down: G in {2, 4}, whole waves per part)
+            auto ws_expected = [&](int blk) { return (G == 2 || G == 4) && (blk / G) % 64 == 0 && c->wsplit_force != 1; };
             auto lds_for = [&](int blk) {
                 size_t need = 0;
                 for (int a = 0; a < n_agents; a++) {
@@ -775,8 +782,13 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                     // time table + rows + wave-split exchange block (5 f64 + 5 u32 per slot) + tail: the knots' arc lengths
                     // during the prologue, one staging block of the step's hot obstacle table per wave during the walk
                     // (fx_eval_grid_kernel.h: the two share the bytes)
+                    // lane split with the obstacle stage in the kernel: the record table + the two step masks behind the arc lengths
+                    // (fx_eval_grid_kernel.h, LSTAGE; same rule there)
+                    const bool lane_split = G > 1 && !(ws_expected(blk));
+                    const size_t rec_bytes = sizeof(double) * (size_t)S_rec_doubles((int)S, std::max(p->K, 0));
+                    const size_t rec_lds = (lane_split && obst_any && p->K > 0 && rec_bytes <= FX_REC_LDS_MAX) ? rec_bytes + 16 * S : 0;
                     need = std::max(need, sizeof(double) * FX_TP * S + 128 * n_pairs * S + (G > 1 ? (size_t)64 * blk : 0) +
-                                              std::max(sizeof(double) * (((size_t)p->M + 1) & ~(size_t)1), (size_t)(blk / 64) * hot_block));
+                                              std::max(sizeof(double) * (((size_t)p->M + 1) & ~(size_t)1), (size_t)(blk / 64) * hot_block) + rec_lds);
                 }
                 return need;
             };
@@ -820,6 +832,11 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     size_t planes_need = 0, obs_part_need = 0, obs_colm_need = 0, obs_tick_need = 0;
     c->any_bundle = c->any_obst = c->any_extra = false;
     c->fusable_step = true;
+    c->count_step = false;
+    c->wt_step = false;
+    // candidates per agent up to which the agent's last workgroup counts the collisions in front of the winner itself (it re-reads
+    // the agent's flag words: one round trip per 16 x workgroup-size candidates); larger steps keep fx_select_kernel's slices
+    static const int64_t tail_max_c = [] { const char *e = getenv("FX_TAIL_MAX_C"); return e ? (int64_t)atoll(e) : (int64_t)16384; }();
     c->max_blocks_step = 0;
     c->obs_blocks_step = 0;
     c->obs_tiles_step = 0;
@@ -978,6 +995,9 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         d.part_cost = c->d_part_cost + block_off;
         d.part_idx = c->d_part_idx + block_off;
         d.counters = c->d_counters + (size_t)a * FX_CNT_COUNT;
+        d.pkg_out = c->h_pkg_dev + (size_t)a * c->pkg_stride;
+        d.pkg_seq = reinterpret_cast<unsigned long long *>(d.pkg_out + c->pkg_stride - 1);
+        d.pkg_plane_rows = c->pkg_plane_rows;
         if (d.mode & FX_MODE_WRITE_BUNDLE) {
             if ((uint64_t)ld * 8u >= (1ull << 32))  // the walk addresses a row with a 32-bit byte offset per lane
                 return set_err(FX_ERR_CAPACITY, "agent %d: %lld candidates with a materialised bundle (rows are limited to 4 GiB)", a, (long long)C);
@@ -986,7 +1006,11 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             c->any_bundle = true;
         }
         c->any_obst |= (p->K > 0 && !deferred) || (d.mode & FX_MODE_ROAD_BOUNDARY);
-        if ((d.mode & FX_MODE_COLLISION) || d.n_blocks == 0 || deferred) c->fusable_step = false;
+        if (d.n_blocks == 0 || deferred) c->fusable_step = false;
+        if (d.mode & FX_MODE_COLLISION) {
+            c->count_step = true;
+            if (C > tail_max_c && !c->fuse_any_size) c->fusable_step = false;
+        }
         c->any_extra |= extra;
         c->max_blocks_step = std::max(c->max_blocks_step, walk_blocks);
         c->M_max_step = std::max(c->M_max_step, p->M);
@@ -1005,6 +1029,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             c->h_probs[a].mode &= ~FX_MODE_INT_STORE_WT;
             if (wt) c->h_probs[a].mode |= FX_MODE_INT_STORE_WT;
         }
+        c->wt_step = wt;
         for (int a = 0; a < n_agents; a++)
             if (c->h_probs[a].mode & FX_MODE_WRITE_BUNDLE)
                 c->h_probs[a].planes = reinterpret_cast<double *>(reinterpret_cast<char *>(c->d_planes) +
@@ -1101,7 +1126,19 @@ int32_t fx_evaluate(FxContext *c) {
     c->fused_step = c->fuse_enabled && c->fusable_step && c->eval_launched;
     c->pkg_step = c->package_enabled && c->any_bundle;
     double *winner = c->dev_winner ? c->dev_winner : (c->pkg_step ? c->d_winner_own : nullptr);
-    FuseArgs fuse{c->fused_step ? c->h_counters_dev : nullptr, c->seq, winner, c->K_max_step};
+    // the agent's last workgroup ends the step (fx_tail.h): collision count where a collision stage ran in this kernel, winner
+    // package where the bundle is stored write-through -- a planner-sized step with everything on is ONE launch
+    // (the tail is compiled into the planner-sized decompositions only, FX_TAIL_IN_KERNEL: a step of another decomposition that
+    // needs the collision count keeps the selection kernel, one that only needs the package keeps the package kernel)
+    const bool tail_kernel = FX_TAIL_IN_KERNEL(c->G_step, c->any_extra);
+    if (c->fused_step && c->count_step && !tail_kernel) c->fused_step = false;
+    c->tail_step = 0;
+    if (c->fused_step && tail_kernel) {
+        if (c->count_step) c->tail_step |= FX_TAIL_COUNT;
+        if (c->pkg_step && c->wt_step) c->tail_step |= FX_TAIL_PACKAGE;
+    }
+    const bool pkg_in_tail = (c->tail_step & FX_TAIL_PACKAGE) != 0;
+    FuseArgs fuse{c->fused_step ? c->h_counters_dev : nullptr, c->seq, winner, (int32_t)((uint32_t)c->K_max_step | (c->tail_step << 16))};
     if (c->eval_launched)
     {
         if (c->use_grid)
@@ -1138,13 +1175,15 @@ int32_t fx_evaluate(FxContext *c) {
         for (int a = 0; a < c->n_agents; a++) c_max = std::max(c_max, c->slots[a].C);
         HIP_TRY(fx_launch_select(c->d_probs, c->n_agents, c_max, c->h_counters_dev, c->seq, winner, c->pkg_step ? c->h_pkg_dev : nullptr,
                                  c->pkg_stride, c->pkg_plane_rows, c->stream));
-    } else if (c->pkg_step) {
-        // fused selection publishes while other waves' plane stores may still be in flight: the gather runs as its own small
-        // kernel behind the evaluation; fx_finish waits for its sequence word
+    } else if (c->pkg_step && !pkg_in_tail) {
+        // fused selection without the tail's write-through hand-off (forced write-back plane stores) publishes while other waves'
+        // plane stores may still be in flight: the gather runs as its own small kernel behind the evaluation; fx_finish waits for
+        // its sequence word
         HIP_TRY(fx_launch_package(c->d_probs, c->n_agents, winner, c->h_pkg_dev, c->pkg_stride, c->pkg_plane_rows, c->seq, c->stream));
     }
-    if (timed && (!c->fused_step || c->pkg_step)) HIP_TRY(hipEventRecord(ts->e_end, c->stream));
-    if (timed) { ts->fused = c->fused_step && !c->pkg_step; c->n_timed++; }
+    const bool one_launch = c->fused_step && (!c->pkg_step || pkg_in_tail);
+    if (timed && !one_launch) HIP_TRY(hipEventRecord(ts->e_end, c->stream));
+    if (timed) { ts->fused = one_launch; c->n_timed++; }
     c->timed_step = timed;
     c->evaluated = true;
     c->in_flight = true;
@@ -2201,19 +2240,21 @@ int32_t fx_read_obstacle_kernel_times(FxContext *c, int32_t max_n, double *obst_
 }
 // fx_step_info, extended: out[0 .. 9] as fx_step_info, [10] obstacle stage as its own kernel, [11] steps per work item, [12] work
 // items (waves) per agent (max) and [13] dynamic LDS bytes of that kernel, [14] waves per workgroup when a tile's chunks share one
-// workgroup (0: one wave per (tile, chunk) item), [15] reserved
+// workgroup (0: one wave per (tile, chunk) item), [15] what the agent's last workgroup did beyond the arg-min (1: collision count,
+// 2: winner package; fx_tail.h)
 int32_t fx_step_info_ex(const FxContext *c, int64_t *out16) {
     if (!c || !out16) return set_err(FX_ERR_INVALID_ARGUMENT, "fx_step_info_ex: NULL argument");
     int rc = fx_step_info(c, out16);
     if (rc) return rc;
     out16[10] = c->split_step; out16[11] = c->split_CH; out16[12] = c->obs_blocks_step; out16[13] = (int64_t)c->obs_lds_step;
-    out16[14] = c->obs_wg_step; out16[15] = 0;
+    out16[14] = c->obs_wg_step; out16[15] = c->tail_step;
     return FX_OK;
 }
 
 int32_t fx_set_fused_selection(FxContext *c, int32_t enabled) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     c->fuse_enabled = enabled != 0;
+    c->fuse_any_size = enabled == 2;   // (takes effect at the next upload)
     return FX_OK;
 }
 int32_t fx_set_timing(FxContext *c, int32_t mode) {

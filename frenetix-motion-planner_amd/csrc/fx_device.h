@@ -20,6 +20,10 @@
                                 // step's obstacle masks (pmask, hmask bit patterns; grid kernel with the staged obstacle stage, else 0)
 #define FX_REF_FIELDS 8         // per knot: pos, theta, curv, curv_d, x, y, nx, ny  (64 B, AoS in LDS)
 #define FX_MAX_SAMPLES 128      // N+1 <= 128
+// lane-split kernels keep the agent's obstacle record table rec[S][K][12] (+ the two step masks) in LDS up to this many bytes
+// (fx_eval_grid_kernel.h; K = 5 .. 15 obstacles of a planner-sized step at S = 31: 15 .. 45 KB)
+#define FX_REC_LDS_MAX (48 * 1024)
+__host__ __device__ inline int S_rec_doubles(int S, int K) { return S * K * 12; }
 
 struct DevProblem {
     // ---- scalars (FxProblem) ----
@@ -96,6 +100,11 @@ struct DevProblem {
     const double *lane_poly;        // [.][2] closed outlines
     const int32_t *lane_ctr_off;    // [n_lane + 1]
     const double *lane_ctr;         // [.][2] centre polylines
+    // winner package of this agent in pinned + mapped host memory (fx_tail.h reads these three from the problem in memory, the
+    // evaluation kernels never hold them in registers): [pkg_plane_rows] plane values | FX_PKG_TAIL doubles, and its sequence word
+    double *pkg_out;
+    unsigned long long *pkg_seq;
+    int32_t pkg_plane_rows;
 };
 
 // The same fields held in registers: a kernel loads them all at entry (one batch of scalar loads, one latency).
@@ -190,7 +199,7 @@ extern __device__ unsigned long long fx_probe_stamps[FX_PROBE_WAVES * FX_PROBE_S
     do {                                                                                                         \
         const unsigned w_ = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));                               \
         if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && w_ < FX_PROBE_WAVES)                                   \
-            fx_probe_stamps[(size_t)w_ * FX_PROBE_SLOTS + (k)] = (k) == 0 || (k) == 15 ? wall_clock64() : clock64(); \
+            fx_probe_stamps[(size_t)w_ * FX_PROBE_SLOTS + (k)] = (k) == 0 || (k) == 15 || FX_PROBE == 2 ? wall_clock64() : clock64(); \
     } while (0)
 // the obstacle kernel's own stamp block (it runs behind the walk and would overwrite the walk's stamps)
 extern __device__ unsigned long long fx_probe_stamps_obs[FX_PROBE_WAVES * FX_PROBE_SLOTS];
@@ -226,11 +235,24 @@ enum {
 // Fused selection (no agent asks for the collision stage): the LAST workgroup of an agent to finish reduces the
 // per-workgroup partials and publishes the step's result block, so the step is one launch.  host_result == nullptr:
 // a separate fx_select_kernel follows.
+// tail (fx_tail.h): what the agent's last workgroup does beyond the arg-min -- FX_TAIL_COUNT: the colliding candidates in front of
+// the winner (planner.py:336-357; the step's kernels store cost[] / flags[] write-through), FX_TAIL_PACKAGE: the winner package
+// gathered into host_pkg (the bundle, coefficients and cost map are stored write-through).  0 = the single-wave publication of
+// steps without a collision stage and without a package.
+#define FX_TAIL_COUNT 1u
+#define FX_TAIL_PACKAGE 2u
+// which evaluation kernels carry the tail: the planner-sized decompositions (>= 4 lanes per candidate: steps below 200 waves) and
+// the windowed-cost kernel (one lane per candidate, small by construction); the host asks for a tail only with those
+#define FX_TAIL_IN_KERNEL(G, EXTRA) ((G) >= 4 || (EXTRA))
 struct FuseArgs {
     unsigned long long *host_result;  // pinned + mapped [n_agents][FX_CNT_COUNT + 1]
     unsigned long long seq;           // sequence word the host polls for
     double *dev_winner;               // optional device copy of (cost, index) per agent
     int32_t k_max;                    // largest obstacle count of the launch's agents (sizes the per-wave hot blocks)
+                                      // ... and, in bits 16 / 17, FX_TAIL_* (only with host_result): the struct is a kernel argument
+                                      // that the walk keeps in scalar registers, every further word costs the big kernels a spill
+    __host__ __device__ uint32_t tail() const { return (uint32_t)k_max >> 16; }
+    __host__ __device__ int32_t kmax() const { return k_max & 0xffff; }
 };
 
 // Pointers stored inside DevProblem are loaded from memory, so the compiler only knows them as generic ("flat")

@@ -85,9 +85,85 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     LonRow *__restrict__ rows = reinterpret_cast<LonRow *>(tpw + FX_TP * S);   // FX_TP * S * 8 is a multiple of 16
     char *__restrict__ lds_tail = reinterpret_cast<char *>(rows + (size_t)n_pairs_max * S) + (G > 1 ? (size_t)64 * BLK : 0);
     double *__restrict__ rpos = reinterpret_cast<double *>(lds_tail);  // [M] arc length of the knots (binary search)
+    // Lane split (the planner-sized decompositions: every lane of a wave walks another step): the obstacle loops read one
+    // 96-byte record per (step, obstacle) and lane.  From global memory that is a dependent round trip per visited obstacle -- the
+    // walk of a 630-candidate step with five obstacles took 7 - 9 us against 3 us without obstacles (tools/probe_timeline.py) --, so
+    // the workgroup copies the agent's whole record table and the step masks into LDS with the other tables of phase 1 (where they
+    // fit: FX_REC_LDS_MAX; the host sizes the dynamic LDS by the same rule, fx_api.hip lds_for)
+    constexpr bool LSTAGE = OBST && !(G == 1 || WSPLIT);
+    const int rec_n = P.K > 0 ? S_rec_doubles(P.S, P.K) : 0;
+#ifdef FX_NO_LSTAGE   // (probe builds: A/B of the staging)
+    const bool rec_staged = false;
+#else
+    const bool rec_staged = LSTAGE && rec_n > 0 && (size_t)rec_n * sizeof(double) <= FX_REC_LDS_MAX;
+#endif
+    double *__restrict__ rec_lds = reinterpret_cast<double *>(lds_tail + sizeof(double) * (((size_t)P.M + 1) & ~(size_t)1));
+    unsigned long long *__restrict__ pm_lds = reinterpret_cast<unsigned long long *>(rec_lds + rec_n);   // [S] | [S]
     // the knots themselves are only touched once per (pair, step) item: read them through L1/L2
     const FX_GLOBAL double *__restrict__ kn = as_global(P.ref);
-    {
+    if constexpr (G >= 4) {
+        // Planner-sized decompositions: the step is a chain of round trips, so EVERY table's first batch of loads is requested
+        // before the first LDS write (a copy loop per table is a round trip per table -- and per iteration: 1.9 us of phase 1 grew
+        // to 3.4 us when the record table joined as its own loop, tools/probe_timeline.py); what a batch does not cover loops on.
+        const FX_GLOBAL double *__restrict__ tsrc = as_global(P.tpow);
+        const bool masks = OBST && P.K > 0;
+        const int it = min(tid, S - 1);
+        const double t1 = tsrc[it], t2 = tsrc[S + it], t3 = tsrc[2 * S + it], t4 = tsrc[3 * S + it], t5 = tsrc[4 * S + it];
+        unsigned long long m0 = 0ULL, m1 = 0ULL;
+        if (masks) { m0 = as_global(P.obs_pmask)[it]; m1 = as_global(P.obs_hmask)[it]; }
+        double rp[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) rp[u] = kn[(int64_t)min(tid + u * BLK, M - 1) * FX_REF_FIELDS];
+        const FX_GLOBAL fx_d2 *__restrict__ rsrc = reinterpret_cast<const FX_GLOBAL fx_d2 *>(as_global(P.obs_rec));   // (256-byte aligned slot)
+        fx_d2 *__restrict__ rdst = reinterpret_cast<fx_d2 *>(rec_lds);
+        const int n2 = rec_n / 2;   // (12 doubles per record: even)
+        fx_d2 rv[8];
+        if (rec_staged) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) rv[u] = rsrc[min(tid + u * BLK, n2 - 1)];
+        }
+        int32_t cid = 0;
+        double cw = 0.0;
+        if (tid < P.n_cost) { cid = Pg.cost_id[tid]; cw = Pg.cost_w[tid]; }
+        // ---- LDS writes ----
+        if (tid < S) {
+            fill_time_row(tpw + tid * FX_TP, t1, t2, t3, t4, t5);
+            if (masks) {
+                if (rec_staged) { pm_lds[tid] = m0; pm_lds[S + tid] = m1; }
+                else if (G == 1 || WSPLIT) {   // (four lanes per candidate on four waves: the masks ride in the time table)
+                    unsigned long long *m = reinterpret_cast<unsigned long long *>(tpw + tid * FX_TP + 12);
+                    m[0] = m0; m[1] = m1;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (tid + u * BLK < M) rpos[tid + u * BLK] = rp[u];
+        if (rec_staged) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (tid + u * BLK < n2) rdst[tid + u * BLK] = rv[u];
+        }
+        if (tid < P.n_cost) { sh_cost_id[tid] = cid; sh_cost_w[tid] = cw; }
+        // ---- what the first batch does not cover ----
+        for (int i = tid + BLK; i < S; i += BLK) {
+            fill_time_row(tpw + i * FX_TP, tsrc[i], tsrc[S + i], tsrc[2 * S + i], tsrc[3 * S + i], tsrc[4 * S + i]);
+            if (rec_staged) { pm_lds[i] = as_global(P.obs_pmask)[i]; pm_lds[S + i] = as_global(P.obs_hmask)[i]; }
+        }
+        for (int i0 = tid + 4 * BLK; i0 < M; i0 += 4 * BLK) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) rp[u] = kn[(int64_t)min(i0 + u * BLK, M - 1) * FX_REF_FIELDS];
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (i0 + u * BLK < M) rpos[i0 + u * BLK] = rp[u];
+        }
+        if (rec_staged) {
+            for (int e0 = tid + 8 * BLK; e0 < n2; e0 += 8 * BLK) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) rv[u] = rsrc[min(e0 + u * BLK, n2 - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (e0 + u * BLK < n2) rdst[e0 + u * BLK] = rv[u];
+            }
+        }
+        if (WPE >= 3 && OBST && tid < FX_ATAN_K) sh_atan_k[tid] = fxm::fx_ktab[FX_ATAN_K0 + tid];
+    } else {
         const FX_GLOBAL double *__restrict__ tsrc = as_global(P.tpow);
         for (int i = tid; i < S; i += BLK) {
             fill_time_row(tpw + i * FX_TP, tsrc[i], tsrc[S + i], tsrc[2 * S + i], tsrc[3 * S + i], tsrc[4 * S + i]);
@@ -98,6 +174,11 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
             }
         }
         for (int i = tid; i < M; i += BLK) rpos[i] = kn[(int64_t)i * FX_REF_FIELDS];
+        if (rec_staged) {   // (G = 2 lane split: the plain loops -- these kernels' register allocation is left alone)
+            const FX_GLOBAL double *__restrict__ rsrc = as_global(P.obs_rec);
+            for (int e = tid; e < rec_n; e += BLK) rec_lds[e] = rsrc[e];
+            for (int i = tid; i < S; i += BLK) { pm_lds[i] = as_global(P.obs_pmask)[i]; pm_lds[S + i] = as_global(P.obs_hmask)[i]; }
+        }
         if (tid < P.n_cost) { sh_cost_id[tid] = Pg.cost_id[tid]; sh_cost_w[tid] = Pg.cost_w[tid]; }
         if (WPE >= 3 && OBST && tid < FX_ATAN_K) sh_atan_k[tid] = fxm::fx_ktab[FX_ATAN_K0 + tid];
     }
@@ -174,10 +255,13 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
 
     if (bundle && active && part == 0) {
         FX_GLOBAL double *__restrict__ co = as_global(P.coeffs) + g;
-        co[0 * ld] = s0; co[1 * ld] = ss0; co[2 * ld] = .5 * sss0; co[3 * ld] = cl3; co[4 * ld] = cl4; co[5 * ld] = cl5;
-        co[6 * ld] = L.c0; co[7 * ld] = L.c1; co[8 * ld] = L.c2; co[9 * ld] = L.c3; co[10 * ld] = L.c4; co[11 * ld] = L.c5;
-        co[12 * ld] = tau;  // PolynomialTrajectory.delta_tau of the lateral polynomial (reactive_planner.py:161-171)
-        as_global(P.traj_len)[g] = traj_len;
+        // (write-through where the step's last workgroup gathers the winner package itself, fx_tail.h)
+        const bool wt = FX_TAIL_IN_KERNEL(G, false) && fuse.host_result != nullptr && (fuse.tail() & FX_TAIL_PACKAGE);
+        const double cv[FX_COEFF_ROWS] = {s0, ss0, .5 * sss0, cl3, cl4, cl5, L.c0, L.c1, L.c2, L.c3, L.c4, L.c5,
+                                          tau};  // tau: PolynomialTrajectory.delta_tau of the lateral polynomial (reactive_planner.py:161-171)
+#pragma unroll
+        for (int q = 0; q < FX_COEFF_ROWS; q++) st_out(co + q * ld, cv[q], wt);
+        st_out(as_global(P.traj_len) + g, (int32_t)traj_len, wt);
     }
 
     auto lat_eval = [&](int i, double u_lowvel, double &d, double &dv, double &da) {
@@ -194,7 +278,10 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     const int CH = G == 1 ? S : (S + G - 1) / G;
     const int i_begin = part * CH;
     const int i_end = min(S, i_begin + CH);
-    const int i_first = (G > 1 && part > 0) ? i_begin - 1 : i_begin;
+    // one step per lane (32 lanes per candidate, horizons up to 32 samples): no carry-in step -- the left lane walks step i - 1 in
+    // the same call and hands its heading, curvature and box over (walk_step, `neigh`)
+    const bool neigh = G == 32 && !WSPLIT && CH == 1;
+    const int i_first = (G > 1 && part > 0 && !neigh) ? i_begin - 1 : i_begin;
 
     // The walk's wave-uniform doubles live in VGPRs (KV): the loop keeps ~50 lane masks and pointers in scalar registers and
     // the allocator otherwise parks these constants in VGPR lanes and reads them back (v_readlane) every step.
@@ -240,7 +327,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     Hs.lds = nullptr; Hs.tab = as_global(P.obs_hot); Hs.n_el = P.K * FX_HOT_STRIDE; Hs.lane = tid & 63;
     if (HOT && P.K > 0) {
         char *hot_base = lds_tail;   // over the knots' arc lengths, which only the prologue reads
-        const size_t hot_block = (sizeof(double) * FX_HOT_STRIDE * (size_t)fuse.k_max + 15) & ~(size_t)15;
+        const size_t hot_block = (sizeof(double) * FX_HOT_STRIDE * (size_t)fuse.kmax() + 15) & ~(size_t)15;
         Hs.lds = reinterpret_cast<double *>(hot_base + (size_t)(tid >> 6) * hot_block);
         if (i_first < i_end) Hs.prefetch(i_first);
     }
@@ -272,10 +359,15 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     for (int i = i_first; i < i_end; i++) {
         const bool emit = i >= i_begin;
         const LonRow r = my[i];
+        if (LSTAGE && rec_staged)   // (workgroup-uniform: the obstacle records and masks of the step come from LDS)
+            walk_step<OBST, false, false, false>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit, planes + (int64_t)i * ld + g, 0u,
+                                                 ps, Cy, A, O, (const double *)rec_lds, (const unsigned long long *)pm_lds,
+                                                 (const unsigned long long *)(pm_lds + S), Bv, &Hs, -1, neigh, part > 0);
+        else
         walk_step<OBST, (G == 1 || WSPLIT), HOT, (WPE >= 3 && OBST)>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit,
                                                  USTEP32 ? planes + (int64_t)i * ld : planes + (int64_t)i * ld + g,
                                                  USTEP32 ? (uint32_t)g * 8u : 0u, ps, Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv,
-                                                 &Hs, i + 1 < i_end ? i + 1 : -1);
+                                                 &Hs, i + 1 < i_end ? i + 1 : -1, neigh, part > 0);
 #ifdef FX_CULL_STATS
         {   // how many (wave, step) pairs lie behind the point where every lane of the wave is decided (production flag set), and
             // behind the point where every lane is decided or its cost so far already exceeds a bound (the winner's cost)
@@ -296,6 +388,6 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     W.cl3 = cl3; W.cl4 = cl4; W.cl5 = cl5; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
     // wave split: the exchange block sits behind the rows in dynamic LDS
     double *xch = reinterpret_cast<double *>(rows + (size_t)n_pairs_max * S);
-    finish_candidate<G, BUNDLE, OBST, false, WSPLIT>(P, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D,
+    finish_candidate<G, BUNDLE, OBST, false, WSPLIT>(P, Pg, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D,
                                                      red_cost, red_idx, red_cnt, fuse, xch, CPB, cand_local);
 }

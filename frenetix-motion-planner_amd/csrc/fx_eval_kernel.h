@@ -21,6 +21,7 @@
 
 #include "fx_device.h"
 #include "fx_math.h"
+#include "fx_tail.h"
 
 namespace fxk {
 
@@ -221,7 +222,7 @@ struct WalkResult {
 // lane of G different lane-groups of the workgroup (WSPLIT = true: part = tid / CPB, combined through the LDS block
 // `xch` of G * CPB * 56 bytes).  The second form keeps every store of the walk a contiguous row segment per wave.
 template <int G, bool BUNDLE, bool OBST, bool EXTRA, bool WSPLIT = false>
-__device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResult &W, int64_t g, bool active, int part,
+__device__ __forceinline__ void finish_candidate(const ProblemRegs &P, const DevProblem &Pg, WalkResult &W, int64_t g, bool active, int part,
                                                  int i_begin, int i_end, bool bundle, bool do_collision, bool dbg, bool D,
                                                  double *red_cost, long long *red_idx, unsigned int *red_cnt,
                                                  const FuseArgs &fuse, double *xch = nullptr, int CPB = 0,
@@ -230,6 +231,12 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     const int S = P.S, K = P.K, Pn = P.P;
     const int64_t ld = P.ld;
     const double dt = P.dt;
+    // the agent's last workgroup ends the step itself (fx_tail.h): what it reads of other workgroups' outputs is stored write-through
+    // Compiled into the planner-sized decompositions only (four or more lanes per candidate: below 200 waves; and the windowed-cost
+    // kernel): the kernels of the large grids stay exactly what they were -- their register allocation is tuned to the last VGPR.
+    constexpr bool TAIL = FX_TAIL_IN_KERNEL(G, EXTRA);
+    const bool tail_mode = TAIL && fuse.host_result != nullptr && fuse.tail() != 0u;
+    const bool tail_pkg = tail_mode && (fuse.tail() & FX_TAIL_PACKAGE);
     FX_GLOBAL double *__restrict__ planes = as_global(P.planes);
     const FX_GLOBAL double *__restrict__ obs_pos = as_global(P.obs_pos);
     const FX_GLOBAL double *__restrict__ obs_cov_inv = as_global(P.obs_cov_inv);
@@ -267,8 +274,8 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
                 const int64_t ps = (int64_t)S * ld;
                 for (int i = i_begin; i < i_end; i++) {
                     FX_GLOBAL double *__restrict__ row = planes + (int64_t)i * ld + g;
-                    row[FX_PL_X * ps] = 0.0;
-                    row[FX_PL_Y * ps] = 0.0;
+                    st_out(row + FX_PL_X * ps, 0.0, (P.mode & FX_MODE_INT_STORE_WT) != 0);   // (store mode of the walk's plane stores)
+                    st_out(row + FX_PL_Y * ps, 0.0, (P.mode & FX_MODE_INT_STORE_WT) != 0);
                 }
             }
             if (OBST) {
@@ -442,10 +449,10 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
             if (defer && id == FX_COST_PREDICTION) {
                 pre = sum; have_pre = true;
                 // (the obstacle kernel fills the cost-map entry of the candidates it visits -- the costed ones)
-                if ((P.mode & FX_MODE_WRITE_COSTMAP) && active && leader && !costed) as_global(P.costmap)[(int64_t)n * ld + g] = 0.0;
+                if ((P.mode & FX_MODE_WRITE_COSTMAP) && active && leader && !costed) st_out(as_global(P.costmap) + (int64_t)n * ld + g, 0.0, tail_pkg);
                 continue;
             }
-            if ((P.mode & FX_MODE_WRITE_COSTMAP) && active && leader) as_global(P.costmap)[(int64_t)n * ld + g] = costed ? c : 0.0;
+            if ((P.mode & FX_MODE_WRITE_COSTMAP) && active && leader) st_out(as_global(P.costmap) + (int64_t)n * ld + g, costed ? c : 0.0, tail_pkg);
             if (have_pre) tail += w * c;
             sum += w * c;
         }
@@ -459,8 +466,8 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     }
     if (active && leader) {
         if (defer) as_global(P.cost_tail)[g] = tail;
-        as_global(P.cost)[g] = costed ? (have_pre ? pre : total) : 0.0;
-        as_global(P.flags)[g] = flags;
+        st_out(as_global(P.cost) + g, costed ? (have_pre ? pre : total) : 0.0, tail_mode);
+        st_out(as_global(P.flags) + g, flags, tail_mode);
         if (OBST && (P.mode & FX_MODE_ROAD_BOUNDARY)) as_global(P.bound_step)[g] = (selectable && off_road) ? (int)bound_step : -1;
     }
 
@@ -498,76 +505,94 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, WalkResul
     }
     if (lane == 0) { red_cost[wave] = bc; red_idx[wave] = bi; }
     FX_STAMP(9);
+    // tail mode: this wave's cost / flag / coefficient / plane stores are performed before the workgroup takes its ticket
+    if (tail_mode) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // Only the first wave goes on (it owns the lanes that publish); the others are done.
-    if (wave != 0) return;
-    for (int w = 1; w < (int)blockDim.x / 64; w++)
-        if (red_cost[w] < bc || (red_cost[w] == bc && red_idx[w] < bi)) { bc = red_cost[w]; bi = red_idx[w]; }
-    if (lane == 0 && !defer) {   // deferred obstacle stage: fx_obstacle_kernel owns this agent's partials
-        // agent-scope stores: visible to whichever XCD runs the reducing workgroup without an L2 write-back
-        __hip_atomic_store(as_global(P.part_cost) + blockIdx.x, bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(as_global(P.part_idx) + blockIdx.x, (int64_t)bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (lane < 2 + FX_NUM_REASONS && red_cnt[lane]) atomicAdd(&P.counters[lane], (unsigned long long)red_cnt[lane]);
-    FX_STAMP(10);
-    if (fuse.host_result == nullptr) return;  // a selection kernel follows
+    // Only the first wave goes on (it owns the lanes that publish); the others are done -- or, tail mode, wait to learn whether
+    // theirs is the agent's last workgroup.
+    if (wave != 0 && !tail_mode) return;
+    if (wave == 0) {
+        for (int w = 1; w < (int)blockDim.x / 64; w++)
+            if (red_cost[w] < bc || (red_cost[w] == bc && red_idx[w] < bi)) { bc = red_cost[w]; bi = red_idx[w]; }
+        if (lane == 0 && !defer) {   // deferred obstacle stage: fx_obstacle_kernel owns this agent's partials
+            // agent-scope stores: visible to whichever XCD runs the reducing workgroup without an L2 write-back
+            __hip_atomic_store(as_global(P.part_cost) + blockIdx.x, bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(as_global(P.part_idx) + blockIdx.x, (int64_t)bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane < 2 + FX_NUM_REASONS && red_cnt[lane]) atomicAdd(&P.counters[lane], (unsigned long long)red_cnt[lane]);
+        FX_STAMP(10);
+        if (fuse.host_result == nullptr) return;  // a selection kernel follows
 
-    // ---- fused selection: the last workgroup of this agent to arrive reduces and publishes ----
-    // Partials and counters above are agent-scope atomics issued by THIS wave; once they are acknowledged
-    // (vmcnt 0) they are performed, so a relaxed ticket is enough -- no L2 write-back in the way of the bundle's
-    // store stream, no workgroup barrier.  (The other waves' cost / flag / plane stores may still be in flight
-    // when the result is published: every consumer of those is ordered behind the kernel on the stream.)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    FX_STAMP(11);
-    unsigned long long ticket = 0;
-    if (lane == 0) ticket = atomicAdd(&P.counters[FX_DCNT_TICKET], 1ULL);
-    ticket = __shfl(ticket, 0);
-    FX_STAMP(12);
-    FX_STAMP(15);
-    if (ticket != (unsigned long long)(P.n_blocks - 1)) return;
-    unsigned long long *out = fuse.host_result + (size_t)blockIdx.y * (FX_CNT_COUNT + 1);
-    // counters: read and zero in one agent-scope exchange (the next step starts from a clean block); issued first so
-    // that its round trip overlaps the loads of the partials
-    unsigned long long cnt = 0ULL;
-    if (lane < FX_CNT_BEST_IDX) cnt = atomicExch(&P.counters[lane], 0ULL);
-    bc = INFINITY;
-    bi = 0x7fffffffffffffffLL;
-    // device-coherent loads cross the fabric (~1 us each): eight per lane in flight before the first comparison
-    for (int b0 = lane; b0 < P.n_blocks; b0 += 8 * 64) {
-        double c[8];
-        long long ix[8];
+        // ---- fused selection: the last workgroup of this agent to arrive reduces and publishes ----
+        // Partials and counters above are agent-scope atomics issued by THIS wave; once they are acknowledged
+        // (vmcnt 0) they are performed, so a relaxed ticket is enough -- no L2 write-back in the way of the bundle's
+        // store stream, no workgroup barrier.  (The other waves' cost / flag / plane stores may still be in flight
+        // when the result is published: every consumer of those is ordered behind the kernel on the stream.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FX_STAMP(11);
+        unsigned long long ticket = 0;
+        if (lane == 0) ticket = atomicAdd(&P.counters[FX_DCNT_TICKET], 1ULL);
+        ticket = __shfl(ticket, 0);
+        FX_STAMP(12);
+        FX_STAMP(15);
+        if (TAIL && tail_mode) {   // every wave of the agent's last workgroup runs the tail (fx_tail.h): tell the others
+            if (lane == 0) red_cnt[2 + FX_NUM_REASONS] = ticket == (unsigned long long)(P.n_blocks - 1) ? 1u : 0u;
+        } else {
+            if (ticket != (unsigned long long)(P.n_blocks - 1)) return;
+            unsigned long long *out = fuse.host_result + (size_t)blockIdx.y * (FX_CNT_COUNT + 1);
+            // counters: read and zero in one agent-scope exchange (the next step starts from a clean block); issued first so
+            // that its round trip overlaps the loads of the partials
+            unsigned long long cnt = 0ULL;
+            if (lane < FX_CNT_BEST_IDX) cnt = atomicExch(&P.counters[lane], 0ULL);
+            bc = INFINITY;
+            bi = 0x7fffffffffffffffLL;
+            // device-coherent loads cross the fabric (~1 us each): eight per lane in flight before the first comparison
+            for (int b0 = lane; b0 < P.n_blocks; b0 += 8 * 64) {
+                double c[8];
+                long long ix[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int b = min(b0 + u * 64, P.n_blocks - 1);   // a repeated entry does not change the minimum
-            c[u] = __hip_atomic_load(as_global(P.part_cost) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ix[u] = __hip_atomic_load(as_global(P.part_idx) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+                for (int u = 0; u < 8; u++) {
+                    const int b = min(b0 + u * 64, P.n_blocks - 1);   // a repeated entry does not change the minimum
+                    c[u] = __hip_atomic_load(as_global(P.part_cost) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ix[u] = __hip_atomic_load(as_global(P.part_idx) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
 #pragma unroll
-        for (int u = 0; u < 8; u++)
-            if (c[u] < bc || (c[u] == bc && ix[u] < bi)) { bc = c[u]; bi = ix[u]; }
-    }
+                for (int u = 0; u < 8; u++)
+                    if (c[u] < bc || (c[u] == bc && ix[u] < bi)) { bc = c[u]; bi = ix[u]; }
+            }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double oc = __shfl_xor(bc, off);
-        const long long oi = __shfl_xor(bi, off);
-        if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double oc = __shfl_xor(bc, off);
+                const long long oi = __shfl_xor(bi, off);
+                if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+            }
+            const bool none = bi == 0x7fffffffffffffffLL;
+            {   // the result block in ONE store instruction: lanes 0 .. 12 the counters, 13 .. 15 winner index, cost bits, collisions
+                unsigned long long w = cnt;
+                if (lane == FX_CNT_BEST_IDX) w = none ? ~0ULL : (unsigned long long)bi;
+                if (lane == FX_CNT_BEST_COST) w = none ? 0ULL : (unsigned long long)__double_as_longlong(bc);
+                if (lane == FX_CNT_COLLISIONS) w = 0ULL;
+                if (lane < FX_CNT_COUNT) put_host(out + lane, w);
+            }
+            if (lane == 0) {
+                if (fuse.dev_winner) {
+                    fuse.dev_winner[2 * blockIdx.y] = none ? INFINITY : bc;
+                    reinterpret_cast<long long *>(fuse.dev_winner)[2 * blockIdx.y + 1] = none ? -1 : bi;
+                }
+                __hip_atomic_store(&P.counters[FX_DCNT_TICKET], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // every lane's result words have been acknowledged (the counter is per wave) before lane 0 sends the sequence
+            // word behind them (no L2 write-back fence: fx_tail.h)
+            drain_stores();
+            if (lane == 0) st_host(out + FX_CNT_COUNT, fuse.seq);
+            return;
+        }   // (single-wave publication)
+    }   // (wave 0)
+    if (TAIL) {
+        __syncthreads();
+        if (!red_cnt[2 + FX_NUM_REASONS]) return;
+        fx_fused_tail(P, Pg, fuse, (int)blockIdx.y);
     }
-    if (lane < FX_CNT_BEST_IDX) out[lane] = cnt;
-    if (lane == 0) {
-        const bool none = bi == 0x7fffffffffffffffLL;
-        if (fuse.dev_winner) {
-            fuse.dev_winner[2 * blockIdx.y] = none ? INFINITY : bc;
-            reinterpret_cast<long long *>(fuse.dev_winner)[2 * blockIdx.y + 1] = none ? -1 : bi;
-        }
-        out[FX_CNT_BEST_IDX] = none ? ~0ULL : (unsigned long long)bi;
-        out[FX_CNT_BEST_COST] = none ? 0ULL : (unsigned long long)__double_as_longlong(bc);
-        out[FX_CNT_COLLISIONS] = 0ULL;
-        __hip_atomic_store(&P.counters[FX_DCNT_TICKET], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // every lane's result words have been acknowledged (the counter is per wave) before lane 0 releases the sequence
-    // word; the release store itself orders lane 0's own stores
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(&out[FX_CNT_COUNT], fuse.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace fxk
@@ -676,10 +701,13 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
 
     if (bundle && active && part == 0) {
         FX_GLOBAL double *__restrict__ co = as_global(P.coeffs) + g;
-        co[0 * ld] = cl0; co[1 * ld] = cl1; co[2 * ld] = cl2; co[3 * ld] = cl3; co[4 * ld] = cl4; co[5 * ld] = cl5;
-        co[6 * ld] = L.c0; co[7 * ld] = L.c1; co[8 * ld] = L.c2; co[9 * ld] = L.c3; co[10 * ld] = L.c4; co[11 * ld] = L.c5;
-        co[12 * ld] = tau;  // PolynomialTrajectory.delta_tau of the lateral polynomial (reactive_planner.py:161-171)
-        as_global(P.traj_len)[g] = traj_len;
+        // (write-through where the step's last workgroup gathers the winner package itself, fx_tail.h)
+        const bool wt = FX_TAIL_IN_KERNEL(G, EXTRA) && fuse.host_result != nullptr && (fuse.tail() & FX_TAIL_PACKAGE);
+        const double cv[FX_COEFF_ROWS] = {cl0, cl1, cl2, cl3, cl4, cl5, L.c0, L.c1, L.c2, L.c3, L.c4, L.c5,
+                                          tau};  // tau: PolynomialTrajectory.delta_tau of the lateral polynomial (reactive_planner.py:161-171)
+#pragma unroll
+        for (int q = 0; q < FX_COEFF_ROWS; q++) st_out(co + q * ld, cv[q], wt);
+        st_out(as_global(P.traj_len) + g, (int32_t)traj_len, wt);
     }
 
     const double rp_first = knots[0].pos, rp_last = knots[M - 1].pos;
@@ -708,7 +736,10 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     const int CH = G == 1 ? S : (S + G - 1) / G;
     const int i_begin = part * CH;
     const int i_end = min(S, i_begin + CH);
-    const int i_first = (G > 1 && part > 0) ? i_begin - 1 : i_begin;  // carry-in step re-evaluated, not emitted
+    // one step per lane (32 lanes per candidate, horizons up to 32 samples): the left lane hands heading, curvature and box of
+    // step i - 1 over (walk_step, `neigh`) -- otherwise parts > 0 re-evaluate their carry-in step without emitting it
+    const bool neigh = G == 32 && CH == 1;
+    const int i_first = (G > 1 && part > 0 && !neigh) ? i_begin - 1 : i_begin;
 
     StepConst K;
     K.dt = dt; K.r_dt = 1.0 / dt; K.kappa_max = P.veh.kappa_max; K.a_max = a_max; K.v_switch = P.veh.v_switch;
@@ -762,7 +793,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
         const bool emit = i >= i_begin;  // false only for the carry-in step of parts > 0
         const LonRow r = row_at(i);
         walk_step<OBST, G == 1>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit, planes + (int64_t)i * ld + g, 0u, ps,
-                                Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv);
+                                Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv, nullptr, -1, neigh, part > 0);
         if (EXTRA) {
             sim_acc.push(O.a * O.a, S);                                 // partial_cost_functions.py:29-31
             sim_path.push(O.v, S);                                      // :194-195
@@ -790,6 +821,6 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     W.sum_abs_d = A.sum_abs_d; W.sum_voff = A.sum_voff; W.pred = A.pred; W.dto = dto; W.lane_off = lane_off; W.d_end = A.d_end; W.v_end = A.v_end;
     W.cl3 = cl3; W.cl4 = cl4; W.cl5 = cl5; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
     if (EXTRA) { W.sim_acc = sim_acc; W.sim_jerk = sim_jerk; W.sim_orient = sim_orient; W.sim_path = sim_path; }
-    finish_candidate<G, BUNDLE, OBST, EXTRA>(P, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D, red_cost,
+    finish_candidate<G, BUNDLE, OBST, EXTRA>(P, Pg, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D, red_cost,
                                              red_idx, red_cnt, fuse);
 }

@@ -68,45 +68,14 @@ extern "C" int fx_probe_read_obs(unsigned long long *out, size_t n_words) {
 }
 #endif
 
-// Winner package: everything the planner reads of the chosen trajectory -- planes [14][S], coefficients, raw partial costs,
-// cost, horizon, flag word -- gathered from the SoA outputs straight into pinned host memory behind the selection, so that a
-// plan step ends with ONE wait instead of a second round of strided copies and a stream synchronisation
-// (reactive_planner_cpp.py:355-357 reads the optimal trajectory's arrays, planner.py:394-447 packages them).
-// grid = n_agents, block = 256.  Layout per agent (doubles): planes | lon6 lat6 | raw[FX_NUM_COSTS] | cost | traj_len | flags |
-// index | found | tau_lat, then the sequence word at stride - 1.
-// The gather itself, for one agent, by the 256 threads of a workgroup; every wave leaves with its stores performed at system
-// scope (the caller orders the sequence word behind a barrier).
-__device__ __forceinline__ void fx_package_gather(const DevProblem &P, long long gi, double *out, int plane_rows) {
-    double *tail = out + plane_rows;
-    const bool found = gi >= 0 && (P.mode & FX_MODE_WRITE_BUNDLE);
-    const int tid = threadIdx.x;
-    if (found) {
-        const int64_t l = gi - P.g_base, ld = P.ld;
-        const int n_pl = FX_NUM_PLANES * P.S;
-        const FX_GLOBAL double *pl = as_global(P.planes);
-        for (int t = tid; t < n_pl; t += 256) out[t] = pl[(size_t)t * ld + l];
-        if (tid < 12) tail[tid] = as_global(P.coeffs)[(size_t)tid * ld + l];
-        if (tid >= 64 && tid < 64 + FX_NUM_COSTS)
-            tail[12 + tid - 64] = (tid - 64 < P.n_cost && (P.mode & FX_MODE_WRITE_COSTMAP)) ? as_global(P.costmap)[(size_t)(tid - 64) * ld + l] : 0.0;
-        if (tid == 128) {
-            tail[12 + FX_NUM_COSTS] = as_global(P.cost)[l];
-            tail[13 + FX_NUM_COSTS] = (double)as_global(P.traj_len)[l];
-            tail[14 + FX_NUM_COSTS] = (double)as_global(P.flags)[l];
-            tail[15 + FX_NUM_COSTS] = (double)gi;
-        }
-        if (tid == 130) tail[17 + FX_NUM_COSTS] = as_global(P.coeffs)[(size_t)12 * ld + l];
-    }
-    if (tid == 129) tail[16 + FX_NUM_COSTS] = found ? 1.0 : 0.0;
-    __threadfence_system();
-}
-
+// (fx_package_gather: fx_tail.h)
 __global__ __launch_bounds__(256) void fx_package_kernel(const DevProblem *__restrict__ probs, const double *__restrict__ winner,
                                                          double *host_pkg, int stride, int plane_rows, unsigned long long seq) {
     double *out = host_pkg + (size_t)blockIdx.x * stride;
-    fx_package_gather(probs[blockIdx.x], reinterpret_cast<const long long *>(winner)[2 * blockIdx.x + 1], out, plane_rows);
-    __syncthreads();
-    if (threadIdx.x == 0)
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(out + stride - 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    fxk::fx_package_gather<false>(probs[blockIdx.x], reinterpret_cast<const long long *>(winner)[2 * blockIdx.x + 1], out, plane_rows,
+                                  (int)threadIdx.x, 256);
+    __syncthreads();   // (every wave's package words are acknowledged: fx_tail.h, st_host / drain_stores)
+    if (threadIdx.x == 0) fxk::st_host(reinterpret_cast<unsigned long long *>(out + stride - 1), seq);
 }
 
 extern "C" hipError_t fx_launch_package(const DevProblem *d_probs, int n_agents, const double *winner, double *host_pkg, int stride,
@@ -233,18 +202,21 @@ __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__rest
     // paying for a D2H copy and a stream synchronisation) and leave the device counters zeroed for the next step.  The
     // counters were accumulated by the evaluation kernel, which is complete: plain loads and stores.
     unsigned long long *out = host_result + (size_t)blockIdx.y * (FX_CNT_COUNT + 1);
-    if (tid < FX_CNT_BEST_IDX) {
-        out[tid] = cnt_pre;
-        as_global(P.counters)[tid] = 0ULL;
+    // (host words: system-scope stores, drained per wave, the sequence word behind a barrier -- no L2 write-back fence: fx_tail.h)
+    {   // the result block in ONE store instruction (a wave's system-scope stores issue one behind the other): lanes 0 .. 12 the
+        // counters, 13 .. 15 winner index, cost bits, collisions
+        unsigned long long w = cnt_pre;
+        if (tid == FX_CNT_BEST_IDX) w = none ? ~0ULL : (unsigned long long)bi;
+        if (tid == FX_CNT_BEST_COST) w = none ? 0ULL : (unsigned long long)__double_as_longlong(bc);
+        if (tid == FX_CNT_COLLISIONS) w = collisions;
+        if (tid < FX_CNT_COUNT) fxk::put_host(out + tid, w);
     }
+    if (tid < FX_CNT_BEST_IDX) as_global(P.counters)[tid] = 0ULL;
     if (tid == 0 && dev_winner) {  // (cost, index bits) of the winner, device-resident for the multi-GPU exchange
         dev_winner[2 * blockIdx.y] = none ? INFINITY : bc;
         reinterpret_cast<long long *>(dev_winner)[2 * blockIdx.y + 1] = none ? -1 : bi;
     }
     if (tid == 0) {
-        out[FX_CNT_BEST_IDX] = none ? ~0ULL : (unsigned long long)bi;
-        out[FX_CNT_BEST_COST] = none ? 0ULL : (unsigned long long)__double_as_longlong(bc);
-        out[FX_CNT_COLLISIONS] = collisions;
         __hip_atomic_store(&P.counters[FX_DCNT_TICKET], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the obstacle kernel's candidate list (deferred obstacle stage) starts the next step empty
         if (P.mode & FX_MODE_INT_DEFER_OBST) as_global(P.counters)[FX_DCNT_LIVE] = 0ULL;
@@ -252,12 +224,12 @@ __global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__rest
     // the winner package (fx_set_package): the evaluation kernel is complete, so the publishing workgroup gathers the chosen
     // trajectory right here -- no further launch; its sequence word goes out behind the result block's
     double *pkg = host_pkg ? host_pkg + (size_t)blockIdx.y * pkg_stride : nullptr;
-    if (pkg) fx_package_gather(P, none ? -1LL : bi, pkg, pkg_plane_rows);
+    if (pkg) fxk::fx_package_gather<false>(P, none ? -1LL : bi, pkg, pkg_plane_rows, tid, 256);
+    else if (tid < 64) fxk::drain_stores();
     __syncthreads();
     if (tid == 0) {
-        __threadfence_system();
-        __hip_atomic_store(&out[FX_CNT_COUNT], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (pkg) __hip_atomic_store(reinterpret_cast<unsigned long long *>(pkg + pkg_stride - 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        fxk::st_host(out + FX_CNT_COUNT, seq);
+        if (pkg) fxk::st_host(reinterpret_cast<unsigned long long *>(pkg + pkg_stride - 1), seq);
     }
 }
 
@@ -511,12 +483,10 @@ __global__ __launch_bounds__(64) void fx_topk_merge_wave_kernel(int k, const dou
 // the host polls instead of paying for a D2H copy + stream synchronisation.
 __global__ __launch_bounds__(256) void fx_publish_kernel(const double *__restrict__ src, int n, double *host_dst,
                                                          unsigned long long *host_seq, unsigned long long seq) {
-    for (int i = threadIdx.x; i < n; i += 256) host_dst[i] = src[i];
-    __threadfence_system();  // per wave: its stores are performed before the barrier lets thread 0 release the sequence word
+    for (int i = threadIdx.x; i < n; i += 256) fxk::put_host(host_dst + i, src[i]);
+    fxk::drain_stores();  // per wave: its stores are acknowledged before the barrier lets thread 0 send the sequence word
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (threadIdx.x == 0) fxk::st_host(host_seq, seq);
 }
 
 extern "C" hipError_t fx_launch_publish(const double *src, int n, double *host_dst, unsigned long long *host_seq,

@@ -409,7 +409,12 @@ template <bool OBST, bool USTEP, bool HOT = false, bool KTAB = false, typename P
 __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, const LatPoly &L, const double *tp, int i,
                                           int traj_len, double d_ext, bool emit, bool store, PlanePtr planes_i, uint32_t lane_off, int64_t ps,
                                           StepCarry &C, StepAcc &A, StepOut &O, ObsD obs_rec, ObsM obs_pmask, ObsM obs_hmask,
-                                          const BoundView &B, ObsHot *H = nullptr, int i_next = -1) {
+                                          const BoundView &B, ObsHot *H = nullptr, int i_next = -1, const bool neigh = false,
+                                          const bool has_prev = false) {
+    // neigh (wave-uniform; lane split with ONE step per lane): the lane to the left walks step i - 1 of the same candidate in this
+    // very call, so what this step needs of it -- heading, curvature, ego box -- is taken from that lane (has_prev: it exists, i.e.
+    // this is not the candidate's first part) instead of being recomputed in a carry-in step: the same arithmetic on the same step
+    // by another lane, bit for bit, and one walk_step per lane instead of two.
     const int S = K.S;
     if (OBST && HOT && USTEP && K.K > 0) H->stage(__builtin_amdgcn_readfirstlane(i), i_next);
     const double s_i = r.s, sv_i = r.sv, sa_i = r.sa;
@@ -465,6 +470,10 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
     const double kap = fma(fma(fma(k_r, dp, k_r_d * d_i), tanTheta, dpp) * cosTheta, cok * cok, cok * k_r);
     const double v_i = sv_i * okc;
     const double a_i = fma(sa_i, okc, (sv2 * secTheta) * (oneKrD * tanTheta * fma(kap, okc, -k_r) - fma(k_r, dp, k_r_d * d_i)));
+    if (neigh) {
+        const double th_left = __shfl_up(th_gl, 1), kap_left = __shfl_up(kap, 1);
+        if (has_prev) { C.th_prev = th_left; C.kap_prev = kap_left; }
+    }
     // -- constraints (:480-533): bit r = reason r --
     if (emit) {
         uint32_t hit = 0;
@@ -723,10 +732,17 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                 any_now |= obs_hmask[w * S + iu];
                 any_next |= iu + 1 < S ? obs_hmask[w * S + iu + 1] : 0ULL;
             }
-            if ((any_now | any_next) != 0ULL && i >= 1) {
-                double su, cu;
+            const bool boxed = (any_now | any_next) != 0ULL && i >= 1;
+            double su = 0.0, cu = 0.0, bx = 0.0, by = 0.0;
+            if (boxed) {
                 heading_trig(r, cosTheta, tanTheta, cu, su);
-                const double bx = fma(K.wb, cu, x_i), by = fma(K.wb, su, y_i);
+                bx = fma(K.wb, cu, x_i); by = fma(K.wb, su, y_i);
+            }
+            if (neigh) {   // the left lane's box of step i - 1 (it built one whenever this step meets a hull: its `any_next` is this step's `any_now`)
+                const double bx_l = __shfl_up(bx, 1), by_l = __shfl_up(by, 1), cu_l = __shfl_up(cu, 1), su_l = __shfl_up(su, 1);
+                if (has_prev) { C.bx_prev = bx_l; C.by_prev = by_l; C.ux_prev = cu_l; C.uy_prev = su_l; }
+            }
+            if (boxed) {
                 if (!emit) any_now = 0ULL;
                 if (USTEP) any_now = uniform_u64(any_now);
                 if (any_now) {

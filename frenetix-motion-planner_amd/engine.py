@@ -259,9 +259,12 @@ class FrenetEngine:
         check(lib().fx_wait_published(self._ctx, out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
-    def set_fused_selection(self, enabled: bool):
-        """Selection fused into the evaluation kernel (default on; applies when no agent runs the collision stage)."""
-        check(lib().fx_set_fused_selection(self._ctx, int(bool(enabled))))
+    def set_fused_selection(self, enabled):
+        """Selection fused into the evaluation kernel (fx_set_fused_selection; default on): the agent's last workgroup reduces
+        the arg-min partials, counts the collisions in front of the winner (agents of at most 16 384 candidates whose obstacle
+        stage runs in the evaluation kernel), gathers the winner package and publishes -- one launch per step.  False / 0: always
+        the separate selection kernel; 2: in-kernel whatever the candidate count.  Takes effect at the next upload."""
+        check(lib().fx_set_fused_selection(self._ctx, 2 if enabled == 2 else int(bool(enabled))))
 
     def set_obstacle_stage(self, stage: int = 0, steps_per_item: int = 0):
         """Where the obstacle stage runs: 0 auto, 1 fused into the walk, 2 its own (candidate x step)-parallel kernel
@@ -276,7 +279,7 @@ class FrenetEngine:
         check(lib().fx_step_info_ex(self._ctx, v.ctypes.data))
         keys = ("grid_kernel", "lanes_per_candidate", "waves_per_simd", "block", "wave_split", "fused_selection", "blocks", "agents",
                 "package", "lds_bytes", "obstacle_kernel", "obstacle_steps_per_item", "obstacle_items", "obstacle_lds_bytes",
-                "obstacle_workgroup_waves")
+                "obstacle_workgroup_waves", "tail")
         return dict(zip(keys, (int(x) for x in v)))
 
     def obstacle_kernel_times(self, max_n: int = 256):

@@ -465,16 +465,21 @@ int32_t fx_device_views(FxContext *ctx, int32_t agent, void **cost, void **flags
 int64_t fx_device_bytes(const FxContext *ctx);
 double fx_last_kernel_ms(const FxContext *ctx);
 double fx_last_eval_kernel_ms(const FxContext *ctx);
-/* selection fused into the evaluation kernel (default on): when no agent of the step asks for FX_MODE_COLLISION the
- * evaluation kernel's last workgroup reduces the partial arg-mins and publishes the result, so a plan step is a
- * single launch; off = always run the separate selection kernel (same results; used by the parity tests) */
+/* selection fused into the evaluation kernel (default on): the evaluation kernel's last workgroup of an agent reduces the
+ * partial arg-mins and publishes the result, so a plan step is a single launch.  With FX_MODE_COLLISION it also counts the
+ * colliding candidates in front of the winner (planner.py:336-357) -- for agents of at most 16 384 candidates whose obstacle
+ * stage runs inside the evaluation kernel (planner-sized steps; larger ones and steps whose obstacle stage is its own kernel keep
+ * fx_select_kernel) -- and with fx_set_package it gathers the winner package: ReactivePlanner.plan() at the reference's operating
+ * point (planning.yaml:34-35, 630 / 800 candidates) is ONE launch.  0 = always run the separate selection kernel (same results;
+ * used by the parity tests), 1 = automatic, 2 = in-kernel whatever the candidate count (tests).  Takes effect at the next upload. */
 int32_t fx_set_fused_selection(FxContext *ctx, int32_t enabled);
 /* how the last evaluation was launched: grid kernel, lanes per candidate, waves per SIMD, workgroup size, wave split, fused
  * selection, workgroups per agent, agents, winner package, dynamic LDS bytes */
 int32_t fx_step_info(const FxContext *ctx, int64_t *out10);
 /* the same ten values, then: [10] obstacle stage ran as its own kernel, [11] its steps per work item, [12] work items (waves) per
  * agent (max), [13] dynamic LDS bytes, [14] waves per workgroup when the chunks of a tile share one workgroup (0: one wave per
- * (tile, chunk) item), [15] reserved */
+ * (tile, chunk) item), [15] what the agent's last workgroup did beyond the arg-min: bit 0 counted the collisions in front of the
+ * winner, bit 1 gathered the winner package (0 with a separate selection kernel) */
 int32_t fx_step_info_ex(const FxContext *ctx, int64_t *out16);
 /* HIP-event time of the obstacle kernel of the latest timed step / of the most recent <= max_n timed steps (FX_TIMING_KERNEL;
  * 0 where the stage ran fused into the walk) */

@@ -556,6 +556,111 @@ def test_fused_selection_equals_selection_kernel(eng, name, lanes):
         eng.set_tuning(0, 0, 0)
 
 
+@pytest.mark.parametrize("lanes", [0, 1, 4, 32])
+@pytest.mark.parametrize("name", ["dense_debug_obs", "dense_prod_obs", "dense_prod_scurve", "dense_lowvel", "dense_horizon5", "allcosts"])
+def test_fused_tail_counts_collisions_and_gathers_the_package(eng, name, lanes):
+    """One launch per step WITH the collision stage and the winner package (fx_tail.h): the agent's last workgroup counts the
+    colliding candidates in front of the winner (planner.py:336-357) and gathers the chosen trajectory itself.  Result block,
+    package block, coefficients and raw costs equal what the selection kernel (+ its gather) publishes, and the oracle's
+    collision count; repeated steps start from clean counters."""
+    from oracle import oracle
+    kw = dict(CASES[name])
+    kw.setdefault("n_obstacles", 6)
+    inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+    assert inp.collision and inp.obstacles["K"] > 0
+    want = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw), want_planes=False)["result"]
+    extra = any(n in inp.cost_names for n in ("acceleration", "jerk", "orientation_offset", "path_length", "distance_to_obstacles"))
+    eng.set_tuning(0 if extra else lanes, 0, 0)
+    eng.set_obstacle_stage(1)   # (the obstacle stage inside the evaluation kernel: what planner-sized steps run)
+    try:
+        eng.set_fused_selection(False)
+        ref, ref_pkg = eng.plan_step_packaged(inp, yaw_rate0=0.25)
+        info = eng.step_info()
+        assert not info["fused_selection"] and info["tail"] == 0
+        assert ref["n_collisions"] == want["n_collisions"] and ref["best_index"] == want["best_index"]
+        eng.set_fused_selection(2)
+        eng.upload(inp)   # (the choice is taken at upload time)
+        eng._resident_key = None
+        for rep in range(3):
+            got, pkg = eng.plan_step_packaged(inp, yaw_rate0=0.25)
+            info = eng.step_info()
+            # the tail lives in the planner-sized decompositions (>= 4 lanes per candidate) and in the windowed-cost kernel; a
+            # forced one-lane decomposition keeps the selection kernel
+            in_kernel = info["lanes_per_candidate"] >= 4 or extra
+            assert (info["fused_selection"], info["tail"]) == ((1, 3) if in_kernel else (0, 0)), info
+            for k in RESULT_KEYS:
+                assert got[k] == ref[k], (k, rep)
+            assert (pkg is None) == (ref_pkg is None)
+            if pkg is not None:
+                assert pkg.index == ref_pkg.index and pkg.cost == ref_pkg.cost and pkg.flags == ref_pkg.flags
+                assert pkg.traj_len == ref_pkg.traj_len and pkg.tau_lat == ref_pkg.tau_lat
+                assert np.array_equal(pkg.block, ref_pkg.block)
+                assert np.array_equal(pkg.lon, ref_pkg.lon) and np.array_equal(pkg.lat, ref_pkg.lat)
+                assert np.array_equal(pkg.raw_costs, ref_pkg.raw_costs)
+        # without the package: the count alone (tail = 1), several evaluations in a row before one finish
+        eng.upload(inp)
+        for _ in range(3):
+            eng.evaluate()
+        got = eng.finish()[0]
+        assert eng.step_info()["tail"] == (1 if in_kernel else 0)
+        for k in RESULT_KEYS:
+            assert got[k] == ref[k], k
+    finally:
+        eng.set_fused_selection(True)
+        eng.set_obstacle_stage(0)
+        eng.set_tuning(0, 0, 0)
+        eng._resident_key = None
+
+
+def _walled_in(hull_builder, **kw):
+    """inputs whose every candidate runs into a wall of five wide obstacles standing 7 m ahead across the whole road"""
+    from frenetix_motion_planner_amd import pack_predictions
+    inp = synthetic.make_inputs(hull_builder=hull_builder, n_obstacles=1, **kw)
+    cs, s0 = inp.coordinate_system, float(inp.x0_lon[0])
+    preds = {}
+    for j, dd in enumerate(np.linspace(-5.0, 5.0, 5)):
+        xy = np.array([cs.convert_to_cartesian_coords(s0 + 7.0, float(dd))] * 31, dtype=float)
+        preds[j] = dict(pos_list=xy, cov_list=np.tile(np.eye(2) * 0.1, (31, 1, 1)), orientation_list=np.full(31, float(cs.ref_theta[cs.segment_of(s0 + 7.0)])),
+                        shape=dict(length=4.0, width=3.5))
+    inp.obstacles = pack_predictions(preds, inp.n_samples, hull_builder)
+    inp.predictions = preds
+    inp._skey = None
+    return inp
+
+
+def test_fused_tail_everything_collides_and_nothing_selectable(eng):
+    """No collision-free candidate: every selectable candidate is counted, no winner, no package (`found` = 0); and a step in
+    which nothing is selectable at all (an ego far above every velocity the constraints allow)."""
+    from oracle import oracle
+    cases = [("wall", dict(ref_kind="straight", v0=8.0, grid=(3, 5, 7))), ("infeasible", dict(ref_kind="arc", kappa=0.05, v0=40.0, v_des=40.0, grid=(3, 5, 5), n_obstacles=2))]
+    for tag, kw in cases:
+        if tag == "wall":
+            inp, ref_inp = _walled_in(hip_hulls(), **kw), _walled_in(oracle.build_obstacle_hulls, **kw)
+        else:
+            inp = synthetic.make_inputs(hull_builder=hip_hulls(), **kw)
+            ref_inp = synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw)
+        want = oracle.plan_step(ref_inp, want_planes=False)
+        assert want["result"]["best_index"] == -1, tag
+        if tag == "wall":
+            assert want["result"]["n_collisions"] == int(want["selectable"].sum()) > 0
+        else:
+            assert int(want["selectable"].sum()) == 0
+        eng.set_obstacle_stage(1)
+        try:
+            eng.set_fused_selection(2)
+            eng._resident_key = None
+            for _ in range(2):
+                got, pkg = eng.plan_step_packaged(inp)
+                assert eng.step_info()["tail"] == 3
+                for k in ("best_index", "n_collisions", "n_feasible", "n_returned"):
+                    assert got[k] == want["result"][k], (tag, k)
+                assert pkg is None
+        finally:
+            eng.set_fused_selection(True)
+            eng.set_obstacle_stage(0)
+            eng._resident_key = None
+
+
 def test_fused_selection_batch(eng):
     kws = [dict(ref_kind="arc", v0=10.0, grid=(5, 9, 11), seed=1),
            dict(ref_kind="scurve", kappa=0.02, v0=6.0, grid=(4, 7, 9), seed=2, draw_traj_set=True, kinematic_debug=True),

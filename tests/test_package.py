@@ -221,3 +221,29 @@ def test_plan_batch_packaged_one_call_and_two_halves():
         res = (_abi.FxResult * 4)()
         pkg = (_abi.FxPackage * 4)()
         assert lib().fx_plan_batch_packaged(fresh._ctx, 4, None, None, res, pkg, None) != 0   # nothing uploaded yet
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_published_blocks_are_never_torn(fused):
+    """The result block and the winner package reach pinned host memory through system-scope stores that every wave drains
+    (`s_waitcnt vmcnt(0)`) before the sequence word is sent -- no L2 write-back fence (fx_tail.h).  4 000 steps alternating between
+    two agents' inputs with different winners: whenever the host sees a step's sequence word, every word of THAT step's result and
+    package is there (a torn publication would pair one step's winner with the other's arrays)."""
+    a = _inputs(seed=3)
+    b = _inputs(seed=4, v0=7.5)           # same structure: other ego state, other predictions
+    b.coordinate_system = a.coordinate_system
+    with _engine(max_candidates=4096) as eng:
+        eng.set_fused_selection(fused)
+        want = []
+        for inp in (a, b):
+            res, pkg = eng.plan_step_packaged(inp, yaw_rate0=0.0)
+            assert pkg is not None
+            want.append((res, pkg.index, pkg.cost, pkg.block.copy(), pkg.lon.copy(), pkg.raw_costs.copy()))
+        assert want[0][1] != want[1][1]
+        for k in range(4000):
+            inp, (res0, idx, cost, block, lon, raw) = (a, want[0]) if k % 2 == 0 else (b, want[1])
+            res, pkg = eng.plan_step_packaged(inp, yaw_rate0=0.0)
+            assert res["best_index"] == idx and res["best_cost"] == cost and res["n_collisions"] == res0["n_collisions"], k
+            assert res["n_feasible"] == res0["n_feasible"] and res["reason_hist"] == res0["reason_hist"], k
+            assert pkg.index == idx and pkg.cost == cost, k
+            assert np.array_equal(pkg.block, block) and np.array_equal(pkg.lon, lon) and np.array_equal(pkg.raw_costs, raw), k
