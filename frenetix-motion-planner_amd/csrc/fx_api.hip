@@ -835,8 +835,10 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     c->count_step = false;
     c->wt_step = false;
     // candidates per agent up to which the agent's last workgroup counts the collisions in front of the winner itself (it re-reads
-    // the agent's flag words: one round trip per 16 x workgroup-size candidates); larger steps keep fx_select_kernel's slices
-    static const int64_t tail_max_c = [] { const char *e = getenv("FX_TAIL_MAX_C"); return e ? (int64_t)atoll(e) : (int64_t)16384; }();
+    // the agent's flag words); larger steps keep fx_select_kernel's slices.  Measured (tools/probe_timeline.py, closed_loop_timing.py):
+    // the tail costs ~6.5 us at 630 candidates and 8 - 10 us at 11 000, the selection kernel + gather behind a launch gap ~8.5 - 10 us
+    // whatever the size -- plan() 70 -> 63 us at 630 candidates, 81 -> 84 us at 11 220: the bound sits between them
+    static const int64_t tail_max_c = [] { const char *e = getenv("FX_TAIL_MAX_C"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();
     c->max_blocks_step = 0;
     c->obs_blocks_step = 0;
     c->obs_tiles_step = 0;

@@ -161,19 +161,20 @@ __device__ __forceinline__ void fx_fused_tail(const PR &P, const DevProblem &Pg,
     // round trip overlaps the loads of the partials
     unsigned long long cnt = 0ULL;
     if (tid < FX_CNT_BEST_IDX) cnt = atomicExch(&P.counters[tid], 0ULL);
-    // the step's flag words: the first eight pairs per lane are requested together with the partials (a planner-sized step's
-    // whole flag array: 8 x 2 x nthreads candidates) -- the tail is a chain of round trips, this one rides with the first
+    // the step's flag words: the first FPRE pairs per lane are requested together with the partials (a planner-sized step's
+    // whole flag array) -- the tail is a chain of round trips, this one rides with the first
     const bool count_mode = (fuse.tail() & FX_TAIL_COUNT) && (P.mode & FX_MODE_COLLISION);
     const int64_t C = P.C;
     const int64_t n2 = (C + 1) / 2;   // pairs of flag words (ld is a multiple of 64: the last pair exists)
     const FX_GLOBAL unsigned long long *fl2 = reinterpret_cast<const FX_GLOBAL unsigned long long *>(as_global(P.flags));
     const FX_GLOBAL double *co = as_global(P.cost);
-    unsigned long long f_pre[8];
+    constexpr int FPRE = 24;   // flag pairs per lane requested up front: 48 x nthreads candidates (12 288 with 256 lanes) in ONE round trip
+    unsigned long long f_pre[FPRE];
     fx_d2c c_pre[4];   // ... and the costs of the first four pairs (8 x nthreads candidates: config 1's 630 / 800 with 128 lanes)
     c_pre[0] = c_pre[1] = c_pre[2] = c_pre[3] = fx_d2c{0.0, 0.0};
     if (count_mode) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < FPRE; u++) {
             const int64_t j = (int64_t)tid + (int64_t)u * nthreads;
             f_pre[u] = j < n2 ? ld_agent(fl2 + j) : 0ULL;
         }
@@ -219,31 +220,54 @@ __device__ __forceinline__ void fx_fused_tail(const PR &P, const DevProblem &Pg,
     unsigned long long collisions = 0ULL;
     if (count_mode) {
         unsigned int mine = 0;
-        auto visit = [&](unsigned long long two, int64_t j, bool have, fx_d2c cc) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t f = (uint32_t)(two >> (32 * h));
-                const int64_t g = 2 * j + h;
-                if (g < C && (f & FX_FLAG_SELECTABLE) && (f & FX_FLAG_COLLISION)) {
-                    if (none) mine++;
-                    else {
-                        const double c = have ? (h ? cc.y : cc.x) : ld_agent(co + g);
-                        if (c < bc || (c == bc && g + P.g_base < bi)) mine++;
-                    }
-                }
-            }
+        // one batch = eight flag pairs per lane.  The costs of what collides are requested for the WHOLE batch before the first
+        // comparison (a load inside the per-candidate branch is a round trip per candidate: 8 us for 11 000 candidates); lanes
+        // with nothing to ask read word 0 -- no branch around a load.  The first four pairs' costs came with the flags.
+        auto need = [&](unsigned long long two, int64_t j, int h) {
+            const uint32_t f = (uint32_t)(two >> (32 * h));
+            return 2 * j + h < C && (f & FX_FLAG_SELECTABLE) && (f & FX_FLAG_COLLISION);
         };
+        auto before = [&](double c, int64_t g) { return c < bc || (c == bc && g + P.g_base < bi); };
+        auto batch = [&](const unsigned long long *f2, int64_t j0, const fx_d2c *have) {
+            bool nd[16];
+            bool any = false;
 #pragma unroll
-        for (int u = 0; u < 8; u++) visit(f_pre[u], (int64_t)tid + (int64_t)u * nthreads, u < 4, c_pre[u < 4 ? u : 0]);
-        for (int64_t j0 = (int64_t)tid + 8 * (int64_t)nthreads; j0 < n2; j0 += 8 * (int64_t)nthreads) {
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) { nd[2 * u + h] = need(f2[u], j0 + (int64_t)u * nthreads, h); any |= nd[2 * u + h]; }
+            if (!__any(any)) return;
+            if (none) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) mine += nd[k] ? 1u : 0u;
+                return;
+            }
+            double c[16];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int64_t g = 2 * (j0 + (int64_t)u * nthreads) + h;
+                    if (have && u < 4) c[2 * u + h] = h ? have[u].y : have[u].x;
+                    else c[2 * u + h] = ld_agent(co + (nd[2 * u + h] ? g : 0));
+                }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    if (nd[2 * u + h] && before(c[2 * u + h], 2 * (j0 + (int64_t)u * nthreads) + h)) mine++;
+        };
+        batch(f_pre, (int64_t)tid, c_pre);
+#pragma unroll
+        for (int q = 1; q < FPRE / 8; q++)
+            if ((int64_t)q * 8 * nthreads < n2) batch(f_pre + 8 * q, (int64_t)tid + (int64_t)q * 8 * nthreads, nullptr);
+        for (int64_t j0 = (int64_t)tid + FPRE * (int64_t)nthreads; j0 < n2; j0 += 8 * (int64_t)nthreads) {
             unsigned long long f2[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int64_t j = j0 + (int64_t)u * nthreads;
                 f2[u] = j < n2 ? ld_agent(fl2 + j) : 0ULL;
             }
-#pragma unroll
-            for (int u = 0; u < 8; u++) visit(f2[u], j0 + (int64_t)u * nthreads, false, fx_d2c{0.0, 0.0});
+            batch(f2, j0, nullptr);
         }
         for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
         if (nw > 1) {

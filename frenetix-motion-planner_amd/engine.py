@@ -261,7 +261,7 @@ class FrenetEngine:
 
     def set_fused_selection(self, enabled):
         """Selection fused into the evaluation kernel (fx_set_fused_selection; default on): the agent's last workgroup reduces
-        the arg-min partials, counts the collisions in front of the winner (agents of at most 16 384 candidates whose obstacle
+        the arg-min partials, counts the collisions in front of the winner (agents of at most 8 192 candidates whose obstacle
         stage runs in the evaluation kernel), gathers the winner package and publishes -- one launch per step.  False / 0: always
         the separate selection kernel; 2: in-kernel whatever the candidate count.  Takes effect at the next upload."""
         check(lib().fx_set_fused_selection(self._ctx, 2 if enabled == 2 else int(bool(enabled))))

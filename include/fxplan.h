@@ -467,7 +467,7 @@ double fx_last_kernel_ms(const FxContext *ctx);
 double fx_last_eval_kernel_ms(const FxContext *ctx);
 /* selection fused into the evaluation kernel (default on): the evaluation kernel's last workgroup of an agent reduces the
  * partial arg-mins and publishes the result, so a plan step is a single launch.  With FX_MODE_COLLISION it also counts the
- * colliding candidates in front of the winner (planner.py:336-357) -- for agents of at most 16 384 candidates whose obstacle
+ * colliding candidates in front of the winner (planner.py:336-357) -- for agents of at most 8 192 candidates whose obstacle
  * stage runs inside the evaluation kernel (planner-sized steps; larger ones and steps whose obstacle stage is its own kernel keep
  * fx_select_kernel) -- and with fx_set_package it gathers the winner package: ReactivePlanner.plan() at the reference's operating
  * point (planning.yaml:34-35, 630 / 800 candidates) is ONE launch.  0 = always run the separate selection kernel (same results;

@@ -66,6 +66,9 @@ RUNS = dict(
     c1_g8=lambda: run("config-1 sized, G8", G=8, level=2, n_obstacles=5, draw_traj_set=True, kinematic_debug=True),
     cpp800=lambda: run("800-row sampling matrix (generic kernel)", matrix=True, level=2, cpp_style=True, n_obstacles=5),
     c4agent=lambda: run("10 488 candidates", grid=(19, 23, 24), n_obstacles=9),
+    c4agent_sel=lambda: run("10 488 candidates, selection kernel", fused=False, grid=(19, 23, 24), n_obstacles=9),
+    l4=lambda: run("level 4 (11 220 candidates), 5 obstacles", level=4, n_obstacles=5),
+    l4_sel=lambda: run("level 4 (11 220 candidates), 5 obstacles, selection kernel", fused=False, level=4, n_obstacles=5),
 )
 for name in sys.argv[1:] or ["c1", "c1_sel", "c1_noobs", "cpp800"]:
     RUNS[name]()
