@@ -800,6 +800,21 @@ def test_config3_full_size_vs_oracle():
             c = out["costed"] & robust
             assert (np.abs(cost[c] - out["cost"][c]) / np.maximum(np.abs(out["cost"][c]), 1e-12)).max() < COST_RTOL
             assert res["best_index"] == out["result"]["best_index"] and res["n_collisions"] == out["result"]["n_collisions"]
+            if not select_only:
+                # the planes of the bench-sized bundle: every 64th candidate (and the winner) against the oracle's forced-decision
+                # evaluation of that one candidate, at the fixed tolerance where the reference's own values carry digits
+                from tests.admissible import conditioning_many
+                ref_inp = synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw)
+                ids = np.unique(np.concatenate([np.arange(0, inp.n_candidates, 64), [res["best_index"]]]))
+                ids = ids[robust[ids] & out["returned"][ids] & out["costed"][ids]]
+                assert len(ids) > 300
+                want = np.stack([oracle.eval_forced(ref_inp, int(g))["planes"] for g in ids])
+                got = np.stack([e.sample(int(g)) for g in ids[:8]])
+                bundle_rows = np.stack([e.plane(p)[:, ids].T for p in range(_abi.FX_NUM_PLANES)], axis=1)   # [len(ids), 14, S]
+                assert np.array_equal(bundle_rows[:8], got)
+                err = np.abs(bundle_rows - want) / (1.0 + np.abs(want).max(axis=2, keepdims=True))
+                cond = conditioning_many(want)
+                assert (err.max(axis=(1, 2)) < STATE_TOL + 2e-14 * cond).all(), float(err.max())
     sel = np.nonzero(out["selectable"])[0]
     best500 = sel[np.argsort(out["cost"][sel], kind="stable")][:500]
     assert out["collision"][best500].mean() >= 0.25 and out["result"]["n_collisions"] > 500 and out["result"]["best_index"] >= 0

@@ -271,6 +271,25 @@ def test_closed_loop_on_the_engine_matches_the_oracle_engine(scenario):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_closed_loop_at_the_bench_grid_matches_the_oracle_engine(scenario):
+    """BASELINE config 4 as bench.py --workload config4 runs it: the dense 19 x 23 x 23 (+ d0) grid = 10 488 candidates per agent,
+    five agents, nine simulation steps (three plan steps per agent) -- same winners as the closed loop on the oracle-backed engine
+    at every step, states within 1e-6."""
+    cfg = lambda: PlannerConfig(sampling_min=0, sampling_max=1, dense_grid=(19, 23, 23))
+    ora, w_ora = _run_sim(scenario, 9, engine_factory=OracleEngine, config=cfg())
+    hip, w_hip = _run_sim(scenario, 9, config=cfg())
+    try:
+        sizes = {int(a.planner.last_step.n_candidates) for a in hip.batch.agents if a.planner.last_step is not None}
+        assert sizes and sizes <= {10488, 10488 - 19 * 23}, sizes   # (d0 may coincide with a lateral sample: 19 x 23 x 23)
+        assert w_hip == w_ora
+        assert np.abs(hip.plans - ora.plans).max() < 1e-6
+        assert hip.batch.launches == 3 * len(hip.batch.engines)
+    finally:
+        hip.close()
+
+
+@pytest.mark.gpu
 def test_config4_sized_batch(scenario):
     """Sampling level 4 (10 x 33 x 34 = 11 220 candidates per agent), five agents in one launch vs one agent at a time."""
     cfg = PlannerConfig(sampling_min=4, sampling_max=5)

@@ -93,3 +93,58 @@ def test_full_size_stress_properties():
         c = out["costed"] & robust
         assert (np.abs(cost[c] - out["cost"][c]) / np.maximum(np.abs(out["cost"][c]), 1e-12)).max() < COST_RTOL
         assert res[a]["best_index"] == out["result"]["best_index"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_full_size_batch_of_32_agents():
+    """The launch bench.py --workload config5 (and every rank of SCALE) times: 32 agents x 103 428 candidates x 51 samples x 20
+    obstacles in ONE batched launch (grid.y = 32), select-only, with the per-agent top-32 behind it.  Size-independent properties on
+    all 32 agents (winner = first collision-free entry of the stable cost order, top-k = its sorted prefix, counters = the flag
+    words' counts, collisions counted in front of the winner), batch == single launch for two of them, and the oracle over EVERY
+    candidate of two agents (multi-threaded range evaluation)."""
+    from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
+    from oracle import oracle
+    n = 32
+    agents = synthetic.stress_agents(n, hull_builder=build_obstacle_hulls)
+    assert all(a.n_candidates == 103428 and a.n_samples == 51 and a.obstacles["K"] == 20 for a in agents)
+    with FrenetEngine(max_candidates=n * 103428 + n * 64, max_steps=50, max_agents=n) as eng:
+        res = eng.plan_batch(agents)
+        info = eng.step_info()
+        assert info["agents"] == 32 and info["lanes_per_candidate"] == 1
+        tc, ti = eng.topk(32)
+        keep = {}
+        for a in range(n):
+            cost, flags = eng.costs(a)
+            if a in (5, 29):
+                keep[a] = (cost, flags)
+            sel = (flags & _abi.FX_FLAG_SELECTABLE) != 0
+            ok = sel & ((flags & (_abi.FX_FLAG_COLLISION | _abi.FX_FLAG_BOUNDARY)) == 0)
+            ids = np.nonzero(ok)[0]
+            order = ids[np.lexsort((ids, cost[ids]))]
+            assert res[a]["best_index"] == (order[0] if len(order) else -1), a
+            k = min(32, len(order))
+            assert np.array_equal(ti[a][:k], order[:k]) and np.array_equal(tc[a][:k], cost[order[:k]]) and np.all(ti[a][k:] == -1)
+            ret = (flags & _abi.FX_FLAG_RETURNED) != 0
+            assert res[a]["n_returned"] == int(ret.sum()) and res[a]["n_feasible"] == int((((flags & 3) == 3) & ret).sum())
+            coll = sel & ((flags & _abi.FX_FLAG_COLLISION) != 0)
+            if len(order):
+                w = order[0]
+                before = (cost[coll] < cost[w]) | ((cost[coll] == cost[w]) & (np.nonzero(coll)[0] < w))
+                assert res[a]["n_collisions"] == int(before.sum()), a
+            else:
+                assert res[a]["n_collisions"] == int(coll.sum())
+        assert sum(r["best_index"] >= 0 for r in res) >= 24
+        for a in (5, 29):   # batch == single launch
+            one = eng.plan_step(agents[a])
+            c1, f1 = eng.costs(0)
+            assert np.array_equal(f1, keep[a][1]) and np.allclose(c1, keep[a][0], rtol=1e-12, atol=0) and one["best_index"] == res[a]["best_index"]
+    ora = synthetic.stress_agents(n, hull_builder=oracle.build_obstacle_hulls)
+    for a in (5, 29):
+        out = oracle.plan_step(ora[a], want_planes=False)
+        robust = out["margin"] >= FRAGILE
+        cost, flags = keep[a]
+        assert np.array_equal(flags[robust], out["flags"][robust])
+        c = out["costed"] & robust
+        assert (np.abs(cost[c] - out["cost"][c]) / np.maximum(np.abs(out["cost"][c]), 1e-12)).max() < COST_RTOL
+        assert res[a]["best_index"] == out["result"]["best_index"] and res[a]["n_collisions"] == out["result"]["n_collisions"]
