@@ -264,18 +264,33 @@ def dry_launch(args, world, rank):
     """CPU-only check of the launch path: the ranks rendezvous over gloo, agree on the world size, rank 0 prints a line."""
     import torch
     import torch.distributed as dist
+    # what every rank would work on (no engine, no GPU): the candidate shard of the default workload, the agent slice of config 5,
+    # the (agent, part) items of config 4 -- gathered so that rank 0 can say whether the ranks' pieces cover the job exactly once
+    from frenetix_motion_planner_amd.distributed import hybrid_assignment, shard_range
+    C3 = 19 * 51 * 52 * max(world, 1)   # (make_workload: the velocity range sampled `world` times denser)
+    b, n = shard_range(C3, rank, world)
+    mine = [float(b), float(n), float(rank * args.agents_per_gpu), float(args.agents_per_gpu), float(len(hybrid_assignment(5, world)[rank]))]
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo")
         t = torch.tensor([1.0])
         dist.all_reduce(t)
         seen = int(t.item())
+        rows = [torch.zeros(5, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(rows, torch.tensor(mine, dtype=torch.float64))
+        rows = [r.tolist() for r in rows]
         dist.barrier()
         dist.destroy_process_group()
     else:
-        seen = 1
+        seen, rows = 1, [mine]
     if rank == 0:
-        print(json.dumps({"metric": "dry launch", "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup}))
+        edges = sorted((int(r[0]), int(r[0] + r[1])) for r in rows)
+        covered = edges[0][0] == 0 and edges[-1][1] == C3 and all(edges[i][1] == edges[i + 1][0] for i in range(len(edges) - 1))
+        agents = sorted(int(r[2]) for r in rows)
+        print(json.dumps({"metric": "dry launch", "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
+                          "workload": args.workload, "candidate_shards_cover_the_grid": bool(covered), "candidates_global": C3,
+                          "config5_first_agents": agents, "config5_agents_global": int(world * args.agents_per_gpu),
+                          "config4_items_per_rank": [int(r[4]) for r in rows]}))
     return 0
 
 
@@ -352,7 +367,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["config1", "config2", "config3", "config4", "config5"], default="config3")
+    ap.add_argument("--workload", choices=["config1", "config2", "config3", "config4", "config5"],
+                    default=os.environ.get("FX_BENCH_WORKLOAD", "config3"),
+                    help="default: config3 (the configuration BASELINE.json's metric is quoted on), or $FX_BENCH_WORKLOAD -- a driver that "
+                         "only passes --gpus / --steps / --warmup selects the agent-sharded workloads that way")
     ap.add_argument("--agents-per-gpu", type=int, default=32, help="config5: agents evaluated per GPU in one batched launch")
     ap.add_argument("--sampling-level", type=int, default=-1,
                     help="config4: reference sampling level of every agent instead of the dense 19 x 23 x 23 grid (4 -> 11 220 candidates)")
@@ -509,6 +527,31 @@ def main():
     pipelined = time.perf_counter() - tq
     eng.close()
 
+    # Several ranks, default workload: the line also carries BASELINE config 5 -- 32 agents per GPU, agent sharding, ONE per-agent
+    # top-k all-gather per step -- measured by the same ranks in the same run (`agent_sharding`).  Config 3's 85 us step puts a
+    # latency-bound all-gather on every step (DESIGN.md 6 predicts ~0.75 weak-scaling efficiency at 8 GPUs), config 5's 3.5 ms
+    # step hides it (~0.99): a driver that only passes --gpus N gets both figures.  Collective: every rank runs it or none
+    # (FX_BENCH_SHOWCASE=0 switches it off everywhere); the exchange goes through torch.distributed, the path the steps above
+    # have just used for their barriers.
+    showcase = None
+    sc_env = os.environ.get("FX_BENCH_SHOWCASE", "1")   # "force": also with one rank (what the GPU test-suite runs)
+    if (world > 1 and sc_env != "0") or sc_env == "force":
+        keep_env = os.environ.get("FX_EXCHANGE")
+        os.environ["FX_EXCHANGE"] = "torch"
+        try:
+            sub = argparse.Namespace(**vars(args))
+            sub.steps, sub.warmup, sub.preheat, sub.no_cpu_baseline = min(args.steps, 50), min(args.warmup, 5), 0.0, True
+            showcase = bench_stress(sub, world, rank, local_rank, torch, dist, emit=False)
+            if rank != 0:
+                showcase = None
+        except Exception as e:   # (a Python-level failure is the same on every rank: the headline line still goes out)
+            showcase = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
+        finally:
+            if keep_env is None:
+                os.environ.pop("FX_EXCHANGE", None)
+            else:
+                os.environ["FX_EXCHANGE"] = keep_env
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = C_global * args.steps / elapsed
@@ -581,6 +624,10 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        if showcase is not None:
+            out["agent_sharding"] = showcase if "error" in showcase else {
+                k: showcase[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "config",
+                                         "plan_step_p50_ms", "eval_kernel_ms", "agents_with_winner")}
         if n_obst:
             out["roofline_hbm"] = hbm
         # the whole step against the HBM roofline: algorithmic bytes of the step over the STEP's wall time (launch gaps, obstacle
@@ -653,8 +700,10 @@ def _timed(args, world, dist, torch, step, est_step_s=1e-4):
     return elapsed, lat
 
 
-def bench_stress(args, world, rank, local_rank, torch, dist):
-    """BASELINE config 5: agents sharded over the GPUs, one batched launch per step, per-agent top-k gather."""
+def bench_stress(args, world, rank, local_rank, torch, dist, emit=True):
+    """BASELINE config 5: agents sharded over the GPUs, one batched launch per step, per-agent top-k gather.
+    emit=False: called from the default workload's multi-rank run -- rank 0 returns the record instead of printing it, the
+    process group stays up."""
     from frenetix_motion_planner_amd import synthetic
     from frenetix_motion_planner_amd.distributed import ShardedEvaluator
     from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
@@ -719,8 +768,11 @@ def bench_stress(args, world, rank, local_rank, torch, dist):
             from oracle import oracle
             one = synthetic.stress_agents(1, grid=STRESS_GRID, hull_builder=oracle.build_obstacle_hulls)[0]
             out["cpu_baseline"] = cpu_baseline_of(one, f"agent 0 ({one.n_candidates} candidates x {S} samples, {K} obstacles)")
-        print(json.dumps(out))
+        if emit:
+            print(json.dumps(out))
     eng.close()
+    if not emit:
+        return out if rank == 0 else None   # (`out` exists on rank 0)
     if world > 1:
         dist.destroy_process_group()
 

@@ -460,8 +460,18 @@ class ShardedEvaluator:
                 g = self.engine.wait_published().reshape(w, 2, self.n_local, self.k)
                 surv = (g[:, 0].copy(), g[:, 1].copy().view(np.int64))
             else:
+                # host tensors (gloo, or one rank without a device group): the same rows, gathered with torch.distributed on the host
                 c, i = self.engine.topk(self.k)
-                surv = (c[None], i[None])
+                if self.world > 1:
+                    tc = self.torch.from_numpy(np.ascontiguousarray(c, dtype=np.float64))
+                    ti = self.torch.from_numpy(np.ascontiguousarray(i, dtype=np.int64))
+                    gcl = [self.torch.empty_like(tc) for _ in range(self.world)]
+                    gil = [self.torch.empty_like(ti) for _ in range(self.world)]
+                    self.dist.all_gather(gcl, tc, group=self.group)
+                    self.dist.all_gather(gil, ti, group=self.group)
+                    surv = (self.torch.stack(gcl).numpy(), self.torch.stack(gil).numpy())
+                else:
+                    surv = (c[None], i[None])
         res = self.engine.finish()
         return res, surv
 

@@ -26,8 +26,24 @@ def test_gpus_n_starts_its_own_ranks_dry():
     involved: the launch path the driver uses for the scaling runs."""
     d = run("--gpus", "2", "--dry-launch", "--steps", "3", "--warmup", "1", timeout=300)
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["candidate_shards_cover_the_grid"] and d["candidates_global"] == 2 * 50388 and d["config4_items_per_rank"] == [3, 2]
     one = run("--dry-launch")
-    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1 and one["workload"] == "config3"
+
+
+@pytest.mark.timeout(600)
+def test_dry_launch_at_the_node_size_and_workload_from_the_environment():
+    """The driver's multi-GPU invocation -- plain `--gpus 8 --steps K --warmup W` -- reaches eight ranks that agree on the job:
+    contiguous candidate shards covering the weak-scaled grid exactly once, config 5's 8 x 32 agents, config 4's five agents as one
+    item per rank.  $FX_BENCH_WORKLOAD selects the agent-sharded workloads for a driver that cannot pass --workload."""
+    d = run("--gpus", "8", "--dry-launch", "--steps", "2", "--warmup", "1", timeout=500)
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8
+    assert d["candidate_shards_cover_the_grid"] and d["candidates_global"] == 8 * 50388
+    assert d["config5_first_agents"] == [32 * r for r in range(8)] and d["config5_agents_global"] == 256
+    assert d["config4_items_per_rank"] == [1] * 8
+    env = dict(os.environ, FX_BENCH_WORKLOAD="config5")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-launch"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["workload"] == "config5"
 
 
 @pytest.mark.gpu
@@ -97,3 +113,20 @@ def test_cpu_baseline_object_and_other_workloads():
     # executed work or nothing: a fraction is only printed when the tracked PMC summary holds the kernel that ran
     cp = d5["compute"]
     assert cp["frac"] is None and cp["flops_source"].startswith("stale") or 0 < cp["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_multi_rank_line_carries_the_agent_sharded_workload():
+    """With several ranks the default line also reports BASELINE config 5 measured by the same ranks (`agent_sharding`); here the
+    same code path forced with ONE rank (FX_BENCH_SHOWCASE=force), 8 agents per GPU to keep it short."""
+    env = dict(os.environ, FX_BENCH_SHOWCASE="force")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-north-star",
+                        "--agents-per-gpu", "8"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    a = d["agent_sharding"]
+    assert "error" not in a, a
+    assert "config3" in d["config"]["workload"] and "config5" in a["config"]["workload"]
+    assert a["config"]["agents_per_gpu"] == 8 and a["n_gpus"] == 1 and a["value"] > 1e8 and a["agents_with_winner"] >= 4

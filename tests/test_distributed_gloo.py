@@ -754,3 +754,95 @@ def test_rccl_world2_library_and_torch_exchange():
             eng.plan_batch(agents)
             tc, ti = eng.topk(8)
         assert np.array_equal(si[r], ti) and np.array_equal(sc[r], tc)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Eight real processes over gloo (the node's world size): BASELINE config 5's agent round-robin with the per-agent top-k gather,
+# and BASELINE config 4's five agents on eight ranks (hybrid agent x candidate split).  Reduced grids, the oracle-backed engine.
+# ---------------------------------------------------------------------------------------------------------
+class _BatchOracleEngine(OracleEngine):
+    """the stand-in with the resident-batch surface ShardedEvaluator.step_agents_enqueued drives (upload / evaluate / finish)"""
+
+    def upload(self, inputs):
+        self._resident = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
+
+    def evaluate(self):
+        self._res = self.plan_batch(self._resident)
+
+    def finish(self):
+        return self._res
+
+
+def _world8_worker(rank, world, port, q, n_agents_total, k):
+    sys.path.insert(0, ROOT)
+    import datetime
+    import torch.distributed as dist
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.distributed import ShardedEvaluator, hybrid_assignment
+    from oracle import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        # config 5: agent a of the global list lives on rank a // n_local (bench.py: first_agent = rank * n_local)
+        n_local = n_agents_total // world
+        agents = synthetic.stress_agents(n_local, grid=(3, 5, 5), n_obstacles=3, first_agent=rank * n_local,
+                                         hull_builder=oracle.build_obstacle_hulls)
+        eng = _BatchOracleEngine()
+        ev = ShardedEvaluator(eng, k=k)
+        ev.setup_agents(n_local)
+        eng.upload(agents)
+        res, (sc, si) = ev.step_agents_enqueued()
+        # config 4: five agents on eight ranks, every rank one item, split agents merged by the (cost, index) minimum
+        five = [synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, ref_kind="arc", v0=6.0 + 2 * a, grid=(4, 7, 9),
+                                      n_obstacles=a % 3, seed=a) for a in range(5)]
+        ev2 = ShardedEvaluator(OracleEngine(), k=1)
+        hyb = ev2.plan_agents(five)
+        q.put((rank, sc.shape, sc.tolist(), si.tolist(), [r["best_index"] for r in res],
+               [(h["best_index"], h["best_cost"]) for h in hyb], hybrid_assignment(5, world)[rank]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_world8_agent_round_robin_and_hybrid_split():
+    """WORLD_SIZE = 8 with real processes (gloo): (a) BASELINE config 5's exchange -- 64 agents (8 per rank here; 32 per rank in the
+    bench), one per-agent top-k all-gather -- leaves EVERY rank with every agent's survivors, equal to a single process planning
+    each agent on its own; (b) BASELINE config 4's 5 agents on 8 ranks: three agents split over two ranks each, two whole, nobody
+    idles, every rank ends with every agent's global winner == the unsplit agent's."""
+    from frenetix_motion_planner_amd import synthetic
+    from oracle import oracle
+    world, n_total, k = 8, 64, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q, n_total, k)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in range(world)), key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # (a) every rank holds the same [world, n_local, k] survivor block, and it is what one process finds agent by agent
+    n_local = n_total // world
+    assert all(g[1] == (world, n_local, k) for g in got)
+    assert all(g[2] == got[0][2] and g[3] == got[0][3] for g in got)
+    cost, idx = np.array(got[0][2]), np.array(got[0][3])
+    single = _BatchOracleEngine()
+    agents = synthetic.stress_agents(n_total, grid=(3, 5, 5), n_obstacles=3, hull_builder=oracle.build_obstacle_hulls)
+    want = single.plan_batch(agents)
+    tc, ti = single.topk(k)
+    assert np.array_equal(idx.reshape(n_total, k), ti) and np.array_equal(cost.reshape(n_total, k), tc)
+    for r, g in enumerate(got):   # each rank's local winners are its slice of the global list
+        assert g[4] == [w["best_index"] for w in want[r * n_local:(r + 1) * n_local]]
+    assert sum(w["best_index"] >= 0 for w in want) >= n_total // 2
+    # (b) the hybrid split: 8 = 3 x 2 + 2 x 1, one item per rank, the same winners everywhere
+    items = [g[6] for g in got]
+    assert all(len(it) == 1 for it in items)
+    assert sorted((a, p, n) for ((a, p, n),) in items) == [(0, 0, 2), (0, 1, 2), (1, 0, 2), (1, 1, 2), (2, 0, 2), (2, 1, 2), (3, 0, 1), (4, 0, 1)]
+    assert all(g[5] == got[0][5] for g in got)
+    for a, (bi, bc) in enumerate(got[0][5]):
+        inp = synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, ref_kind="arc", v0=6.0 + 2 * a, grid=(4, 7, 9),
+                                    n_obstacles=a % 3, seed=a)
+        ref = oracle.plan_step(inp, want_planes=False)["result"]
+        assert bi == ref["best_index"] and bc == ref["best_cost"]
