@@ -15,9 +15,11 @@ CMD[config3_modeB]="$R/tools/run_bench_workload.py config3 20"
 CMD[config2_modeB]="$R/tools/run_bench_workload.py config2 20"
 CMD[north_star_obstacles]="$R/tools/run_bench_workload.py north_star_obstacles 8"
 CMD[north_star_bundle]="$R/tools/run_bench_workload.py north_star_bundle 8"
+CMD[north_star_bundle_obstacles]="$R/tools/run_bench_workload.py north_star_bundle_obstacles 8"
+CMD[config1]="$R/bench.py --workload config1 --steps 200 --warmup 20 --no-cpu-baseline"
 CMD[config5_modeA]="$R/bench.py --workload config5 --agents-per-gpu 32 --steps 4 --warmup 1 --no-cpu-baseline --preheat 0"
 GROUPS_PMC=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM")
-for sec in config3_modeB config2_modeB north_star_obstacles north_star_bundle config5_modeA; do
+for sec in config3_modeB config2_modeB north_star_obstacles north_star_bundle north_star_bundle_obstacles config1 config5_modeA; do
   i=0
   for grp in "${GROUPS_PMC[@]}"; do
     (cd /tmp && rocprofv3 --pmc $grp --output-format csv -d $O/pmc_${sec}_$i -- python3 ${CMD[$sec]} > $O/pmc_${sec}_$i.log 2>&1)
@@ -37,6 +39,8 @@ out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "A
 cmds = {"config3_modeB": "python3 tools/run_bench_workload.py config3 20", "config2_modeB": "python3 tools/run_bench_workload.py config2 20",
         "north_star_obstacles": "python3 tools/run_bench_workload.py north_star_obstacles 8",
         "north_star_bundle": "python3 tools/run_bench_workload.py north_star_bundle 8",
+        "north_star_bundle_obstacles": "python3 tools/run_bench_workload.py north_star_bundle_obstacles 8",
+        "config1": "python3 bench.py --workload config1 --steps 200 --warmup 20 --no-cpu-baseline",
         "config5_modeA": "python3 bench.py --workload config5 --agents-per-gpu 32 --steps 4 --warmup 1 --no-cpu-baseline --preheat 0"}
 for sec, cmd in cmds.items():
     agg = collections.defaultdict(lambda: collections.defaultdict(list))

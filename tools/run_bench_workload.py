@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One of bench.py's workloads, a few resident steps with the automatic tuning (driver for rocprofv3 passes; the inputs are built
 by bench.make_workload, so the kernels are exactly those of the bench line).
-usage: run_bench_workload.py <config3|config2|north_star_obstacles|north_star_bundle> [steps]"""
+usage: run_bench_workload.py <config3|config2|north_star_obstacles|north_star_bundle|north_star_bundle_obstacles> [steps]"""
 import os, sys, types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,6 +14,8 @@ if name in ("config3", "config2"):
     inp = bench.make_workload(args, 1)
 elif name == "north_star_obstacles":
     inp = bench.make_workload(args, 1, grid=bench.NORTH_STAR_GRID, n_obst=20, select_only=True)
+elif name == "north_star_bundle_obstacles":
+    inp = bench.make_workload(args, 1, grid=bench.NORTH_STAR_GRID, n_obst=20, select_only=False)
 else:
     inp = bench.make_workload(args, 1, grid=bench.NORTH_STAR_GRID, n_obst=0, select_only=False)
 with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N, max_ref_knots=1024, max_obstacles=32, max_pred_steps=64) as eng:
