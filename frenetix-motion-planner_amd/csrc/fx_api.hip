@@ -209,6 +209,7 @@ struct FxContext {
     bool count_step = false;          // some agent of the upload runs the collision stage inside the evaluation kernel
     bool wt_step = false;             // the upload's plane stores are write-through
     uint32_t tail_step = 0;           // FX_TAIL_* of the last evaluation
+    size_t gen_rec_lds = 0;           // generic kernel, >= 4 lanes per candidate: bytes of the staged obstacle records + step masks
     int64_t dev_bytes = 0;
 };
 
@@ -827,6 +828,25 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         c->wsplit_step = ws_possible && c->wsplit_force != 1;
         if (c->wsplit_force == 2 && !ws_possible && G > 1) return set_err(FX_ERR_INVALID_ARGUMENT, "wave split forced but not applicable");
     }
+    // lane-split kernels with the obstacle stage inside: which agents' record tables ride in LDS (FX_MODE_INT_REC_LDS).  Grid
+    // kernel: lds_for above has made room by the same rule; generic kernel (>= 4 lanes per candidate): behind the knots and the time
+    // table where everything still fits a CU
+    const bool rec_rule_grid = c->use_grid && c->G_step > 1 && !c->wsplit_step;
+    bool rec_rule_gen = false;
+    c->gen_rec_lds = 0;
+    if (!c->use_grid && c->G_step >= 4) {
+        size_t base_max = 0, need = 0;
+        bool any_obst_in = false;
+        for (int a = 0; a < n_agents; a++) {
+            const FxProblem *p = &probs[a];
+            const size_t S = (size_t)p->N + 1;
+            base_max = std::max(base_max, sizeof(double) * ((size_t)p->M * (FX_REF_FIELDS + 1) + 2 + FX_TP * S));
+            const size_t rb = sizeof(double) * (size_t)S_rec_doubles((int)S, std::max(p->K, 0));
+            if (p->K > 0 && p->K <= 64 && rb <= FX_REC_LDS_MAX) need = std::max(need, rb + 16 * S);
+            any_obst_in |= p->K > 0;
+        }
+        if (any_obst_in && need && base_max + need <= (size_t)160 * 1024 - 2048) { rec_rule_gen = true; c->gen_rec_lds = need; }
+    }
     const int CPB = c->block_step / c->G_step;
     int64_t cand_off = 0, block_off = 0;
     size_t planes_need = 0, obs_part_need = 0, obs_colm_need = 0, obs_tick_need = 0;
@@ -863,7 +883,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             return set_err(FX_ERR_CAPACITY, "obstacles K=%d P=%d exceed capacity %d x %d", p->K, p->P, c->max_obs, c->max_pred);
         // only the generic kernel stages the whole knot records (64 B each) in LDS; the grid kernel keeps 8 B per knot and its
         // LDS need was checked when it was chosen above
-        if (!c->use_grid && ((size_t)p->M * FX_REF_FIELDS + FX_TP * (size_t)S) * sizeof(double) > 160 * 1024 - 1024)
+        if (!c->use_grid && ((size_t)p->M * (FX_REF_FIELDS + 1) + 2 + FX_TP * (size_t)S) * sizeof(double) > 160 * 1024 - 1024)
             return set_err(FX_ERR_CAPACITY, "reference with %d knots does not fit the 160 KiB LDS of the generic kernel (sampling matrix / "
                            "windowed costs); resample the reference or use sampling ranges", p->M);
         const int64_t ld = (int64_t)align_up((size_t)std::max<int64_t>(C, 1), 64);
@@ -977,6 +997,10 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         const int walk_blocks = (int)((C + CPB - 1) / CPB);
         d.n_blocks = walk_blocks;
         const bool deferred = c->split_step && p->K > 0;
+        {
+            const size_t rb = sizeof(double) * (size_t)S_rec_doubles(S, std::max(p->K, 0));
+            if (!deferred && p->K > 0 && p->K <= 64 && rb <= FX_REC_LDS_MAX && (rec_rule_grid || rec_rule_gen)) d.mode |= FX_MODE_INT_REC_LDS;
+        }
         if (deferred) {   // the obstacle kernel writes this agent's arg-min partials: one per tile of 64 candidates
             d.mode |= FX_MODE_INT_DEFER_OBST;
             const int n_tiles = (int)((C + 63) / 64), NC = (S - 1 + c->split_CH - 1) / c->split_CH;
@@ -1148,7 +1172,8 @@ int32_t fx_evaluate(FxContext *c) {
                                         c->any_bundle, c->any_obst, c->wpe_step, c->wsplit_step, k0, k1, fuse, c->stream));
         else
             HIP_TRY(fx_launch_eval(c->d_probs, c->n_agents, c->max_blocks_step,
-                                   sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + FX_TP * (size_t)c->S_max_step),
+                                   sizeof(double) * ((size_t)c->M_max_step * FX_REF_FIELDS + FX_TP * (size_t)c->S_max_step +
+                                                     (((size_t)c->M_max_step + 1) & ~(size_t)1)) + c->gen_rec_lds,
                                    c->G_step, c->any_bundle, c->any_obst, c->any_extra, c->wpe_step, k0, k1, fuse, c->stream));
     }
     if (timed && !attached) HIP_TRY(hipEventRecord(ts->e_eval, c->stream));

@@ -14,6 +14,9 @@
 // walk (fx_obstacle_kernel.h): the walk leaves the cost sum up to the prediction term in cost[], the terms behind it in
 // cost_tail[], and no arg-min partial; the obstacle kernel completes cost / flags / cost map and writes the partials
 #define FX_MODE_INT_DEFER_OBST (1u << 29)
+// internal DevProblem.mode bit: the agent's obstacle record table rec[S][K][12] and its two step masks are staged in the dynamic
+// LDS of the lane-split evaluation kernels (the host has sized the launch's LDS for them: fx_api.hip)
+#define FX_MODE_INT_REC_LDS (1u << 28)
 #define FX_HOT_STRIDE 10        // doubles per (step, obstacle) entry of the hot obstacle table (80 B)
 #define FX_HOT_PRE 4            // table elements per lane prefetched one step ahead (covers K <= 25 obstacles)
 #define FX_TP 14                // doubles per step of the time table in LDS: t .. t^5, then 2t, 3t^2, 4t^3, 5t^4, 6t, 12t^2, 20t^3, then the

@@ -89,13 +89,13 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     // 96-byte record per (step, obstacle) and lane.  From global memory that is a dependent round trip per visited obstacle -- the
     // walk of a 630-candidate step with five obstacles took 7 - 9 us against 3 us without obstacles (tools/probe_timeline.py) --, so
     // the workgroup copies the agent's whole record table and the step masks into LDS with the other tables of phase 1 (where they
-    // fit: FX_REC_LDS_MAX; the host sizes the dynamic LDS by the same rule, fx_api.hip lds_for)
+    // fit: FX_REC_LDS_MAX; the host sizes the dynamic LDS for them and says so in the agent's mode word, fx_api.hip)
     constexpr bool LSTAGE = OBST && !(G == 1 || WSPLIT);
     const int rec_n = P.K > 0 ? S_rec_doubles(P.S, P.K) : 0;
 #ifdef FX_NO_LSTAGE   // (probe builds: A/B of the staging)
     const bool rec_staged = false;
 #else
-    const bool rec_staged = LSTAGE && rec_n > 0 && (size_t)rec_n * sizeof(double) <= FX_REC_LDS_MAX;
+    const bool rec_staged = LSTAGE && rec_n > 0 && (P.mode & FX_MODE_INT_REC_LDS) != 0;
 #endif
     double *__restrict__ rec_lds = reinterpret_cast<double *>(lds_tail + sizeof(double) * (((size_t)P.M + 1) & ~(size_t)1));
     unsigned long long *__restrict__ pm_lds = reinterpret_cast<unsigned long long *>(rec_lds + rec_n);   // [S] | [S]

@@ -630,9 +630,84 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     const int64_t g = active ? g_raw : C - 1;
 
     const int M = P.M, S = P.S;
-    {
+    // planner-sized decompositions: the obstacle records of the step and the two step masks behind the time table (every lane
+    // walks another step: from global memory a dependent round trip per visited obstacle; fx_eval_grid_kernel.h has the same)
+    constexpr bool LSTAGE = OBST && G >= 4;
+    const int rec_n = P.K > 0 ? S_rec_doubles(S, P.K) : 0;
+    const bool rec_staged = LSTAGE && rec_n > 0 && (P.mode & FX_MODE_INT_REC_LDS) != 0;   // (the host sized the LDS for it)
+    // the knots' arc lengths once more as a dense array: the segment lookup bisects it (on a non-uniform reference -- the
+    // config-1 route: 0.1 ... 1.0 m between knots -- the uniform-spacing guess misses and every lane walks nine levels; through
+    // the 64-byte knot records that is a 16-way bank conflict per level: 43 us for the 800-row matrix against 25 us on an arc)
+    double *__restrict__ rpos = lds_dyn + (size_t)M * FX_REF_FIELDS + (size_t)FX_TP * S;   // [M], padded to an even count
+    double *__restrict__ rec_lds = rpos + (((size_t)M + 1) & ~(size_t)1);
+    unsigned long long *__restrict__ pm_lds = reinterpret_cast<unsigned long long *>(rec_lds + rec_n);   // [S] | [S]
+    if constexpr (G >= 4) {
+        // every table's first batch of loads is requested before the first LDS write (a copy loop is a round trip per iteration:
+        // the 409 knots of the config-1 route cost thirteen of them)
+        const FX_GLOBAL fx_d2 *__restrict__ src = reinterpret_cast<const FX_GLOBAL fx_d2 *>(as_global(P.ref));   // (256-byte aligned slots)
+        fx_d2 *__restrict__ kdst = reinterpret_cast<fx_d2 *>(lds_dyn);
+        const int nk2 = M * FX_REF_FIELDS / 2;
+        fx_d2 kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) kv[u] = src[min(tid + u * FX_BLOCK, nk2 - 1)];
+        const FX_GLOBAL double *__restrict__ tsrc = as_global(P.tpow);
+        const int it = min(tid, S - 1);
+        const double t1 = tsrc[it], t2 = tsrc[S + it], t3 = tsrc[2 * S + it], t4 = tsrc[3 * S + it], t5 = tsrc[4 * S + it];
+        const FX_GLOBAL fx_d2 *__restrict__ rsrc = reinterpret_cast<const FX_GLOBAL fx_d2 *>(as_global(P.obs_rec));
+        fx_d2 *__restrict__ rdst = reinterpret_cast<fx_d2 *>(rec_lds);
+        const int n2 = rec_n / 2;
+        fx_d2 rv[4];
+        unsigned long long m0 = 0ULL, m1 = 0ULL;
+        if (rec_staged) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) rv[u] = rsrc[min(tid + u * FX_BLOCK, n2 - 1)];
+            m0 = as_global(P.obs_pmask)[it]; m1 = as_global(P.obs_hmask)[it];
+        }
+        int32_t cid = 0;
+        double cw = 0.0;
+        if (tid < P.n_cost) { cid = Pg.cost_id[tid]; cw = Pg.cost_w[tid]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = tid + u * FX_BLOCK;
+            if (e < nk2) { kdst[e] = kv[u]; if ((e & 3) == 0) rpos[e >> 2] = kv[u].x; }   // (pair 4 k holds knot k's arc length)
+        }
+        if (tid < S) {
+            fill_time_row(lds_dyn + M * FX_REF_FIELDS + tid * FX_TP, t1, t2, t3, t4, t5);
+            if (rec_staged) { pm_lds[tid] = m0; pm_lds[S + tid] = m1; }
+        }
+        if (rec_staged) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (tid + u * FX_BLOCK < n2) rdst[tid + u * FX_BLOCK] = rv[u];
+        }
+        if (tid < P.n_cost) { sh_cost_id[tid] = cid; sh_cost_w[tid] = cw; }
+        for (int e0 = tid + 8 * FX_BLOCK; e0 < nk2; e0 += 8 * FX_BLOCK) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) kv[u] = src[min(e0 + u * FX_BLOCK, nk2 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * FX_BLOCK;
+                if (e < nk2) { kdst[e] = kv[u]; if ((e & 3) == 0) rpos[e >> 2] = kv[u].x; }
+            }
+        }
+        for (int i = tid + FX_BLOCK; i < S; i += FX_BLOCK) {
+            fill_time_row(lds_dyn + M * FX_REF_FIELDS + i * FX_TP, tsrc[i], tsrc[S + i], tsrc[2 * S + i], tsrc[3 * S + i], tsrc[4 * S + i]);
+            if (rec_staged) { pm_lds[i] = as_global(P.obs_pmask)[i]; pm_lds[S + i] = as_global(P.obs_hmask)[i]; }
+        }
+        if (rec_staged) {
+            for (int e0 = tid + 4 * FX_BLOCK; e0 < n2; e0 += 4 * FX_BLOCK) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) rv[u] = rsrc[min(e0 + u * FX_BLOCK, n2 - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (e0 + u * FX_BLOCK < n2) rdst[e0 + u * FX_BLOCK] = rv[u];
+            }
+        }
+    } else {
         const FX_GLOBAL double *__restrict__ src = as_global(P.ref);
-        for (int i = tid; i < M * FX_REF_FIELDS; i += FX_BLOCK) lds_dyn[i] = src[i];
+        for (int i = tid; i < M * FX_REF_FIELDS; i += FX_BLOCK) {
+            const double v = src[i];
+            lds_dyn[i] = v;
+            if ((i & (FX_REF_FIELDS - 1)) == 0) rpos[i / FX_REF_FIELDS] = v;
+        }
         const FX_GLOBAL double *__restrict__ tsrc = as_global(P.tpow);
         for (int i = tid; i < S; i += FX_BLOCK)
             fill_time_row(lds_dyn + M * FX_REF_FIELDS + i * FX_TP, tsrc[i], tsrc[S + i], tsrc[2 * S + i], tsrc[3 * S + i], tsrc[4 * S + i]);
@@ -716,7 +791,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     const bool want_trig = OBST && ((do_collision && P.K > 0) || ((P.mode & FX_MODE_ROAD_BOUNDARY) && P.n_bound > 0));
     auto row_at = [&](int i) {
         return make_lon_row(i, S, M, dt, a_max, cl0, cl1, cl2, cl3, cl4, cl5, traj_len, tp, rp_first, rp_last, guess_scale,
-                            want_trig, [&](int k) { return knots[k]; }, [&](int k) { return knots[k].pos; },
+                            want_trig, [&](int k) { return knots[k]; }, [&](int k) { return rpos[k]; },
                             (P.mode & FX_MODE_PROJ_PSEUDO_NORMAL) != 0);
     };
     auto lat_eval = [&](int i, double u_lowvel, double &d, double &dv, double &da) {
@@ -758,11 +833,20 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     StepCarry Cy;
     Cy.th_prev = P.x0_orientation; Cy.kap_prev = 0.0; Cy.bx_prev = Cy.by_prev = Cy.ux_prev = Cy.uy_prev = 0.0;
     if (G > 1 && !low_vel && i_first > 0 && i_first < S) {
-        // the carry-in step keeps the previous heading when it stands still: scan back to the last moving step (:447)
-        if (!(row_at(i_first).flags & LON_MOVING)) {
+        // the carry-in step keeps the previous heading when it stands still: scan back to the last moving step (:447).  The scan
+        // only needs each step's LON_MOVING bit -- the longitudinal velocity, make_lon_row's own expression -- and builds ONE row,
+        // the one it stops at (a full row per scanned step made a braking ego's step 42 us where a cruising one took 23:
+        // BASELINE config 1's 800-row matrix, v0 = 5.6 m/s)
+        auto moving_at = [&](int i) {
+            const double *te = tp + (i < traj_len ? i : traj_len - 1) * FX_TP;
+            double sv = cl1 + 2. * cl2 * te[0] + 3. * cl3 * te[1] + 4. * cl4 * te[2] + 5. * cl5 * te[3];
+            if (fabs(sv) < FX_EPS) sv = 0.0;
+            return sv > 0.001;
+        };
+        if (!moving_at(i_first)) {
             for (int j = i_first - 1; j >= 0; j--) {
-                const LonRow rj = row_at(j);
-                if (rj.flags & LON_MOVING) {
+                if (moving_at(j)) {
+                    const LonRow rj = row_at(j);
                     double d_j, dv_j = 0.0, da_j;
                     if (j < traj_len) lat_eval(j, rj.u1, d_j, dv_j, da_j);
                     Cy.th_prev = heading_of_moving_step(rj, dv_j);
@@ -792,6 +876,11 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
     for (int i = i_first; i < i_end; i++) {
         const bool emit = i >= i_begin;  // false only for the carry-in step of parts > 0
         const LonRow r = row_at(i);
+        if (LSTAGE && rec_staged)   // (workgroup-uniform: the step's obstacle records and masks come from LDS)
+            walk_step<OBST, false>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit, planes + (int64_t)i * ld + g, 0u, ps,
+                                   Cy, A, O, (const double *)rec_lds, (const unsigned long long *)pm_lds,
+                                   (const unsigned long long *)(pm_lds + S), Bv, nullptr, -1, neigh, part > 0);
+        else
         walk_step<OBST, G == 1>(K, r, L, tp, i, traj_len, d_ext, emit, bundle && active && emit, planes + (int64_t)i * ld + g, 0u, ps,
                                 Cy, A, O, obs_rec, obs_pmask, obs_hmask, Bv, nullptr, -1, neigh, part > 0);
         if (EXTRA) {

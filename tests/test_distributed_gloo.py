@@ -54,6 +54,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _single_rank_nccl_group():
+    """a one-rank nccl (= RCCL) group on cuda:0; the port is probed first and may be taken by another test process before the store
+    binds it (pytest -n 2): try a few"""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    torch.cuda.set_device(0)
+    last = None
+    for _ in range(5):
+        os.environ["MASTER_PORT"] = str(_free_port())
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            return dist
+        except Exception as e:   # (DistNetworkError: EADDRINUSE)
+            last = e
+    raise last
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -183,10 +201,7 @@ def test_rccl_exchange_path_single_rank():
     from frenetix_motion_planner_amd import synthetic
     from frenetix_motion_planner_amd.distributed import ShardedEvaluator
     from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(_free_port())
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    _single_rank_nccl_group()
     try:
         inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(9, 21, 21), n_obstacles=8, hull_builder=build_obstacle_hulls)
         with FrenetEngine(max_candidates=8192, device=0) as eng:
@@ -212,10 +227,7 @@ def test_rccl_exchange_k1_uses_selection_result():
     from frenetix_motion_planner_amd import synthetic
     from frenetix_motion_planner_amd.distributed import ShardedEvaluator
     from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(_free_port())
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    _single_rank_nccl_group()
     try:
         inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(9, 21, 21), n_obstacles=8, hull_builder=build_obstacle_hulls)
         with FrenetEngine(max_candidates=8192, device=0) as eng:
@@ -238,10 +250,7 @@ def test_library_side_exchange_single_rank():
     from frenetix_motion_planner_amd import synthetic
     from frenetix_motion_planner_amd.distributed import ShardedEvaluator
     from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(_free_port())
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    _single_rank_nccl_group()
     try:
         for kw in (dict(n_obstacles=8), dict(n_obstacles=0), dict(n_obstacles=6, lead_gap=15.0)):
             inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, grid=(9, 21, 21), hull_builder=build_obstacle_hulls, **kw)
@@ -286,10 +295,7 @@ def test_agent_sharded_topk_gather_single_rank():
     from frenetix_motion_planner_amd import synthetic
     from frenetix_motion_planner_amd.distributed import ShardedEvaluator
     from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(_free_port())
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    _single_rank_nccl_group()
     try:
         agents = synthetic.stress_agents(5, grid=(7, 9, 9), n_obstacles=6, hull_builder=build_obstacle_hulls)
         with FrenetEngine(max_candidates=sum(a.n_candidates for a in agents) + 5 * 64, max_steps=50, max_agents=5, device=0) as eng:
@@ -318,10 +324,7 @@ def test_library_side_topk_exchange_equals_the_torch_path():
     from frenetix_motion_planner_amd import synthetic
     from frenetix_motion_planner_amd.distributed import ShardedEvaluator
     from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(_free_port())
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    _single_rank_nccl_group()
     try:
         agents = synthetic.stress_agents(4, grid=(7, 9, 9), n_obstacles=6, hull_builder=build_obstacle_hulls)
         got = {}

@@ -16,11 +16,33 @@ from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hull
 SL = 16
 
 
-def run(label, G=0, blk=0, fused=True, package=True, stage=1, matrix=False, **kw):
-    inp = synthetic.make_inputs(ref_kind="arc", v0=10.0, hull_builder=build_obstacle_hulls, as_matrix=matrix, **kw)
+def zam_inputs(matrix800):
+    """BASELINE config 1 as bench.py builds it: the ZAM_Tjunction ego's level-2 step, optionally as the C++-style 800-row matrix"""
+    import copy
+    from frenetix_motion_planner_amd import commonroad_xml as crx
+    from frenetix_motion_planner_amd.frenet_interface import FrenetPlannerInterfaceHip
+    from frenetix_motion_planner_amd.sampling import generate_sampling_matrix
+    sc = crx.read_scenario_json(os.path.join(ROOT, "tests", "golden", "ZAM_Tjunction-1_42_T-1.scenario.json"))
+    itf = FrenetPlannerInterfaceHip(60000, sc, sc.planning_problems[60000], device=0)
+    itf.update_planner(None, sc.ground_truth_predictions(0, 30))
+    inp = itf.begin_step()
+    if not matrix800:
+        return inp
+    t = np.union1d(inp.t_samp, [inp.N * inp.dt]); v = np.union1d(inp.v_samp, [inp.x0_lon[1]]); d = np.union1d(inp.d_samp, [inp.x0_lat[0]])
+    m = copy.copy(inp)
+    m.t_samp = m.v_samp = m.d_samp = None
+    m.sampling_matrix = generate_sampling_matrix(
+        t0_range=0.0, t1_range=t, s0_range=inp.x0_lon[0], ss0_range=inp.x0_lon[1], sss0_range=inp.x0_lon[2], ss1_range=v, sss1_range=0.0,
+        d0_range=inp.x0_lat[0], dd0_range=inp.x0_lat[1], ddd0_range=inp.x0_lat[2], d1_range=d, dd1_range=0.0, ddd1_range=0.0)
+    m.__post_init__()
+    return m
+
+
+def run(label, G=0, blk=0, fused=True, package=True, stage=1, matrix=False, zam=None, **kw):
+    inp = zam_inputs(zam == 800) if zam else synthetic.make_inputs(ref_kind="arc", v0=10.0, hull_builder=build_obstacle_hulls, as_matrix=matrix, **kw)
     lib = _lib.lib()
     lib.fx_probe_read.argtypes = [C.c_void_p, C.c_size_t]
-    with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N) as eng:
+    with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N, max_ref_knots=4096) as eng:
         eng.set_timing("kernel"); eng.set_fused_selection(fused); eng.set_tuning(G, 0, 0, blk, 0); eng.set_package(package)
         eng.set_obstacle_stage(stage); eng.upload(inp)
         for _ in range(20): eng.evaluate(); eng.finish()
@@ -66,6 +88,8 @@ RUNS = dict(
     c1_g8=lambda: run("config-1 sized, G8", G=8, level=2, n_obstacles=5, draw_traj_set=True, kinematic_debug=True),
     cpp800=lambda: run("800-row sampling matrix (generic kernel)", matrix=True, level=2, cpp_style=True, n_obstacles=5),
     c4agent=lambda: run("10 488 candidates", grid=(19, 23, 24), n_obstacles=9),
+    zam630=lambda: run("BASELINE config 1 (ZAM_Tjunction ego, level 2)", zam=630, package=False),
+    zam800=lambda: run("BASELINE config 1 as the 800-row C x 13 matrix", zam=800, package=False),
     c4agent_sel=lambda: run("10 488 candidates, selection kernel", fused=False, grid=(19, 23, 24), n_obstacles=9),
     l4=lambda: run("level 4 (11 220 candidates), 5 obstacles", level=4, n_obstacles=5),
     l4_sel=lambda: run("level 4 (11 220 candidates), 5 obstacles, selection kernel", fused=False, level=4, n_obstacles=5),

@@ -39,21 +39,38 @@ for case in range(first, first + n):
         inp = synthetic.make_inputs(hull_builder=build_obstacle_hulls, **kw)
         out = oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw))
         with FrenetEngine(max_candidates=max(inp.n_candidates, 64), max_steps=inp.N, max_pred_steps=max(64, inp.N + 2), max_obstacles=256) as e:
+            tail = bool(os.environ.get("FX_SOAK_TAIL"))   # the step's end inside the evaluation kernel whatever the size (fx_tail.h)
+            if tail:
+                e.set_fused_selection(2)
+                e.set_obstacle_stage(1)
+            step = (lambda i: e.plan_step_packaged(i, yaw_rate0=0.0)) if tail else (lambda i: (e.plan_step(i), None))
+            pkg = None
             if os.environ.get("FX_SOAK_TUNING"):  # also walk through the work decompositions / kernel variants
                 tn = (int(rng.choice([0, 1, 2, 4, 8, 16, 32])), int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 1, 2])),
                       int(rng.choice([0, 64, 128, 256])), int(rng.choice([0, 1, 2])))
                 e.set_tuning(*tn)
                 e.set_store_mode(int(rng.integers(0, 3)))
-                e.set_obstacle_stage(int(rng.choice([0, 1, 2])), int(rng.choice([0, 2, 3, 5])))   # fused / its own kernel
+                e.set_obstacle_stage(1 if tail else int(rng.choice([0, 1, 2])), int(rng.choice([0, 2, 3, 5])))   # fused / its own kernel
                 try:
-                    res = e.plan_step(inp)
+                    res, pkg = step(inp)
                 except ValueError:  # a forced variant that does not apply to this case
                     e.set_tuning(0, 0, 0, 0, 0)
-                    e.set_obstacle_stage(0)
-                    res = e.plan_step(inp)
+                    e.set_obstacle_stage(1 if tail else 0)
+                    e._resident_key = None
+                    res, pkg = step(inp)
             else:
-                res = e.plan_step(inp)
+                res, pkg = step(inp)
             compare(e, inp, out, res)
+            if tail:
+                info = e.step_info()
+                stats["tail_steps"] = stats.get("tail_steps", 0) + (1 if info["tail"] else 0)
+                assert (pkg is None) == (res["best_index"] < 0)
+                if pkg is not None:   # the package the tail gathered = the classic read-back of the same candidate
+                    cand = e.candidate(res["best_index"])
+                    assert pkg.index == res["best_index"] and pkg.cost == res["best_cost"] == cand["cost"] and pkg.flags == cand["flags"]
+                    if cand["planes"] is not None:
+                        assert np.array_equal(pkg.planes, cand["planes"]) and np.array_equal(pkg.lon, cand["lon"]) and pkg.tau_lat == cand["tau_lat"]
+                    stats["packages"] = stats.get("packages", 0) + 1
             if os.environ.get("FX_SOAK_TOPK"):   # the k best collision-free candidates against NumPy on the engine's own costs / flags
                 from frenetix_motion_planner_amd import _abi
                 k = int(rng.integers(1, 65))
