@@ -488,6 +488,7 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_in), c->in_bytes, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_in_dev), c->h_in, 0));
     if (const char *sm = getenv("FX_STAGE")) c->stage_mode = !strcmp(sm, "dma") ? 1 : (!strcmp(sm, "kernel") ? 2 : 0);
+    if (const char *of = getenv("FX_OBST_STAGE")) c->obst_force = std::max(0, std::min(2, atoi(of)));   // experiments: fx_set_obstacle_stage's first argument
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_in), c->in_bytes));
     c->dev_bytes += (int64_t)c->in_bytes;
     c->h_probs = reinterpret_cast<DevProblem *>(c->h_in);

@@ -3,7 +3,7 @@
 # rocprofv3 kernel-trace stats + per-kernel PMC passes (tools/collect_profiles.sh), then the bench lines of every workload and the
 # small measurement tools; everything lands in gpurun_out/<round>final -- copy what is judged into profiles/<round>/.
 cd $GRAFT_REPO_ROOT 2>/dev/null || true
-R=${1:-r4}
+R=${1:-r5}
 O=gpurun_out/${R}final; mkdir -p $O profiles/$R
 if [ "$2" != "--no-profiles" ]; then
   bash tools/collect_profiles.sh ${R}final_prof > $O/collect.log 2>&1
@@ -26,4 +26,6 @@ timeout 300 python tools/seg_config4.py 2>&1 | grep -v amdgpu > $O/config4_segme
 timeout 300 python tools/adapter_matrix_timing.py 2>&1 | grep -v amdgpu > $O/adapter_matrix.txt
 FX_SPLIT_STEPS=2,3,5 timeout 600 python tools/c3_split.py c3B c5B c4 m1oB 2>&1 | grep -v amdgpu | grep -v '^{' > $O/obstacle_stage_ab.txt
 timeout 300 python tools/cull_stats.py m1o c5 c3A sparse 2>&1 | grep -v amdgpu > $O/cull_stats.txt || true
+timeout 300 python tools/generic_kernel_cases.py 2>&1 | grep -v amdgpu > $O/generic_kernel_cases.txt || true
+if [ -f tools/probe_build/libfxplan_p2.so ]; then timeout 300 python tools/probe_timeline.py c1 c1_noobs zam630 l4 c4agent 2>&1 | grep -v amdgpu > $O/probe_timeline.txt || true; fi
 ls -la $O

@@ -1,12 +1,12 @@
 import os, sys, copy
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 os.environ.setdefault("FX_PROBE_LIB", "")
 from frenetix_motion_planner_amd import synthetic
 from frenetix_motion_planner_amd.engine import FrenetEngine, build_obstacle_hulls
 sys.argv = ["x"]
 import importlib.util
-spec = importlib.util.spec_from_file_location("pt", "/root/repo/tools/probe_timeline.py")
+
 def kernel_ms(inp, tag):
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N, max_ref_knots=4096) as eng:
         eng.set_timing("kernel"); eng.upload(inp)
@@ -27,9 +27,9 @@ for dbg in (False, True):
                                 draw_traj_set=dbg, kinematic_debug=dbg)
     kernel_ms(inp, f"synthetic arc matrix v0=5.6 dbg={dbg}")
 # the ZAM inputs
-sys.path.insert(0, "/root/repo/tools")
-src = open("/root/repo/tools/probe_timeline.py").read().split("def run(")[0].split("SL = 16")[1]
-ROOT = "/root/repo"
+
+src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_timeline.py")).read().split("def run(")[0].split("SL = 16")[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 exec(src)
 z = zam_inputs(True)
 kernel_ms(z, "ZAM 800 matrix (debug flags)")
