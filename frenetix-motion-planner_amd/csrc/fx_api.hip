@@ -468,7 +468,14 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     c->max_pred = std::max(max_pred_steps, 2);
     c->max_agents = max_agents;
     *out = c;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {   // FX_STREAM_PRIORITY=low|high: experiments with two contexts sharing the device (tools/ns_two_streams.py)
+        const char *pr = getenv("FX_STREAM_PRIORITY");
+        int least = 0, greatest = 0;
+        if (pr && *pr && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest));
+        else
+            HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
     c->own_stream = true;
     for (auto &t : c->ring) {
         HIP_TRY(hipEventCreate(&t.e0));
@@ -2107,9 +2114,12 @@ int32_t fx_build_obstacle_hulls(int32_t n_pred, const double *pos, const double 
     if (n_pred <= 2) { *n_hull = 0; return FX_OK; }
     if (!hull) return set_err(FX_ERR_INVALID_ARGUMENT, "hull output is NULL");
     const double hl = length / 2, hw = width / 2;
+    double u1x, u1y;   // box j + 1's heading is box j's of the next hull: one cos / sin per box
+    ::sincos(yaw[0], &u1y, &u1x);
     for (int j = 0; j + 1 < n_pred; j++) {
         const double c0x = pos[2 * j], c0y = pos[2 * j + 1], c1x = pos[2 * j + 2], c1y = pos[2 * j + 3];
-        const double u0x = std::cos(yaw[j]), u0y = std::sin(yaw[j]), u1x = std::cos(yaw[j + 1]), u1y = std::sin(yaw[j + 1]);
+        const double u0x = u1x, u0y = u1y;
+        ::sincos(yaw[j + 1], &u1y, &u1x);
         double mx = u0x + u1x, my = u0y + u1y;
         double mn = std::sqrt(mx * mx + my * my);
         double ex, ey;

@@ -209,8 +209,8 @@ extern __device__ unsigned long long fx_probe_stamps_obs[FX_PROBE_WAVES * FX_PRO
 #define FX_OSTAMP(k)                                                                                             \
     do {                                                                                                         \
         const unsigned w_ = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));                               \
-        if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && w_ < FX_PROBE_WAVES)                                   \
-            fx_probe_stamps_obs[(size_t)w_ * FX_PROBE_SLOTS + (k)] = (k) == 0 || (k) == 15 ? wall_clock64() : clock64(); \
+        if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && w_ < FX_PROBE_WAVES && (FX_PROBE != 4 || (k) == 0 || (k) == 15 || (k) == 4))  \
+            fx_probe_stamps_obs[(size_t)w_ * FX_PROBE_SLOTS + (k)] = (k) == 0 || (k) == 15 || FX_PROBE >= 3 ? wall_clock64() : clock64(); \
     } while (0)
 #else
 #define FX_STAMP(k) do { } while (0)

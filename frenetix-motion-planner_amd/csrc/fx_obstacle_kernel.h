@@ -73,8 +73,11 @@ __device__ __forceinline__ double obs_four(double a, double b, double c, double 
 // no partial sums and ballots through global memory, no acknowledged stores, no ticket, no device-coherent re-loads -- the
 // chain that the last chunk of every tile walked at ~1 us per hop.  Dynamic LDS = waves x (CH * K * 48 B) + waves x 64 x 8 B
 // (partial sums) + waves x 8 B (collision ballots).
+#ifndef FX_OBST_WG_WPE
+#define FX_OBST_WG_WPE 1
+#endif
 template <int CH, int WPS, bool WG = false>
-__global__ __launch_bounds__(WG ? 1024 : 64, WG ? 1 : WPS) void fx_obstacle_kernel(const DevProblem *__restrict__ probs) {
+__global__ __launch_bounds__(WG ? 1024 : 64, WG ? FX_OBST_WG_WPE : WPS) void fx_obstacle_kernel(const DevProblem *__restrict__ probs) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];  // per wave: (cu, cw) [CH][K][2] | hull circles [CH][K][4]
     const DevProblem &P = probs[blockIdx.y];
     const uint32_t mode = P.mode;

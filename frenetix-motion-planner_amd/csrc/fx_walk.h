@@ -416,6 +416,13 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
     // this is not the candidate's first part) instead of being recomputed in a carry-in step: the same arithmetic on the same step
     // by another lane, bit for bit, and one walk_step per lane instead of two.
     const int S = K.S;
+#if defined(FX_PROBE) && defined(FX_PROBE_STEP)   // in-step timeline of one step (tools/probe_step.py): core-clock stamps
+#define FX_STEP_STAMP(k) do { if (OBST && HOT && i == FX_PROBE_STEP + ((k) == 5)) FX_OSTAMP((k)); } while (0)
+#else
+#define FX_STEP_STAMP(k) do { } while (0)
+#endif
+    FX_STEP_STAMP(5);   // (the step after the probed one: its entry closes the probed step)
+    FX_STEP_STAMP(1);
     if (OBST && HOT && USTEP && K.K > 0) H->stage(__builtin_amdgcn_readfirstlane(i), i_next);
     const double s_i = r.s, sv_i = r.sv, sa_i = r.sa;
     // -- lateral polynomial (reactive_planner.py:326-346) --
@@ -544,6 +551,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
         if (i >= K.half && i < S - 1) A.sum_voff += fabs(v_i - K.v_des);        // :125-127
         if (i == S - 1) { A.d_end = d_i; A.v_end = v_i; }
     }
+    FX_STEP_STAMP(2);
     if (OBST && HOT && USTEP && K.K > 0) {
         // ---- obstacle stage on the staged table (wave-uniform step index, every branch wave-uniform) ----
         const int iu = __builtin_amdgcn_readfirstlane(i);
@@ -633,6 +641,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
             }
             A.pred += ssum;
         }
+        FX_STEP_STAMP(3);
         // -- collision: OBB-sum hull of ego boxes (i-1, i) against the obstacle hulls of this step --
         if (K.do_collision && (hm_now | hm_next) != 0ULL && i >= 1) {
             double su, cu;
@@ -701,6 +710,7 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
             }
             C.bx_prev = bx; C.by_prev = by; C.ux_prev = cu; C.uy_prev = su;
         }
+        FX_STEP_STAMP(4);
     } else if (OBST && K.K > 0) {  // a batched launch may mix agents with and without obstacles
         const int nK = K.K;
         // per-step masks: one 64-bit word per 64 obstacles, word-major ([word][step]); more than one word only on this path
