@@ -103,6 +103,8 @@ class ReactivePlannerHip:
         self._engine = engine
         self.road_boundary_check = road_boundary_check
         self.fallback_selector: Optional[Callable] = None   # last-level selection among colliding candidates (set_fallback_selector)
+        self.occlusion_module = None       # planner.py:99 (set_occlusion_module)
+        self.use_occ_model = False
         self.road_boundary = None          # segments [n][4]; checked on the GPU (set_road_boundary)
         self._packed_boundary = None
         self.params_harm = {"log_reg": {"ignore_angle": {"const": -4.591, "speed": 0.185}}}  # configurations/harm_parameters.json
@@ -231,6 +233,16 @@ class ReactivePlannerHip:
         sample or None.  `min_risk_selector(risk)` builds the reference's rule from a per-trajectory risk function; the harm
         model that computes the reference's risk is outside this package (out of scope)."""
         self.fallback_selector = selector
+
+    def set_occlusion_module(self, occ_module):
+        """planner.py:271-273.  The occlusion module itself is outside this package (it is not in the reference
+        tree either); its two call points are: `occ_module.calc_costs(trajectories)` on the step's feasible trajectories before
+        they are sorted (trajectories.py:557-560) and `occ_module.trajectory_safety_assessment(trajectory) -> (metric, ok)` for the
+        collision-free candidates of the cost order until one passes (planner.py:384-388).  With a module set the selection of a
+        step runs on the host over TrajectorySample views of the device's results (costs, collision and road-boundary flags of
+        EVERY candidate are there already); None switches back to the device's selection."""
+        self.occlusion_module = occ_module
+        self.use_occ_model = occ_module is not None
 
     @staticmethod
     def min_risk_selector(risk: Callable[[TrajectorySample], float]) -> Callable:
@@ -524,6 +536,8 @@ class ReactivePlannerHip:
         self._collision_counter = res["n_collisions"]
         if self._draw_traj_set or self.save_all_traj:
             self.all_traj = _LazySortedList(step)
+        if self.occlusion_module is not None:
+            return self._occlusion_walk(step, samp_lvl)
         best = step.best
         if best is None:
             return self._fallback(step, samp_lvl)
@@ -540,6 +554,32 @@ class ReactivePlannerHip:
             cand._coll_detected = False
             if harm == 0:
                 return cand
+        return self._fallback(step, samp_lvl)
+
+    def _occlusion_walk(self, step, samp_lvl):
+        """trajectories.py:557-560 + planner.py:329-392 with an occlusion module: the module adds its costs to the feasible
+        trajectories (creation order), the list is sorted stably, and the first candidate that neither collides nor leaves the road
+        AND passes the module's safety assessment is the step's trajectory."""
+        ids = np.nonzero(step.mask(_abi.FX_FLAG_COSTED))[0]
+        trajs = step.samples(ids)
+        if trajs:
+            self.occlusion_module.calc_costs(trajs)
+            trajs.sort(key=lambda t: t.cost)
+        self._collision_counter = 0
+        for cand in trajs:
+            if cand._coll_detected is None:      # kept for drawing / debugging only: not part of the collision walk
+                continue
+            if cand._coll_detected:
+                self._collision_counter += 1
+                continue
+            harm = self.road_boundary_check(cand) if self.road_boundary_check is not None else (cand.boundary_harm or 0)
+            cand.boundary_harm = harm
+            if harm != 0:
+                continue
+            _, ok = self.occlusion_module.trajectory_safety_assessment(cand)
+            if ok is not None and not ok:    # (the reference tests `is False`; a NumPy False from the module is a veto too)
+                continue
+            return cand
         return self._fallback(step, samp_lvl)
 
     # ------------------------------------------------------------------ standstill (reactive_planner.py:579-626)

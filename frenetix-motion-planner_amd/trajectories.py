@@ -142,6 +142,10 @@ class TrajectorySample:
     def cost(self) -> float:
         return self._cost
 
+    @cost.setter
+    def cost(self, value):   # (an occlusion module's calc_costs adds to it before the list is sorted, trajectories.py:557-560)
+        self._cost = float(value)
+
     @property
     def leaves_road(self) -> Optional[bool]:
         """True/False for walked candidates when the step ran the road-boundary stage, else None"""
@@ -360,15 +364,19 @@ class PlanStepResult:
         ids = np.nonzero(self.mask(pool_bit))[0]
         return ids[np.argsort(self.cost[ids], kind="stable")]
 
-    def sorted_trajectories(self, pool_bit=_abi.FX_FLAG_COSTED, limit: Optional[int] = None) -> List[TrajectorySample]:
-        ids = self.sorted_ids(pool_bit)
-        if limit is not None:
-            ids = ids[:limit]
+    def samples(self, ids) -> List[TrajectorySample]:
+        """the samples of `ids` (indices within the shard), in that order"""
         todo = [int(g) for g in ids if int(g) not in self._samples]
         if len(todo) > 8:   # many new samples at once (the adapter's sorted list): built from the arrays in one go
             for t in TrajectorySample.bulk(self, todo):
                 self._samples[t.uniqueId] = t
         return [self.sample(int(g)) for g in ids]
+
+    def sorted_trajectories(self, pool_bit=_abi.FX_FLAG_COSTED, limit: Optional[int] = None) -> List[TrajectorySample]:
+        ids = self.sorted_ids(pool_bit)
+        if limit is not None:
+            ids = ids[:limit]
+        return self.samples(ids)
 
     @property
     def best(self) -> Optional[TrajectorySample]:

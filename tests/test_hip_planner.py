@@ -285,3 +285,24 @@ def test_last_level_fallback_selector_on_the_engine():
         got.append((best.uniqueId, rp.last_step.result["n_collisions"], rp.last_step.result["n_feasible"]))
         rp.close()
     assert got[0] == got[1] and got[0][1] == got[0][2] > 0
+
+
+def test_occlusion_module_call_points_on_the_engine():
+    """planner.py:271-273, 384-388; trajectories.py:557-560: an occlusion module's added costs and vetoes on the real engine -- the
+    module sees the same trajectories in the same order, is asked for the same candidates and the planner returns the same
+    trajectory as on the oracle-backed stand-in."""
+    from tests.test_planner_host import _ToyOcclusionModule, _open_road_planner
+    got = []
+    for engine in (None, "oracle"):
+        probe = _open_road_planner(engine=engine)
+        assert probe.plan() is not None
+        v_veto = float(np.sort(np.unique(probe.last_step.inputs.v_samp))[-2])
+        probe.close()
+        occ = _ToyOcclusionModule(v_veto=v_veto, weight=3.0)
+        rp = _open_road_planner(engine=engine)
+        rp.set_occlusion_module(occ)
+        pair = rp.plan()
+        assert pair is not None and len(occ.assessed) >= 1 and occ.assessed[-1] == rp.optimal_trajectory.uniqueId
+        got.append((occ.calc_calls, occ.assessed, rp.optimal_trajectory.uniqueId, rp._collision_counter))
+        rp.close()
+    assert got[0] == got[1]

@@ -443,3 +443,94 @@ def test_state_update_states_the_array_shapes_and_refuses_arrays_that_do_not_fit
         h[0].state_update(C.addressof(u), a, a, 0.0, 1.0, 0, t, t, t, o["pos"], o["cov_inv"], o["npred"], o["hull"][:, :-1].copy(), o["nhull"])
     with pytest.raises(ValueError):   # a state of two values
         h[0].state_update(C.addressof(u), a[:2], a, 0.0, 1.0, 0, t, t, t, None, None, None, None, None)
+
+
+class _ToyOcclusionModule:
+    """An occlusion module by its two call points only (the real one is outside the reference tree): calc_costs adds a visibility
+    cost that grows with the lateral end offset to the LEFT, trajectory_safety_assessment vetoes end velocities above a bound."""
+
+    def __init__(self, v_veto=None, weight=0.0):
+        self.v_veto, self.weight, self.calc_calls, self.assessed = v_veto, weight, [], []
+
+    def calc_costs(self, trajectories):
+        self.calc_calls.append([t.uniqueId for t in trajectories])
+        for t in trajectories:
+            t.cost = t.cost + self.weight * max(0.0, t.sampling_parameters[10])
+
+    def trajectory_safety_assessment(self, trajectory):
+        self.assessed.append(trajectory.uniqueId)
+        ok = self.v_veto is None or trajectory.sampling_parameters[5] <= self.v_veto
+        return 0.5, ok
+
+
+def _open_road_planner(engine="oracle", **cfg):
+    rp = ReactivePlannerHip(PlannerConfig(**cfg), VehicleParams(), engine=OracleEngine() if engine == "oracle" else engine)
+    ref = synthetic.reference_polyline("arc", 400, 0.5, 0.01)
+    cs = synthetic.CoordinateSystem(ref)
+    xy = cs.convert_to_cartesian_coords(float(cs.ref_pos[40]) + 0.1, 0.2)
+    x0 = ReactivePlannerState(time_step=0, position=np.array(xy), orientation=float(cs.ref_theta[40]), velocity=9.0)
+    n = 31
+    car = dict(pos_list=np.stack([xy[0] + 12.0 + 0.4 * np.arange(n), np.full(n, xy[1] + 0.3)], axis=1), cov_list=np.tile(np.eye(2) * 0.2, (n, 1, 1)),
+               orientation_list=np.full(n, float(cs.ref_theta[40])), shape=dict(length=4.5, width=1.9))
+    rp.update_externals(reference_path=ref, x_0=x0, desired_velocity=9.0, predictions={3: car})
+    return rp
+
+
+def test_occlusion_module_call_points():
+    """planner.py:271-273, 384-388 and trajectories.py:557-560: with an occlusion module set, its calc_costs sees the step's feasible
+    trajectories in creation order before they are sorted, and its safety assessment is asked for the collision-free candidates in
+    cost order until one passes.  Restated over the step's arrays."""
+    base = _open_road_planner()
+    assert base.plan() is not None
+    want_plain = base.optimal_trajectory.uniqueId
+
+    # a module that changes nothing and vetoes nothing: the device's own winner, asked exactly once
+    occ = _ToyOcclusionModule()
+    rp = _open_road_planner()
+    rp.set_occlusion_module(occ)
+    assert rp.use_occ_model and rp.plan() is not None
+    step = rp.last_step
+    costed = np.nonzero(step.mask(_abi.FX_FLAG_COSTED))[0]
+    assert occ.calc_calls == [list(costed)] and rp.optimal_trajectory.uniqueId == want_plain == step.result["best_index"]
+    assert occ.assessed == [want_plain] and rp._collision_counter == step.result["n_collisions"]
+
+    # added costs re-order the list, a veto skips candidates: the walk restated with NumPy on the device's arrays
+    occ = _ToyOcclusionModule(v_veto=float(np.sort(np.unique(base.last_step.inputs.v_samp))[-2]), weight=3.0)
+    rp = _open_road_planner()
+    rp.set_occlusion_module(occ)
+    assert rp.plan() is not None
+    step = rp.last_step
+    inp = step.inputs
+    ids = np.nonzero(step.mask(_abi.FX_FLAG_COSTED))[0]
+    sp = np.array([step.sample(int(g)).sampling_parameters for g in ids])
+    cost = step.cost[ids] + 3.0 * np.maximum(0.0, sp[:, 10])
+    order = ids[np.argsort(cost, kind="stable")]
+    sel, col = step.mask(_abi.FX_FLAG_SELECTABLE), step.mask(_abi.FX_FLAG_COLLISION)
+    expect_asked, n_col, want = [], 0, None
+    for g in order:
+        if not sel[g]:
+            continue
+        if col[g]:
+            n_col += 1
+            continue
+        expect_asked.append(int(g))
+        if step.sample(int(g)).sampling_parameters[5] <= occ.v_veto:
+            want = int(g)
+            break
+    assert want is not None and occ.assessed == expect_asked and rp.optimal_trajectory.uniqueId == want
+    assert rp._collision_counter == n_col and rp.optimal_trajectory.cost == pytest.approx(float(cost[list(ids).index(want)]))
+    # the batched path's phases take the same decision
+    occ2 = _ToyOcclusionModule(v_veto=occ.v_veto, weight=3.0)
+    rp2 = _open_road_planner()
+    rp2.set_occlusion_module(occ2)
+    inp2 = rp2.plan_begin()
+    res = rp2.engine.plan_batch([inp2])[0]
+    assert rp2.plan_consume(inp2, res, rp2.engine, 0).uniqueId == want
+    # a module that vetoes everything leaves the step without a trajectory (the planner escalates, then stands still)
+    occ3 = _ToyOcclusionModule(v_veto=-1.0)
+    rp3 = _open_road_planner(sampling_min=2, sampling_max=3)
+    rp3.set_occlusion_module(occ3)
+    rp3.plan()
+    assert len(occ3.assessed) > 0 and (rp3.optimal_trajectory is None or not hasattr(rp3.optimal_trajectory, "uniqueId") or rp3.optimal_trajectory.uniqueId not in occ3.assessed)
+    rp3.set_occlusion_module(None)
+    assert not rp3.use_occ_model
