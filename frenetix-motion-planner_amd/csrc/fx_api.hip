@@ -797,9 +797,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
                     const size_t rec_bytes = sizeof(double) * (size_t)S_rec_doubles((int)S, std::max(p->K, 0));
                     const size_t rec_lds = (lane_split && obst_any && p->K > 0 && rec_bytes <= FX_REC_LDS_MAX) ? rec_bytes + 16 * S : 0;
                     need = std::max(need, sizeof(double) * FX_TP * S + 128 * n_pairs * S + (G > 1 ? (size_t)64 * blk : 0) +
-                                              std::max(sizeof(double) * (((size_t)p->M + 1) & ~(size_t)1),
-                                                       // (+ two entries: the prediction loop's look-ahead loads run past the last wave's block, fx_walk.h)
-                                                       (size_t)(blk / 64) * hot_block + (hot_block ? 2 * sizeof(double) * FX_HOT_STRIDE : 0)) + rec_lds);
+                                              std::max(sizeof(double) * (((size_t)p->M + 1) & ~(size_t)1), (size_t)(blk / 64) * hot_block) + rec_lds);
                 }
                 return need;
             };

@@ -598,18 +598,13 @@ __device__ __forceinline__ void walk_step(const StepConst &K, const LonRow &r, c
                 fx_d2 la, ca, lb, cb, lc, cc, ld_, cd;
                 double wa, wb, wc, wd;
                 int k = 0;
-#ifdef FX_PRED_UNCLAMPED   // experiment: look-ahead loads run up to two entries past the wave's block (values never used)
-#define FX_LA(j) (j)
-#else
                 const int kz = nK - 1;
-#define FX_LA(j) min((j), kz)
-#endif
                 ld(0, la, ca, wa);
-                ld(FX_LA(1), lb, cb, wb);
+                ld(min(1, kz), lb, cb, wb);
                 for (; k + 3 < nK; k += 4) {
                     ld(k + 2, lc, cc, wc); ld(k + 3, ld_, cd, wd);
                     const double qa = msq(la, ca, wa), qb = msq(lb, cb, wb);
-                    ld(FX_LA(k + 4), la, ca, wa); ld(FX_LA(k + 5), lb, cb, wb);
+                    ld(min(k + 4, kz), la, ca, wa); ld(min(k + 5, kz), lb, cb, wb);
                     s0 += four(qa, qb, msq(lc, cc, wc), msq(ld_, cd, wd));
                 }
                 // entries k (a) and k + 1 (b) are loaded where they exist; up to three remain
