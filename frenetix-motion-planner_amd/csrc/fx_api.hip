@@ -21,6 +21,8 @@
 #include <thread>
 #include <vector>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include "fx_device.h"
 
@@ -72,6 +74,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 #define FX_STORE_WT_MAX_BYTES (~(size_t)0)
 // state updates up to this many bytes are staged by a copy kernel reading the mapped pinned block, larger ones by the DMA engine
 #define FX_STAGE_KERNEL_MAX ((size_t)1 << 20)
+#define FX_STAGE_HOST_MAX ((size_t)4 << 20)     // host writes into the device arena (large BAR): ~50 GB/s of posted writes
 #define FX_PUB_MAX 16384  // doubles: 8 ranks x 64 survivors x 2 x 16 agents
 
 struct FxAgentSlot {
@@ -112,7 +115,11 @@ struct FxContext {
     size_t in_bytes = 0;
     char *h_in = nullptr;   // pinned + mapped
     char *h_in_dev = nullptr;  // device address of the same block (the staging kernel reads it)
-    int stage_mode = 0;        // 0 auto: kernel copy up to FX_STAGE_KERNEL_MAX bytes, DMA above; 1 DMA; 2 kernel (FX_STAGE=dma|kernel)
+    int stage_mode = 0;        // 0 auto: host writes (below) where the device memory is host-visible, else kernel copy up to
+                               // FX_STAGE_KERNEL_MAX bytes, DMA above; 1 DMA; 2 kernel; 3 host writes or fail (FX_STAGE=dma|kernel|bar)
+    bool bar_ok = false;       // the input arena d_in is mapped into this process (large BAR) and host stores reach it: state updates
+                               // are written straight into device memory, no staging launch (probed at fx_create)
+    int stage_path = 0;        // how the latest inputs reached the device: 1 DMA copy, 2 staging kernel, 3 host writes
     char *d_in = nullptr;
     // problems
     DevProblem *h_probs = nullptr;  // [max_agents], the front of the pinned staging block h_in ...
@@ -446,6 +453,38 @@ int32_t fx_device_count(int32_t *count) {
     return FX_OK;
 }
 
+// Host writes into device memory (large BAR).  On boxes where the whole VRAM is mapped into the process a state update needs no
+// staging launch: the host copies the rewritten range of its pinned block into the device arena itself -- posted PCIe writes, ordered
+// in front of the launch that follows (a posted write is never passed by the doorbell write or by the completion that carries the
+// packet to the command processor), ~50 GB/s and no round trip; every kernel start invalidates the XCDs' L2s, so the evaluation
+// kernel reads what the host wrote (tools/micro/bar_write.hip, bar_bw.hip).  The probe cannot fault: the mapping is tested through
+// a system call (read(2) into the address returns EFAULT where nothing is mapped), then a pattern written by the host is read
+// back by a device-to-host copy.
+static bool probe_host_writes(int device, char *d_in, size_t bytes) {
+    int large = 0;
+    if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large || bytes < 64) return false;
+    const int fd = open("/dev/zero", O_RDONLY);
+    if (fd < 0) return false;
+    char *first = d_in, *last = d_in + ((bytes - 64) & ~(size_t)63);
+    const bool mapped = read(fd, first, 64) == 64 && read(fd, last, 64) == 64;
+    close(fd);
+    if (!mapped) return false;
+    unsigned long long pat[8], back[8];
+    for (char *at : {first, last}) {
+        for (int i = 0; i < 8; i++) pat[i] = 0x9e3779b97f4a7c15ULL * (unsigned long long)(i + 1) ^ (unsigned long long)(uintptr_t)at;
+        memcpy(at, pat, sizeof(pat));
+        __builtin_ia32_sfence();
+        if (hipMemcpy(back, at, sizeof(back), hipMemcpyDeviceToHost) != hipSuccess || memcmp(pat, back, sizeof(pat))) return false;
+    }
+    return true;
+}
+// the rewritten range of the pinned block, copied by the host (bar_ok, nothing of this context in flight)
+static void host_stage(FxContext *c, size_t lo, size_t hi) {
+    memcpy(c->d_in + lo, c->h_in + lo, hi - lo);
+    __builtin_ia32_sfence();
+    c->stage_path = 3;
+}
+
 int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int64_t max_candidates_total,
                         int32_t max_steps, int32_t max_ref_knots, int32_t max_obstacles, int32_t max_pred_steps) {
     if (!out || max_candidates_total < 1 || max_steps < 1 || max_steps + 1 > FX_MAX_SAMPLES || max_ref_knots < 2 ||
@@ -494,10 +533,15 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     c->in_bytes += c->probs_bytes;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_in), c->in_bytes, hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_in_dev), c->h_in, 0));
-    if (const char *sm = getenv("FX_STAGE")) c->stage_mode = !strcmp(sm, "dma") ? 1 : (!strcmp(sm, "kernel") ? 2 : 0);
+    if (const char *sm = getenv("FX_STAGE")) c->stage_mode = !strcmp(sm, "dma") ? 1 : (!strcmp(sm, "kernel") ? 2 : (!strcmp(sm, "bar") ? 3 : 0));
     if (const char *of = getenv("FX_OBST_STAGE")) c->obst_force = std::max(0, std::min(2, atoi(of)));   // experiments: fx_set_obstacle_stage's first argument
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_in), c->in_bytes));
     c->dev_bytes += (int64_t)c->in_bytes;
+    if (c->stage_mode == 0 || c->stage_mode == 3) {
+        c->bar_ok = probe_host_writes(device, c->d_in, c->in_bytes);
+        if (c->stage_mode == 3 && !c->bar_ok)
+            return set_err(FX_ERR_HIP, "FX_STAGE=bar: the device memory of GPU %d is not host-writable from this process", device);
+    }
     c->h_probs = reinterpret_cast<DevProblem *>(c->h_in);
     c->d_probs = reinterpret_cast<DevProblem *>(c->d_in);
     int rc;
@@ -1106,10 +1150,15 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     // problems + inputs: small uploads through the staging kernel as well (the DMA engine's submission latency dominates below ~1 MiB)
     {
         const size_t up = (ar.off + 15) & ~(size_t)15;
-        if (c->stage_mode == 2 || (c->stage_mode == 0 && up <= FX_STAGE_KERNEL_MAX && up <= c->in_bytes))
+        if (c->bar_ok && !c->in_flight && up <= FX_STAGE_HOST_MAX && up <= c->in_bytes)
+            host_stage(c, 0, up);   // (in_flight was drained above: no kernel of this context reads the arena)
+        else if (c->stage_mode == 2 || (c->stage_mode != 1 && up <= FX_STAGE_KERNEL_MAX && up <= c->in_bytes)) {
             HIP_TRY(fx_launch_stage(c->h_in_dev, c->d_in, up, c->stream));
-        else
+            c->stage_path = 2;
+        } else {
             HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, ar.off, hipMemcpyHostToDevice, c->stream));
+            c->stage_path = 1;
+        }
     }
     if (br.off) HIP_TRY(hipMemcpyAsync(c->d_bound, c->h_bound, br.off, hipMemcpyHostToDevice, c->stream));
     c->uploaded = true;
@@ -1131,10 +1180,17 @@ int32_t fx_evaluate(FxContext *c) {
         const size_t hi = std::max(c->dirty_hi > c->dirty_lo ? c->dirty_hi : 0, c->probs_dirty ? sizeof(DevProblem) * (size_t)c->n_agents : 0);
         // (offsets inside the block are multiples of 256, so the 16-byte lanes of the staging kernel line up)
         const size_t lo16 = lo & ~(size_t)15, hi16 = (hi + 15) & ~(size_t)15;
-        if (c->stage_mode == 2 || (c->stage_mode == 0 && hi16 - lo16 <= FX_STAGE_KERNEL_MAX))
+        // host writes only while nothing of this context is in flight: fx_update_state drained the stream (or fx_finish saw the
+        // previous step's last word) before the block was rewritten, so no kernel still reads the arena
+        if (c->bar_ok && !c->in_flight && hi16 - lo16 <= FX_STAGE_HOST_MAX)
+            host_stage(c, lo16, hi16);
+        else if (c->stage_mode == 2 || (c->stage_mode != 1 && hi16 - lo16 <= FX_STAGE_KERNEL_MAX)) {
             HIP_TRY(fx_launch_stage(c->h_in_dev + lo16, c->d_in + lo16, hi16 - lo16, c->stream));
-        else
+            c->stage_path = 2;
+        } else {
             HIP_TRY(hipMemcpyAsync(c->d_in + lo, c->h_in + lo, hi - lo, hipMemcpyHostToDevice, c->stream));
+            c->stage_path = 1;
+        }
         c->dirty_lo = (size_t)-1; c->dirty_hi = 0;
         c->probs_dirty = false;
     }
@@ -2285,7 +2341,7 @@ int32_t fx_step_info_ex(const FxContext *c, int64_t *out16) {
     int rc = fx_step_info(c, out16);
     if (rc) return rc;
     out16[10] = c->split_step; out16[11] = c->split_CH; out16[12] = c->obs_blocks_step; out16[13] = (int64_t)c->obs_lds_step;
-    out16[14] = c->obs_wg_step; out16[15] = c->tail_step;
+    out16[14] = c->obs_wg_step; out16[15] = c->tail_step | ((int64_t)c->stage_path << 8);
     return FX_OK;
 }
 

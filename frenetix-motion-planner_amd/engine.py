@@ -280,7 +280,12 @@ class FrenetEngine:
         keys = ("grid_kernel", "lanes_per_candidate", "waves_per_simd", "block", "wave_split", "fused_selection", "blocks", "agents",
                 "package", "lds_bytes", "obstacle_kernel", "obstacle_steps_per_item", "obstacle_items", "obstacle_lds_bytes",
                 "obstacle_workgroup_waves", "tail")
-        return dict(zip(keys, (int(x) for x in v)))
+        info = dict(zip(keys, (int(x) for x in v)))
+        # [15]: bits 0-1 what the agent's last workgroup did (fx_tail.h), bits 8-9 how the latest inputs reached the device:
+        # 1 DMA copy, 2 staging kernel, 3 written by the host into device memory (large BAR)
+        info["staging"] = ("none", "dma", "kernel", "host_writes")[(info["tail"] >> 8) & 3]
+        info["tail"] &= 0xff
+        return info
 
     def obstacle_kernel_times(self, max_n: int = 256):
         """obstacle-kernel ms of the most recent timed steps, oldest first (0 where the stage ran fused)"""

@@ -479,7 +479,10 @@ int32_t fx_step_info(const FxContext *ctx, int64_t *out10);
 /* the same ten values, then: [10] obstacle stage ran as its own kernel, [11] its steps per work item, [12] work items (waves) per
  * agent (max), [13] dynamic LDS bytes, [14] waves per workgroup when the chunks of a tile share one workgroup (0: one wave per
  * (tile, chunk) item), [15] what the agent's last workgroup did beyond the arg-min: bit 0 counted the collisions in front of the
- * winner, bit 1 gathered the winner package (0 with a separate selection kernel) */
+ * winner, bit 1 gathered the winner package (0 with a separate selection kernel); bits 8-9 how the latest inputs (upload or state
+ * update) reached the device: 1 DMA copy, 2 staging kernel reading the pinned block, 3 written by the host straight into device
+ * memory -- where the device memory is mapped into the process (large BAR; probed at fx_create without risking a fault) a state
+ * update needs no staging launch: posted writes, ordered in front of the evaluation launch.  FX_STAGE=kernel|dma|bar forces a path */
 int32_t fx_step_info_ex(const FxContext *ctx, int64_t *out16);
 /* HIP-event time of the obstacle kernel of the latest timed step / of the most recent <= max_n timed steps (FX_TIMING_KERNEL;
  * 0 where the stage ran fused into the walk) */

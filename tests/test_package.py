@@ -247,3 +247,39 @@ def test_published_blocks_are_never_torn(fused):
             assert res["n_feasible"] == res0["n_feasible"] and res["reason_hist"] == res0["reason_hist"], k
             assert pkg.index == idx and pkg.cost == cost, k
             assert np.array_equal(pkg.block, block) and np.array_equal(pkg.lon, lon) and np.array_equal(pkg.raw_costs, raw), k
+
+
+def test_state_updates_written_by_the_host_equal_the_staging_kernel(monkeypatch):
+    """Where the device memory is mapped into the process (large BAR) a state update is written by the host straight into the device
+    arena -- posted writes in front of the evaluation launch, no staging kernel (fx_api.hip, probe_host_writes / host_stage).  The
+    same alternating inputs through a context that stages with the kernel (FX_STAGE=kernel) and through the automatic one: every
+    step's result and package are identical, at a planner-sized step (5 obstacles) and at config 3's size (20 obstacles: 140 KB per
+    update); the automatic context reports which path it took."""
+    from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd.engine import build_obstacle_hulls
+    cases = []
+    a = _inputs(seed=3); b = _inputs(seed=4, v0=7.5); b.coordinate_system = a.coordinate_system
+    cases.append((a, b, 300))
+    kw = dict(ref_kind="arc", grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0, hull_builder=build_obstacle_hulls)
+    c = synthetic.make_inputs(v0=10.0, seed=11, **kw); d = synthetic.make_inputs(v0=9.0, seed=12, **kw); d.coordinate_system = c.coordinate_system
+    cases.append((c, d, 60))
+    for x, y, n in cases:
+        monkeypatch.setenv("FX_STAGE", "kernel")
+        ek = _engine(max_candidates=x.n_candidates + 64)
+        monkeypatch.delenv("FX_STAGE")
+        ea = _engine(max_candidates=x.n_candidates + 64)
+        try:
+            for k in range(n):
+                inp = x if k % 2 == 0 else y
+                rk, pk = ek.plan_step_packaged(inp, yaw_rate0=0.0)
+                ra, pa = ea.plan_step_packaged(inp, yaw_rate0=0.0)
+                assert rk == ra, k
+                assert (pk is None) == (pa is None)
+                if pk is not None:
+                    assert pk.index == pa.index and np.array_equal(pk.block, pa.block) and np.array_equal(pk.raw_costs, pa.raw_costs), k
+            assert ek.step_info()["staging"] == "kernel"
+            assert ea.step_info()["staging"] in ("host_writes", "kernel")   # (kernel where the device memory is not host-visible)
+            cost_k, flags_k = ek.costs(); cost_a, flags_a = ea.costs()
+            assert np.array_equal(flags_k, flags_a) and np.array_equal(cost_k, cost_a)
+        finally:
+            ek.close(); ea.close()
