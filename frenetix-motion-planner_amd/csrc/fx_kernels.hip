@@ -568,7 +568,8 @@ extern "C" hipError_t fx_launch_eval(const DevProblem *d_probs, int n_agents, in
         FX_LAUNCH(1, false, false, true, 2);
     }
     switch (G) {
-    case 32: FX_BO(32, 2);   // planner-sized sampling matrices: one or two steps per lane, one occupancy target
+    case 32: FX_BO(32, 1);   // planner-sized sampling matrices: one or two steps per lane; one wave per SIMD is all they fill, so the
+                             // allocator may use the whole register file (at two waves per SIMD: 12 registers spilled to scratch)
     case 16: FX_BO(16, 2);
     case 8: FX_W(8);
     case 4: FX_W(4);
