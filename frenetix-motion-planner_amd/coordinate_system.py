@@ -127,6 +127,7 @@ class CoordinateSystem:
         self._ref_curv_dd = np.gradient(self._ref_curv_d, self._ref_pos)
         self._normals = vertex_normals(ref, vertex_tangent)
         self._c_args = None
+        self._ref_lists = None   # (reference_at: the knot arrays as Python floats, built on first use)
         self.uid = next(_UIDS)   # identity that is never reused (id() of a collected object can be)
 
     reference = property(lambda self: self._reference)
@@ -141,12 +142,18 @@ class CoordinateSystem:
         """(theta_ref unwrapped, kappa_ref, kappa_ref') linearly interpolated at arc length s -- the segment is the one the
         reference's `argmax(ref_pos > s) - 1` picks (planner.py:580-597)."""
         rp = self._ref_pos
-        k = int(np.argmax(rp > s)) - 1
-        lam = (s - rp[k]) / (rp[k + 1] - rp[k])
-        th = self._ref_theta   # unwrapped at construction
-        theta = interpolate_angle(s, rp[k], rp[k + 1], th[k], th[k + 1])
-        return theta, (self.ref_curv[k + 1] - self.ref_curv[k]) * lam + self.ref_curv[k], \
-            (self.ref_curv_d[k + 1] - self.ref_curv_d[k]) * lam + self.ref_curv_d[k]
+        # (np.argmax(rp > s): the first knot behind s, 0 when there is none -- as a binary search instead of a mask over the path)
+        k = int(np.searchsorted(rp, s, side="right"))
+        k = (k if k < len(rp) else 0) - 1
+        lst = self._ref_lists   # the four arrays as Python floats: scalar arithmetic on NumPy scalars costs three times as much
+        if lst is None:
+            lst = self._ref_lists = (rp.tolist(), self._ref_theta.tolist(), np.asarray(self.ref_curv, dtype=np.float64).tolist(),
+                                     np.asarray(self.ref_curv_d, dtype=np.float64).tolist())
+        rpl, th, kc, kd = lst
+        s = float(s)
+        lam = (s - rpl[k]) / (rpl[k + 1] - rpl[k])
+        theta = interpolate_angle(s, rpl[k], rpl[k + 1], th[k], th[k + 1])   # (th: unwrapped at construction)
+        return theta, (kc[k + 1] - kc[k]) * lam + kc[k], (kd[k + 1] - kd[k]) * lam + kd[k]
 
     def frenet_state(self, x: float, y: float, heading: float, speed: float, acceleration: float, curvature: float,
                      arc_length_lateral: bool):
@@ -162,10 +169,11 @@ class CoordinateSystem:
         (d' = speed sin e, d'' = s'' dd/ds + s'^2 d2d/ds2).  Raises ValueError outside the projection domain and when the
         vehicle faces against the reference (s' < 0)."""
         import math
-        s, d = self.convert_to_curvilinear_coords(x, y)
+        s, d = self.convert_to_curvilinear_coords(x, y).tolist()
         theta_ref, k_ref, k_ref_s = self.reference_at(s)
-        e = heading - theta_ref
-        tan_e, cos_e = np.tan(e), math.cos(e)
+        e = float(heading) - float(theta_ref)
+        speed, acceleration, curvature = float(speed), float(acceleration), float(curvature)
+        tan_e, cos_e = float(np.tan(e)), math.cos(e)   # (np.tan, not math.tan: the two differ in the last bit for some arguments)
         w = 1 - k_ref * d
         d_s = w * tan_e
         bend = k_ref_s * d + k_ref * d_s          # d/ds of (kappa_ref d)
