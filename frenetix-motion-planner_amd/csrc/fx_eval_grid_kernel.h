@@ -302,10 +302,23 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
 
     StepCarry Cy;
     Cy.th_prev = P.x0_orientation; Cy.kap_prev = 0.0; Cy.bx_prev = Cy.by_prev = Cy.ux_prev = Cy.uy_prev = 0.0;
+    // one step per lane: the 32 lanes of a candidate hold its steps in order, so ONE ballot of "my step moves" tells every lane
+    // the last moving step in front of its own (a lane-by-lane scan back through the LDS rows cost the workgroups whose pair ends
+    // in the extension at the slowest sampled velocity -- every step behind T stands still there -- 2 us: they were the last to take
+    // their ticket, and the step's tail waits for the last)
+    unsigned long long moving_lanes = 0ULL;
+    if (neigh) moving_lanes = __ballot(!low_vel && i_begin < S && (my[min(i_begin, S - 1)].flags & LON_MOVING) != 0);
     if (G > 1 && !low_vel && i_first > 0 && i_first < S && !(my[i_first].flags & LON_MOVING)) {
-        // the carry-in step keeps the previous heading: scan back to the last moving step (:447)
-        int j = i_first - 1;
-        while (j >= 0 && !(my[j].flags & LON_MOVING)) j--;
+        // the carry-in step keeps the previous heading: the last moving step in front of it (:447)
+        int j;
+        if (neigh) {
+            const unsigned int grp = (unsigned int)(moving_lanes >> ((tid & 63) & 32));        // this candidate's 32 steps
+            const unsigned int below = grp & ((1u << part) - 1u);                              // (part = step, 1 <= part <= 31 here)
+            j = below ? 31 - __clz((int)below) : -1;
+        } else {
+            j = i_first - 1;
+            while (j >= 0 && !(my[j].flags & LON_MOVING)) j--;
+        }
         if (j >= 0) {
             double d_j, dv_j = 0.0, da_j;
             if (j < traj_len) lat_eval(j, 0.0, d_j, dv_j, da_j);
