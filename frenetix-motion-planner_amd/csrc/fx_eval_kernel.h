@@ -832,6 +832,20 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
 
     StepCarry Cy;
     Cy.th_prev = P.x0_orientation; Cy.kap_prev = 0.0; Cy.bx_prev = Cy.by_prev = Cy.ux_prev = Cy.uy_prev = 0.0;
+    // one step per lane (32 lanes per candidate): the lanes ARE the candidate's steps, so one ballot of "my step moves" answers
+    // every lane's "last moving step in front of mine" (fx_eval_grid_kernel.h has the same; a lane-by-lane scan made the
+    // workgroups of rows that end in the extension at the slowest sampled velocity the last to take their ticket)
+    unsigned long long moving_lanes = 0ULL;
+    if (neigh) {
+        bool mv = false;
+        if (!low_vel && i_begin < S) {
+            const double *te = tp + (i_begin < traj_len ? i_begin : traj_len - 1) * FX_TP;
+            double sv = cl1 + 2. * cl2 * te[0] + 3. * cl3 * te[1] + 4. * cl4 * te[2] + 5. * cl5 * te[3];
+            if (fabs(sv) < FX_EPS) sv = 0.0;
+            mv = sv > 0.001;
+        }
+        moving_lanes = __ballot(mv);
+    }
     if (G > 1 && !low_vel && i_first > 0 && i_first < S) {
         // the carry-in step keeps the previous heading when it stands still: scan back to the last moving step (:447).  The scan
         // only needs each step's LON_MOVING bit -- the longitudinal velocity, make_lon_row's own expression -- and builds ONE row,
@@ -844,14 +858,19 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_kernel(const DevProblem
             return sv > 0.001;
         };
         if (!moving_at(i_first)) {
-            for (int j = i_first - 1; j >= 0; j--) {
-                if (moving_at(j)) {
-                    const LonRow rj = row_at(j);
-                    double d_j, dv_j = 0.0, da_j;
-                    if (j < traj_len) lat_eval(j, rj.u1, d_j, dv_j, da_j);
-                    Cy.th_prev = heading_of_moving_step(rj, dv_j);
-                    break;
-                }
+            int j = i_first - 1;
+            if (neigh) {   // one step per lane: the last moving step in front of this one from the candidate's ballot (below)
+                const unsigned int grp = (unsigned int)(moving_lanes >> ((tid & 63) & 32));
+                const unsigned int below = grp & ((1u << part) - 1u);
+                j = below ? 31 - __clz((int)below) : -1;
+            } else {
+                while (j >= 0 && !moving_at(j)) j--;
+            }
+            if (j >= 0) {
+                const LonRow rj = row_at(j);
+                double d_j, dv_j = 0.0, da_j;
+                if (j < traj_len) lat_eval(j, rj.u1, d_j, dv_j, da_j);
+                Cy.th_prev = heading_of_moving_step(rj, dv_j);
             }
         }
     }
