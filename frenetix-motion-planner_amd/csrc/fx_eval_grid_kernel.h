@@ -306,14 +306,30 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     // the last moving step in front of its own (a lane-by-lane scan back through the LDS rows cost the workgroups whose pair ends
     // in the extension at the slowest sampled velocity -- every step behind T stands still there -- 2 us: they were the last to take
     // their ticket, and the step's tail waits for the last)
-    unsigned long long moving_lanes = 0ULL;
-    if (neigh) moving_lanes = __ballot(!low_vel && i_begin < S && (my[min(i_begin, S - 1)].flags & LON_MOVING) != 0);
+    // (two steps per lane -- 16 lanes per candidate, horizons up to 32 samples -- the same from two ballots, interleaved)
+    const bool pairs = G == 16 && !WSPLIT && CH == 2;
+    unsigned long long moving_lanes = 0ULL, moving_lanes1 = 0ULL;
+    if (neigh || pairs) {
+        moving_lanes = __ballot(!low_vel && i_begin < S && (my[min(i_begin, S - 1)].flags & LON_MOVING) != 0);
+        if (pairs) moving_lanes1 = __ballot(!low_vel && i_begin + 1 < S && (my[min(i_begin + 1, S - 1)].flags & LON_MOVING) != 0);
+    }
     if (G > 1 && !low_vel && i_first > 0 && i_first < S && !(my[i_first].flags & LON_MOVING)) {
         // the carry-in step keeps the previous heading: the last moving step in front of it (:447)
         int j;
         if (neigh) {
             const unsigned int grp = (unsigned int)(moving_lanes >> ((tid & 63) & 32));        // this candidate's 32 steps
             const unsigned int below = grp & ((1u << part) - 1u);                              // (part = step, 1 <= part <= 31 here)
+            j = below ? 31 - __clz((int)below) : -1;
+        } else if (pairs) {
+            auto spread = [](unsigned int x) {   // bit k of a 16-bit word -> bit 2k
+                x = (x | (x << 8)) & 0x00ff00ffu; x = (x | (x << 4)) & 0x0f0f0f0fu;
+                x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+                return x;
+            };
+            const int sh = (tid & 63) & 48;                                                    // this candidate's 16 lanes
+            const unsigned int steps = spread((unsigned int)(moving_lanes >> sh) & 0xffffu) |
+                                       (spread((unsigned int)(moving_lanes1 >> sh) & 0xffffu) << 1);   // bit i = step i moves
+            const unsigned int below = steps & ((1u << i_first) - 1u);                         // (1 <= i_first <= 29: the carry-in step)
             j = below ? 31 - __clz((int)below) : -1;
         } else {
             j = i_first - 1;
