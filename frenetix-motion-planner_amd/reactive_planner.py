@@ -567,6 +567,8 @@ class ReactivePlannerHip:
             trajs.sort(key=lambda t: t.cost)
         self._collision_counter = 0
         for cand in trajs:
+            if cand.valid is False:              # planner.py:338-339: invalidated by the module's calc_costs (harm above its limit)
+                continue
             if cand._coll_detected is None:      # kept for drawing / debugging only: not part of the collision walk
                 continue
             if cand._coll_detected:
@@ -667,6 +669,20 @@ class ReactivePlannerHip:
         lon_list = np.stack([k.s, k.s_dot, k.s_ddot], axis=1).tolist()
         lat_list = np.stack([k.d, k.d_dot, k.d_ddot], axis=1).tolist()
         return cart_list, cl_list, lon_list, lat_list
+
+    def _compute_cart_traj(self, trajectory) -> list:
+        """planner.py:449-486: the Cartesian state list the collision walk builds per candidate -- yaw rate is the CENTRAL
+        difference np.gradient(theta) / dT here (x_0.yaw_rate at 0), and the heading is not shifted."""
+        c = trajectory.cartesian
+        theta = np.asarray(c.theta, dtype=np.float64)
+        yaw_rate = np.gradient(theta) / self.dT
+        yaw_rate[0] = self.x_0.yaw_rate
+        steer = np.arctan2(self.vehicle_params.wheelbase * np.asarray(c.kappa, dtype=np.float64), 1.0)
+        pos = np.vstack((c.x, c.y)).T
+        t0 = self.x_0.time_step
+        v, a = np.asarray(c.v).tolist(), np.asarray(c.a).tolist()
+        return [ReactivePlannerState(t0 + i, pos[i], th, v[i], a[i], yr, st)
+                for i, (th, yr, st) in enumerate(zip(theta.tolist(), yaw_rate.tolist(), steer.tolist()))]
 
     @staticmethod
     def shift_orientation(state_list, interval_start=-np.pi, interval_end=np.pi):

@@ -17,10 +17,16 @@ SEED = 20241008
 
 
 def reference_polyline(kind: str = "arc", n_knots: int = 400, spacing: float = 0.5, kappa: float = 0.01, knot_jitter: float = 0.0,
-                       seed: int = SEED):
+                       seed: int = SEED, heading0: float = 0.0):
     """straight | arc (constant curvature) | scurve (curvature sign change) polyline.  knot_jitter > 0 (straight / arc): the
     knots sit at deliberately NON-uniform arc lengths -- segment lengths spacing * (1 +- knot_jitter), seeded -- as a route
-    polyline does after spline smoothing (the segment lookup and every interpolation weight then differ from knot to knot)."""
+    polyline does after spline smoothing (the segment lookup and every interpolation weight then differ from knot to knot).
+    heading0: the polyline rotated about its first knot so that it starts with that heading (a route whose heading runs through
+    +-pi: the unwrapped reference heading leaves (-pi, pi] while vehicle states keep theirs inside)."""
+    if heading0 != 0.0:
+        p = reference_polyline(kind, n_knots, spacing, kappa, knot_jitter, seed)
+        c, sn = np.cos(heading0), np.sin(heading0)
+        return np.stack([c * p[:, 0] - sn * p[:, 1], sn * p[:, 0] + c * p[:, 1]], axis=1)
     s = np.arange(n_knots) * spacing
     if knot_jitter > 0.0:
         if kind == "scurve":
@@ -95,7 +101,8 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
                 n_obstacles=0, n_pred=30, cost_weights=None, draw_traj_set=False, kinematic_debug=False,
                 write_bundle=True, write_costmap=True, collision=True, low_vel_threshold=2.0, hull_builder=None,
                 seed=SEED, vehicle=None, x0_orientation=None, as_matrix=False, stop_point_s=None, road_half_width=None,
-                obstacle_min_gap=0.0, lead_gap=0.0, knot_jitter=0.0, pseudo_normal=False, vertex_tangent="chord", lanelets=None):
+                obstacle_min_gap=0.0, lead_gap=0.0, knot_jitter=0.0, pseudo_normal=False, vertex_tangent="chord", lanelets=None,
+                heading0=0.0, wrap_x0_orientation=False):
     """One agent's PlanInputs on a synthetic reference.
 
     level: reference sampling level (set-ordered ranges, SamplingHandler) -- or
@@ -104,8 +111,8 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
     stop_point_s: distance ahead of s0 of a stop point -> stop-point sampling (end positions in
     [(s0 + s_stop) / 2, s_stop], reactive_planner.py:637) instead of end velocities."""
     veh = vehicle or VehicleParams()
-    cs = CoordinateSystem(reference_polyline(ref_kind, n_knots, spacing, kappa, knot_jitter, seed), pseudo_normal=pseudo_normal,
-                          vertex_tangent=vertex_tangent)
+    cs = CoordinateSystem(reference_polyline(ref_kind, n_knots, spacing, kappa, knot_jitter, seed, heading0),
+                          pseudo_normal=pseudo_normal, vertex_tangent=vertex_tangent)
     N = int(horizon / dt)
     s0 = float(cs.ref_pos[s_knot] + s_off)
     low_vel = v0 < low_vel_threshold
@@ -126,6 +133,8 @@ def make_inputs(*, ref_kind="arc", n_knots=400, spacing=0.5, kappa=0.01, v0=10.0
     seg = cs.segment_of(s0)
     if x0_orientation is None:
         x0_orientation = float(cs.ref_theta[seg])
+        if wrap_x0_orientation:   # a vehicle state's heading lies in (-pi, pi]; the unwrapped reference heading need not
+            x0_orientation = float(np.arctan2(np.sin(x0_orientation), np.cos(x0_orientation)))
     rng = np.random.default_rng(seed)
     preds = synthetic_predictions(cs, n_obstacles, n_pred, dt, s0, rng, min_gap=obstacle_min_gap,
                                   lead_gap=lead_gap) if n_obstacles else None

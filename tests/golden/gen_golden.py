@@ -79,6 +79,11 @@ SCENARIOS = {
     # deliberately non-uniform knot spacing (0.5 m * (1 +- 0.65)): segment lookup, interpolation weights, projection
     "arc_hv_l2_nonuniform_kd_obs3": (dict(ref_kind="arc", kappa=0.015, knot_jitter=0.65, v0=11.0, level=2, n_obstacles=3,
                                           kinematic_debug=True), 7),
+    # route heading running through +-pi: the unwrapped reference heading leaves (-pi, pi], the vehicle's initial heading stays
+    # inside (the state lists of planner.py:394-447 are shifted back into x_0.orientation +- pi); second case: negative curvature
+    "arc_rot_hv_l1_prod": (dict(ref_kind="arc", heading0=3.0, wrap_x0_orientation=True, v0=10.0, level=1), 1),
+    "arc_rot_negk_lv_l1_debug": (dict(ref_kind="arc", kappa=-0.02, heading0=-2.9, wrap_x0_orientation=True, v0=1.5, level=1,
+                                      v_des=3.0, draw_traj_set=True, kinematic_debug=True), 1),
     "straight_lv_l1_nonuniform_debug": (dict(ref_kind="straight", knot_jitter=0.5, v0=1.4, d0=-0.3, level=1, v_des=3.0,
                                              draw_traj_set=True, kinematic_debug=True), 1),
 }

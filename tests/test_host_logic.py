@@ -113,7 +113,10 @@ def test_initial_state_roundtrip():
     lon, lat = rp._compute_initial_states(x0)
     assert abs(lon[0] - s) < 1e-8 and abs(lat[0] - d) < 1e-8
     assert abs(lat[1]) < 1e-6              # heading along the reference -> no lateral velocity
-    assert abs(lon[1] - 8.0 / (1 - 0.01 * d)) < 0.02
+    # s' = v cos(e) / (1 - kappa_ref d) with the polyline's OWN interpolated curvature and heading (planner.py:607); the values
+    # themselves are held to the reference's vectors in tests/test_host_golden.py
+    th_ref, k_ref, _ = cs.reference_at(lon[0])
+    assert abs(lon[1] - 8.0 * np.cos(theta - th_ref) / (1 - k_ref * lat[0])) < 1e-12
     assert not rp._LOW_VEL_MODE
     rp.set_x_0(ReactivePlannerState(position=xy, orientation=theta, velocity=1.0))
     assert rp._LOW_VEL_MODE

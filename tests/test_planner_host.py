@@ -449,13 +449,15 @@ class _ToyOcclusionModule:
     """An occlusion module by its two call points only (the real one is outside the reference tree): calc_costs adds a visibility
     cost that grows with the lateral end offset to the LEFT, trajectory_safety_assessment vetoes end velocities above a bound."""
 
-    def __init__(self, v_veto=None, weight=0.0):
-        self.v_veto, self.weight, self.calc_calls, self.assessed = v_veto, weight, [], []
+    def __init__(self, v_veto=None, weight=0.0, invalidate=()):
+        self.v_veto, self.weight, self.calc_calls, self.assessed, self.invalidate = v_veto, weight, [], [], set(invalidate)
 
     def calc_costs(self, trajectories):
         self.calc_calls.append([t.uniqueId for t in trajectories])
         for t in trajectories:
             t.cost = t.cost + self.weight * max(0.0, t.sampling_parameters[10])
+            if t.uniqueId in self.invalidate:      # the real module: harm above the maximum harm -> valid = False
+                t.valid = False
 
     def trajectory_safety_assessment(self, trajectory):
         self.assessed.append(trajectory.uniqueId)
@@ -526,6 +528,24 @@ def test_occlusion_module_call_points():
     inp2 = rp2.plan_begin()
     res = rp2.engine.plan_batch([inp2])[0]
     assert rp2.plan_consume(inp2, res, rp2.engine, 0).uniqueId == want
+    # candidates the module invalidated in calc_costs never reach the collision walk (planner.py:338-339): neither counted
+    # as collisions, nor assessed, nor returned -- here the plain winner and the first colliding candidate of the cost order
+    order0 = step.sorted_ids()
+    first_col = next(int(g) for g in base.last_step.sorted_ids() if base.last_step.mask(_abi.FX_FLAG_COLLISION)[g])
+    occ4 = _ToyOcclusionModule(invalidate=(want_plain, first_col))
+    rp4 = _open_road_planner()
+    rp4.set_occlusion_module(occ4)
+    assert rp4.plan() is not None
+    st4 = rp4.last_step
+    walk4 = [int(g) for g in st4.sorted_ids() if st4.mask(_abi.FX_FLAG_SELECTABLE)[g] and int(g) not in occ4.invalidate]
+    n_col4 = 0
+    for g in walk4:
+        if st4.mask(_abi.FX_FLAG_COLLISION)[g]:
+            n_col4 += 1
+            continue
+        break
+    assert rp4.optimal_trajectory.uniqueId == g != want_plain and want_plain not in occ4.assessed
+    assert rp4._collision_counter == n_col4
     # a module that vetoes everything leaves the step without a trajectory (the planner escalates, then stands still)
     occ3 = _ToyOcclusionModule(v_veto=-1.0)
     rp3 = _open_road_planner(sampling_min=2, sampling_max=3)
