@@ -35,7 +35,7 @@ def exported_symbols():
     """Entry points include/fxplan.h declares (checked against the .so by the CPU test-suite)."""
     return [
         "fx_abi_version", "fx_last_error", "fx_device_count", "fx_create", "fx_create_batch", "fx_destroy",
-        "fx_set_stream", "fx_set_tuning", "fx_set_block_size", "fx_set_store_mode", "fx_set_winner_buffer", "fx_publish", "fx_wait_published", "fx_set_part_mapping", "fx_build_boundary_bins", "fx_read_boundary_steps", "fx_read_boundary_steps_agent", "fx_set_timing", "fx_set_timing_interval", "fx_read_kernel_times", "fx_set_fused_selection", "fx_step_info", "fx_step_info_ex", "fx_set_obstacle_stage", "fx_last_obstacle_kernel_ms", "fx_read_obstacle_kernel_times", "fx_math_selftest", "fx_upload", "fx_upload_batch", "fx_update_state", "fx_update_step", "fx_comm_unique_id", "fx_comm_check", "fx_comm_set_agents", "fx_comm_info", "fx_set_exchange_mode", "fx_step_exchange_topk", "fx_set_timeout_ms", "fx_wait_word", "fx_comm_init", "fx_comm_destroy", "fx_step_exchange", "fx_set_package", "fx_read_package", "fx_plan_and_package", "fx_plan_batch_packaged", "fx_plan_batch_begin", "fx_plan_batch_end", "fx_cs_to_curvilinear", "fx_cs_to_curvilinear_ex", "fx_build_obstacle_hulls_batch", "fx_invert_cov2", "fx_pack_predictions", "fx_evaluate", "fx_finish", "fx_finish_batch", "fx_plan_step", "fx_step",
+        "fx_set_stream", "fx_set_tuning", "fx_set_block_size", "fx_set_store_mode", "fx_set_winner_buffer", "fx_publish", "fx_wait_published", "fx_set_part_mapping", "fx_build_boundary_bins", "fx_read_boundary_steps", "fx_read_boundary_steps_agent", "fx_set_timing", "fx_set_timing_interval", "fx_read_kernel_times", "fx_set_fused_selection", "fx_set_step_kernel", "fx_step_info", "fx_step_info_ex", "fx_set_obstacle_stage", "fx_last_obstacle_kernel_ms", "fx_read_obstacle_kernel_times", "fx_math_selftest", "fx_upload", "fx_upload_batch", "fx_update_state", "fx_update_step", "fx_comm_unique_id", "fx_comm_check", "fx_comm_set_agents", "fx_comm_info", "fx_set_exchange_mode", "fx_step_exchange_topk", "fx_set_timeout_ms", "fx_wait_word", "fx_comm_init", "fx_comm_destroy", "fx_step_exchange", "fx_set_package", "fx_read_package", "fx_plan_and_package", "fx_plan_batch_packaged", "fx_plan_batch_begin", "fx_plan_batch_end", "fx_cs_to_curvilinear", "fx_cs_to_curvilinear_ex", "fx_build_obstacle_hulls_batch", "fx_invert_cov2", "fx_pack_predictions", "fx_evaluate", "fx_finish", "fx_finish_batch", "fx_plan_step", "fx_step",
         "fx_read_costs", "fx_read_costs_agent", "fx_read_costmap", "fx_read_costmap_agent", "fx_read_coeffs",
         "fx_read_coeffs_agent", "fx_read_lat_tau_agent", "fx_read_sample", "fx_read_sample_agent", "fx_read_candidate_agent", "fx_read_plane", "fx_read_plane_agent",
         "fx_read_topk", "fx_read_topk_batch", "fx_topk_to_device", "fx_build_obstacle_hulls", "fx_device_bytes",
@@ -72,6 +72,7 @@ def lib():
         "fx_set_block_size": ([vp, C.c_int32], C.c_int32),
         "fx_set_timing": ([vp, C.c_int32], C.c_int32),
         "fx_set_fused_selection": ([vp, C.c_int32], C.c_int32),
+        "fx_set_step_kernel": ([vp, C.c_int32, C.c_int32], C.c_int32),
         "fx_step_info": ([vp, vp], C.c_int32),
         "fx_step_info_ex": ([vp, vp], C.c_int32),
         "fx_set_obstacle_stage": ([vp, C.c_int32, C.c_int32], C.c_int32),

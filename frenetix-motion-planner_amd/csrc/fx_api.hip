@@ -15,10 +15,12 @@
 #include <cstring>
 #include <atomic>
 
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
+#include <tuple>
 #include <vector>
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -34,6 +36,9 @@ extern "C" hipError_t fx_launch_eval_grid(const DevProblem *d_probs, int n_agent
                                           hipEvent_t ev_start, hipEvent_t ev_stop, FuseArgs fuse, hipStream_t stream);
 extern "C" hipError_t fx_launch_obstacle(const DevProblem *d_probs, int n_agents, int max_items, size_t lds_bytes, int CH,
                                          hipEvent_t ev_start, hipEvent_t ev_stop, hipStream_t stream, int wg_waves, int max_tiles);
+extern "C" hipError_t fx_step_kernel_capacity(int CH, size_t lds_bytes, int *blocks_out);
+extern "C" hipError_t fx_launch_step(const DevProblem *d_probs, int n_agents, int blocks, size_t lds_bytes, int CH, hipEvent_t ev_start,
+                                     hipEvent_t ev_stop, FuseArgs fuse, StepArgs sa, hipStream_t stream);
 extern "C" hipError_t fx_launch_select(const DevProblem *d_probs, int n_agents, int64_t max_candidates, unsigned long long *host_result,
                                        unsigned long long seq, double *dev_winner, double *host_pkg, int pkg_stride, int pkg_plane_rows,
                                        hipStream_t stream);
@@ -202,6 +207,16 @@ struct FxContext {
     int obs_wg_waves = 0, obs_tiles_step = 0;   // obstacle kernel with one workgroup per tile: waves per workgroup (0: one wave per (tile, chunk) item), tiles
     int obs_wg_step = 0;                        // waves per workgroup of the last obstacle-kernel launch (0: single-wave items)
     size_t obs_lds_step = 0;
+    // the whole step in ONE launch (fx_step_kernel.h): walk | grid barrier | obstacle items | grid barrier | selection
+    int step_kernel_force = 0;             // 0 auto, 1 off, 2 on where applicable (fx_set_step_kernel; FX_STEP_KERNEL=0/1 in the environment)
+    int step_kernel_CH = 0;                // steps per obstacle item in that kernel (0 auto; 3, 5 or 8)
+    bool step_kernel_ok = false;           // the upload's step qualifies
+    bool step_kernel_step = false;         // the last evaluation ran it
+    int step_blocks = 0, step_CH = 0;      // workgroups per agent / steps per item of that launch
+    size_t step_lds = 0;
+    int64_t last_live = -1;                // costed candidates of the previous step's agents (max): sizes the obstacle items
+    unsigned long long *d_bar = nullptr;   // the two grid barriers' counter + release-flag blocks, monotonic
+    unsigned long long bar_base = 0;       // their value before the next launch
     int store_force = 0;                   // 0 auto, 1 write-back, 2 write-through plane stores
     bool wsplit_step = false;
     int block_step = FX_BLOCK;
@@ -563,6 +578,9 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     // a non-blocking stream does not wait for the null stream -- on a busy GPU (a second process) the zeroing landed behind the
     // first step's counter atomics and the step published zeros (tests/test_soak_parity.py, once in a few hundred contexts)
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * max_agents * FX_CNT_COUNT, c->stream));
+    if ((rc = dev_alloc(c, &c->d_bar, 2 * 16 * 65))) return rc;   // (two barrier blocks: fx_step_kernel.h, FX_BAR_WORDS)
+    HIP_TRY(hipMemsetAsync(c->d_bar, 0, sizeof(unsigned long long) * 2 * 16 * 65, c->stream));
+    if (const char *e = getenv("FX_STEP_KERNEL")) c->step_kernel_force = atoi(e) ? 2 : 1;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_pub), sizeof(double) * (FX_PUB_MAX + 1), hipHostMallocMapped | hipHostMallocCoherent));
     memset(c->h_pub, 0, sizeof(double) * (FX_PUB_MAX + 1));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_pub_dev), c->h_pub, 0));
@@ -606,6 +624,7 @@ int32_t fx_destroy(FxContext *c) {
     if (c->d_obs_colm) (void)hipFree(c->d_obs_colm);
     if (c->d_obs_ticket) (void)hipFree(c->d_obs_ticket);
     if (c->d_obs_list) (void)hipFree(c->d_obs_list);
+    if (c->d_bar) (void)hipFree(c->d_bar);
     if (c->d_bound) (void)hipFree(c->d_bound);
     if (c->h_bound) (void)hipHostFree(c->h_bound);
     if (c->comm) (void)fx_comm_destroy(c);
@@ -911,6 +930,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     // the tail costs ~6.5 us at 630 candidates and 8 - 10 us at 11 000, the selection kernel + gather behind a launch gap ~8.5 - 10 us
     // whatever the size -- plan() 70 -> 63 us at 630 candidates, 81 -> 84 us at 11 220: the bound sits between them
     static const int64_t tail_max_c = [] { const char *e = getenv("FX_TAIL_MAX_C"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();
+    bool all_deferred = n_agents > 0;
     c->max_blocks_step = 0;
     c->obs_blocks_step = 0;
     c->obs_tiles_step = 0;
@@ -1053,9 +1073,11 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             const size_t rb = sizeof(double) * (size_t)S_rec_doubles(S, std::max(p->K, 0));
             if (!deferred && p->K > 0 && p->K <= 64 && rb <= FX_REC_LDS_MAX && (rec_rule_grid || rec_rule_gen)) d.mode |= FX_MODE_INT_REC_LDS;
         }
+        all_deferred = all_deferred && deferred;
         if (deferred) {   // the obstacle kernel writes this agent's arg-min partials: one per tile of 64 candidates
             d.mode |= FX_MODE_INT_DEFER_OBST;
             const int n_tiles = (int)((C + 63) / 64), NC = (S - 1 + c->split_CH - 1) / c->split_CH;
+            const int NC_alloc = std::max(NC, (S - 1 + 2) / 3);   // (the one-launch step picks its own steps per item: 3, 5 or 8)
             d.n_blocks = n_tiles;
             c->obs_blocks_step = std::max(c->obs_blocks_step, n_tiles * NC);
             c->obs_tiles_step = std::max(c->obs_tiles_step, n_tiles);
@@ -1063,8 +1085,8 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             d.obs_part = reinterpret_cast<double *>(obs_part_need);      // offsets for now, patched below
             d.obs_colm = reinterpret_cast<unsigned long long *>(obs_colm_need);
             d.obs_ticket = reinterpret_cast<unsigned int *>(obs_tick_need);
-            obs_part_need += (size_t)NC * (size_t)ld;
-            obs_colm_need += (size_t)NC * (size_t)n_tiles;
+            obs_part_need += (size_t)NC_alloc * (size_t)ld;
+            obs_colm_need += (size_t)NC_alloc * (size_t)n_tiles;
             obs_tick_need += (size_t)n_tiles;
         }
         if (block_off + d.n_blocks > c->max_blocks_total)
@@ -1144,6 +1166,13 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
             d.obs_list = c->d_obs_list + (d.cost - c->d_cost);   // the agent's slab of the per-candidate arrays
         }
     }
+    // the whole step in one launch (fx_step_kernel.h): the split step of the tuned two-lanes-per-candidate walk with a write-through
+    // bundle, every agent's obstacle stage deferred; whether the device holds the launch is asked when it is sized (fx_evaluate)
+    // (opt-in: measured slower than the three launches on config 3, fx_step_kernel.h -- `force` 2 or FX_STEP_KERNEL=1)
+    c->step_kernel_ok = c->step_kernel_force == 2 && c->split_step && all_deferred && c->use_grid && c->G_step == 2 && c->wsplit_step &&
+                        c->block_step == FX_BLOCK && c->wpe_step == 2 && c->any_bundle && !c->any_obst && !c->any_extra && c->wt_step &&
+                        c->obs_blocks_step > 0 && c->K_max_step <= 64;
+    c->last_live = -1;
     c->n_agents = n_agents;
     c->in_used = ar.off;
     c->dirty_lo = (size_t)-1; c->dirty_hi = 0; c->probs_dirty = false;
@@ -1229,6 +1258,63 @@ int32_t fx_evaluate(FxContext *c) {
     }
     const bool pkg_in_tail = (c->tail_step & FX_TAIL_PACKAGE) != 0;
     FuseArgs fuse{c->fused_step ? c->h_counters_dev : nullptr, c->seq, winner, (int32_t)((uint32_t)c->K_max_step | (c->tail_step << 16))};
+    // ---- the whole step in ONE launch (fx_step_kernel.h) where the upload qualifies and the device holds the launch at once ----
+    c->step_kernel_step = false;
+    if (c->step_kernel_ok && !c->fused_step && c->eval_launched) {
+        // sizing: (tile, chunk of CH steps) items over all waves of the launch, in as few rounds as the resident workgroups allow --
+        // the list's length is the previous step's (a planner's consecutive steps differ little), two thirds of the grid at first
+        int64_t c_max = 0;
+        for (int a = 0; a < c->n_agents; a++) c_max = std::max(c_max, c->slots[a].C);
+        const int64_t live_est = c->last_live >= 0 ? std::min(c->last_live, c_max) : (2 * c_max + 2) / 3;
+        const int tiles_est = (int)std::max<int64_t>(1, (live_est + 63) / 64);
+        int best_CH = 0, best_blocks = 0, best_score = 1 << 30;
+        size_t best_lds = 0;
+        static const int chs[3] = {3, 5, 8};
+        for (int q = 0; q < 3; q++) {
+            const int CH = chs[q];
+            if (c->step_kernel_CH && c->step_kernel_CH != CH) continue;
+            const size_t lds = std::max(c->lds_step, (size_t)(FX_BLOCK / 64) * sizeof(double) * 16 * (size_t)CH * (size_t)c->K_max_step);   // FX_OBST_LDS_DOUBLES(.., true)
+            int cap = 0;
+            {   // (one occupancy query per (CH, lds) of this process and device)
+                static std::mutex mu;
+                static std::map<std::tuple<int, int, size_t>, int> seen;
+                std::lock_guard<std::mutex> lk(mu);
+                const auto key = std::make_tuple(c->device, CH, lds);
+                auto it = seen.find(key);
+                if (it == seen.end()) {
+                    int v = 0;
+                    if (fx_step_kernel_capacity(CH, lds, &v) != hipSuccess) { (void)hipGetLastError(); v = 0; }
+                    it = seen.emplace(key, v).first;
+                }
+                cap = it->second;
+            }
+            const int cap_agent = cap / std::max(c->n_agents, 1);
+            if (cap_agent < c->max_blocks_step) continue;   // the walk alone does not fit at once: three launches
+            const int NC = (c->S_max_step - 1 + CH - 1) / CH;
+            const int64_t items = (int64_t)((tiles_est + FX_STEP_T - 1) / FX_STEP_T) * NC;   // (T tiles x one chunk per wave)
+            const int blocks = (int)std::min<int64_t>(cap_agent, std::max<int64_t>(c->max_blocks_step, (items + FX_BLOCK / 64 - 1) / (FX_BLOCK / 64)));
+            const int rounds = (int)((items + (int64_t)blocks * (FX_BLOCK / 64) - 1) / ((int64_t)blocks * (FX_BLOCK / 64)));
+            const int score = rounds * CH;
+            if (score < best_score) { best_score = score; best_CH = CH; best_blocks = blocks; best_lds = lds; }
+        }
+        if (best_CH) {
+            StepArgs sa{};
+            sa.bar = c->d_bar; sa.bar_base = c->bar_base;
+            sa.host_result = c->h_counters_dev; sa.seq = c->seq; sa.dev_winner = winner;
+            sa.host_pkg = c->pkg_step ? c->h_pkg_dev : nullptr; sa.pkg_stride = c->pkg_stride; sa.pkg_plane_rows = c->pkg_plane_rows;
+            sa.walk_blocks = c->max_blocks_step;
+            HIP_TRY(fx_launch_step(c->d_probs, c->n_agents, best_blocks, best_lds, best_CH, k0, k1, fuse, sa, c->stream));
+            c->bar_base += (unsigned long long)best_blocks * (unsigned long long)c->n_agents;
+            c->step_kernel_step = true;
+            c->step_blocks = best_blocks; c->step_CH = best_CH; c->step_lds = best_lds;
+            if (timed && !attached) HIP_TRY(hipEventRecord(ts->e_eval, c->stream));
+            if (timed) { ts->obst_timed = false; ts->fused = true; c->n_timed++; }
+            c->timed_step = timed;
+            c->evaluated = true;
+            c->in_flight = true;
+            return FX_OK;
+        }
+    }
     if (c->eval_launched)
     {
         if (c->use_grid)
@@ -1321,6 +1407,9 @@ int32_t fx_finish_batch(FxContext *c, FxResult *res) {
         r.n_collisions = (int64_t)cn[FX_CNT_COLLISIONS];
         r.feasible_percentage = r.n_returned ? 100.0 * ((double)r.n_feasible / (double)r.n_returned) : 0.0;
         r.kernel_ms = step_ms;
+        // (costed candidates of the step: the feasible ones, with draw_traj_set everything returned -- sizes the next one-launch step)
+        const int64_t live = (c->slots[a].mode & FX_MODE_DRAW_TRAJ_SET) ? r.n_returned : r.n_feasible;
+        c->last_live = a == 0 ? live : std::max(c->last_live, live);
     }
     return FX_OK;
 }
@@ -2342,9 +2431,21 @@ int32_t fx_step_info_ex(const FxContext *c, int64_t *out16) {
     if (rc) return rc;
     out16[10] = c->split_step; out16[11] = c->split_CH; out16[12] = c->obs_blocks_step; out16[13] = (int64_t)c->obs_lds_step;
     out16[14] = c->obs_wg_step; out16[15] = c->tail_step | ((int64_t)c->stage_path << 8);
+    if (c->step_kernel_step) {   // the whole step in one launch: steps per item, waves, LDS of THAT kernel; bit 16 says so
+        out16[11] = c->step_CH; out16[12] = (int64_t)c->step_blocks * (FX_BLOCK / 64); out16[13] = (int64_t)c->step_lds; out16[14] = 0;
+        out16[15] |= 1 << 16;
+    }
     return FX_OK;
 }
 
+int32_t fx_set_step_kernel(FxContext *c, int32_t mode, int32_t steps_per_item) {
+    if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
+    if (mode < 0 || mode > 2) return set_err(FX_ERR_INVALID_ARGUMENT, "mode must be 0 (auto), 1 (off: three launches) or 2 (on where applicable)");
+    if (steps_per_item != 0 && steps_per_item != 3 && steps_per_item != 5 && steps_per_item != 8)
+        return set_err(FX_ERR_INVALID_ARGUMENT, "steps_per_item must be 0 (auto), 3, 5 or 8");
+    c->step_kernel_force = mode; c->step_kernel_CH = steps_per_item;   // (the mode takes effect at the next upload)
+    return FX_OK;
+}
 int32_t fx_set_fused_selection(FxContext *c, int32_t enabled) {
     if (!c) return set_err(FX_ERR_INVALID_ARGUMENT, "context is NULL");
     c->fuse_enabled = enabled != 0;

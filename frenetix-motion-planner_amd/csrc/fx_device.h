@@ -212,9 +212,17 @@ extern __device__ unsigned long long fx_probe_stamps_obs[FX_PROBE_WAVES * FX_PRO
         if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && w_ < FX_PROBE_WAVES && (FX_PROBE != 4 || (k) == 0 || (k) == 15 || (k) == 4))  \
             fx_probe_stamps_obs[(size_t)w_ * FX_PROBE_SLOTS + (k)] = (k) == 0 || (k) == 15 || FX_PROBE >= 3 ? wall_clock64() : clock64(); \
     } while (0)
+// the one-launch step's phase boundaries (fx_step_kernel.h), wall clock, in the obstacle kernel's block
+#define FX_MSTAMP(k)                                                                                             \
+    do {                                                                                                         \
+        const unsigned w_ = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));                               \
+        if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && w_ < FX_PROBE_WAVES)                                   \
+            fx_probe_stamps_obs[(size_t)w_ * FX_PROBE_SLOTS + (k)] = wall_clock64();                             \
+    } while (0)
 #else
 #define FX_STAMP(k) do { } while (0)
 #define FX_OSTAMP(k) do { } while (0)
+#define FX_MSTAMP(k) do { } while (0)
 #endif
 
 // rows of the per-candidate coefficient table: lon[6] | lat[6] | tau_lat (the lateral polynomial's delta_tau: t, or s_lon_goal in
@@ -256,6 +264,21 @@ struct FuseArgs {
                                       // that the walk keeps in scalar registers, every further word costs the big kernels a spill
     __host__ __device__ uint32_t tail() const { return (uint32_t)k_max >> 16; }
     __host__ __device__ int32_t kmax() const { return k_max & 0xffff; }
+};
+
+#ifndef FX_STEP_T
+#define FX_STEP_T 1   // tiles of 64 listed candidates per obstacle item of the one-launch step (fx_step_kernel.h)
+#endif
+// arguments of the one-launch step (fx_step_kernel.h) beyond the walk's
+struct StepArgs {
+    unsigned long long *bar;        // two barrier blocks of FX_BAR_WORDS words (fx_step_kernel.h), monotonic: never reset
+    unsigned long long bar_base;    // their value before this launch (the host counts: + workgroups of the launch per step)
+    unsigned long long *host_result;
+    unsigned long long seq;
+    double *dev_winner;
+    double *host_pkg;
+    int32_t pkg_stride, pkg_plane_rows;
+    int32_t walk_blocks;            // workgroups [0, walk_blocks) of every agent walk candidates
 };
 
 // Pointers stored inside DevProblem are loaded from memory, so the compiler only knows them as generic ("flat")

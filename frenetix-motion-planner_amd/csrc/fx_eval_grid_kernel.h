@@ -24,9 +24,12 @@
 
 // Workgroup size is a launch parameter (64, 128 or 256 lanes); the host guarantees that the rows of a workgroup
 // ((CPB + nD - 2) / nD + 1 pairs) fit its dynamic LDS.
-template <int G, bool BUNDLE, bool OBST, int WPE, bool WSPLIT>
-__global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevProblem *__restrict__ probs,
-                                                                         const FuseArgs fuse) {
+// The kernel's body is a function of its own: fx_step_kernel.h runs it as the first phase of a whole plan step in ONE launch
+// (MEGA: every per-candidate output a later phase of the same launch reads -- cost sums, flag words, list entries, coefficients,
+// cost map -- is stored write-through, agent scope; the returns below are then returns into that kernel, never past a barrier
+// some other wave of the workgroup still waits at).
+template <int G, bool BUNDLE, bool OBST, int WPE, bool WSPLIT, bool MEGA = false>
+__device__ __forceinline__ void fx_eval_grid_body(const DevProblem *__restrict__ probs, const FuseArgs &fuse) {
     using namespace fxk;
     const int BLK = blockDim.x;
     const int CPB = BLK / G;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     if (bundle && active && part == 0) {
         FX_GLOBAL double *__restrict__ co = as_global(P.coeffs) + g;
         // (write-through where the step's last workgroup gathers the winner package itself, fx_tail.h)
-        const bool wt = FX_TAIL_IN_KERNEL(G, false) && fuse.host_result != nullptr && (fuse.tail() & FX_TAIL_PACKAGE);
+        const bool wt = MEGA || (FX_TAIL_IN_KERNEL(G, false) && fuse.host_result != nullptr && (fuse.tail() & FX_TAIL_PACKAGE));
         const double cv[FX_COEFF_ROWS] = {s0, ss0, .5 * sss0, cl3, cl4, cl5, L.c0, L.c1, L.c2, L.c3, L.c4, L.c5,
                                           tau};  // tau: PolynomialTrajectory.delta_tau of the lateral polynomial (reactive_planner.py:161-171)
 #pragma unroll
@@ -417,6 +420,12 @@ __global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevPr
     W.cl3 = cl3; W.cl4 = cl4; W.cl5 = cl5; W.ct3 = L.c3; W.ct4 = L.c4; W.ct5 = L.c5;
     // wave split: the exchange block sits behind the rows in dynamic LDS
     double *xch = reinterpret_cast<double *>(rows + (size_t)n_pairs_max * S);
-    finish_candidate<G, BUNDLE, OBST, false, WSPLIT>(P, Pg, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D,
-                                                     red_cost, red_idx, red_cnt, fuse, xch, CPB, cand_local);
+    finish_candidate<G, BUNDLE, OBST, false, WSPLIT, MEGA>(P, Pg, W, g, active, part, i_begin, i_end, bundle, do_collision, dbg, D,
+                                                           red_cost, red_idx, red_cnt, fuse, xch, CPB, cand_local);
+}
+
+template <int G, bool BUNDLE, bool OBST, int WPE, bool WSPLIT>
+__global__ __launch_bounds__(FX_BLOCK, WPE) void fx_eval_grid_kernel(const DevProblem *__restrict__ probs,
+                                                                         const FuseArgs fuse) {
+    fx_eval_grid_body<G, BUNDLE, OBST, WPE, WSPLIT, false>(probs, fuse);
 }

@@ -221,7 +221,7 @@ struct WalkResult {
 // The G parts of a candidate are either G adjacent lanes (WSPLIT = false: combined with wave shuffles) or the same
 // lane of G different lane-groups of the workgroup (WSPLIT = true: part = tid / CPB, combined through the LDS block
 // `xch` of G * CPB * 56 bytes).  The second form keeps every store of the walk a contiguous row segment per wave.
-template <int G, bool BUNDLE, bool OBST, bool EXTRA, bool WSPLIT = false>
+template <int G, bool BUNDLE, bool OBST, bool EXTRA, bool WSPLIT = false, bool MEGA = false>
 __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, const DevProblem &Pg, WalkResult &W, int64_t g, bool active, int part,
                                                  int i_begin, int i_end, bool bundle, bool do_collision, bool dbg, bool D,
                                                  double *red_cost, long long *red_idx, unsigned int *red_cnt,
@@ -235,8 +235,10 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, const Dev
     // Compiled into the planner-sized decompositions only (four or more lanes per candidate: below 200 waves; and the windowed-cost
     // kernel): the kernels of the large grids stay exactly what they were -- their register allocation is tuned to the last VGPR.
     constexpr bool TAIL = FX_TAIL_IN_KERNEL(G, EXTRA);
+    // MEGA (fx_step_kernel.h: the whole step in one launch): later phases of the SAME launch read what this one stores -- write-through
     const bool tail_mode = TAIL && fuse.host_result != nullptr && fuse.tail() != 0u;
-    const bool tail_pkg = tail_mode && (fuse.tail() & FX_TAIL_PACKAGE);
+    const bool tail_pkg = MEGA || (tail_mode && (fuse.tail() & FX_TAIL_PACKAGE));
+    const bool out_wt = MEGA || tail_mode;
     FX_GLOBAL double *__restrict__ planes = as_global(P.planes);
     const FX_GLOBAL double *__restrict__ obs_pos = as_global(P.obs_pos);
     const FX_GLOBAL double *__restrict__ obs_cov_inv = as_global(P.obs_cov_inv);
@@ -462,12 +464,12 @@ __device__ __forceinline__ void finish_candidate(const ProblemRegs &P, const Dev
         const int src = __ffsll((long long)live_mask) - 1;
         const unsigned lo = (unsigned)__shfl((int)(unsigned)(list_base & 0xffffffffULL), src);   // (lists stay below 2^31 entries)
         if (active && leader && costed)
-            as_global(P.obs_list)[lo + __popcll(live_mask & ((1ULL << (tid & 63)) - 1ULL))] = (int32_t)g;
+            st_out(as_global(P.obs_list) + (lo + __popcll(live_mask & ((1ULL << (tid & 63)) - 1ULL))), (int32_t)g, MEGA);
     }
     if (active && leader) {
-        if (defer) as_global(P.cost_tail)[g] = tail;
-        st_out(as_global(P.cost) + g, costed ? (have_pre ? pre : total) : 0.0, tail_mode);
-        st_out(as_global(P.flags) + g, flags, tail_mode);
+        if (defer) st_out(as_global(P.cost_tail) + g, tail, MEGA);
+        st_out(as_global(P.cost) + g, costed ? (have_pre ? pre : total) : 0.0, out_wt);
+        st_out(as_global(P.flags) + g, flags, out_wt);
         if (OBST && (P.mode & FX_MODE_ROAD_BOUNDARY)) as_global(P.bound_step)[g] = (selectable && off_road) ? (int)bound_step : -1;
     }
 

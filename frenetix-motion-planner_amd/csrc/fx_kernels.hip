@@ -28,6 +28,7 @@
 #include "fx_eval_kernel.h"
 #include "fx_eval_grid_kernel.h"
 #include "fx_obstacle_kernel.h"
+#include "fx_step_kernel.h"
 
 using fxk::wave_count;
 
@@ -84,154 +85,7 @@ extern "C" hipError_t fx_launch_package(const DevProblem *d_probs, int n_agents,
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Selection kernel: one workgroup per agent.  Reduces the per-workgroup partials to the winner and
-// counts the colliding candidates that the reference's cost-ordered walk would have visited before it
-// (planner.py:336-357 `_collision_counter`).
-// ---------------------------------------------------------------------------------------------------
-// grid = (slices, n_agents): every workgroup reduces the (few hundred) partials to the winner on its own, counts
-// the colliding candidates ordered before the winner in its slice of the candidates (loads of four iterations in
-// flight), adds its count to the agent's device counter and takes a ticket; the workgroup that draws the last ticket
-// publishes the result block.  One workgroup scanning 50 000 candidates took ~30 us; the slices take ~5.
-// The number of slices grows with the candidate count (host: fx_launch_select): 32 for planner-sized and 50 000-candidate steps,
-// 256 at a million candidates -- with a fixed 32 every workgroup scanned 31 000 cost / flag pairs there while 224 CUs idled.
-#define FX_SELECT_SLICES_MIN 32
-#define FX_SELECT_SLICES_MAX 512
-__global__ __launch_bounds__(256) void fx_select_kernel(const DevProblem *__restrict__ probs, unsigned long long *host_result,
-                                                        unsigned long long seq, double *dev_winner, double *host_pkg, int pkg_stride,
-                                                        int pkg_plane_rows) {
-    __shared__ double sc[4];
-    __shared__ long long si[4];
-    __shared__ unsigned int scnt;
-    __shared__ unsigned long long s_ticket;
-    const DevProblem &P = probs[blockIdx.y];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double bc = INFINITY;
-    long long bi = 0x7fffffffffffffffLL;
-    // Everything that does not depend on the winner is requested NOW, together with the partials -- the first eight (flag, cost)
-    // pairs per thread of this workgroup's slice (the whole slice up to 2 048 candidates: planner-sized steps, config 3) and the
-    // step's counters: the kernel is a chain of memory round trips, and these two used to be links of their own.
-    const bool count_mode = (P.mode & FX_MODE_COLLISION) != 0;
-    const int64_t per = (P.C + gridDim.x - 1) / gridDim.x;
-    const int64_t g0 = (int64_t)blockIdx.x * per, g1 = min(P.C, g0 + per);
-    uint32_t f_pre[8];
-    double c_pre[8];
-    if (count_mode) {
-        const FX_GLOBAL uint32_t *__restrict__ fl = as_global(P.flags);
-        const FX_GLOBAL double *__restrict__ co = as_global(P.cost);
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int64_t gu = g0 + tid + u * 256;
-            f_pre[u] = gu < g1 ? fl[gu] : 0u;
-            c_pre[u] = gu < g1 ? co[gu] : 0.0;
-        }
-    }
-    unsigned long long cnt_pre = 0ULL;
-    if (tid < FX_CNT_BEST_IDX) cnt_pre = as_global(P.counters)[tid];   // (accumulated by the evaluation kernel, which is complete)
-    {
-        // the partials were written by the evaluation kernel, which is complete: plain loads, four per thread in flight
-        // (device-coherent atomic loads, as the in-kernel selection needs them, serialise at ~1 us each)
-        const FX_GLOBAL double *__restrict__ pc = as_global(P.part_cost);
-        const FX_GLOBAL int64_t *__restrict__ pi = as_global(P.part_idx);
-        for (int b0 = tid; b0 < P.n_blocks; b0 += 4 * 256) {
-            double c[4];
-            long long ix[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int b = b0 + u * 256;
-                c[u] = b < P.n_blocks ? pc[b] : INFINITY;
-                ix[u] = b < P.n_blocks ? (long long)pi[b] : 0x7fffffffffffffffLL;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (c[u] < bc || (c[u] == bc && ix[u] < bi)) { bc = c[u]; bi = ix[u]; }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double oc = __shfl_xor(bc, off);
-        const long long oi = __shfl_xor(bi, off);
-        if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
-    }
-    if (lane == 0) { sc[wave] = bc; si[wave] = bi; }
-    if (tid == 0) scnt = 0;
-    __syncthreads();
-    bc = sc[0]; bi = si[0];
-    for (int w = 1; w < 4; w++)
-        if (sc[w] < bc || (sc[w] == bc && si[w] < bi)) { bc = sc[w]; bi = si[w]; }
-    const bool none = bi == 0x7fffffffffffffffLL;
-    // colliding selectable candidates ordered before the winner (all of them when nothing is collision-free)
-    if (count_mode) {
-        const FX_GLOBAL uint32_t *__restrict__ fl = as_global(P.flags);
-        const FX_GLOBAL double *__restrict__ co = as_global(P.cost);
-        unsigned int cnt = 0;
-#pragma unroll
-        for (int u = 0; u < 8; u++) {   // the pairs requested at entry
-            const int64_t gu = g0 + tid + u * 256;
-            if ((f_pre[u] & FX_FLAG_SELECTABLE) && (f_pre[u] & FX_FLAG_COLLISION) &&
-                (none || c_pre[u] < bc || (c_pre[u] == bc && gu + P.g_base < bi))) cnt++;
-        }
-        for (int64_t g = g0 + tid + 8 * 256; g < g1; g += 4 * 256) {
-            uint32_t f[4];
-            double c[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int64_t gu = g + u * 256;
-                f[u] = gu < g1 ? fl[gu] : 0u;
-                c[u] = gu < g1 ? co[gu] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int64_t gu = g + u * 256;
-                if ((f[u] & FX_FLAG_SELECTABLE) && (f[u] & FX_FLAG_COLLISION) && (none || c[u] < bc || (c[u] == bc && gu + P.g_base < bi))) cnt++;
-            }
-        }
-        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
-        if (lane == 0 && cnt) atomicAdd(&scnt, cnt);
-        __syncthreads();
-    }
-    // The workgroup that draws the last ticket of this agent publishes.  ONE device-scope atomic per workgroup carries both
-    // the ticket (low 16 bits) and the slice's count (upper bits): no second atomic, no fence between them -- the chain of
-    // device-coherent round trips is what this kernel's 8 us are made of.
-    static_assert(FX_SELECT_SLICES_MAX < 65536, "the ticket lives in the low 16 bits");
-    if (tid == 0) s_ticket = atomicAdd(&P.counters[FX_DCNT_TICKET], ((unsigned long long)scnt << 16) | 1ULL);
-    __syncthreads();
-    if ((s_ticket & 0xffffULL) != (unsigned long long)(gridDim.x - 1)) return;
-    const unsigned long long collisions = (s_ticket >> 16) + scnt;
-    // Publish the step's result straight into pinned host memory (the host polls the sequence word instead of
-    // paying for a D2H copy and a stream synchronisation) and leave the device counters zeroed for the next step.  The
-    // counters were accumulated by the evaluation kernel, which is complete: plain loads and stores.
-    unsigned long long *out = host_result + (size_t)blockIdx.y * (FX_CNT_COUNT + 1);
-    // (host words: system-scope stores, drained per wave, the sequence word behind a barrier -- no L2 write-back fence: fx_tail.h)
-    {   // the result block in ONE store instruction (a wave's system-scope stores issue one behind the other): lanes 0 .. 12 the
-        // counters, 13 .. 15 winner index, cost bits, collisions
-        unsigned long long w = cnt_pre;
-        if (tid == FX_CNT_BEST_IDX) w = none ? ~0ULL : (unsigned long long)bi;
-        if (tid == FX_CNT_BEST_COST) w = none ? 0ULL : (unsigned long long)__double_as_longlong(bc);
-        if (tid == FX_CNT_COLLISIONS) w = collisions;
-        if (tid < FX_CNT_COUNT) fxk::put_host(out + tid, w);
-    }
-    if (tid < FX_CNT_BEST_IDX) as_global(P.counters)[tid] = 0ULL;
-    if (tid == 0 && dev_winner) {  // (cost, index bits) of the winner, device-resident for the multi-GPU exchange
-        dev_winner[2 * blockIdx.y] = none ? INFINITY : bc;
-        reinterpret_cast<long long *>(dev_winner)[2 * blockIdx.y + 1] = none ? -1 : bi;
-    }
-    if (tid == 0) {
-        __hip_atomic_store(&P.counters[FX_DCNT_TICKET], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the obstacle kernel's candidate list (deferred obstacle stage) starts the next step empty
-        if (P.mode & FX_MODE_INT_DEFER_OBST) as_global(P.counters)[FX_DCNT_LIVE] = 0ULL;
-    }
-    // the winner package (fx_set_package): the evaluation kernel is complete, so the publishing workgroup gathers the chosen
-    // trajectory right here -- no further launch; its sequence word goes out behind the result block's
-    double *pkg = host_pkg ? host_pkg + (size_t)blockIdx.y * pkg_stride : nullptr;
-    if (pkg) fxk::fx_package_gather<false>(P, none ? -1LL : bi, pkg, pkg_plane_rows, tid, 256);
-    else if (tid < 64) fxk::drain_stores();
-    __syncthreads();
-    if (tid == 0) {
-        fxk::st_host(out + FX_CNT_COUNT, seq);
-        if (pkg) fxk::st_host(reinterpret_cast<unsigned long long *>(pkg + pkg_stride - 1), seq);
-    }
-}
+#include "fx_select.h"   // fx_select_kernel
 
 // ---------------------------------------------------------------------------------------------------
 // Top-k: the k best selectable collision-free candidates in (cost, index) order (k <= 64).
@@ -658,6 +512,44 @@ extern "C" hipError_t fx_launch_obstacle(const DevProblem *d_probs, int n_agents
     if (CH == 2) FX_LAUNCH(2);
     if (CH == 3) FX_LAUNCH(3);
     if (CH == 5) FX_LAUNCH(5);
+#undef FX_LAUNCH
+    return hipErrorInvalidValue;
+}
+
+// The whole step in one launch (fx_step_kernel.h): grid = (blocks, n_agents), 256 lanes.  fx_step_kernel_capacity: how many of
+// its workgroups the device holds at once with `lds_bytes` of dynamic LDS (the grid barrier needs them all resident).
+#define FX_STEP_CASES(X) X(3) X(5) X(8)
+extern "C" hipError_t fx_step_kernel_capacity(int CH, size_t lds_bytes, int *blocks_out) {
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+#define FX_CAP(CHv)                                                                                                              \
+    if (CH == CHv) {                                                                                                             \
+        if (lds_bytes > 48 * 1024) {                                                                                             \
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fx_step_kernel<CHv>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds_bytes);                                                                             \
+            if (e != hipSuccess) return e;                                                                                       \
+        }                                                                                                                        \
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fx_step_kernel<CHv>, FX_BLOCK, lds_bytes);                     \
+        if (e != hipSuccess) return e;                                                                                           \
+        *blocks_out = per_cu * cus;                                                                                              \
+        return hipSuccess;                                                                                                       \
+    }
+    FX_STEP_CASES(FX_CAP)
+#undef FX_CAP
+    return hipErrorInvalidValue;
+}
+extern "C" hipError_t fx_launch_step(const DevProblem *d_probs, int n_agents, int blocks, size_t lds_bytes, int CH, hipEvent_t ev_start,
+                                     hipEvent_t ev_stop, FuseArgs fuse, StepArgs sa, hipStream_t stream) {
+#define FX_LAUNCH(CHv)                                                                                                           \
+    if (CH == CHv) {                                                                                                             \
+        hipExtLaunchKernelGGL((fx_step_kernel<CHv>), dim3(blocks, n_agents), dim3(FX_BLOCK), lds_bytes, stream, ev_start, ev_stop, 0, \
+                              d_probs, fuse, sa);                                                                                \
+        return hipGetLastError();                                                                                                \
+    }
+    FX_STEP_CASES(FX_LAUNCH)
 #undef FX_LAUNCH
     return hipErrorInvalidValue;
 }

@@ -273,6 +273,14 @@ class FrenetEngine:
         self._resident_key = None   # the decomposition is chosen at upload time
         self._resident_keys = None
 
+    def set_step_kernel(self, mode: int = 0, steps_per_item: int = 0):
+        """The whole plan step in ONE launch (fx_set_step_kernel, csrc/fx_step_kernel.h), opt-in: 0 / 1 off (walk, obstacle kernel,
+        selection as three launches -- faster on the MI355X), 2 on where applicable; steps_per_item 0 auto / 3 / 5 / 8.  Takes effect
+        at the next upload.  Same results (bit for bit at three steps per item)."""
+        check(lib().fx_set_step_kernel(self._ctx, int(mode), int(steps_per_item)))
+        self._resident_key = None
+        self._resident_keys = None
+
     def step_info(self) -> dict:
         """how the last evaluation was launched (fx_step_info_ex)"""
         v = np.zeros(16, np.int64)
@@ -284,6 +292,7 @@ class FrenetEngine:
         # [15]: bits 0-1 what the agent's last workgroup did (fx_tail.h), bits 8-9 how the latest inputs reached the device:
         # 1 DMA copy, 2 staging kernel, 3 written by the host into device memory (large BAR)
         info["staging"] = ("none", "dma", "kernel", "host_writes")[(info["tail"] >> 8) & 3]
+        info["step_kernel"] = (info["tail"] >> 16) & 1   # the whole step ran as ONE launch (fx_step_kernel.h)
         info["tail"] &= 0xff
         return info
 

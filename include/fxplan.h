@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 8
+#define FX_ABI_VERSION 9
 
 /* ---- status codes (planner.py / reactive_planner_cpp.py raise Python exceptions; the shim maps
  *      <0 -> ValueError, >0 -> RuntimeError, see SURVEY 8b "Error conventions") ---- */
@@ -473,6 +473,16 @@ double fx_last_eval_kernel_ms(const FxContext *ctx);
  * point (planning.yaml:34-35, 630 / 800 candidates) is ONE launch.  0 = always run the separate selection kernel (same results;
  * used by the parity tests), 1 = automatic, 2 = in-kernel whatever the candidate count (tests).  Takes effect at the next upload. */
 int32_t fx_set_fused_selection(FxContext *ctx, int32_t enabled);
+/* The whole plan step in ONE launch (csrc/fx_step_kernel.h; ABI 9), OPT-IN: steps whose obstacle stage runs as its own kernel
+ * behind the walk (200 ... 3 072 waves with a materialised bundle: BASELINE config 3, config 4's batch) can run walk | grid barrier |
+ * obstacle items | grid barrier | sliced selection (+ winner package) as phases of one kernel.  Same results (bit for bit at three
+ * steps per item).  Measured slower on the MI355X -- config 3: 94 us against 86 us -- because the obstacle phase then runs with the
+ * walk's register allocation (three waves per SIMD; a wave issues one FP64 instruction per ~16 cycles), so it is off unless asked
+ * for.  Needs every workgroup of the launch resident at once: the library sizes the launch by the occupancy query and keeps the three
+ * launches where the walk alone would not fit.  mode 0 / 1 = off (three launches), 2 = on where applicable (FX_STEP_KERNEL=1 in
+ * the environment does the same for every context); steps_per_item 0 = automatic, or 3 / 5 / 8 steps of the horizon per obstacle
+ * work item.  Takes effect at the next upload.  fx_step_info_ex [15] bit 16 reports that the last step ran this way. */
+int32_t fx_set_step_kernel(FxContext *ctx, int32_t mode, int32_t steps_per_item);
 /* how the last evaluation was launched: grid kernel, lanes per candidate, waves per SIMD, workgroup size, wave split, fused
  * selection, workgroups per agent, agents, winner package, dynamic LDS bytes */
 int32_t fx_step_info(const FxContext *ctx, int64_t *out10);

@@ -91,6 +91,11 @@ RUNS = dict(
     zam630=lambda: run("BASELINE config 1 (ZAM_Tjunction ego, level 2)", zam=630, package=False),
     zam800=lambda: run("BASELINE config 1 as the 800-row C x 13 matrix", zam=800, package=False),
     c4agent_sel=lambda: run("10 488 candidates, selection kernel", fused=False, grid=(19, 23, 24), n_obstacles=9),
+    c3=lambda: run("config 3 (walk of the split step)", grid=(19, 51, 51), n_obstacles=20, lead_gap=25.0, package=False),
+    c2=lambda: run("config 2 (bundle, no obstacles)", grid=(19, 51, 51), package=False),
+    c2g4=lambda: run("config 2, four lanes per candidate", G=4, grid=(19, 51, 51), package=False),
+    c2g8=lambda: run("config 2, eight lanes per candidate", G=8, grid=(19, 51, 51), package=False),
+    c2g1=lambda: run("config 2, one lane per candidate", G=1, grid=(19, 51, 51), package=False),
     l4=lambda: run("level 4 (11 220 candidates), 5 obstacles", level=4, n_obstacles=5),
     l4_sel=lambda: run("level 4 (11 220 candidates), 5 obstacles, selection kernel", fused=False, level=4, n_obstacles=5),
 )
