@@ -120,10 +120,12 @@ struct FxContext {
     size_t in_bytes = 0;
     char *h_in = nullptr;   // pinned + mapped
     char *h_in_dev = nullptr;  // device address of the same block (the staging kernel reads it)
-    int stage_mode = 0;        // 0 auto: host writes (below) where the device memory is host-visible, else kernel copy up to
-                               // FX_STAGE_KERNEL_MAX bytes, DMA above; 1 DMA; 2 kernel; 3 host writes or fail (FX_STAGE=dma|kernel|bar)
-    bool bar_ok = false;       // the input arena d_in is mapped into this process (large BAR) and host stores reach it: state updates
-                               // are written straight into device memory, no staging launch (probed at fx_create)
+    int stage_mode = 0;        // 0 auto: kernel copy up to FX_STAGE_KERNEL_MAX bytes, DMA above; 1 DMA; 2 kernel; 3 host writes into
+                               // device memory -- OPT-IN, or fail (FX_STAGE=dma|kernel|bar)
+    bool user_stream = false;  // fx_set_stream handed in a caller's stream: what else is queued on it is unknown
+    bool bar_ok = false;       // FX_STAGE=bar and the input arena d_in is mapped into this process (large BAR), host stores reach it
+                               // and a kernel that had the lines cached sees a second write (probed at fx_create)
+    volatile uint32_t *hdp_flush = nullptr;   // the device's HDP flush register (hipDeviceAttributeHdpMemFlushCntl), written behind host stores
     int stage_path = 0;        // how the latest inputs reached the device: 1 DMA copy, 2 staging kernel, 3 host writes
     char *d_in = nullptr;
     // problems
@@ -172,6 +174,9 @@ struct FxContext {
     int pub_n = 0;
     double *dev_winner = nullptr;          // caller-owned device buffer [n_agents][2] the selection kernel also fills
     bool in_flight = false;                // work enqueued whose completion the host has not observed yet
+    bool tail_work = false;                // work queued behind the evaluation whose completion NO sequence word reports (top-k, publication,
+                                           // exchange) or a caller's own stream (fx_set_stream): cleared only by a stream synchronise --
+                                           // fx_finish_batch clears in_flight when the evaluation's words arrive, which says nothing about these
     double *d_topk_cost = nullptr;
     long long *d_topk_idx = nullptr;
     double *d_topk_scr_cost = nullptr;     // [max_agents][64 slices][64]
@@ -468,36 +473,72 @@ int32_t fx_device_count(int32_t *count) {
     return FX_OK;
 }
 
-// Host writes into device memory (large BAR).  On boxes where the whole VRAM is mapped into the process a state update needs no
-// staging launch: the host copies the rewritten range of its pinned block into the device arena itself -- posted PCIe writes, ordered
-// in front of the launch that follows (a posted write is never passed by the doorbell write or by the completion that carries the
-// packet to the command processor), ~50 GB/s and no round trip; every kernel start invalidates the XCDs' L2s, so the evaluation
-// kernel reads what the host wrote (tools/micro/bar_write.hip, bar_bw.hip).  The probe cannot fault: the mapping is tested through
-// a system call (read(2) into the address returns EFAULT where nothing is mapped), then a pattern written by the host is read
-// back by a device-to-host copy.
-static bool probe_host_writes(int device, char *d_in, size_t bytes) {
+// Host writes into device memory (large BAR) -- OPT-IN (FX_STAGE=bar).  On boxes where the whole VRAM is mapped into the process a
+// state update needs no staging launch: the host copies the rewritten range of its pinned block into the device arena itself --
+// posted PCIe writes, ~50 GB/s and no round trip (tools/micro/bar_write.hip, bar_bw.hip; ~3 us of a host-fed step).  Round 5 ran it
+// by default; it is opt-in now because two links of the chain are not a documented contract of HIP: (a) the writes pass through the
+// host data path (HDP) of the GPU, which the driver flushes behind ITS OWN writes to VRAM -- the library now does the same: it reads
+// the device's HDP flush register address (hipDeviceAttributeHdpMemFlushCntl), writes 1 behind the stores and reads it back; without
+// that attribute the path is refused -- and (b) a kernel must not find a stale copy of a rewritten line in an XCD's L2: kernel start
+// invalidates the L2s on gfx942 / gfx950, and the probe below checks exactly that (write, kernel reads every line, write again,
+// kernel reads again), failing closed to the staging kernel.  The default path -- staging kernel reading the pinned block, DMA above
+// 1 MiB -- is stream-ordered and needs neither.
+// The probe cannot fault: the mapping is tested through a system call (read(2) into the address returns EFAULT where nothing is
+// mapped), then patterns written by the host are read by a device-to-host copy AND by a kernel launch, twice with different
+// contents (the second read finds the first pattern's lines in whatever cache kept them).
+extern "C" hipError_t fx_launch_probe_read(const void *src, void *dst, int blocks, hipStream_t stream);
+static bool probe_host_writes(FxContext *c, int device, char *d_in, size_t bytes) {
     int large = 0;
     if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large || bytes < 64) return false;
+    uint32_t *flush = nullptr;
+    if (hipDeviceGetAttribute(reinterpret_cast<int *>(&flush), hipDeviceAttributeHdpMemFlushCntl, device) != hipSuccess || !flush) {
+        (void)hipGetLastError();
+        return false;
+    }
     const int fd = open("/dev/zero", O_RDONLY);
     if (fd < 0) return false;
     char *first = d_in, *last = d_in + ((bytes - 64) & ~(size_t)63);
     const bool mapped = read(fd, first, 64) == 64 && read(fd, last, 64) == 64;
     close(fd);
     if (!mapped) return false;
+    c->hdp_flush = flush;
+    // a kernel reads what the host wrote: 64 workgroups (all XCDs) copy the probed line into a scratch buffer, which a plain copy
+    // brings back; three rounds with different patterns over the SAME lines
+    constexpr int kProbeBlocks = 64;
+    char *scratch = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&scratch), 64 * kProbeBlocks) != hipSuccess) { (void)hipGetLastError(); return false; }
+    bool ok = true;
     unsigned long long pat[8], back[8];
-    for (char *at : {first, last}) {
-        for (int i = 0; i < 8; i++) pat[i] = 0x9e3779b97f4a7c15ULL * (unsigned long long)(i + 1) ^ (unsigned long long)(uintptr_t)at;
-        memcpy(at, pat, sizeof(pat));
-        __builtin_ia32_sfence();
-        if (hipMemcpy(back, at, sizeof(back), hipMemcpyDeviceToHost) != hipSuccess || memcmp(pat, back, sizeof(pat))) return false;
-    }
-    return true;
+    std::vector<unsigned long long> seen(8 * kProbeBlocks);
+    for (int round = 0; round < 3 && ok; round++)
+        for (char *at : {first, last}) {
+            for (int i = 0; i < 8; i++)
+                pat[i] = 0x9e3779b97f4a7c15ULL * (unsigned long long)(i + 1 + 8 * round) ^ (unsigned long long)(uintptr_t)at;
+            memcpy(at, pat, sizeof(pat));
+            __builtin_ia32_sfence();
+            *c->hdp_flush = 1u; (void)*c->hdp_flush;
+            ok = ok && fx_launch_probe_read(at, scratch, kProbeBlocks, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
+                 hipMemcpy(seen.data(), scratch, 64 * kProbeBlocks, hipMemcpyDeviceToHost) == hipSuccess &&
+                 hipMemcpy(back, at, sizeof(back), hipMemcpyDeviceToHost) == hipSuccess && !memcmp(pat, back, sizeof(pat));
+            for (int b = 0; b < kProbeBlocks && ok; b++) ok = !memcmp(pat, seen.data() + 8 * b, sizeof(pat));
+        }
+    (void)hipFree(scratch);
+    if (!ok) { (void)hipGetLastError(); c->hdp_flush = nullptr; }
+    return ok;
 }
-// the rewritten range of the pinned block, copied by the host (bar_ok, nothing of this context in flight)
+// the rewritten range of the pinned block, copied by the host (bar_ok; the caller has made sure the context's stream is idle)
 static void host_stage(FxContext *c, size_t lo, size_t hi) {
     memcpy(c->d_in + lo, c->h_in + lo, hi - lo);
     __builtin_ia32_sfence();
+    *c->hdp_flush = 1u; (void)*c->hdp_flush;   // flush the GPU's host data path behind the stores (what the driver does behind its own)
     c->stage_path = 3;
+}
+// host writes only while NOTHING of this context's stream is pending: not the evaluation, not a top-k or publication kernel queued
+// behind it, not work a caller put on a stream handed in with fx_set_stream -- any of them may still read the arena
+static bool host_stage_allowed(FxContext *c, size_t bytes) {
+    // (hipStreamQuery is no help here: it reports hipErrorNotReady for a stream whose last kernel ended milliseconds ago until somebody
+    // synchronises -- measured on ROCm 7.2 -- so the library keeps its own account of what may still read the arena)
+    return c->bar_ok && !c->in_flight && !c->tail_work && bytes <= FX_STAGE_HOST_MAX;
 }
 
 int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int64_t max_candidates_total,
@@ -552,10 +593,11 @@ int32_t fx_create_batch(FxContext **out, int32_t device, int32_t max_agents, int
     if (const char *of = getenv("FX_OBST_STAGE")) c->obst_force = std::max(0, std::min(2, atoi(of)));   // experiments: fx_set_obstacle_stage's first argument
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_in), c->in_bytes));
     c->dev_bytes += (int64_t)c->in_bytes;
-    if (c->stage_mode == 0 || c->stage_mode == 3) {
-        c->bar_ok = probe_host_writes(device, c->d_in, c->in_bytes);
-        if (c->stage_mode == 3 && !c->bar_ok)
-            return set_err(FX_ERR_HIP, "FX_STAGE=bar: the device memory of GPU %d is not host-writable from this process", device);
+    if (c->stage_mode == 3) {   // opt-in (see probe_host_writes)
+        c->bar_ok = probe_host_writes(c, device, c->d_in, c->in_bytes);
+        if (!c->bar_ok)
+            return set_err(FX_ERR_HIP, "FX_STAGE=bar: the device memory of GPU %d is not host-writable from this process, has no HDP flush "
+                           "register, or a kernel did not see a rewritten line", device);
     }
     c->h_probs = reinterpret_cast<DevProblem *>(c->h_in);
     c->d_probs = reinterpret_cast<DevProblem *>(c->d_in);
@@ -654,7 +696,7 @@ int32_t fx_publish(FxContext *c, const void *d_src, int32_t n) {
     c->pub_n = n;
     HIP_TRY(fx_launch_publish(reinterpret_cast<const double *>(d_src), n, c->h_pub_dev,
                               reinterpret_cast<unsigned long long *>(c->h_pub_dev + FX_PUB_MAX), c->pub_seq, c->stream));
-    c->in_flight = true;
+    c->in_flight = true; c->tail_work = true;
     return FX_OK;
 }
 
@@ -727,6 +769,7 @@ int32_t fx_set_stream(FxContext *c, void *hip_stream) {
     if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     c->stream = reinterpret_cast<hipStream_t>(hip_stream);
     c->own_stream = false;
+    c->user_stream = c->tail_work = true;   // (whatever else the caller queues on it may read the arena: no host writes, ever)
     return FX_OK;
 }
 
@@ -737,7 +780,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     if (c->timed_out) return set_err(FX_ERR_TIMEOUT, "an earlier wait on this context timed out (its stream may never drain): destroy it");
     HIP_TRY(hipSetDevice(c->device));
     if (c->in_flight) {  // the pinned staging block is about to be rewritten: earlier copies must have landed
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        { HIP_TRY(hipStreamSynchronize(c->stream)); c->tail_work = c->user_stream; }
         c->in_flight = false;
     }
     c->uploaded = c->evaluated = false;
@@ -830,7 +873,10 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         // 651 us at 2 waves per SIMD, 697 us at 4 -- tools/sweep_1m_modeB.py)
         bool bundle_any = false;
         for (int a = 0; a < n_agents; a++) bundle_any |= (probs[a].mode & FX_MODE_WRITE_BUNDLE) != 0;
-        c->wpe_step = c->wpe_force ? c->wpe_force : (waves1 >= 3072 ? (bundle_any ? 2 : (obst_any ? 3 : 4)) : 2);
+        // ... but with the obstacle stage in the walk as well (the north star as written) the kernel is bound by what a wave issues: one
+        // FP64 instruction per ~16 cycles (tools/micro/clockrate.hip), so the third wave per SIMD pays (168 registers, no vector
+        // spill): 1 062 -> 1 004 us same-box, tools/ns_wpe.py
+        c->wpe_step = c->wpe_force ? c->wpe_force : (waves1 >= 3072 ? (bundle_any ? (obst_any ? 3 : 2) : (obst_any ? 3 : 4)) : 2);
         // grid kernel: sampling ranges, no windowed costs, and the longitudinal rows of a workgroup fit in LDS.
         // Workgroup size: the smallest of 64/128/256 lanes whose LDS footprint still lets a CU hold the target
         // number of waves (small workgroups balance small grids at wave granularity).
@@ -1137,7 +1183,7 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     }
     if (obs_part_need) {   // scratch of the obstacle kernel: grown on demand, tickets start (and are left) zeroed
         if (obs_part_need > c->obs_part_cap || obs_colm_need > c->obs_colm_cap) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            { HIP_TRY(hipStreamSynchronize(c->stream)); c->tail_work = c->user_stream; }
             if (c->d_obs_part) { (void)hipFree(c->d_obs_part); c->dev_bytes -= (int64_t)(sizeof(double) * c->obs_part_cap); }
             if (c->d_obs_colm) { (void)hipFree(c->d_obs_colm); c->dev_bytes -= (int64_t)(sizeof(unsigned long long) * c->obs_colm_cap); }
             c->d_obs_part = nullptr; c->d_obs_colm = nullptr;
@@ -1179,8 +1225,8 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
     // problems + inputs: small uploads through the staging kernel as well (the DMA engine's submission latency dominates below ~1 MiB)
     {
         const size_t up = (ar.off + 15) & ~(size_t)15;
-        if (c->bar_ok && !c->in_flight && up <= FX_STAGE_HOST_MAX && up <= c->in_bytes)
-            host_stage(c, 0, up);   // (in_flight was drained above: no kernel of this context reads the arena)
+        if (up <= c->in_bytes && host_stage_allowed(c, up))
+            host_stage(c, 0, up);
         else if (c->stage_mode == 2 || (c->stage_mode != 1 && up <= FX_STAGE_KERNEL_MAX && up <= c->in_bytes)) {
             HIP_TRY(fx_launch_stage(c->h_in_dev, c->d_in, up, c->stream));
             c->stage_path = 2;
@@ -1211,7 +1257,7 @@ int32_t fx_evaluate(FxContext *c) {
         const size_t lo16 = lo & ~(size_t)15, hi16 = (hi + 15) & ~(size_t)15;
         // host writes only while nothing of this context is in flight: fx_update_state drained the stream (or fx_finish saw the
         // previous step's last word) before the block was rewritten, so no kernel still reads the arena
-        if (c->bar_ok && !c->in_flight && hi16 - lo16 <= FX_STAGE_HOST_MAX)
+        if (host_stage_allowed(c, hi16 - lo16))
             host_stage(c, lo16, hi16);
         else if (c->stage_mode == 2 || (c->stage_mode != 1 && hi16 - lo16 <= FX_STAGE_KERNEL_MAX)) {
             HIP_TRY(fx_launch_stage(c->h_in_dev + lo16, c->d_in + lo16, hi16 - lo16, c->stream));
@@ -1428,7 +1474,7 @@ int32_t fx_update_state(FxContext *c, int32_t agent, const FxStateUpdate *u) {
     if (agent < 0 || agent >= c->n_agents) return set_err(FX_ERR_INVALID_ARGUMENT, "agent %d out of range", agent);
     if (c->in_flight) {  // a copy out of the staging block may still be running: let it land before rewriting its source
         HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        { HIP_TRY(hipStreamSynchronize(c->stream)); c->tail_work = c->user_stream; }
         c->in_flight = false;
     }
     FxAgentSlot &sl = c->slots[agent];
@@ -1691,7 +1737,7 @@ static int exchange_signal(FxContext *c, int32_t total) {
     c->pub_seq++;
     c->pub_n = total;
     HIP_TRY(hipStreamWriteValue64(c->stream, c->h_pub_dev + FX_PUB_MAX, c->pub_seq, 0));
-    c->in_flight = true;
+    c->in_flight = true; c->tail_work = true;
     return FX_OK;
 }
 
@@ -2096,7 +2142,7 @@ int32_t fx_read_costs_agent(FxContext *c, int32_t agent, double *cost, uint32_t 
     int rc = check_agent(c, agent);
     if (rc) return rc;
     const FxAgentSlot &s = c->slots[agent];
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { HIP_TRY(hipStreamSynchronize(c->stream)); c->tail_work = c->user_stream; }
     if (cost) HIP_TRY(hipMemcpy(cost, c->d_cost + s.cand_off, sizeof(double) * s.C, hipMemcpyDeviceToHost));
     if (flags) HIP_TRY(hipMemcpy(flags, c->d_flags + s.cand_off, sizeof(uint32_t) * s.C, hipMemcpyDeviceToHost));
     return FX_OK;
@@ -2108,7 +2154,7 @@ int32_t fx_read_costmap_agent(FxContext *c, int32_t agent, double *raw) {
     if (rc) return rc;
     const FxAgentSlot &s = c->slots[agent];
     if (!(s.mode & FX_MODE_WRITE_COSTMAP)) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_COSTMAP");
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { HIP_TRY(hipStreamSynchronize(c->stream)); c->tail_work = c->user_stream; }
     HIP_TRY(hipMemcpy2D(raw, sizeof(double) * s.C, c->d_costmap + (size_t)FX_NUM_COSTS * s.cand_off, sizeof(double) * s.ld,
                         sizeof(double) * s.C, s.n_cost, hipMemcpyDeviceToHost));
     return FX_OK;
@@ -2122,7 +2168,7 @@ static int32_t read_coeff_rows(FxContext *c, int32_t agent, int64_t index, doubl
     if (!(s.mode & FX_MODE_WRITE_BUNDLE)) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_BUNDLE");
     if (index < 0 || index >= s.C) return set_err(FX_ERR_INVALID_ARGUMENT, "candidate %lld out of range", (long long)index);
     double tmp[FX_COEFF_ROWS];
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { HIP_TRY(hipStreamSynchronize(c->stream)); c->tail_work = c->user_stream; }
     HIP_TRY(hipMemcpy2D(tmp, sizeof(double), c->d_coeffs + (size_t)FX_COEFF_ROWS * s.cand_off + index, sizeof(double) * s.ld,
                         sizeof(double), FX_COEFF_ROWS, hipMemcpyDeviceToHost));
     if (lon6) memcpy(lon6, tmp, 6 * sizeof(double));
@@ -2145,7 +2191,7 @@ int32_t fx_read_boundary_steps_agent(FxContext *c, int32_t agent, int32_t *steps
     const FxAgentSlot &s = c->slots[agent];
     if (!(s.mode & FX_MODE_ROAD_BOUNDARY)) return set_err(FX_ERR_NOT_READY, "the step ran without FX_MODE_ROAD_BOUNDARY");
     HIP_TRY(hipMemcpyAsync(steps, c->d_bstep + s.cand_off, sizeof(int32_t) * s.C, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { HIP_TRY(hipStreamSynchronize(c->stream)); c->tail_work = c->user_stream; }
     return FX_OK;
 }
 int32_t fx_read_boundary_steps(FxContext *c, int32_t *steps) { return fx_read_boundary_steps_agent(c, 0, steps); }
@@ -2160,7 +2206,7 @@ int32_t fx_read_sample_agent(FxContext *c, int32_t agent, int64_t index, double 
     const FxAgentSlot &s = c->slots[agent];
     if (!(s.mode & FX_MODE_WRITE_BUNDLE)) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_BUNDLE");
     if (index < 0 || index >= s.C) return set_err(FX_ERR_INVALID_ARGUMENT, "candidate %lld out of range", (long long)index);
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { HIP_TRY(hipStreamSynchronize(c->stream)); c->tail_work = c->user_stream; }
     // one strided gather: 14*S elements, pitch = ld doubles
     HIP_TRY(hipMemcpy2D(planes, sizeof(double), c->h_probs[agent].planes + index, sizeof(double) * s.ld, sizeof(double),
                         (size_t)FX_NUM_PLANES * s.S, hipMemcpyDeviceToHost));
@@ -2196,7 +2242,7 @@ int32_t fx_read_candidate_agent(FxContext *c, int32_t agent, int64_t index, doub
                                  sizeof(double), s.n_cost, hipMemcpyDeviceToHost, c->stream));
     if (cost) HIP_TRY(hipMemcpyAsync(h_c, c->d_cost + s.cand_off + index, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (flags) HIP_TRY(hipMemcpyAsync(h_fl, c->d_flags + s.cand_off + index, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { HIP_TRY(hipStreamSynchronize(c->stream)); c->tail_work = c->user_stream; }
     if (planes) memcpy(planes, hp, sizeof(double) * n_pl);
     if (coeffs13) memcpy(coeffs13, h_co, sizeof(double) * FX_COEFF_ROWS);
     if (traj_len) *traj_len = *h_tl;
@@ -2212,7 +2258,7 @@ int32_t fx_read_plane_agent(FxContext *c, int32_t agent, int32_t plane, double *
     const FxAgentSlot &s = c->slots[agent];
     if (!(s.mode & FX_MODE_WRITE_BUNDLE)) return set_err(FX_ERR_NOT_READY, "plan step ran without FX_MODE_WRITE_BUNDLE");
     if (plane < 0 || plane >= FX_NUM_PLANES) return set_err(FX_ERR_INVALID_ARGUMENT, "plane %d out of range", plane);
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { HIP_TRY(hipStreamSynchronize(c->stream)); c->tail_work = c->user_stream; }
     HIP_TRY(hipMemcpy2D(out, sizeof(double) * s.C, c->h_probs[agent].planes + (size_t)plane * s.S * s.ld, sizeof(double) * s.ld,
                         sizeof(double) * s.C, s.S, hipMemcpyDeviceToHost));
     return FX_OK;
@@ -2226,7 +2272,7 @@ int32_t fx_topk_to_device(FxContext *c, int32_t k, void *d_cost, void *d_index) 
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(fx_launch_topk(c->d_probs, c->n_agents, max_candidates_of(c), k, c->d_topk_scr_cost, c->d_topk_scr_idx, reinterpret_cast<double *>(d_cost),
                            reinterpret_cast<long long *>(d_index), c->stream));
-    c->in_flight = true;
+    c->in_flight = true; c->tail_work = true;
     return FX_OK;
 }
 
@@ -2236,7 +2282,7 @@ int32_t fx_read_topk_batch(FxContext *c, int32_t k, double *cost, int64_t *index
     const size_t n = (size_t)k * c->n_agents;
     HIP_TRY(hipMemcpyAsync(c->h_topk_cost, c->d_topk_cost, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(c->h_topk_idx, c->d_topk_idx, sizeof(long long) * n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { HIP_TRY(hipStreamSynchronize(c->stream)); c->tail_work = c->user_stream; }
     memcpy(cost, c->h_topk_cost, sizeof(double) * n);
     for (size_t i = 0; i < n; i++) index[i] = (int64_t)c->h_topk_idx[i];
     return FX_OK;

@@ -365,6 +365,16 @@ extern "C" hipError_t fx_launch_stage(const void *src_mapped, void *dst, size_t 
 }
 
 // element-wise check of the fx_math kernels (tests/test_hip_math.py)
+// probe of the host-write path (fx_api.hip, probe_host_writes): every workgroup -- they are spread over all XCDs -- copies the same
+// 64 bytes of the arena into its own slot, so that a stale copy of the line in ANY XCD's L2 shows
+__global__ void fx_probe_read_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst) {
+    if (threadIdx.x < 4) dst[blockIdx.x * 4 + threadIdx.x] = src[threadIdx.x];
+}
+extern "C" hipError_t fx_launch_probe_read(const void *src, void *dst, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(fx_probe_read_kernel, dim3(blocks), dim3(64), 0, stream, reinterpret_cast<const uint4 *>(src), reinterpret_cast<uint4 *>(dst));
+    return hipGetLastError();
+}
+
 __global__ void fx_math_test_kernel(int n, const double *__restrict__ x, double *__restrict__ at, double *__restrict__ sn,
                                     double *__restrict__ cs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

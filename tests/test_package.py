@@ -250,12 +250,15 @@ def test_published_blocks_are_never_torn(fused):
 
 
 def test_state_updates_written_by_the_host_equal_the_staging_kernel(monkeypatch):
-    """Where the device memory is mapped into the process (large BAR) a state update is written by the host straight into the device
-    arena -- posted writes in front of the evaluation launch, no staging kernel (fx_api.hip, probe_host_writes / host_stage).  The
-    same alternating inputs through a context that stages with the kernel (FX_STAGE=kernel) and through the automatic one: every
-    step's result and package are identical, at a planner-sized step (5 obstacles) and at config 3's size (20 obstacles: 140 KB per
-    update); the automatic context reports which path it took."""
+    """OPT-IN path (FX_STAGE=bar): where the device memory is mapped into the process (large BAR) a state update is written by the
+    host straight into the device arena -- posted writes + HDP flush in front of the evaluation launch, no staging kernel (fx_api.hip,
+    probe_host_writes / host_stage; refused at fx_create where the mapping, the HDP flush register or the probe's kernel read-back
+    is missing).  The same alternating inputs through a context that stages with the kernel (FX_STAGE=kernel), through the default
+    one (stream-ordered staging: kernel or DMA) and through the opt-in one: every step's result and package are identical, at a
+    planner-sized step (5 obstacles) and at config 3's size (20 obstacles: 140 KB per update) -- every step rewrites lines the
+    previous step's kernels have read."""
     from frenetix_motion_planner_amd import synthetic
+    from frenetix_motion_planner_amd._lib import FxError
     from frenetix_motion_planner_amd.engine import build_obstacle_hulls
     cases = []
     a = _inputs(seed=3); b = _inputs(seed=4, v0=7.5); b.coordinate_system = a.coordinate_system
@@ -266,20 +269,42 @@ def test_state_updates_written_by_the_host_equal_the_staging_kernel(monkeypatch)
     for x, y, n in cases:
         monkeypatch.setenv("FX_STAGE", "kernel")
         ek = _engine(max_candidates=x.n_candidates + 64)
+        monkeypatch.setenv("FX_STAGE", "bar")
+        try:
+            eb = _engine(max_candidates=x.n_candidates + 64)
+        except FxError:
+            eb = None   # (no large BAR / no HDP flush register on this box: the opt-in is refused loudly, nothing to compare)
         monkeypatch.delenv("FX_STAGE")
         ea = _engine(max_candidates=x.n_candidates + 64)
         try:
+            import time
+            paths = set()
             for k in range(n):
                 inp = x if k % 2 == 0 else y
                 rk, pk = ek.plan_step_packaged(inp, yaw_rate0=0.0)
-                ra, pa = ea.plan_step_packaged(inp, yaw_rate0=0.0)
-                assert rk == ra, k
-                assert (pk is None) == (pa is None)
-                if pk is not None:
-                    assert pk.index == pa.index and np.array_equal(pk.block, pa.block) and np.array_equal(pk.raw_costs, pa.raw_costs), k
+                for e in (ea, eb):
+                    if e is None:
+                        continue
+                    if e is eb and k % 3 == 0:
+                        time.sleep(2e-4)   # host writes need the context's stream IDLE (hipStreamQuery), else the staging kernel runs: both happen
+                    ra, pa = e.plan_step_packaged(inp, yaw_rate0=0.0)
+                    if e is eb:
+                        paths.add(e.step_info()["staging"])
+                    assert rk == ra, k
+                    assert (pk is None) == (pa is None)
+                    if pk is not None:
+                        assert pk.index == pa.index and np.array_equal(pk.block, pa.block) and np.array_equal(pk.raw_costs, pa.raw_costs), k
             assert ek.step_info()["staging"] == "kernel"
-            assert ea.step_info()["staging"] in ("host_writes", "kernel")   # (kernel where the device memory is not host-visible)
-            cost_k, flags_k = ek.costs(); cost_a, flags_a = ea.costs()
-            assert np.array_equal(flags_k, flags_a) and np.array_equal(cost_k, cost_a)
+            assert ea.step_info()["staging"] in ("kernel", "dma")      # the default is stream-ordered
+            cost_k, flags_k = ek.costs()
+            for e in (ea, eb):
+                if e is None:
+                    continue
+                cost_a, flags_a = e.costs()
+                assert np.array_equal(flags_k, flags_a) and np.array_equal(cost_k, cost_a)
+            if eb is not None:
+                assert "host_writes" in paths and paths <= {"host_writes", "kernel"}, paths
         finally:
             ek.close(); ea.close()
+            if eb is not None:
+                eb.close()
