@@ -100,6 +100,13 @@ def test_config2_line_keeps_the_hbm_roofline():
     assert rf["algorithmic_bytes_per_launch"] == 50388 * 3472 and rf["launches_timed"] == 24 and "north_star" not in d
 
 
+def test_reference_python_record_is_committed():
+    """CPU check of the same record (no GPU): the file bench.py copies into cpu_baseline.reference_python"""
+    import json
+    rp = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_python_timing.json")))
+    assert rp["cores"] == 1 and rp["candidates"] == 630 and rp["value"] == pytest.approx(630 / (rp["plan_step_p50_ms"] * 1e-3))
+
+
 @pytest.mark.gpu
 def test_cpu_baseline_object_and_other_workloads():
     d = run("--workload", "config1", "--steps", "20", "--warmup", "2")
@@ -108,6 +115,10 @@ def test_cpu_baseline_object_and_other_workloads():
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e4 and d["config"]["candidates"] == 630
     assert "not run" in cb["upstream_handler"]
+    # the reference's own number (tests/golden/time_reference_python.py -> reference_python_timing.json): carried, never re-measured here
+    rp = cb["reference_python"]
+    assert rp["cores"] == 1 and rp["unit"] == "trajectories/s" and 100 < rp["value"] < 1e5 and rp["candidates"] == 630
+    assert "build container" in rp["measured_in"] and "time_reference_python.py" in rp["method"] and rp["cpu"]
     d5 = run("--workload", "config5", "--agents-per-gpu", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert d5["config"]["agents_per_gpu"] == 2 and d5["config"]["candidates_per_gpu"] == 2 * 103428
     # executed work or nothing: a fraction is only printed when the tracked PMC summary holds the kernel that ran
