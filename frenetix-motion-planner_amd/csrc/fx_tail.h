@@ -44,16 +44,28 @@ __device__ __forceinline__ void st_agent(FX_GLOBAL T *p, T v) {
 // fence a result block reached the host AFTER its sequence word (test_work_decomposition..., test_adapter_replay failed on it)
 template <typename T>
 __device__ __forceinline__ void put_host(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// Sequence word of a host block.  Payload-before-sequence ordering here is NOT the memory model's (relaxed atomics carry none): it
+// is the hardware's -- system-scope stores of gfx942 / gfx950 are write-through and `s_waitcnt vmcnt(0)` returns when they are
+// performed, and every wave has waited for its own before the barrier in front of this store (measured:
+// test_published_blocks_are_never_torn).  Any other target gets the portable form: a system-scope RELEASE.
 template <typename T>
-__device__ __forceinline__ void st_host(T *p, T v) {   // sequence word of a host block
+__device__ __forceinline__ void st_host(T *p, T v) {
+#if defined(__gfx942__) || defined(__gfx950__)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
 }
 // two adjacent payload words with ONE 16-byte system-scope store (p 16-byte aligned): the number of store INSTRUCTIONS a wave issues
 // is what the publication costs
 __device__ __forceinline__ void put_host2(double *p, double a, double b) {
     typedef double d2_t __attribute__((ext_vector_type(2)));
     const d2_t v = {a, b};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#if defined(__gfx942__) || defined(__gfx950__)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");   // (the gfx940+ spelling of a system-scope store)
+#else
+    put_host(p, a); put_host(p + 1, b);
+#endif
 }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // a per-candidate output: write-through where a later workgroup of the SAME launch reads it (the tail), plain otherwise
