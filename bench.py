@@ -62,7 +62,7 @@ NORTH_STAR_GRID = (19, 230, 229)  # 19 x 230 x 230 (d0 added) = 1 005 100 candid
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: FP64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
 LEAD_GAP = 25.0                # obstacle 0 is a slow lead vehicle 25 m ahead (the cheapest candidates collide)
 STRESS_GRID = (39, 51, 51)     # config 5: T = 1.1 .. 4.9 (39) x 51 x 51 (+ d0), 5 s horizon
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r5", "summary.json")  # rocprofv3 summaries of these commands (tools/collect_profiles.sh)
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r6", "summary.json")  # rocprofv3 summaries of these commands (tools/collect_profiles.sh)
 UPSTREAM_NOTE = "upstream OpenMP C++ handler (frenetix 0.4.0): not run -- not installable offline, not in the reference tree"
 
 
