@@ -17,4 +17,6 @@ run tail FX_SOAK_TAIL=1
 run tail+tuning FX_SOAK_TAIL=1 FX_SOAK_TUNING=1
 run tail+crowded+costs FX_SOAK_TAIL=1 FX_SOAK_MANY=1 FX_SOAK_COSTS=1
 run tail+matrix+tuning FX_SOAK_TAIL=1 FX_SOAK_MATRIX=1 FX_SOAK_TUNING=1
+run step-kernel FX_SOAK_STEPK=1
+run step-kernel+crowded FX_SOAK_STEPK=1 FX_SOAK_MANY=1
 echo "== batch"; timeout 900 python3 tools/soak_batch.py $f 300 2>&1 | grep -v amdgpu | tail -3

@@ -45,7 +45,21 @@ for case in range(first, first + n):
                 e.set_obstacle_stage(1)
             step = (lambda i: e.plan_step_packaged(i, yaw_rate0=0.0)) if tail else (lambda i: (e.plan_step(i), None))
             pkg = None
-            if os.environ.get("FX_SOAK_TUNING"):  # also walk through the work decompositions / kernel variants
+            stepk = bool(os.environ.get("FX_SOAK_STEPK"))   # the whole step in ONE launch where it applies (fx_step_kernel.h): two lanes per
+            if stepk:                                        # candidate on two waves, obstacle stage deferred, 3 / 5 / 8 steps per item
+                e.set_step_kernel(2, int(rng.choice([0, 3, 5, 8])))
+                e.set_tuning(2, 2, 2, 256, 2)
+                e.set_obstacle_stage(2, 0)
+                e.set_package(bool(rng.integers(0, 2)))
+                try:
+                    res = e.plan_step(inp)
+                except ValueError:   # (no obstacles / a windowed cost / a road boundary: the forced stage does not apply)
+                    e.set_tuning(0, 0, 0, 0, 0); e.set_obstacle_stage(0); e._resident_key = None
+                    res = e.plan_step(inp)
+                stats["step_kernel_steps"] = stats.get("step_kernel_steps", 0) + e.step_info()["step_kernel"]
+                compare(e, inp, out, res)
+                res = e.plan_step(inp)      # a second step on the same context (barrier words, tickets, counters left clean)
+            elif os.environ.get("FX_SOAK_TUNING"):  # also walk through the work decompositions / kernel variants
                 tn = (int(rng.choice([0, 1, 2, 4, 8, 16, 32])), int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 1, 2])),
                       int(rng.choice([0, 64, 128, 256])), int(rng.choice([0, 1, 2])))
                 e.set_tuning(*tn)
