@@ -479,7 +479,9 @@ int32_t fx_set_fused_selection(FxContext *ctx, int32_t enabled);
  * steps per item).  Measured slower on the MI355X -- config 3: 94 us against 86 us -- because the obstacle phase then runs with the
  * walk's register allocation (three waves per SIMD; a wave issues one FP64 instruction per ~16 cycles), so it is off unless asked
  * for.  Needs every workgroup of the launch resident at once: the library sizes the launch by the occupancy query and keeps the three
- * launches where the walk alone would not fit.  mode 0 / 1 = off (three launches), 2 = on where applicable (FX_STEP_KERNEL=1 in
+ * launches where the walk alone would not fit.  The query assumes the device to itself: two such launches at a time (two contexts, two
+ * processes) can hold each other's slots until the in-kernel barrier gives up after 2 s and the step ends in FX_ERR_TIMEOUT -- use it
+ * from ONE context per device.  mode 0 / 1 = off (three launches), 2 = on where applicable (FX_STEP_KERNEL=1 in
  * the environment does the same for every context); steps_per_item 0 = automatic, or 3 / 5 / 8 steps of the horizon per obstacle
  * work item.  Takes effect at the next upload.  fx_step_info_ex [15] bit 16 reports that the last step ran this way. */
 int32_t fx_set_step_kernel(FxContext *ctx, int32_t mode, int32_t steps_per_item);
