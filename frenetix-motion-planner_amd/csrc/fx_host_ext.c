@@ -562,6 +562,95 @@ done:
     return out;
 }
 
+/* the values of a Python set in ITERATION order as a float64 vector (the reference iterates sets: the candidate index depends on
+ * CPython's set order, reactive_planner.py:149-158) */
+static PyObject *set_to_array(PyObject *set) {
+    npy_intp dim = (npy_intp)PySet_GET_SIZE(set);
+    PyObject *a = PyArray_SimpleNew(1, &dim, NPY_DOUBLE);
+    if (!a) return NULL;
+    double *p = (double *)PyArray_DATA((PyArrayObject *)a);
+    PyObject *it = PyObject_GetIter(set), *item;
+    npy_intp i = 0;
+    if (!it) { Py_DECREF(a); return NULL; }
+    while ((item = PyIter_Next(it))) {
+        const double x = PyFloat_AsDouble(item);
+        Py_DECREF(item);
+        if ((x == -1.0 && PyErr_Occurred()) || i >= dim) { Py_DECREF(it); Py_DECREF(a); if (!PyErr_Occurred()) PyErr_SetString(PyExc_RuntimeError, "set changed size"); return NULL; }
+        p[i++] = x;
+    }
+    Py_DECREF(it);
+    if (PyErr_Occurred() || i != dim) { Py_DECREF(a); if (!PyErr_Occurred()) PyErr_SetString(PyExc_RuntimeError, "set changed size"); return NULL; }
+    return a;
+}
+
+/* next_inputs_level(prev, low_vel_mode, x_lon, x_lat, x0_orientation, v_des, v_lo, v_hi, n_v, d_level_set, d0, obstacles) -> inputs
+ * The closed loop's usual step at a SAMPLING LEVEL of the reference (sampling_matrix.py:156-182): the velocity samples are
+ * set(np.linspace(v_lo, v_hi, n_v)) and the lateral ones d_level_set.union({d0}) IN THE SETS' ITERATION ORDER -- built here with the
+ * same set operations (PySet_New over the linspace values, set.union), so the order is CPython's own -- on a copy of the last inputs
+ * (see next_inputs).  NotImplemented: a case the Python path handles. */
+static PyObject *s_union;
+static PyObject *next_inputs_level(PyObject *self, PyObject *args) {
+    PyObject *prev, *lvm, *x_lon, *x_lat, *d_set, *obstacles;
+    double x0o, v_des, v_lo, v_hi, d0;
+    Py_ssize_t n_v;
+    if (!PyArg_ParseTuple(args, "OOOOddddnOdO", &prev, &lvm, &x_lon, &x_lat, &x0o, &v_des, &v_lo, &v_hi, &n_v, &d_set, &d0, &obstacles))
+        return NULL;
+    PyObject *pd = PyObject_GenericGetDict(prev, NULL);   /* new reference */
+    if (!pd) return NULL;
+    PyObject *out = NULL, *nd = NULL, *v = NULL, *d = NULL, *lon = NULL, *lat = NULL, *tmp, *lst = NULL, *vs = NULL, *one = NULL, *du = NULL;
+    PyObject *pv = PyDict_GetItemWithError(pd, s_v_samp_k), *pdd = PyDict_GetItemWithError(pd, s_d_samp_k);
+    PyObject *pobs = PyDict_GetItemWithError(pd, s_obst_k);
+    if (!pv || !pdd || !pobs || !is_f64_vector(pv) || !is_f64_vector(pdd) || !PyAnySet_Check(d_set) || !PyDict_Check(obstacles) ||
+        !PyDict_Check(pobs) || n_v < 2 || n_v > 4096 || v_hi == v_lo || !(v_hi == v_hi) || !(v_lo == v_lo)) {
+        if (!PyErr_Occurred()) { out = Py_NotImplemented; Py_INCREF(out); }
+        goto done;
+    }
+    {   /* set(np.linspace(v_lo, v_hi, n_v)): np.linspace's arithmetic, inserted in order */
+        if (!(lst = PyList_New(n_v))) goto done;
+        const double step = (v_hi - v_lo) / (double)(n_v - 1);
+        for (Py_ssize_t i = 0; i < n_v; i++) {
+            const double x = i == n_v - 1 ? v_hi : (double)i * step + v_lo;
+            if (!(tmp = PyFloat_FromDouble(x))) goto done;
+            PyList_SET_ITEM(lst, i, tmp);
+        }
+        if (!(vs = PySet_New(lst)) || !(v = set_to_array(vs))) goto done;
+    }
+    {   /* d_level_set.union({d0}) */
+        if (!(one = PySet_New(NULL)) || !(tmp = PyFloat_FromDouble(d0))) goto done;
+        const int rc = PySet_Add(one, tmp);
+        Py_DECREF(tmp);
+        if (rc != 0 || !(du = PyObject_CallMethodObjArgs(d_set, s_union, one, NULL)) || !PyAnySet_Check(du) || !(d = set_to_array(du))) goto done;
+    }
+    if (!(lon = array3(x_lon)) || !(lat = array3(x_lat))) goto done;
+    out = PyBaseObject_Type.tp_new(Py_TYPE(prev), s_empty_tuple, NULL);
+    if (!out) goto done;
+    if (!(nd = PyObject_GenericGetDict(out, NULL)) || PyDict_Update(nd, pd) != 0) { Py_CLEAR(out); goto done; }
+    {
+        int bad = 0;
+        bad |= PyDict_SetItem(nd, s_lvm_k, lvm);
+        bad |= (tmp = PyFloat_FromDouble(x0o)) ? PyDict_SetItem(nd, s_x0o_k, tmp) : 1; Py_XDECREF(tmp);
+        bad |= (tmp = PyFloat_FromDouble(v_des)) ? PyDict_SetItem(nd, s_vdes_k, tmp) : 1; Py_XDECREF(tmp);
+        bad |= PyDict_SetItem(nd, s_obst_k, obstacles);
+        bad |= PyDict_SetItem(nd, s_shard_k, Py_None);
+        bad |= PyDict_SetItem(nd, s_x0_lon_k, lon);
+        bad |= PyDict_SetItem(nd, s_x0_lat_k, lat);
+        bad |= PyDict_SetItem(nd, s_v_samp_k, v);
+        bad |= PyDict_SetItem(nd, s_d_samp_k, d);
+        /* the structure key survives equal lengths and equal (K, P) */
+        PyObject *k0 = PyDict_GetItemWithError(pobs, s_K), *k1 = PyDict_GetItemWithError(obstacles, s_K);
+        PyObject *p0 = PyDict_GetItemWithError(pobs, s_P_k), *p1 = PyDict_GetItemWithError(obstacles, s_P_k);
+        int same = k0 && k1 && p0 && p1 && PyObject_RichCompareBool(k0, k1, Py_EQ) == 1 && PyObject_RichCompareBool(p0, p1, Py_EQ) == 1 &&
+                   PyArray_DIM((PyArrayObject *)d, 0) == PyArray_DIM((PyArrayObject *)pdd, 0) &&
+                   PyArray_DIM((PyArrayObject *)v, 0) == PyArray_DIM((PyArrayObject *)pv, 0);
+        if (!same && PyDict_GetItemWithError(nd, s_skey_k)) bad |= PyDict_DelItem(nd, s_skey_k);
+        if (bad || PyErr_Occurred()) Py_CLEAR(out);
+    }
+done:
+    Py_XDECREF(nd); Py_XDECREF(pd); Py_XDECREF(v); Py_XDECREF(d); Py_XDECREF(lon); Py_XDECREF(lat);
+    Py_XDECREF(lst); Py_XDECREF(vs); Py_XDECREF(one); Py_XDECREF(du);
+    return out;
+}
+
 /* plan_batch_begin(fn_addr, ctx_addr, inputs, update) -> None | int (library error code): the first half of plan_batch --
  * fx_plan_batch_begin: every agent's state rewritten from its inputs (update true) and the evaluation launched; returns without
  * waiting.  plan_batch_end(fn_addr, ctx_addr, n, yaw_rates, blocks, pkg_addr) -> [result dict per agent] | int: the second half
@@ -632,6 +721,8 @@ static PyObject *plan_batch_end(PyObject *self, PyObject *args) {
 }
 
 static PyMethodDef methods[] = {
+    {"next_inputs_level", next_inputs_level, METH_VARARGS,
+     "next_inputs_level(prev, low_vel_mode, x_lon, x_lat, x0_orientation, v_des, v_lo, v_hi, n_v, d_level_set, d0, obstacles) -> inputs | NotImplemented"},
     {"next_inputs", next_inputs, METH_VARARGS,
      "next_inputs(prev, low_vel_mode, x_lon, x_lat, x0_orientation, v_des, v_lo, v_hi, d_cached, d0, obstacles) -> PlanInputs | NotImplemented"},
     {"plan_batch_begin", plan_batch_begin, METH_VARARGS, "plan_batch_begin(fn_addr, ctx_addr, inputs, update) -> None | error code"},
@@ -663,6 +754,7 @@ PyMODINIT_FUNC PyInit__fxhost(void) {
     s_shard_k = PyUnicode_InternFromString("shard");
     s_skey_k = PyUnicode_InternFromString("_skey");
     s_P_k = PyUnicode_InternFromString("P");
+    s_union = PyUnicode_InternFromString("union");
     s_pos = PyUnicode_InternFromString("pos_list");
     s_cov = PyUnicode_InternFromString("cov_list");
     s_yaw = PyUnicode_InternFromString("orientation_list");

@@ -31,6 +31,10 @@ try:   # the CPython helper built next to the package (csrc/fx_host_ext.c); Plan
     from ._fxhost import next_inputs as _NEXT_INPUTS
 except ImportError:
     _NEXT_INPUTS = None
+try:
+    from ._fxhost import next_inputs_level as _NEXT_INPUTS_LEVEL
+except ImportError:
+    _NEXT_INPUTS_LEVEL = None
 from .trajectories import (CartesianSample, CurviLinearSample, PlanStepResult, PolynomialView, StandstillSample,
                            TrajectorySample)
 
@@ -142,6 +146,7 @@ class ReactivePlannerHip:
         self._packed_predictions = None
         self._packed_lanelets = None      # set_lanelets: the lane_center_offset cost's lanelets
         self._prev_inputs = None          # the last PlanInputs built (a closed loop's next step differs in a few fields)
+        self._prev_level = self._prev_sh = self._prev_t = None   # the sampling level / handler / time sampling those inputs were built from
         self.logger = None               # logging_formats.DataLoggingCosts (planner.py:150-158)
         self.record_state_list = []
         self.record_input_list = []
@@ -323,6 +328,28 @@ class ReactivePlannerHip:
                     if inp is not NotImplemented:
                         self._prev_inputs = inp
                         return inp
+        if (_NEXT_INPUTS_LEVEL is not None and prev is not None and stop_point_s is None and self.config.dense_grid is None
+                and self.road_boundary is None and prev.road_boundary is None and not prev.stop_point
+                and prev.sampling_matrix is None and self._prev_level == samp_level):
+            # the closed loop's usual step at a sampling level of the reference, in ONE extension call (`_fxhost.next_inputs_level`):
+            # set(np.linspace(v_min, v_max, n)) and d_level.union({d}) in the sets' own iteration order (built with the same set
+            # operations, in C), the state arrays and the copy of the last inputs with those replaced; the time set of the level is
+            # the last step's
+            cw = self.cost_weights
+            if (self._weights_src is cw and self._weights_sig == tuple(cw.items()) and prev.cost_weights is self._weights_nz
+                    and prev.coordinate_system is self.coordinate_system and prev.lanelets is self._packed_lanelets
+                    and prev.vehicle is self.vehicle_params and prev.N == self.N and prev.dt == self.dT
+                    and prev.draw_traj_set == self._draw_traj_set and prev.kinematic_debug == self._kinematic_debug
+                    and prev.collision == self.use_prediction):
+                sh = self.sampling_handler
+                vs = sh.v_sampling
+                if 0 <= samp_level < vs.max_density and self._prev_sh is sh and self._prev_t is sh.t_sampling:
+                    inp = _NEXT_INPUTS_LEVEL(prev, self._LOW_VEL_MODE, x_lon, x_lat, self.x_0.orientation, self.desired_velocity,
+                                             vs.minimum, vs.maximum, 2 ** (samp_level + 1) + 1, sh.d_sampling.to_range(samp_level),
+                                             x_lat[0], self._packed_predictions)
+                    if inp is not NotImplemented:
+                        self._prev_inputs = inp
+                        return inp
         if self.config.dense_grid is not None and stop_point_s is None:
             from .sampling import dense_ranges
             n_t, n_v, n_d = self.config.dense_grid
@@ -369,6 +396,9 @@ class ReactivePlannerHip:
                              write_costmap=True, collision=self.use_prediction, obstacles=self._packed_predictions,
                              road_boundary=boundary, lanelets=self._packed_lanelets)
         self._prev_inputs = inp
+        # (what the one-call path above needs to know of THIS step: its level, and that the level's time set came from this handler)
+        self._prev_level = samp_level if (self.config.dense_grid is None and stop_point_s is None) else None
+        self._prev_sh, self._prev_t = self.sampling_handler, self.sampling_handler.t_sampling
         return inp
 
     def _create_end_point_trajectory_bundle(self, x_0_lon, x_0_lat, stop_point_s, samp_level: int) -> PlanInputs:

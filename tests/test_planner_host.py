@@ -554,3 +554,43 @@ def test_occlusion_module_call_points():
     assert len(occ3.assessed) > 0 and (rp3.optimal_trajectory is None or not hasattr(rp3.optimal_trajectory, "uniqueId") or rp3.optimal_trajectory.uniqueId not in occ3.assessed)
     rp3.set_occlusion_module(None)
     assert not rp3.use_occ_model
+
+
+def test_level_inputs_in_one_extension_call_equal_the_python_path(monkeypatch):
+    """`_fxhost.next_inputs_level` (the closed loop's usual step at a sampling level of the reference: set(np.linspace(v_min, v_max, n)) and
+    d_level.union({d}) in the sets' OWN iteration order, built with the same set operations in C) against the Python path -- ordered
+    ranges + PlanInputs.next_step -- step by step: same arrays, same scalars, same structure key; levels 1 and 2, lateral positions on
+    and off the level's values, a changed time sampling and a changed level fall back to the Python path and come out equal too."""
+    from frenetix_motion_planner_amd import reactive_planner as rpm
+    fn = rpm._NEXT_INPUTS_LEVEL
+    if fn is None:
+        pytest.skip("_fxhost is not built")
+    ref = synthetic.reference_polyline("arc", 400, 0.5, 0.01)
+    cs = synthetic.CoordinateSystem(ref)
+    s0 = float(cs.ref_pos[40] + 0.1)
+    preds = synthetic.synthetic_predictions(cs, 5, 30, 0.1, s0, np.random.default_rng(1))
+    pa = ReactivePlannerHip(PlannerConfig(sampling_min=1, sampling_max=3), VehicleParams(), engine=OracleEngine())
+    pb = ReactivePlannerHip(PlannerConfig(sampling_min=1, sampling_max=3), VehicleParams(), engine=OracleEngine())
+    rng = np.random.default_rng(5)
+    calls = []
+    counted = lambda *a: (calls.append(1), fn(*a))[1]
+    for k in range(120):
+        v = float(rng.uniform(0.5, 20.0))
+        d = float(rng.choice([rng.uniform(-1.5, 1.5), 0.0, -3.0, 0.75, 1.5]))
+        x0 = ReactivePlannerState(k, np.asarray(cs.convert_to_cartesian_coords(s0 + 0.3 * k, d)), float(cs.ref_theta[40] + 0.005 * k), v)
+        for p in (pa, pb):
+            p.update_externals(reference_path=ref if k == 0 else None, x_0=x0, desired_velocity=12.0 + 0.01 * k, predictions=preds)
+            if k == 60:
+                p.set_sampling_parameters(1.3, 3.0, -2.5, 2.5)    # new time / lateral sampling objects
+        lvl = 1 if k % 25 == 24 else 2
+        monkeypatch.setattr(rpm, "_NEXT_INPUTS_LEVEL", counted)
+        ia = pa._inputs_for_level(lvl)
+        monkeypatch.setattr(rpm, "_NEXT_INPUTS_LEVEL", None)
+        ib = pb._inputs_for_level(lvl)
+        for f in ("t_samp", "v_samp", "d_samp", "x0_lon", "x0_lat"):
+            assert np.array_equal(getattr(ia, f), getattr(ib, f)), (k, f)
+        ka, kb = ia.structure_key(), ib.structure_key()
+        assert ka[:5] + ka[6:] == kb[:5] + kb[6:]      # (entry 5 is the coordinate system's identity: one per planner)
+        assert (ia.low_vel_mode, ia.x0_orientation, ia.v_des, ia.n_candidates) == (ib.low_vel_mode, ib.x0_orientation, ib.v_des, ib.n_candidates)
+        assert ia.obstacles is pa._packed_predictions and ia.cost_weights == ib.cost_weights
+    assert 100 <= len(calls) < 120      # the first step, the level changes and the new sampling objects took the long way
