@@ -13,6 +13,9 @@ CASES = dict(
     c4agent=dict(grid=(19, 23, 23), n_obstacles=5),
     mid=dict(grid=(19, 31, 41), n_obstacles=12, ref_kind="scurve", kappa=0.02),
     h5=dict(grid=(39, 21, 31), n_obstacles=20, horizon=5.0, n_pred=50, n_knots=700),
+    quarter=dict(grid=(19, 25, 26), n_obstacles=20, n_pred=30, lead_gap=25.0),
+    half=dict(grid=(19, 36, 36), n_obstacles=20, n_pred=30, lead_gap=25.0),
+    few_obst=dict(grid=(19, 51, 51), n_obstacles=5, n_pred=30, lead_gap=25.0),
 )
 
 
@@ -32,8 +35,10 @@ def run(name, mode, ch=0, package=False):
     inp = synthetic.make_inputs(**kw)
     with FrenetEngine(max_candidates=inp.n_candidates + 64, max_steps=inp.N, max_ref_knots=1024) as e:
         e.set_step_kernel(mode, ch)
+        e.set_obstacle_stage(2)
         e.set_package(package)
-        e.set_timing("kernel")
+        if not os.environ.get("FX_NO_TIMING"):
+            e.set_timing("kernel")
         e.upload(inp)
         for _ in range(3):
             e.evaluate(); res = e.finish()[0]
