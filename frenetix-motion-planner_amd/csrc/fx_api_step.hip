@@ -104,9 +104,9 @@ int32_t fx_upload_batch(FxContext *c, int32_t n_agents, const FxProblem *probs) 
         // 651 us at 2 waves per SIMD, 697 us at 4 -- tools/sweep_1m_modeB.py)
         bool bundle_any = false;
         for (int a = 0; a < n_agents; a++) bundle_any |= (probs[a].mode & FX_MODE_WRITE_BUNDLE) != 0;
-        // ... but with the obstacle stage in the walk as well (the north star as written) the kernel is bound by what a wave issues: one
-        // FP64 instruction per ~16 cycles (tools/micro/clockrate.hip), so the third wave per SIMD pays (168 registers, no vector
-        // spill): 1 062 -> 1 004 us same-box, tools/ns_wpe.py
+        // ... but with the obstacle stage in the walk as well (the north star as written) the kernel is bound by the vector unit and
+        // by latency as much as by its stores: the third wave per SIMD pays (168 registers, no vector spill): 1 062 -> 1 004 us
+        // same-box, tools/ns_wpe.py
         c->wpe_step = c->wpe_force ? c->wpe_force : (waves1 >= 3072 ? (bundle_any ? (obst_any ? 3 : 2) : (obst_any ? 3 : 4)) : 2);
         // grid kernel: sampling ranges, no windowed costs, and the longitudinal rows of a workgroup fit in LDS.
         // Workgroup size: the smallest of 64/128/256 lanes whose LDS footprint still lets a CU hold the target

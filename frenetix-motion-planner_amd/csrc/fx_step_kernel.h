@@ -21,12 +21,12 @@
 // Results are those of the three launches bit for bit at three steps per item (the phases are the kernels' bodies and expression
 // trees; tests/test_step_kernel.py).  Measured (tools/c3_step_kernel.py, tools/probe_step_kernel.py; profiles/r6/NOTES.md): walk
 // done at 38 us, each barrier ~1 us, selection 5 - 9 us -- and the obstacle phase 40 - 45 us against the obstacle kernel's 32:
-// config 3 takes 94 us this way, 86 us as three launches.  Why: a wave issues one FP64 instruction per ~16 cycles whatever its
-// independence (tools/micro/clockrate.hip: 16.5 cycles per FMA for one wave, the SIMD's 4-cycle rate only with four or more waves),
-// the launch runs with the walk's 165 registers -- three waves per SIMD, 3 072 waves for 5 030 three-step items -- where the
-// obstacle kernel's 73 registers give every item its own wave at six per SIMD.  What the fixed costs return (two launches and gaps,
-// ~12 us) the obstacle phase loses twice over.  The kernel stays as the measured alternative and as the place where a walk of at
-// most 128 registers would make the trade the other way.
+// config 3 takes 94 us this way, 86 us as three launches.  Why: the launch runs with the walk's 165 registers -- three waves per SIMD,
+// 3 072 waves for 5 030 three-step items --, so every wave runs TWO items' latency chains back to back (entry round trips, visits with
+// their LDS waits, hand-off, closing), where the obstacle kernel's 73 registers give every item its own wave at six per SIMD and
+// overlap those latencies across waves.  (The vector unit itself is not the limit: two waves per SIMD already reach its FP64 rate,
+// tools/micro/clockrate.hip.)  What the fixed costs return (two launches and gaps, ~12 us) the obstacle phase loses twice over; it
+// wins at no grid size (profiles/r6/NOTES.md).  The kernel stays as the measured alternative.
 //
 // The grid barrier needs every workgroup of the launch resident at once: the host launches at most what the occupancy query says
 // the device holds (fx_api.hip) and otherwise keeps the three launches.  A barrier that does not complete within FX_BAR_TIMEOUT

@@ -477,7 +477,7 @@ int32_t fx_set_fused_selection(FxContext *ctx, int32_t enabled);
  * behind the walk (200 ... 3 072 waves with a materialised bundle: BASELINE config 3, config 4's batch) can run walk | grid barrier |
  * obstacle items | grid barrier | sliced selection (+ winner package) as phases of one kernel.  Same results (bit for bit at three
  * steps per item).  Measured slower on the MI355X -- config 3: 94 us against 86 us -- because the obstacle phase then runs with the
- * walk's register allocation (three waves per SIMD; a wave issues one FP64 instruction per ~16 cycles), so it is off unless asked
+ * walk's register allocation (3 072 waves for ~5 000 work items: every wave runs two items' latency chains back to back), so it is off unless asked
  * for.  Needs every workgroup of the launch resident at once: the library sizes the launch by the occupancy query and keeps the three
  * launches where the walk alone would not fit.  The query assumes the device to itself: two such launches at a time (two contexts, two
  * processes) can hold each other's slots until the in-kernel barrier gives up after 2 s and the step ends in FX_ERR_TIMEOUT -- use it
