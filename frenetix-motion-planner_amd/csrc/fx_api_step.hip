@@ -550,7 +550,7 @@ int32_t fx_evaluate(FxContext *c) {
         for (int q = 0; q < 3; q++) {
             const int CH = chs[q];
             if (c->step_kernel_CH && c->step_kernel_CH != CH) continue;
-            const size_t lds = std::max(c->lds_step, (size_t)(FX_BLOCK / 64) * sizeof(double) * 16 * (size_t)CH * (size_t)c->K_max_step);   // FX_OBST_LDS_DOUBLES(.., true)
+            const size_t lds = std::max(c->lds_step, (size_t)(FX_BLOCK / 64) * sizeof(double) * 6 * (size_t)CH * (size_t)c->K_max_step);   // FX_STEP_ITEM_DOUBLES
             int cap = 0;
             {   // (one occupancy query per (CH, lds) of this process and device)
                 static std::mutex mu;
@@ -568,7 +568,7 @@ int32_t fx_evaluate(FxContext *c) {
             const int cap_agent = cap / std::max(c->n_agents, 1);
             if (cap_agent < c->max_blocks_step) continue;   // the walk alone does not fit at once: three launches
             const int NC = (c->S_max_step - 1 + CH - 1) / CH;
-            const int64_t items = (int64_t)((tiles_est + FX_STEP_T - 1) / FX_STEP_T) * NC;   // (T tiles x one chunk per wave)
+            const int64_t items = (int64_t)tiles_est * NC;   // (one tile x one chunk per wave)
             const int blocks = (int)std::min<int64_t>(cap_agent, std::max<int64_t>(c->max_blocks_step, (items + FX_BLOCK / 64 - 1) / (FX_BLOCK / 64)));
             const int rounds = (int)((items + (int64_t)blocks * (FX_BLOCK / 64) - 1) / ((int64_t)blocks * (FX_BLOCK / 64)));
             const int score = rounds * CH;

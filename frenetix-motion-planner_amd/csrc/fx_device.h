@@ -266,9 +266,6 @@ struct FuseArgs {
     __host__ __device__ int32_t kmax() const { return k_max & 0xffff; }
 };
 
-#ifndef FX_STEP_T
-#define FX_STEP_T 1   // tiles of 64 listed candidates per obstacle item of the one-launch step (fx_step_kernel.h)
-#endif
 // arguments of the one-launch step (fx_step_kernel.h) beyond the walk's
 struct StepArgs {
     unsigned long long *bar;        // two barrier blocks of FX_BAR_WORDS words (fx_step_kernel.h), monotonic: never reset
@@ -288,4 +285,18 @@ struct StepArgs {
 template <typename T>
 __device__ __forceinline__ FX_GLOBAL T *as_global(T *p) {
     return (FX_GLOBAL T *)p;
+}
+// Input tables that NO kernel of the step writes, as pointers into the constant address space: a wave-uniform read stays a scalar
+// load even behind an atomic, a fenced barrier or a wait loop.  (The compiler turns a uniform load from the GLOBAL address space into
+// a scalar load only while nothing in front of it in the kernel may have written memory; behind the one-launch step's grid barrier
+// every uniform table read became a vector load with a round trip and a register pair of its own -- profiles/r6/NOTES.md.)
+#define FX_CONSTAS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const FX_CONSTAS T *as_const(const T *p) {
+    return (const FX_CONSTAS T *)p;
+}
+template <bool CONSTANT, typename T>
+__device__ __forceinline__ auto as_table(const T *p) {
+    if constexpr (CONSTANT) return as_const(p);
+    else return as_global(p);
 }

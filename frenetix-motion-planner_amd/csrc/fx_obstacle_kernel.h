@@ -45,8 +45,9 @@ struct ObsEntry {
     double l11, l12, l22;
     fx_d2 cc;
 };
-__device__ __forceinline__ ObsEntry obs_load(const FX_GLOBAL double *hot_i, const fx_d2 *cc_i, int k) {
-    const FX_GLOBAL double *q = hot_i + (size_t)k * FX_HOT_STRIDE;
+template <class HotPtr>
+__device__ __forceinline__ ObsEntry obs_load(HotPtr hot_i, const fx_d2 *cc_i, int k) {
+    const auto q = hot_i + (size_t)k * FX_HOT_STRIDE;
     ObsEntry e;
     e.l11 = q[FX_HOT_L11]; e.l12 = q[FX_HOT_L12]; e.l22 = q[FX_HOT_L22];
     e.cc = cc_i[k];
@@ -76,18 +77,30 @@ __device__ __forceinline__ double obs_four(double a, double b, double c, double 
 #ifndef FX_OBST_WG_WPE
 #define FX_OBST_WG_WPE 1
 #endif
-template <int CH, int WPS, bool WG = false>
-__global__ __launch_bounds__(WG ? 1024 : 64, WG ? FX_OBST_WG_WPE : WPS) void fx_obstacle_kernel(const DevProblem *__restrict__ probs) {
-    extern __shared__ __attribute__((aligned(16))) double lds_all[];  // per wave: (cu, cw) [CH][K][2] | hull circles [CH][K][4]
-    const DevProblem &P = probs[blockIdx.y];
+// The kernel's body for one (tile, chunk) item.  COH (the one-launch step, fx_step_kernel.h; single-wave items): the walk ran in the
+// SAME launch on other workgroups --
+//   * the tables no kernel writes (hot table, records, step masks) are read through the constant address space: behind the grid
+//     barrier a wave-uniform read from the global address space is no scalar load any more (fx_device.h, as_const);
+//   * the list's count comes from the caller (one agent-scope load per workgroup, not one per item), the tile's list entries are an
+//     agent-scope load: every wave of the walk appends to the list, its lines are shared between XCDs;
+//   * the walk's per-candidate results -- flag words, rows, cost sums -- are read with PLAIN loads: they were stored write-through and
+//     acknowledged before the barrier, no two workgroups of the walk share a cache line of them (a workgroup's candidates are
+//     128-aligned), and this XCD's L2 was invalidated at the launch's start and has not read them since -- the load misses and fetches
+//     what the walk wrote;
+//   * what the selection phase reads is stored write-through.
+// The arithmetic is the same instruction sequence either way.
+template <int CH, bool WG, bool COH>
+__device__ __forceinline__ void fx_obstacle_body(const DevProblem &P, double *__restrict__ lds_all, const int tile, const int chunk,
+                                                 const long long n_live_known = -1) {
+    static_assert(!COH || !WG, "the one-launch step runs single-wave items");
+    auto LD = [](auto p) { return *p; };
+    auto ST = [](auto p, auto v) { if (COH) st_agent(p, v); else *p = v; };
     const uint32_t mode = P.mode;
     if (!(mode & FX_MODE_INT_DEFER_OBST)) return;
     const int S = P.S, K = P.K;
     const int NC = (S - 1 + CH - 1) / CH;
     const int64_t C = P.C, ld = P.ld;
     const int n_wave = WG ? (int)(blockDim.x >> 6) : 1;
-    const int tile = WG ? (int)blockIdx.x : (int)(blockIdx.x / NC);
-    const int chunk = WG ? (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(blockIdx.x - tile * NC);
     const int64_t c0 = (int64_t)tile * 64;
     if (c0 >= C) return;
     const int lane = threadIdx.x & 63;
@@ -102,8 +115,15 @@ __global__ __launch_bounds__(WG ? 1024 : 64, WG ? FX_OBST_WG_WPE : WPS) void fx_
     // entries and the chunk's slice of the hot table are requested TOGETHER: the list slot c0 + lane always exists (c0 < C <= ld);
     // past the list's end it holds whatever an earlier step left -- clamped to a valid candidate, loaded from, never stored for.
     const FX_GLOBAL unsigned long long *cnt_live = as_global(P.counters) + FX_DCNT_LIVE;
-    const unsigned long long n_live_raw = *cnt_live;
-    const int32_t g_listed = as_global(P.obs_list)[c0 + lane];
+    unsigned long long n_live_raw = 0ULL;
+    int32_t g_listed = 0;
+    if (!COH) {
+        n_live_raw = *cnt_live;
+        g_listed = as_global(P.obs_list)[c0 + lane];
+    } else {
+        n_live_raw = (unsigned long long)n_live_known;
+        g_listed = ld_agent(as_global(P.obs_list) + (c0 + lane));
+    }
 
     const int i_a = 1 + chunk * CH, i_b = min(S, i_a + CH);
     const int64_t ps = (int64_t)S * ld;
@@ -112,7 +132,7 @@ __global__ __launch_bounds__(WG ? 1024 : 64, WG ? FX_OBST_WG_WPE : WPS) void fx_
     // the chunk's slice of the hot table -> LDS: per (step, obstacle) the addends (cu, cw) as one 16-byte pair, then the hull
     // circles (hx2, hy2, hr2, ck) as 32 bytes; entry e of the slice is handled by lane e, e + 64, ... (two entries in flight).
     // The first round's loads go out here, its LDS writes follow the row requests below.
-    const FX_GLOBAL double *__restrict__ hot_a = as_global(P.obs_hot) + (size_t)i_a * K * FX_HOT_STRIDE;
+    const auto hot_a = as_table<COH>(P.obs_hot) + (size_t)i_a * K * FX_HOT_STRIDE;   // (COH: constant address space, fx_device.h)
     fx_d2 *__restrict__ cc_tab = reinterpret_cast<fx_d2 *>(lds_dyn);   // [CH][K]
     double *__restrict__ circ_tab = lds_dyn + 2 * (size_t)CH * K;       // [CH][K][4]
     const int n_e = max((i_b - i_a) * K, 0);
@@ -120,40 +140,12 @@ __global__ __launch_bounds__(WG ? 1024 : 64, WG ? FX_OBST_WG_WPE : WPS) void fx_
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int e = max(min(lane + 64 * u, n_e - 1), 0);
-        const FX_GLOBAL double *q = hot_a + (size_t)e * FX_HOT_STRIDE;
+        const auto q = hot_a + (size_t)e * FX_HOT_STRIDE;
         const bool on = n_e > 0 && K > 0;
         hv[u][0] = on ? q[FX_HOT_CU] : 0.0; hv[u][1] = on ? q[FX_HOT_CW] : 0.0;
         hv[u][2] = on ? q[FX_HOT_HX2] : 0.0; hv[u][3] = on ? q[FX_HOT_HY2] : 0.0; hv[u][4] = on ? q[FX_HOT_HR2] : 0.0; hv[u][5] = on ? q[FX_HOT_CK] : 0.0;
     }
-    // ---- everything the chunk needs, requested before the count and the flags are looked at (nearly every tile needs it) ----
-    const int64_t g = (uint32_t)g_listed < (uint64_t)C ? (int64_t)g_listed : 0;
-    const int64_t g_raw = g;   // (scratch rows are indexed by the candidate: lanes past the list's end hold SOME candidate and never store)
-    const uint32_t f = as_global(P.flags)[g];
-    // rows i_a - 1 .. i_b - 1 of x, y (and theta with the collision stage)
-    double xs[CH + 1], ys[CH + 1], ts[CH + 1];
-#pragma unroll
-    for (int j = 0; j <= CH; j++) {
-        const int i = min(i_a - 1 + j, S - 1);
-        xs[j] = pl[(int64_t)FX_PL_X * ps + (int64_t)i * ld + g];
-        ys[j] = pl[(int64_t)FX_PL_Y * ps + (int64_t)i * ld + g];
-        ts[j] = col_mode ? pl[(int64_t)FX_PL_THETA * ps + (int64_t)i * ld + g] : 0.0;
-    }
-    // the closing wave of a workgroup (chunk 0) continues the candidate's cost sum: its two operands come with the rows
-    double pre_cost = 0.0, pre_tail = 0.0;
-    if (WG && chunk == 0) {
-        pre_cost = as_global(P.cost)[g];
-        pre_tail = as_global(P.cost_tail)[g];
-    }
-    const int64_t n_live = (int64_t)n_live_raw;
-    if (c0 >= n_live) {
-        if (chunk == 0 && lane == 0) {
-            as_global(P.part_cost)[tile] = INFINITY;
-            as_global(P.part_idx)[tile] = 0x7fffffffffffffffLL;
-        }
-        return;
-    }
-    const bool act = c0 + lane < n_live;
-    {
+    auto park_tables = [&]() {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int e = lane + 64 * u;
@@ -167,7 +159,7 @@ __global__ __launch_bounds__(WG ? 1024 : 64, WG ? FX_OBST_WG_WPE : WPS) void fx_
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int e = min(e0 + 64 * u, n_e - 1);
-                const FX_GLOBAL double *q = hot_a + (size_t)e * FX_HOT_STRIDE;
+                const auto q = hot_a + (size_t)e * FX_HOT_STRIDE;
                 v[u][0] = q[FX_HOT_CU]; v[u][1] = q[FX_HOT_CW];
                 v[u][2] = q[FX_HOT_HX2]; v[u][3] = q[FX_HOT_HY2]; v[u][4] = q[FX_HOT_HR2]; v[u][5] = q[FX_HOT_CK];
             }
@@ -180,7 +172,36 @@ __global__ __launch_bounds__(WG ? 1024 : 64, WG ? FX_OBST_WG_WPE : WPS) void fx_
                 }
             }
         }
+    };
+    // ---- everything the chunk needs, requested before the count and the flags are looked at (nearly every tile needs it) ----
+    const int64_t g = (uint32_t)g_listed < (uint64_t)C ? (int64_t)g_listed : 0;
+    const int64_t g_raw = g;   // (scratch rows are indexed by the candidate: lanes past the list's end hold SOME candidate and never store)
+    const uint32_t f = LD(as_global(P.flags) + g);
+    // rows i_a - 1 .. i_b - 1 of x, y (and theta with the collision stage)
+    double xs[CH + 1], ys[CH + 1], ts[CH + 1];
+#pragma unroll
+    for (int j = 0; j <= CH; j++) {
+        const int i = min(i_a - 1 + j, S - 1);
+        xs[j] = LD(pl + ((int64_t)FX_PL_X * ps + (int64_t)i * ld + g));
+        ys[j] = LD(pl + ((int64_t)FX_PL_Y * ps + (int64_t)i * ld + g));
+        ts[j] = col_mode ? LD(pl + ((int64_t)FX_PL_THETA * ps + (int64_t)i * ld + g)) : 0.0;
     }
+    // the closing wave of a workgroup (chunk 0) continues the candidate's cost sum: its two operands come with the rows
+    double pre_cost = 0.0, pre_tail = 0.0;
+    if (WG && chunk == 0) {
+        pre_cost = LD(as_global(P.cost) + g);
+        pre_tail = LD(as_global(P.cost_tail) + g);
+    }
+    const int64_t n_live = (int64_t)n_live_raw;
+    if (c0 >= n_live) {
+        if (chunk == 0 && lane == 0) {
+            ST(as_global(P.part_cost) + tile, (double)INFINITY);
+            ST(as_global(P.part_idx) + tile, (int64_t)0x7fffffffffffffffLL);
+        }
+        return;
+    }
+    const bool act = c0 + lane < n_live;
+    park_tables();
 
     // where the prediction term sits in the (id-sorted) cost function
     int n_pred = -1;
@@ -198,9 +219,9 @@ __global__ __launch_bounds__(WG ? 1024 : 64, WG ? FX_OBST_WG_WPE : WPS) void fx_
     const bool work = do_pred || do_col;
     if (!work && chunk != 0) return;   // nothing to add: chunk 0 closes the tile on its own (tile-uniform: no barrier is skipped)
     if (work && chunk < NC) {          // (WG: a launch sized for a longer horizon has waves without a chunk of this agent)
-        const FX_GLOBAL double *__restrict__ rec = as_global(P.obs_rec);
-        const FX_GLOBAL unsigned long long *__restrict__ pmask = as_global(P.obs_pmask);
-        const FX_GLOBAL unsigned long long *__restrict__ hmask = as_global(P.obs_hmask);
+        const auto rec = as_table<COH>(P.obs_rec);
+        const auto pmask = as_table<COH>(P.obs_pmask);
+        const auto hmask = as_table<COH>(P.obs_hmask);
         const double ox = P.hot_origin[0], oy = P.hot_origin[1];
         const double wb = P.veh.wb_rear_axle, half_len = P.veh.length / 2, half_wid = P.veh.width / 2;
         const double gap_margin = P.hot_gap_margin;
@@ -221,7 +242,7 @@ __global__ __launch_bounds__(WG ? 1024 : 64, WG ? FX_OBST_WG_WPE : WPS) void fx_
             if (i < i_b) {
                 const unsigned long long pm = do_pred ? uniform_u64(pmask[i]) : 0ULL;
                 const unsigned long long hm = (do_col && i >= 2) ? uniform_u64(hmask[i]) : 0ULL;
-                const FX_GLOBAL double *__restrict__ hot_i = hot_a + (size_t)(j - 1) * K * FX_HOT_STRIDE;
+                const auto hot_i = hot_a + (size_t)(j - 1) * K * FX_HOT_STRIDE;
                 const fx_d2 *__restrict__ cc_i = cc_tab + (size_t)(j - 1) * K;
                 const double *__restrict__ circ_i = circ_tab + 4 * (size_t)(j - 1) * K;
                 // ---- prediction cost: sum over the obstacles of 1 / m^2 (collision_probability.py:283-292) ----
@@ -387,13 +408,13 @@ __global__ __launch_bounds__(WG ? 1024 : 64, WG ? FX_OBST_WG_WPE : WPS) void fx_
         if (has_tail) sum += WG ? pre_tail : as_global(P.cost_tail)[g];
         total = 0.0 + sum;
         if (act) {
-            as_global(P.cost)[g] = costed ? total : 0.0;
-            if (mode & FX_MODE_WRITE_COSTMAP) as_global(P.costmap)[(int64_t)n_pred * ld + g] = costed ? pred : 0.0;
+            ST(as_global(P.cost) + g, costed ? total : 0.0);
+            if (mode & FX_MODE_WRITE_COSTMAP) ST(as_global(P.costmap) + ((int64_t)n_pred * ld + g), costed ? pred : 0.0);
         }
     }
     if (selectable && (mode & FX_MODE_COLLISION) && ((cmask >> lane) & 1ULL)) {
         fl |= FX_FLAG_COLLISION;
-        if (act) as_global(P.flags)[g] = fl;
+        if (act) ST(as_global(P.flags) + g, fl);
     }
     // (cost, index) arg-min of the tile: the lanes hold the list's candidates in no particular order, so among the lanes with the
     // minimum cost the smallest index is reduced as well
@@ -406,10 +427,20 @@ __global__ __launch_bounds__(WG ? 1024 : 64, WG ? FX_OBST_WG_WPE : WPS) void fx_
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { const long long o = __shfl_xor(bi, off); bi = o < bi ? o : bi; }
     if (lane == 0) {
-        as_global(P.part_cost)[tile] = m;
-        as_global(P.part_idx)[tile] = (int64_t)bi;
+        ST(as_global(P.part_cost) + tile, m);
+        ST(as_global(P.part_idx) + tile, (int64_t)bi);
     }
     FX_OSTAMP(15);
+}
+
+template <int CH, int WPS, bool WG = false>
+__global__ __launch_bounds__(WG ? 1024 : 64, WG ? FX_OBST_WG_WPE : WPS) void fx_obstacle_kernel(const DevProblem *__restrict__ probs) {
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];  // per wave: (cu, cw) [CH][K][2] | hull circles [CH][K][4]
+    const DevProblem &P = probs[blockIdx.y];
+    const int NC = (P.S - 1 + CH - 1) / CH;
+    const int tile = WG ? (int)blockIdx.x : (int)(blockIdx.x / NC);
+    const int chunk = WG ? (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(blockIdx.x - tile * NC);
+    fx_obstacle_body<CH, WG, false>(P, lds_all, tile, chunk);
 }
 
 }  // namespace fxk
