@@ -25,7 +25,7 @@
 // config 3 takes 94 us this way, 86 us as three launches (the same with a first version of phase 2 that parked EVERY operand of
 // the visit loops in LDS and walked several tiles per wave: 94 - 99 us).  Why: the launch runs with the walk's 165 registers -- three waves per SIMD,
 // 3 072 waves for 5 030 three-step items --, so every wave runs TWO items' latency chains back to back (entry round trips, visits with
-// their LDS waits, hand-off, closing), where the obstacle kernel's 73 registers give every item its own wave at six per SIMD and
+// their LDS waits, hand-off, closing), where the obstacle kernel's 74 registers give every item its own wave at six per SIMD and
 // overlap those latencies across waves.  (The vector unit itself is not the limit: two waves per SIMD already reach its FP64 rate,
 // tools/micro/clockrate.hip.)  What the fixed costs return (two launches and gaps, ~12 us) the obstacle phase loses twice over; it
 // wins at no grid size (profiles/r6/NOTES.md).  The kernel stays as the measured alternative.
