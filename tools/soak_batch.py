@@ -31,8 +31,16 @@ for case in range(first, first + n):
             for a, (inp, out) in enumerate(zip(inps, outs)):
                 compare(e, inp, out, res[a], agent=a)
                 if bool(np.all(out["margin"] >= FRAGILE)):
-                    assert res[a]["best_index"] == out["result"]["best_index"], (a, res[a]["best_index"], out["result"]["best_index"])
-                    assert res[a]["n_collisions"] == out["result"]["n_collisions"], a
+                    ga, gb = res[a]["best_index"], out["result"]["best_index"]
+                    if ga != gb:
+                        # the rule of soak_parity.py: compare() has held the two winners' costs to 1e-9; what may still differ is a TIE --
+                        # two candidates whose costs agree to the last ulp or two (here: the lateral grid's -1.2000000000000002 beside the
+                        # appended current offset -1.2, case 2170242) sort by index on one side and by that ulp on the other.  Counted,
+                        # and bounded at the end of the run.
+                        assert ga >= 0 and gb >= 0 and abs(out["cost"][ga] - out["cost"][gb]) <= 8 * np.spacing(abs(out["cost"][gb])), (a, ga, gb)
+                        stats["tie_decided"] = stats.get("tie_decided", 0) + 1
+                    else:
+                        assert res[a]["n_collisions"] == out["result"]["n_collisions"], a
             res2 = e.plan_batch(inps)   # the in-place update path with unchanged inputs
             for a in range(len(inps)):
                 assert res2[a]["best_index"] == res[a]["best_index"] and res2[a]["best_cost"] == res[a]["best_cost"], a
@@ -40,4 +48,7 @@ for case in range(first, first + n):
     except Exception as ex:
         bad += 1
         print("CASE", case, "FAILED:", repr(ex)[:300], [(k.get("grid"), k.get("level"), k["horizon"], k["n_obstacles"]) for k in kws], flush=True)
+if stats.get("tie_decided", 0) > max(1, 2e-4 * stats["agents"]):
+    print("batch soak: too many winners decided by a last-ulp tie", flush=True)
+    bad += 1
 print(f"batch soak: {n} cases from {first}: {bad} failures; {stats}", flush=True)
