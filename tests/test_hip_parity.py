@@ -1170,6 +1170,41 @@ def test_more_than_sixty_four_obstacles(K, tuning):
 
 
 @pytest.mark.gpu
+def test_winner_decided_by_a_last_ulp_cost_tie_is_an_admissible_outcome():
+    """Soak case 2170242 (round 6, tools/soak_batch.py), agent 1: the lateral grid holds -1.2000000000000002 and the appended current
+    offset -1.2 -- two candidates (519, 527) whose total costs are the SAME double in the oracle's arithmetic and one ulp apart in
+    the lane-split kernel's (its sums over the horizon are trees, the reference's are sequential).  The stable (cost, index) arg-min
+    then answers 519 on one side and 527 on the other.  What is held: every other field by compare(), the two winners' reference
+    costs within 8 ulp, the device's own winner = arg-min of the device's own costs with the index as tie-break."""
+    from frenetix_motion_planner_amd import _abi
+    from frenetix_motion_planner_amd.engine import FrenetEngine
+    from oracle import oracle
+    rng = np.random.default_rng([20241008, 2170242])
+    kws = [_random_case(rng) for _ in range(int(rng.integers(2, 6)))]
+    for kw in kws:
+        kw.pop("stop_point_s", None) if rng.uniform() < 0.5 else None
+    inps = [synthetic.make_inputs(hull_builder=hip_hulls(), **kw) for kw in kws]
+    outs = [oracle.plan_step(synthetic.make_inputs(hull_builder=oracle.build_obstacle_hulls, **kw)) for kw in kws]
+    assert -1.2 in inps[1].d_samp and np.count_nonzero(np.abs(np.asarray(inps[1].d_samp) + 1.2) < 1e-12) == 2
+    cap = sum(max(i.n_candidates, 64) + 64 for i in inps)
+    with FrenetEngine(max_candidates=cap, max_steps=max(i.N for i in inps), max_pred_steps=64, max_obstacles=256, max_agents=len(inps)) as e:
+        res = e.plan_batch(inps)
+        for a, (inp, out) in enumerate(zip(inps, outs)):
+            compare(e, inp, out, res[a], agent=a)
+            assert bool(np.all(out["margin"] >= FRAGILE))
+            ga, gb = res[a]["best_index"], out["result"]["best_index"]
+            assert ga >= 0 and gb >= 0 and abs(out["cost"][ga] - out["cost"][gb]) <= 8 * np.spacing(abs(out["cost"][gb]))
+            if a != 1:
+                assert ga == gb and res[a]["n_collisions"] == out["result"]["n_collisions"]
+            cost, flags = e.costs(a)
+            ok = ((flags & _abi.FX_FLAG_SELECTABLE) != 0) & ((flags & (_abi.FX_FLAG_COLLISION | _abi.FX_FLAG_BOUNDARY)) == 0) & ~np.isnan(cost)
+            ids = np.nonzero(ok)[0]
+            assert ga == int(ids[np.lexsort((ids, cost[ids]))][0]) and res[a]["best_cost"] == cost[ga]
+        assert {res[1]["best_index"], outs[1]["result"]["best_index"]} <= {519, 527}
+        assert outs[1]["cost"][519] == outs[1]["cost"][527]
+
+
+@pytest.mark.gpu
 def test_obstacle_limit_is_reported():
     from frenetix_motion_planner_amd.problem import MAX_OBSTACLES
     with pytest.raises(ValueError, match="at most"):
