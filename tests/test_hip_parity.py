@@ -1193,7 +1193,10 @@ def test_winner_decided_by_a_last_ulp_cost_tie_is_an_admissible_outcome():
             compare(e, inp, out, res[a], agent=a)
             assert bool(np.all(out["margin"] >= FRAGILE))
             ga, gb = res[a]["best_index"], out["result"]["best_index"]
-            assert ga >= 0 and gb >= 0 and abs(out["cost"][ga] - out["cost"][gb]) <= 8 * np.spacing(abs(out["cost"][gb]))
+            if gb < 0:   # (an agent of the batch without a survivor)
+                assert ga == gb
+                continue
+            assert ga >= 0 and abs(out["cost"][ga] - out["cost"][gb]) <= 8 * np.spacing(abs(out["cost"][gb]))
             if a != 1:
                 assert ga == gb and res[a]["n_collisions"] == out["result"]["n_collisions"]
             cost, flags = e.costs(a)
