@@ -86,6 +86,16 @@ SCENARIOS = {
                                       v_des=3.0, draw_traj_set=True, kinematic_debug=True), 1),
     "straight_lv_l1_nonuniform_debug": (dict(ref_kind="straight", knot_jitter=0.5, v0=1.4, d0=-0.3, level=1, v_des=3.0,
                                              draw_traj_set=True, kinematic_debug=True), 1),
+    # round 6, regions the set above does not reach: the largest default sampling level (17 x 17 x 17 + the current d: the grid a
+    # 16-lanes-per-candidate launch walks), a reference tight enough that curvature and yaw rate decide, motorway speed, the
+    # low-velocity branch with predicted obstacles, a large initial lateral state, negative curvature with obstacles
+    "arc_hv_l3_prod_obs6": (dict(ref_kind="arc", v0=10.0, level=3, n_obstacles=6), 23),
+    "tight_hv_l1_kd": (dict(ref_kind="arc", kappa=0.11, n_knots=400, v0=11.0, level=1, kinematic_debug=True), 1),
+    "arc_fast_l1_prod": (dict(ref_kind="arc", kappa=0.004, n_knots=700, v0=26.0, v_des=28.0, level=1), 1),
+    "arc_lv_l2_kd_obs3": (dict(ref_kind="arc", v0=1.5, level=2, v_des=3.0, n_obstacles=3, kinematic_debug=True), 7),
+    "arc_hv_l1_latstate_debug": (dict(ref_kind="arc", v0=9.0, d0=1.8, dd0=-0.9, ddd0=0.5, level=1, draw_traj_set=True,
+                                      kinematic_debug=True), 1),
+    "scurve_negk_hv_l2_prod_obs2": (dict(ref_kind="scurve", kappa=-0.025, v0=12.0, level=2, n_obstacles=2), 7),
 }
 
 
