@@ -96,6 +96,11 @@ SCENARIOS = {
     "arc_hv_l1_latstate_debug": (dict(ref_kind="arc", v0=9.0, d0=1.8, dd0=-0.9, ddd0=0.5, level=1, draw_traj_set=True,
                                       kinematic_debug=True), 1),
     "scurve_negk_hv_l2_prod_obs2": (dict(ref_kind="scurve", kappa=-0.025, v0=12.0, level=2, n_obstacles=2), 7),
+    # sampling level 4: 11 220 candidates (four lanes per candidate, selection as its own kernel) and, with the 5 s horizon, 23 529 --
+    # the grid size at which the device runs the headline decomposition of BASELINE config 3 (two lanes per candidate on two waves, the
+    # obstacle stage as its own kernel, the sliced selection) -- through the reference itself
+    "arc_hv_l4_prod_obs8": (dict(ref_kind="arc", v0=10.0, level=4, n_obstacles=8), 61),
+    "arc_hv_l4_horizon5_prod_obs8": (dict(ref_kind="arc", n_knots=700, v0=10.0, level=4, horizon=5.0, n_pred=50, n_obstacles=8), 211),
 }
 
 
