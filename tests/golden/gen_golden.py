@@ -101,6 +101,9 @@ SCENARIOS = {
     # obstacle stage as its own kernel, the sliced selection) -- through the reference itself
     "arc_hv_l4_prod_obs8": (dict(ref_kind="arc", v0=10.0, level=4, n_obstacles=8), 61),
     "arc_hv_l4_horizon5_prod_obs8": (dict(ref_kind="arc", n_knots=700, v0=10.0, level=4, horizon=5.0, n_pred=50, n_obstacles=8), 211),
+    # BASELINE config 3 itself: the bench's 19 x 51 x 52 grid (50 388 candidates), 20 predicted obstacles, production flags -- the
+    # inputs of `python bench.py` through the reference's own loops (ref_harness: custom_sampling)
+    "config3_grid_prod_obs20": (dict(ref_kind="arc", v0=10.0, grid=(19, 51, 51), n_obstacles=20, n_pred=30, lead_gap=25.0), 397),
 }
 
 
@@ -130,8 +133,11 @@ def to_reference_problem(inp, kw):
                      length=veh.length, width=veh.width, wb_rear_axle=veh.wb_rear_axle, v_max=veh.v_max),
         ref_xy=cs.reference, ref_pos=cs.ref_pos, ref_theta=cs.ref_theta, ref_curv=cs.ref_curv, ref_curv_d=cs.ref_curv_d,
         x0_orientation=inp.x0_orientation, x0_lon=[float(v) for v in inp.x0_lon], x0_lat=[float(v) for v in inp.x0_lat],
-        v_des=inp.v_des, predictions=inp.predictions, sampling_level=kw["level"], t_min=1.1, d_min=-3.0, d_max=3.0,
+        v_des=inp.v_des, predictions=inp.predictions, sampling_level=kw.get("level", 2), t_min=1.1, d_min=-3.0, d_max=3.0,
         cost_weights=inp.cost_weights)
+    if kw.get("grid") is not None:   # explicit grid: the values of this package's dense ranges, the current d left to the reference's union
+        d_vals = [float(x) for x in inp.d_samp[:-1]] if len(inp.d_samp) and float(inp.d_samp[-1]) == float(inp.x0_lat[0]) else list(inp.d_samp)
+        prob["custom_sampling"] = dict(t=[float(x) for x in inp.t_samp], v=[float(x) for x in inp.v_samp], d=d_vals)
     from frenetix_motion_planner_amd.sampling import v_sampling_bounds
     prob["v_min"], prob["v_max"] = v_sampling_bounds(float(getattr(inp, "x0_velocity", inp.x0_lon[1])), veh.a_max,
                                                      kw.get("horizon", 3.0), veh.v_max)
@@ -156,10 +162,15 @@ def main():
         inp = scenario_inputs(kw) if "scenario" in kw else synthetic.make_inputs(**kw)
         prob = to_reference_problem(inp, kw)
         out = ref_harness.run_reference(prob)
-        # G1: the build's own SamplingHandler must iterate in the same order as the reference's
-        assert np.array_equal(out["t_order"], inp.t_samp), (name, out["t_order"], inp.t_samp)
-        assert np.array_equal(out["v_order"], inp.v_samp), name
-        assert np.array_equal(out["d_order"], inp.d_samp), name
+        if kw.get("grid") is None:
+            # G1: the build's own SamplingHandler must iterate in the same order as the reference's
+            assert np.array_equal(out["t_order"], inp.t_samp), (name, out["t_order"], inp.t_samp)
+            assert np.array_equal(out["v_order"], inp.v_samp), name
+            assert np.array_equal(out["d_order"], inp.d_samp), name
+        else:
+            # explicit grid: the reference iterates ITS sets; the fixture keeps that order (the engine takes ranges in any order)
+            assert sorted(out["t_order"]) == sorted(set(inp.t_samp)) and sorted(out["v_order"]) == sorted(set(inp.v_samp)), name
+            assert sorted(out["d_order"]) == sorted(set(float(x) for x in inp.d_samp)), name
         Cn = len(out["valid"])
         sel = np.arange(0, Cn, stride)
         fx = dict(

@@ -247,6 +247,20 @@ def make_planner(prob):
     sh = SamplingHandler(dt=rp.dT, max_sampling_number=max(rp._sampling_max, 5), t_min=prob["t_min"],
                          horizon=rp.horizon, delta_d_min=prob["d_min"], delta_d_max=prob["d_max"], d_ego_pos=False)
     sh.set_v_sampling(prob["v_min"], prob["v_max"])
+    if prob.get("custom_sampling"):
+        # an explicit (t, v, d) grid instead of a level of the handler (BASELINE configs 2 / 3 / 5 are such grids): the reference's
+        # loops take whatever `to_range(level)` hands them -- sets, as its own Sampling classes return them (sampling_matrix.py:
+        # `self._sampling_vec[level]`), so the candidate order is CPython's iteration order of these sets
+        cs_ = prob["custom_sampling"]
+
+        class _Fixed:
+            def __init__(self, values):
+                self._set = set(float(x) for x in values)
+
+            def to_range(self, level=0):
+                return set(self._set)
+
+        sh.t_sampling, sh.v_sampling, sh.d_sampling = _Fixed(cs_["t"]), _Fixed(cs_["v"]), _Fixed(cs_["d"])
     rp.sampling_handler = sh
 
     cf = object.__new__(AdaptableCostFunction)

@@ -267,7 +267,7 @@ def test_golden_cases_vs_reference_vectors(eng, name):
     inp = inputs_from_fixture(fx, hip_hulls(), collision=False)
     ref_inp = inputs_from_fixture(fx, oracle.build_obstacle_hulls, collision=False)
     res = eng.plan_step(inp)
-    if name == "arc_hv_l4_horizon5_prod_obs8":   # 22 440 candidates: BASELINE config 3's decomposition, against the reference itself
+    if name in ("arc_hv_l4_horizon5_prod_obs8", "config3_grid_prod_obs20"):   # 22 440 candidates / BASELINE config 3 itself: config 3's decomposition, against the reference itself
         info = eng.step_info()
         assert info["lanes_per_candidate"] == 2 and info["wave_split"] == 1 and info["obstacle_kernel"] == 1 and not info["fused_selection"]
     cost, flags = eng.costs()
