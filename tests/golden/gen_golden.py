@@ -104,6 +104,11 @@ SCENARIOS = {
     # BASELINE config 3 itself: the bench's 19 x 51 x 52 grid (50 388 candidates), 20 predicted obstacles, production flags -- the
     # inputs of `python bench.py` through the reference's own loops (ref_harness: custom_sampling)
     "config3_grid_prod_obs20": (dict(ref_kind="arc", v0=10.0, grid=(19, 51, 51), n_obstacles=20, n_pred=30, lead_gap=25.0), 397),
+    # BASELINE config 5, agent 0 of synthetic.stress_agents (the draw of (SEED, 0) written out): 39 x 51 x 52 = 103 428 candidates,
+    # 5 s horizon, its own 20 predicted obstacles
+    "config5_agent0_prod_obs20": (dict(ref_kind="arc", n_knots=500, spacing=0.5, kappa=-0.016930735639397048, v0=9.998381575342757,
+                                       d0=-0.32, horizon=5.0, grid=(39, 51, 51), v_des=9.612307151201891, n_obstacles=20, n_pred=50,
+                                       seed=506913439, obstacle_min_gap=12.0), 811),
 }
 
 
