@@ -1,6 +1,7 @@
 """Times the REFERENCE's own Python hot path (/root/reference, imported through ref_harness.py) on BASELINE config 1 -- the
 ZAM_Tjunction ego's default plan step, 630 candidates x 31 samples, 5 predicted obstacles, production flag set -- on ONE core of
-the build container, and writes tests/golden/reference_python_timing.json (data only).  bench.py copies that record into its
+the build container -- and ONE step of BASELINE config 3's own inputs (the bench default) --, and writes
+tests/golden/reference_python_timing.json (data only).  bench.py copies that record into its
 line as cpu_baseline.reference_python: the only figure on the line that is the reference's own (it cannot be measured on the GPU
 box, where /root/reference does not exist).  Run in the build container only:   python tests/golden/time_reference_python.py
 
@@ -71,6 +72,31 @@ def main():
                method="tests/golden/time_reference_python.py: the reference's _create_trajectory_bundle -> check_feasibility -> "
                       "TrajectoryBundle.sort imported from /root/reference, one pinned core, median of whole plan steps over 20 s",
                python=platform.python_version(), numpy=np.__version__)
+    # the bench's DEFAULT workload as well -- BASELINE config 3's own inputs (50 388 candidates x 31 samples, 20 predicted obstacles)
+    # through the same three calls, ONE step (two minutes): golden config3_grid_prod_obs20 holds what it returns
+    name3 = "config3_grid_prod_obs20"
+    kw3, _ = gen_golden.SCENARIOS[name3]
+    from frenetix_motion_planner_amd import synthetic
+    prob3 = gen_golden.to_reference_problem(synthetic.make_inputs(**kw3), kw3)
+
+    def step3():
+        rp = ref_harness.make_planner(prob3)
+        bundle = rp._create_trajectory_bundle(rp.x_cl[0], rp.x_cl[1], rp.cost_function, samp_level=rp._sampling_min)
+        trajs = list(bundle.trajectories)
+        returned = rp.check_feasibility(trajs, None, None)
+        feas = [o for o in returned if o.valid is True and o.feasible is True]
+        b2 = TrajectoryBundle(feas, cost_function=rp.cost_function, multiproc=False, num_workers=1)
+        b2.sort()
+        return len(trajs), len(feas), b2.trajectories[0].uniqueId
+
+    t0 = time.perf_counter()
+    n3, n3_feas, best3 = step3()
+    t3 = time.perf_counter() - t0
+    fx3 = np.load(os.path.join(HERE, name3 + ".npz"))
+    assert n3 == len(fx3["valid"]) and best3 == int(fx3["walk_ids"][0]), "not the step of the committed config-3 golden"
+    rec["config3"] = dict(value=n3 / t3, unit="trajectories/s", plan_step_s=t3, steps_timed=1, candidates=n3, feasible=n3_feas,
+                          workload="BASELINE config 3 (the bench default): 19 x 51 x 52 grid = 50 388 candidates x 31 samples, 20 predicted "
+                                   "obstacles, production flags, multiproc=False -- the inputs of golden config3_grid_prod_obs20")
     with open(os.path.join(HERE, "reference_python_timing.json"), "w") as f:
         json.dump(rec, f, indent=1, sort_keys=True)
     print(json.dumps(rec, indent=1))
