@@ -105,6 +105,11 @@ def test_reference_python_record_is_committed():
     import json
     rp = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_python_timing.json")))
     assert rp["cores"] == 1 and rp["candidates"] == 630 and rp["value"] == pytest.approx(630 / (rp["plan_step_p50_ms"] * 1e-3))
+    # ... and one step of the bench's default workload itself (BASELINE config 3's inputs: golden config3_grid_prod_obs20)
+    c3 = rp["config3"]
+    assert c3["candidates"] == 50388 and c3["steps_timed"] >= 1 and c3["value"] == pytest.approx(50388 / c3["plan_step_s"]) and 10 < c3["value"] < 1e5
+    idx = json.load(open(os.path.join(ROOT, "tests", "golden", "INDEX.json")))
+    assert idx["config3_grid_prod_obs20"]["candidates"] == 50388 and idx["config3_grid_prod_obs20"]["feasible"] == c3["feasible"]
 
 
 @pytest.mark.gpu
